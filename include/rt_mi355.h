@@ -1,0 +1,213 @@
+/*
+ * rt_mi355.h -- C ABI of librt_mi355.so, the MI355X (gfx950) engine behind
+ * rayopt's GeometricTrace.propagate() hot path.
+ *
+ * The reference (quartiq/rayopt) has no FFI seam on this path: it is plain
+ * Python method dispatch.  The seam adopted here is the narrowest one that
+ * keeps every consumer of GeometricTrace working; each
+ * entry point below names the reference interface it replaces.  All functions
+ * are extern "C", take plain pointers and sizes, return 0 on success and a
+ * negative rt_status on failure (text via rt_last_error); nothing throws
+ * across the boundary.  Per-ray numerical failure (clipped ray, missed
+ * surface, total internal reflection, Newton non-convergence) is NOT an
+ * error: it is an in-band NaN exactly as in the reference
+ * (rayopt/elements.py:206-209, :496, :367, :347-348).
+ *
+ * Threading: a context is not thread safe; use one context per (thread,
+ * device).  Calls that enqueue work are asynchronous with respect to the
+ * host and ordered on the context's private HIP stream; rt_download,
+ * rt_sync and rt_kernel_ms synchronise.
+ *
+ * Device-resident result layout (all float64), L = number of elements of the
+ * System, ld = padded ray count (rt_ld):
+ *
+ *      Y, U, I : [L][3][ld]     (surface, component, ray)   "SoA"
+ *      T       : [L][ld]
+ *
+ * The Python side exposes them with the reference's shapes (L,N,3)/(L,N)
+ * (rayopt/geometric_trace.py:41-47) as strided numpy views, no transpose.
+ */
+#ifndef RT_MI355_H
+#define RT_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+#define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
+#define RT_MAX_SURFACES 256 /* elements per System */
+
+/* rt_surface.flags */
+#define RT_F_ROTATED 0x01u /* element.rotated (elements.py:139): apply rot */
+#define RT_F_CURVED  0x02u /* curvature != 0 (elements.py:482) */
+#define RT_F_CONIC   0x04u /* conic != 0 (elements.py:484) */
+#define RT_F_ASPH    0x08u /* aspherics is not None -> Newton (elements.py:478) */
+#define RT_F_ALT     0x10u /* alternate_intersection (elements.py:497) */
+#define RT_F_REFRACT 0x20u /* mu != 0 and mu != 1: Snell (elements.py:313,356) */
+#define RT_F_MIRROR  0x40u /* mu == -1: reflection (elements.py:363) */
+
+/* which array (rt_download / rt_upload_row / rt_device_ptr) */
+#define RT_Y 0 /* intercepts, element-normal frame, relative to vertex */
+#define RT_U 1 /* outgoing direction (after clip + refract) */
+#define RT_I 2 /* incoming direction in the element frame (pre-clip) */
+#define RT_T 3 /* optical path length of the segment (t * n0) */
+
+/* host ray layouts */
+#define RT_LAYOUT_SOA 0 /* (3, N) component-major */
+#define RT_LAYOUT_AOS 1 /* (N, 3) ray-major, the reference's layout */
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_ARG = -1,     /* bad argument */
+    RT_ERR_STATE = -2,   /* call order (no system / no rays uploaded) */
+    RT_ERR_HIP = -3,     /* HIP runtime error, see rt_last_error */
+    RT_ERR_RCCL = -4,    /* RCCL error, see rt_last_error */
+    RT_ERR_NOMEM = -5    /* device allocation failed */
+} rt_status;
+
+/*
+ * One element of the System for ONE wavelength, evaluated on the host.
+ * Everything that the reference computes as a Python scalar per element is
+ * computed by the host with the reference's own expression and handed over,
+ * so the kernel (and the oracle, which consumes the same table) reproduce
+ * the reference's rounding:
+ *   c, k           Spheroid.curvature / .conic       (elements.py:419-420)
+ *   kw             1 + k      z-weight of the conic dot products (:489)
+ *   kc2            (1 + k)*c**2                      (:451, :468)
+ *   radius2        radius**2  clip limit             (:207)
+ *   mu             n0/n | 1. | -1.  from get_n_mu    (:283-289)
+ *   muf,smu,mu2m1  abs(mu), sign(mu), mu**2 - 1      (:358-366)
+ *   n0             index in front of the element; t is stored as t*n0 (:315)
+ *   offset[3]      element.offset  (distance*direction, :130)
+ *   rot[9]         element.rot_normal row-major; identity if not rotated
+ *   asph[i]        aspherics[i], coefficient of r^(2(i+1))      (:448-454)
+ *   dasph[i]       2*(i + 1)*aspherics[i]                       (:469-473)
+ */
+typedef struct rt_surface {
+    double c, k, kw, kc2;
+    double radius2;
+    double mu, muf, smu, mu2m1;
+    double n0;
+    double offset[3];
+    double rot[9];
+    double asph[RT_MAX_ASPH];
+    double dasph[RT_MAX_ASPH];
+    int32_t nasph;
+    uint32_t flags;
+} rt_surface;
+
+typedef struct rt_ctx rt_ctx;
+
+int rt_abi_version(void);
+int rt_sizeof_surface(void); /* sizeof(rt_surface), layout check for FFI */
+/* number of visible HIP devices (0 and RT_ERR_HIP text when there is none) */
+int rt_device_count(int *count);
+
+/* one context per device: owns the stream, events and all device buffers */
+int rt_create(int device, rt_ctx **out);
+int rt_destroy(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: global */
+
+/*
+ * Replaces the per-call reads of element attributes in System.propagate /
+ * Element.propagate (rayopt/system.py:459-464, elements.py:306-315).  surf[j]
+ * describes element j (j = 0 is the object surface); nsurf = len(system).
+ * Elements are mutable in the reference (refocus edits system[at].distance,
+ * geometric_trace.py:98-99) so the host re-packs and re-uploads on every
+ * propagate(); the copy is O(L) and tiny.
+ */
+int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf);
+
+/*
+ * GeometricTrace.allocate(nrays) (geometric_trace.py:37-47): size the device
+ * result arrays for len(system) x nrays.  Grows only; contents are undefined
+ * after a growth.
+ */
+int rt_reserve(rt_ctx *ctx, int64_t nrays);
+int64_t rt_nrays(const rt_ctx *ctx);
+int64_t rt_ld(const rt_ctx *ctx); /* padded ray stride of the SoA arrays */
+int rt_nsurf(const rt_ctx *ctx);
+
+/*
+ * GeometricTrace.rays_given (geometric_trace.py:49-70): seed row 0 from host
+ * arrays of n rays x 3 components in `layout` (the host completes missing
+ * components exactly as the reference does, :60-66).  Also sets I[0] = U[0]
+ * and T[0] = 0 (:67,:69).  Calls rt_reserve(n) itself.
+ */
+int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
+                int layout);
+/* same, y/u already in device memory (rays generated on the device) */
+int rt_set_rays_device(rt_ctx *ctx, const double *d_y, const double *d_u,
+                       int64_t n, int layout);
+/* overwrite one surface row of one array from a host SoA buffer */
+int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa);
+
+/*
+ * GeometricTrace.propagate(start, stop, clip) (geometric_trace.py:72-80)
+ * fused with System.propagate (system.py:459-464): reads rows start-1 of Y and
+ * U (element start-1's normal frame), applies from_normal of element start-1,
+ * then marches elements start..stop-1 and writes rows start..stop-1 of
+ * Y,U,I,T.  stop <= 0 or stop > nsurf means nsurf.  Asynchronous.
+ */
+int rt_trace(rt_ctx *ctx, int start, int stop, int clip);
+int rt_sync(rt_ctx *ctx);
+/* HIP-event time of the last rt_trace kernel in ms (synchronises) */
+int rt_kernel_ms(rt_ctx *ctx, double *ms);
+/*
+ * Measurement support: record HIP event `slot` (0..7) on the stream the
+ * trace kernel is launched on; rt_event_elapsed synchronises on `b`.
+ */
+int rt_event_record(rt_ctx *ctx, int slot);
+int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
+/*
+ * Kernel variant selection for A/B measurements (defaults are the tuned
+ * ones): key "rays_per_thread" (1,2,4), "nontemporal" (0,1), "xcd_remap"
+ * (0,1), "block" (64..1024).
+ */
+int rt_set_option(rt_ctx *ctx, const char *key, int value);
+
+/*
+ * Lazy D2H of surface rows [surf_lo, surf_hi) of one array into a caller
+ * owned host buffer, compact SoA: (rows,3,n) for Y/U/I, (rows,n) for T.
+ * This is what backs the numpy attributes y,u,i,t of the drop-in
+ * GeometricTrace.  Synchronises.
+ */
+int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst);
+
+/* raw device pointer to row `surf` of an array (interop, collectives) */
+int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out);
+
+/*
+ * Multi-GPU (one process per GPU).  The trace itself needs no exchange: rays
+ * are independent and the ray batch is sharded contiguously.  The only
+ * exchange is the gather of the last-surface intercepts to a root rank
+ * (RCCL over xGMI): grouped ncclSend/ncclRecv, direct peer->root links, no
+ * ring.  id is a 128-byte ncclUniqueId created on rank 0 and distributed by
+ * the host (any out-of-band channel).
+ */
+int rt_comm_unique_id(void *id128);
+int rt_comm_init(rt_ctx *ctx, const void *id128, int nranks, int rank);
+int rt_comm_destroy(rt_ctx *ctx);
+/*
+ * Gather row `surf` of array `which` from every rank to `root`.  counts[r] =
+ * rays held by rank r.  On root, d_dst is a device buffer of
+ * ncomp*sum(counts) doubles laid out [component][global ray]; ignored
+ * elsewhere.  Runs on the context's communication stream after the trace
+ * that produced the row; rt_comm_sync waits for it.
+ */
+int rt_gather_final(rt_ctx *ctx, int which, int surf, const int64_t *counts,
+                    int root, double *d_dst);
+int rt_comm_sync(rt_ctx *ctx);
+
+/* device scratch owned by the context (e.g. gather destination on root) */
+int rt_scratch(rt_ctx *ctx, int64_t bytes, void **out);
+/* D2H copy helper for buffers obtained from rt_scratch / rt_device_ptr */
+int rt_copy_to_host(rt_ctx *ctx, void *dst, const void *d_src, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355_H */

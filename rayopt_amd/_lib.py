@@ -1,0 +1,111 @@
+"""ctypes binding of librt_mi355.so (C ABI: include/rt_mi355.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible
+the product raises.  ``SURFACE_DTYPE`` mirrors ``struct rt_surface`` field for
+field; the layout is verified against ``rt_sizeof_surface()`` at load time.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+RT_MAX_ASPH = 10
+RT_MAX_SURFACES = 256
+
+F_ROTATED, F_CURVED, F_CONIC, F_ASPH, F_ALT, F_REFRACT, F_MIRROR = (
+    0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40)
+RT_Y, RT_U, RT_I, RT_T = 0, 1, 2, 3
+LAYOUT_SOA, LAYOUT_AOS = 0, 1
+
+SURFACE_DTYPE = np.dtype([
+    ("c", "f8"), ("k", "f8"), ("kw", "f8"), ("kc2", "f8"),
+    ("radius2", "f8"),
+    ("mu", "f8"), ("muf", "f8"), ("smu", "f8"), ("mu2m1", "f8"),
+    ("n0", "f8"),
+    ("offset", "f8", (3,)),
+    ("rot", "f8", (9,)),
+    ("asph", "f8", (RT_MAX_ASPH,)),
+    ("dasph", "f8", (RT_MAX_ASPH,)),
+    ("nasph", "i4"), ("flags", "u4"),
+], align=True)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                        "librt_mi355.so")
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+_ctx = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/rt_mi355.h declares
+SIGNATURES = {
+    "rt_abi_version": (ctypes.c_int, []),
+    "rt_sizeof_surface": (ctypes.c_int, []),
+    "rt_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "rt_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_ctx)]),
+    "rt_destroy": (ctypes.c_int, [_ctx]),
+    "rt_last_error": (ctypes.c_char_p, [_ctx]),
+    "rt_upload_system": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_int]),
+    "rt_reserve": (ctypes.c_int, [_ctx, ctypes.c_int64]),
+    "rt_nrays": (ctypes.c_int64, [_ctx]),
+    "rt_ld": (ctypes.c_int64, [_ctx]),
+    "rt_nsurf": (ctypes.c_int, [_ctx]),
+    "rt_set_rays": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_int64, ctypes.c_int]),
+    "rt_set_rays_device": (ctypes.c_int, [_ctx, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_int64,
+                                          ctypes.c_int]),
+    "rt_upload_row": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_void_p]),
+    "rt_trace": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
+                                ctypes.c_int]),
+    "rt_sync": (ctypes.c_int, [_ctx]),
+    "rt_kernel_ms": (ctypes.c_int, [_ctx, _c_double_p]),
+    "rt_event_record": (ctypes.c_int, [_ctx, ctypes.c_int]),
+    "rt_event_elapsed": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
+                                        _c_double_p]),
+    "rt_set_option": (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int]),
+    "rt_download": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_void_p]),
+    "rt_device_ptr": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_void_p)]),
+    "rt_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "rt_comm_init": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_int]),
+    "rt_comm_destroy": (ctypes.c_int, [_ctx]),
+    "rt_gather_final": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
+                                       _c_int64_p, ctypes.c_int,
+                                       ctypes.c_void_p]),
+    "rt_comm_sync": (ctypes.c_int, [_ctx]),
+    "rt_scratch": (ctypes.c_int, [_ctx, ctypes.c_int64,
+                                  ctypes.POINTER(ctypes.c_void_p)]),
+    "rt_copy_to_host": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int64]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """Load librt_mi355.so; raises EngineError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            "%s not found: build it with `python -m rayopt_amd._build` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rt_sizeof_surface() != SURFACE_DTYPE.itemsize:
+        raise EngineError("struct rt_surface is %d bytes in the library but "
+                          "%d in SURFACE_DTYPE" % (lib.rt_sizeof_surface(),
+                                                   SURFACE_DTYPE.itemsize))
+    _lib = lib
+    return lib

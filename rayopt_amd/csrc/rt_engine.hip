@@ -1,0 +1,917 @@
+/*
+ * rt_engine.hip -- gfx950 kernels + C ABI (include/rt_mi355.h) of the
+ * sequential geometric ray-trace engine.
+ *
+ * Kernel design (MI355X first):
+ *  - one lane owns R adjacent rays (R = 2 by default -> 16-byte global
+ *    accesses, 1 KiB per wave instruction) and keeps their state (y, u) in
+ *    VGPRs across the whole surface loop: the fused march reads 48 B per ray
+ *    once and writes 80 B per ray-surface op, nothing is ever re-read;
+ *  - results are SoA [surface][component][ray] so every store instruction of
+ *    a wave covers one contiguous, 1 KiB aligned segment;
+ *  - the surface table is wave-uniform: it is read with scalar loads
+ *    (s_load_dwordx*) through the scalar cache into SGPRs, costing no VGPRs
+ *    and no LDS traffic; all per-surface branches are scalar branches;
+ *  - the even-asphere Newton solve is the only divergent loop; its trip count
+ *    is decided per wavefront with a 64-bit ballot (rt_math.h);
+ *  - FP64 VALU only: the path is elementwise, there is no contraction to put
+ *    on MFMA.  Bound: HBM write bandwidth (80 B / ray-surface op).
+ *
+ * No CPU fallback lives here: every entry point either runs on the GPU or
+ * returns an error.
+ */
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rt_math.h"
+
+/* ------------------------------------------------------------------ */
+/* kernels                                                            */
+/* ------------------------------------------------------------------ */
+
+template <int R> struct rt_vec;
+template <> struct rt_vec<1> { typedef double type; };
+template <> struct rt_vec<2> {
+    typedef double type __attribute__((ext_vector_type(2)));
+};
+template <> struct rt_vec<4> {
+    typedef double type __attribute__((ext_vector_type(4)));
+};
+
+template <int R>
+__device__ __forceinline__ void rt_load(const double *__restrict__ p,
+                                        double (&v)[R])
+{
+    typedef typename rt_vec<R>::type V;
+    const V x = *reinterpret_cast<const V *>(p);
+    if constexpr (R == 1) {
+        v[0] = x;
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            v[r] = x[r];
+    }
+}
+
+template <int R, bool NT>
+__device__ __forceinline__ void rt_store(double *__restrict__ p,
+                                         const double (&v)[R])
+{
+    typedef typename rt_vec<R>::type V;
+    V x;
+    if constexpr (R == 1) {
+        x = v[0];
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            x[r] = v[r];
+    }
+    if constexpr (NT)
+        __builtin_nontemporal_store(x, reinterpret_cast<V *>(p));
+    else
+        *reinterpret_cast<V *>(p) = x;
+}
+
+/*
+ * blockIdx -> chunk of rays.  Workgroup b is dispatched to XCD b % 8
+ * (observed, used for speed only).  With XCD = true the chunks are dealt so
+ * that each XCD streams one contiguous eighth of every result row instead of
+ * every eighth 4 KiB chunk.
+ */
+template <bool XCD>
+__device__ __forceinline__ int64_t rt_chunk(int64_t nblocks)
+{
+    const int64_t b = blockIdx.x;
+    if constexpr (!XCD)
+        return b;
+    const int64_t per = (nblocks + 7) / 8;
+    const int64_t c = (b & 7) * per + (b >> 3);
+    return c; /* may be >= nblocks for the ragged tail: caller checks */
+}
+
+template <int R, bool NT, bool XCD>
+__global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
+                                int stop, int clip, double *__restrict__ Y,
+                                double *__restrict__ U, double *__restrict__ I,
+                                double *__restrict__ T, int64_t ld,
+                                int64_t nblocks)
+{
+    const int64_t chunk = rt_chunk<XCD>(nblocks);
+    const int64_t j = (chunk * blockDim.x + threadIdx.x) * R;
+    if (j >= ld)
+        return;
+
+    double y[R][3], u[R][3], iv[R][3], t[R];
+    {
+        const int64_t row = (int64_t)(start - 1) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double a[R], b[R];
+            rt_load<R>(Y + (row + c) * ld + j, a);
+            rt_load<R>(U + (row + c) * ld + j, b);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                y[r][c] = a[r];
+                u[r][c] = b[r];
+            }
+        }
+        const rt_surface *S0 = surf + (start - 1);
+        rt_leave<R>(S0, S0->flags, y, u);
+    }
+
+    for (int s = start; s < stop; ++s) {
+        const rt_surface *S = surf + s;
+        const unsigned flags = S->flags;
+        rt_step<R>(S, flags, clip, y, u, iv, t);
+
+        const int64_t row = (int64_t)s * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double a[R], b[R], d[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                a[r] = y[r][c];
+                b[r] = u[r][c];
+                d[r] = iv[r][c];
+            }
+            rt_store<R, NT>(Y + (row + c) * ld + j, a);
+            rt_store<R, NT>(U + (row + c) * ld + j, b);
+            rt_store<R, NT>(I + (row + c) * ld + j, d);
+        }
+        rt_store<R, NT>(T + (int64_t)s * ld + j, t);
+
+        rt_leave<R>(S, flags, y, u);
+    }
+}
+
+/* rays_given: AoS (n,3) staging -> SoA row 0 of Y,U,I and T[0] = 0 */
+__global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
+                                   const double *__restrict__ u_aos,
+                                   int64_t n, double *__restrict__ Y,
+                                   double *__restrict__ U,
+                                   double *__restrict__ I,
+                                   double *__restrict__ T, int64_t ld)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld)
+        return;
+    const bool in = j < n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double a = in ? y_aos[j * 3 + c] : 0.;
+        const double b = in ? u_aos[j * 3 + c] : 0.;
+        Y[c * ld + j] = a;
+        U[c * ld + j] = b;
+        I[c * ld + j] = b;
+    }
+    T[j] = 0.;
+}
+
+/* rays_given for SoA (3,n) device/staged input */
+__global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
+                                   const double *__restrict__ u_soa,
+                                   int64_t n, double *__restrict__ Y,
+                                   double *__restrict__ U,
+                                   double *__restrict__ I,
+                                   double *__restrict__ T, int64_t ld)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld)
+        return;
+    const bool in = j < n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double a = in ? y_soa[c * n + j] : 0.;
+        const double b = in ? u_soa[c * n + j] : 0.;
+        Y[c * ld + j] = a;
+        U[c * ld + j] = b;
+        I[c * ld + j] = b;
+    }
+    T[j] = 0.;
+}
+
+/* ------------------------------------------------------------------ */
+/* context                                                            */
+/* ------------------------------------------------------------------ */
+
+#define RT_NEVENTS 8
+
+struct rt_rccl_api {
+    void *lib;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*GroupStart)(void);
+    ncclResult_t (*GroupEnd)(void);
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t,
+                         hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t,
+                         hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+};
+
+struct rt_ctx {
+    int device;
+    hipStream_t stream;      /* trace + copies */
+    hipStream_t comm_stream; /* RCCL gather */
+    hipEvent_t k0, k1;       /* around the last trace kernel */
+    hipEvent_t ev[RT_NEVENTS];
+    int traced;
+
+    rt_surface *d_surf;
+    int nsurf;
+    rt_surface h_surf[RT_MAX_SURFACES];
+
+    double *d_buf; /* Y | U | I | T */
+    size_t cap_doubles;
+    int64_t n, ld;
+    int buf_nsurf; /* L the buffer is laid out for */
+
+    void *d_scratch;
+    size_t scratch_bytes;
+    void *d_user; /* rt_scratch */
+    size_t user_bytes;
+
+    /* kernel variant */
+    int opt_r, opt_nt, opt_xcd, opt_block;
+
+    /* multi GPU */
+    ncclComm_t comm;
+    int nranks, rank;
+    double *d_stage[2];
+    size_t stage_bytes;
+    hipEvent_t staged[2], gathered[2];
+    int gather_pending[2];
+    int parity;
+
+    char err[512];
+};
+
+static char g_err[512] = "";
+static rt_rccl_api g_rccl = {};
+
+static int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...)
+{
+    char *dst = ctx ? ctx->err : g_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        snprintf(g_err, sizeof g_err, "%s", ctx->err);
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                     \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess)                                                 \
+            return rt_fail(ctx, RT_ERR_HIP, "%s: %s (%s:%d)", #call,          \
+                           hipGetErrorString(e_), __FILE__, __LINE__);        \
+    } while (0)
+
+#define RT_NCCL(ctx, call)                                                    \
+    do {                                                                      \
+        ncclResult_t r_ = (call);                                             \
+        if (r_ != ncclSuccess)                                                \
+            return rt_fail(ctx, RT_ERR_RCCL, "%s: %s (%s:%d)", #call,         \
+                           g_rccl.GetErrorString(r_), __FILE__, __LINE__);    \
+    } while (0)
+
+static inline double *rt_arr(const rt_ctx *c, int which)
+{
+    /* Y,U,I are [L][3][ld]; T is [L][ld] */
+    const size_t plane = (size_t)c->buf_nsurf * 3 * (size_t)c->ld;
+    return c->d_buf + (size_t)which * plane;
+}
+
+static inline int rt_ncomp(int which) { return which == RT_T ? 1 : 3; }
+
+template <int R, bool NT, bool XCD>
+static void rt_launch(rt_ctx *c, int start, int stop, int clip)
+{
+    const int block = c->opt_block;
+    const int64_t per_block = (int64_t)block * R;
+    const int64_t nblocks = (c->ld + per_block - 1) / per_block;
+    const int64_t grid = XCD ? (nblocks + 7) / 8 * 8 : nblocks;
+    hipLaunchKernelGGL((rt_trace_kernel<R, NT, XCD>), dim3((unsigned)grid),
+                       dim3(block), 0, c->stream, c->d_surf, start, stop, clip,
+                       rt_arr(c, RT_Y), rt_arr(c, RT_U), rt_arr(c, RT_I),
+                       rt_arr(c, RT_T), c->ld, nblocks);
+}
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+int rt_sizeof_surface(void) { return (int)sizeof(rt_surface); }
+
+int rt_device_count(int *count)
+{
+    if (!count)
+        return rt_fail(NULL, RT_ERR_ARG, "rt_device_count: NULL");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return rt_fail(NULL, RT_ERR_HIP, "hipGetDeviceCount: %s",
+                       hipGetErrorString(e));
+    }
+    return RT_OK;
+}
+
+const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+int rt_create(int device, rt_ctx **out)
+{
+    if (!out)
+        return rt_fail(NULL, RT_ERR_ARG, "rt_create: out is NULL");
+    *out = NULL;
+    int count = 0;
+    int rc = rt_device_count(&count);
+    if (rc != RT_OK)
+        return rc;
+    if (device < 0 || device >= count)
+        return rt_fail(NULL, RT_ERR_ARG,
+                       "rt_create: device %d not in [0,%d): no MI355X visible",
+                       device, count);
+    rt_ctx *c = (rt_ctx *)calloc(1, sizeof(rt_ctx));
+    if (!c)
+        return rt_fail(NULL, RT_ERR_NOMEM, "rt_create: host allocation");
+    c->device = device;
+    c->opt_r = 2;
+    c->opt_nt = 0;
+    c->opt_xcd = 0;
+    c->opt_block = 256;
+#define RT_HIP_C(call)                                                        \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) {                                               \
+            rt_fail(NULL, RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+            free(c);                                                          \
+            return RT_ERR_HIP;                                                \
+        }                                                                     \
+    } while (0)
+    RT_HIP_C(hipSetDevice(device));
+    RT_HIP_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    RT_HIP_C(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    RT_HIP_C(hipEventCreate(&c->k0));
+    RT_HIP_C(hipEventCreate(&c->k1));
+    for (int i = 0; i < RT_NEVENTS; ++i)
+        RT_HIP_C(hipEventCreate(&c->ev[i]));
+    for (int i = 0; i < 2; ++i) {
+        RT_HIP_C(hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
+        RT_HIP_C(
+            hipEventCreateWithFlags(&c->gathered[i], hipEventDisableTiming));
+    }
+    RT_HIP_C(hipMalloc((void **)&c->d_surf,
+                       sizeof(rt_surface) * RT_MAX_SURFACES));
+#undef RT_HIP_C
+    *out = c;
+    return RT_OK;
+}
+
+int rt_comm_destroy(rt_ctx *ctx);
+
+int rt_destroy(rt_ctx *ctx)
+{
+    if (!ctx)
+        return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->comm_stream);
+    rt_comm_destroy(ctx);
+    if (ctx->d_buf)
+        (void)hipFree(ctx->d_buf);
+    if (ctx->d_scratch)
+        (void)hipFree(ctx->d_scratch);
+    if (ctx->d_user)
+        (void)hipFree(ctx->d_user);
+    if (ctx->d_surf)
+        (void)hipFree(ctx->d_surf);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->d_stage[i])
+            (void)hipFree(ctx->d_stage[i]);
+        (void)hipEventDestroy(ctx->staged[i]);
+        (void)hipEventDestroy(ctx->gathered[i]);
+    }
+    for (int i = 0; i < RT_NEVENTS; ++i)
+        (void)hipEventDestroy(ctx->ev[i]);
+    (void)hipEventDestroy(ctx->k0);
+    (void)hipEventDestroy(ctx->k1);
+    (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->comm_stream);
+    free(ctx);
+    return RT_OK;
+}
+
+int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf)
+{
+    if (!ctx || !surf)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_upload_system: NULL argument");
+    if (nsurf < 2 || nsurf > RT_MAX_SURFACES)
+        return rt_fail(ctx, RT_ERR_ARG,
+                       "rt_upload_system: nsurf=%d not in [2,%d]", nsurf,
+                       RT_MAX_SURFACES);
+    for (int j = 0; j < nsurf; ++j) {
+        if (surf[j].nasph < 0 || surf[j].nasph > RT_MAX_ASPH)
+            return rt_fail(ctx, RT_ERR_ARG,
+                           "rt_upload_system: element %d has %d aspheric "
+                           "terms, limit %d",
+                           j, surf[j].nasph, RT_MAX_ASPH);
+    }
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    /* the previous table may still be read by a kernel in flight and the
+     * pageable host copy must be stable until the DMA is done */
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(ctx->h_surf, surf, sizeof(rt_surface) * nsurf);
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_surf, ctx->h_surf,
+                               sizeof(rt_surface) * nsurf,
+                               hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nsurf = nsurf;
+    return RT_OK;
+}
+
+int rt_reserve(rt_ctx *ctx, int64_t nrays)
+{
+    if (!ctx || nrays < 1)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_reserve: bad argument");
+    if (ctx->nsurf < 2)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_reserve: rt_upload_system must come first");
+    const int64_t ld = (nrays + 63) / 64 * 64;
+    if (ld == ctx->ld && ctx->buf_nsurf == ctx->nsurf && ctx->d_buf) {
+        ctx->n = nrays;
+        return RT_OK;
+    }
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld;
+    if (need > ctx->cap_doubles) {
+        if (ctx->d_buf)
+            RT_HIP(ctx, hipFree(ctx->d_buf));
+        ctx->d_buf = NULL;
+        ctx->cap_doubles = 0;
+        hipError_t e = hipMalloc((void **)&ctx->d_buf, need * sizeof(double));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return rt_fail(ctx, RT_ERR_NOMEM,
+                           "rt_reserve: hipMalloc of %.3f GB failed: %s",
+                           need * 8e-9, hipGetErrorString(e));
+        }
+        ctx->cap_doubles = need;
+    }
+    ctx->n = nrays;
+    ctx->ld = ld;
+    ctx->buf_nsurf = ctx->nsurf;
+    ctx->traced = 0;
+    return RT_OK;
+}
+
+int64_t rt_nrays(const rt_ctx *ctx) { return ctx ? ctx->n : 0; }
+int64_t rt_ld(const rt_ctx *ctx) { return ctx ? ctx->ld : 0; }
+int rt_nsurf(const rt_ctx *ctx) { return ctx ? ctx->nsurf : 0; }
+
+static int rt_need_scratch(rt_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes)
+        return RT_OK;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_scratch)
+        RT_HIP(ctx, hipFree(ctx->d_scratch));
+    ctx->d_scratch = NULL;
+    ctx->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->d_scratch, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return rt_fail(ctx, RT_ERR_NOMEM, "scratch hipMalloc(%zu): %s", bytes,
+                       hipGetErrorString(e));
+    }
+    ctx->scratch_bytes = bytes;
+    return RT_OK;
+}
+
+static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
+                   int64_t n, int layout)
+{
+    const int block = 256;
+    const unsigned grid = (unsigned)((ctx->ld + block - 1) / block);
+    double *Y = rt_arr(ctx, RT_Y), *U = rt_arr(ctx, RT_U),
+           *I = rt_arr(ctx, RT_I), *T = rt_arr(ctx, RT_T);
+    if (layout == RT_LAYOUT_AOS)
+        hipLaunchKernelGGL(rt_seed_aos_kernel, dim3(grid), dim3(block), 0,
+                           ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld);
+    else
+        hipLaunchKernelGGL(rt_seed_soa_kernel, dim3(grid), dim3(block), 0,
+                           ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
+                int layout)
+{
+    if (!ctx || !y || !u || n < 1 ||
+        (layout != RT_LAYOUT_AOS && layout != RT_LAYOUT_SOA))
+        return rt_fail(ctx, RT_ERR_ARG, "rt_set_rays: bad argument");
+    int rc = rt_reserve(ctx, n);
+    if (rc != RT_OK)
+        return rc;
+    const size_t bytes = (size_t)n * 3 * sizeof(double);
+    rc = rt_need_scratch(ctx, 2 * bytes);
+    if (rc != RT_OK)
+        return rc;
+    double *sy = (double *)ctx->d_scratch;
+    double *su = sy + (size_t)n * 3;
+    RT_HIP(ctx, hipMemcpyAsync(sy, y, bytes, hipMemcpyHostToDevice,
+                               ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(su, u, bytes, hipMemcpyHostToDevice,
+                               ctx->stream));
+    rc = rt_seed(ctx, sy, su, n, layout);
+    if (rc != RT_OK)
+        return rc;
+    /* caller's host arrays may be released as soon as we return */
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_set_rays_device(rt_ctx *ctx, const double *d_y, const double *d_u,
+                       int64_t n, int layout)
+{
+    if (!ctx || !d_y || !d_u || n < 1 ||
+        (layout != RT_LAYOUT_AOS && layout != RT_LAYOUT_SOA))
+        return rt_fail(ctx, RT_ERR_ARG, "rt_set_rays_device: bad argument");
+    int rc = rt_reserve(ctx, n);
+    if (rc != RT_OK)
+        return rc;
+    return rt_seed(ctx, d_y, d_u, n, layout);
+}
+
+int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
+{
+    if (!ctx || !src_soa || which < RT_Y || which > RT_T)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_upload_row: bad argument");
+    if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_upload_row: no such row %d",
+                       surf);
+    const int nc = rt_ncomp(which);
+    double *dst = rt_arr(ctx, which) + (size_t)surf * nc * ctx->ld;
+    RT_HIP(ctx, hipMemcpy2DAsync(dst, ctx->ld * sizeof(double), src_soa,
+                                 ctx->n * sizeof(double),
+                                 ctx->n * sizeof(double), nc,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
+{
+    if (!ctx)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_trace: NULL context");
+    if (ctx->nsurf < 2 || !ctx->d_buf || ctx->n < 1)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_trace: upload a system and rays first");
+    if (ctx->buf_nsurf != ctx->nsurf)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_trace: system length changed (%d -> %d) after the "
+                       "rays were set",
+                       ctx->buf_nsurf, ctx->nsurf);
+    if (stop <= 0 || stop > ctx->nsurf)
+        stop = ctx->nsurf;
+    if (start < 1 || start > stop)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_trace: start=%d stop=%d nsurf=%d",
+                       start, stop, ctx->nsurf);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
+    if (start < stop) {
+        const int key = ctx->opt_r * 4 + ctx->opt_nt * 2 + ctx->opt_xcd;
+        switch (key) {
+#define RT_CASE(R, NT, X)                                                     \
+    case (R) * 4 + (NT) * 2 + (X):                                            \
+        rt_launch<R, NT, X>(ctx, start, stop, clip);                          \
+        break;
+            RT_CASE(1, 0, 0) RT_CASE(1, 0, 1) RT_CASE(1, 1, 0) RT_CASE(1, 1, 1)
+            RT_CASE(2, 0, 0) RT_CASE(2, 0, 1) RT_CASE(2, 1, 0) RT_CASE(2, 1, 1)
+            RT_CASE(4, 0, 0) RT_CASE(4, 0, 1) RT_CASE(4, 1, 0) RT_CASE(4, 1, 1)
+#undef RT_CASE
+        default:
+            return rt_fail(ctx, RT_ERR_STATE, "rt_trace: bad variant %d", key);
+        }
+        RT_HIP(ctx, hipGetLastError());
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
+    ctx->traced = 1;
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx *ctx)
+{
+    if (!ctx)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_sync: NULL context");
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_kernel_ms(rt_ctx *ctx, double *ms)
+{
+    if (!ctx || !ms)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_kernel_ms: NULL argument");
+    if (!ctx->traced)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_kernel_ms: nothing traced yet");
+    RT_HIP(ctx, hipEventSynchronize(ctx->k1));
+    float f = 0.f;
+    RT_HIP(ctx, hipEventElapsedTime(&f, ctx->k0, ctx->k1));
+    *ms = f;
+    return RT_OK;
+}
+
+int rt_event_record(rt_ctx *ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= RT_NEVENTS)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_event_record: bad slot");
+    RT_HIP(ctx, hipEventRecord(ctx->ev[slot], ctx->stream));
+    return RT_OK;
+}
+
+int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms)
+{
+    if (!ctx || !ms || a < 0 || a >= RT_NEVENTS || b < 0 || b >= RT_NEVENTS)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_event_elapsed: bad argument");
+    RT_HIP(ctx, hipEventSynchronize(ctx->ev[b]));
+    float f = 0.f;
+    RT_HIP(ctx, hipEventElapsedTime(&f, ctx->ev[a], ctx->ev[b]));
+    *ms = f;
+    return RT_OK;
+}
+
+int rt_set_option(rt_ctx *ctx, const char *key, int value)
+{
+    if (!ctx || !key)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_set_option: NULL argument");
+    if (!strcmp(key, "rays_per_thread")) {
+        if (value != 1 && value != 2 && value != 4)
+            return rt_fail(ctx, RT_ERR_ARG, "rays_per_thread must be 1, 2, 4");
+        ctx->opt_r = value;
+    } else if (!strcmp(key, "nontemporal")) {
+        ctx->opt_nt = value ? 1 : 0;
+    } else if (!strcmp(key, "xcd_remap")) {
+        ctx->opt_xcd = value ? 1 : 0;
+    } else if (!strcmp(key, "block")) {
+        if (value < 64 || value > 1024 || value % 64)
+            return rt_fail(ctx, RT_ERR_ARG, "block must be k*64 in [64,1024]");
+        ctx->opt_block = value;
+    } else {
+        return rt_fail(ctx, RT_ERR_ARG, "rt_set_option: unknown key '%s'", key);
+    }
+    return RT_OK;
+}
+
+int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
+{
+    if (!ctx || !dst || which < RT_Y || which > RT_T)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_download: bad argument");
+    if (!ctx->d_buf || surf_lo < 0 || surf_hi > ctx->buf_nsurf ||
+        surf_lo >= surf_hi)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_download: rows [%d,%d) of %d",
+                       surf_lo, surf_hi, ctx->buf_nsurf);
+    const int nc = rt_ncomp(which);
+    const double *src = rt_arr(ctx, which) + (size_t)surf_lo * nc * ctx->ld;
+    const size_t rows = (size_t)(surf_hi - surf_lo) * nc;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpy2DAsync(dst, ctx->n * sizeof(double), src,
+                                 ctx->ld * sizeof(double),
+                                 ctx->n * sizeof(double), rows,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
+{
+    if (!ctx || !out || which < RT_Y || which > RT_T)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_device_ptr: bad argument");
+    if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_device_ptr: no such row %d", surf);
+    *out = rt_arr(ctx, which) + (size_t)surf * rt_ncomp(which) * ctx->ld;
+    return RT_OK;
+}
+
+int rt_scratch(rt_ctx *ctx, int64_t bytes, void **out)
+{
+    if (!ctx || !out || bytes < 1)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_scratch: bad argument");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if ((size_t)bytes > ctx->user_bytes) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+        if (ctx->d_user)
+            RT_HIP(ctx, hipFree(ctx->d_user));
+        ctx->d_user = NULL;
+        ctx->user_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->d_user, (size_t)bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return rt_fail(ctx, RT_ERR_NOMEM, "rt_scratch: hipMalloc(%lld): %s",
+                           (long long)bytes, hipGetErrorString(e));
+        }
+        ctx->user_bytes = (size_t)bytes;
+    }
+    *out = ctx->d_user;
+    return RT_OK;
+}
+
+int rt_copy_to_host(rt_ctx *ctx, void *dst, const void *d_src, int64_t bytes)
+{
+    if (!ctx || !dst || !d_src || bytes < 0)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_copy_to_host: bad argument");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+    RT_HIP(ctx, hipMemcpyAsync(dst, d_src, (size_t)bytes,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* multi GPU: RCCL gather of one result row to a root rank            */
+/* ------------------------------------------------------------------ */
+
+static int rt_rccl_load(rt_ctx *ctx)
+{
+    if (g_rccl.lib)
+        return RT_OK;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib)
+        lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib)
+        return rt_fail(ctx, RT_ERR_RCCL, "dlopen(librccl.so): %s", dlerror());
+#define RT_SYM(field, name)                                                   \
+    do {                                                                      \
+        *(void **)(&g_rccl.field) = dlsym(lib, name);                         \
+        if (!g_rccl.field)                                                    \
+            return rt_fail(ctx, RT_ERR_RCCL, "dlsym(%s) failed", name);       \
+    } while (0)
+    RT_SYM(GetUniqueId, "ncclGetUniqueId");
+    RT_SYM(CommInitRank, "ncclCommInitRank");
+    RT_SYM(CommDestroy, "ncclCommDestroy");
+    RT_SYM(GroupStart, "ncclGroupStart");
+    RT_SYM(GroupEnd, "ncclGroupEnd");
+    RT_SYM(Send, "ncclSend");
+    RT_SYM(Recv, "ncclRecv");
+    RT_SYM(GetErrorString, "ncclGetErrorString");
+#undef RT_SYM
+    g_rccl.lib = lib;
+    return RT_OK;
+}
+
+int rt_comm_unique_id(void *id128)
+{
+    if (!id128)
+        return rt_fail(NULL, RT_ERR_ARG, "rt_comm_unique_id: NULL");
+    int rc = rt_rccl_load(NULL);
+    if (rc != RT_OK)
+        return rc;
+    ncclUniqueId id;
+    RT_NCCL(NULL, g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, NCCL_UNIQUE_ID_BYTES);
+    return RT_OK;
+}
+
+int rt_comm_init(rt_ctx *ctx, const void *id128, int nranks, int rank)
+{
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_comm_init: bad argument");
+    if (ctx->comm)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_comm_init: already initialised");
+    int rc = rt_rccl_load(ctx);
+    if (rc != RT_OK)
+        return rc;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
+    RT_NCCL(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, id, rank));
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    return RT_OK;
+}
+
+int rt_comm_destroy(rt_ctx *ctx)
+{
+    if (!ctx || !ctx->comm)
+        return RT_OK;
+    (void)hipStreamSynchronize(ctx->comm_stream);
+    g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = NULL;
+    ctx->nranks = 0;
+    return RT_OK;
+}
+
+int rt_gather_final(rt_ctx *ctx, int which, int surf, const int64_t *counts,
+                    int root, double *d_dst)
+{
+    if (!ctx || !counts || which < RT_Y || which > RT_T)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_gather_final: bad argument");
+    if (!ctx->comm)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_gather_final: rt_comm_init first");
+    if (root < 0 || root >= ctx->nranks)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_gather_final: root %d", root);
+    if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_gather_final: no row %d", surf);
+    if (counts[ctx->rank] != ctx->n)
+        return rt_fail(ctx, RT_ERR_ARG,
+                       "rt_gather_final: counts[%d]=%lld but this rank holds "
+                       "%lld rays",
+                       ctx->rank, (long long)counts[ctx->rank],
+                       (long long)ctx->n);
+    if (ctx->rank == root && !d_dst)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_gather_final: root needs d_dst");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+
+    const int nc = rt_ncomp(which);
+    const int p = ctx->parity;
+    ctx->parity ^= 1;
+    const size_t row_bytes = (size_t)nc * ctx->n * sizeof(double);
+    if (row_bytes > ctx->stage_bytes) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->d_stage[i])
+                RT_HIP(ctx, hipFree(ctx->d_stage[i]));
+            ctx->d_stage[i] = NULL;
+            RT_HIP(ctx, hipMalloc((void **)&ctx->d_stage[i], row_bytes));
+            ctx->gather_pending[i] = 0;
+        }
+        ctx->stage_bytes = row_bytes;
+    }
+
+    /* trace stream: snapshot the row (compact, ld -> n) into stage[p], so the
+     * next trace may overwrite the row while RCCL is still sending it.  The
+     * snapshot of step k+2 must wait for the gather of step k. */
+    if (ctx->gather_pending[p])
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gathered[p], 0));
+    const double *src = rt_arr(ctx, which) + (size_t)surf * nc * ctx->ld;
+    RT_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage[p], ctx->n * sizeof(double), src,
+                                 ctx->ld * sizeof(double),
+                                 ctx->n * sizeof(double), nc,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    RT_HIP(ctx, hipEventRecord(ctx->staged[p], ctx->stream));
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->staged[p], 0));
+
+    int64_t total = 0, my_off = 0;
+    for (int r = 0; r < ctx->nranks; ++r) {
+        if (r == ctx->rank)
+            my_off = total;
+        total += counts[r];
+    }
+    const double *stage = ctx->d_stage[p];
+    if (ctx->rank == root) {
+        /* own shard: device-to-device, no RCCL */
+        for (int c = 0; c < nc; ++c)
+            RT_HIP(ctx, hipMemcpyAsync(d_dst + (size_t)c * total + my_off,
+                                       stage + (size_t)c * ctx->n,
+                                       ctx->n * sizeof(double),
+                                       hipMemcpyDeviceToDevice,
+                                       ctx->comm_stream));
+    }
+    if (ctx->nranks > 1) {
+        RT_NCCL(ctx, g_rccl.GroupStart());
+        if (ctx->rank == root) {
+            int64_t off = 0;
+            for (int r = 0; r < ctx->nranks; ++r) {
+                if (r != root) {
+                    for (int c = 0; c < nc; ++c)
+                        RT_NCCL(ctx, g_rccl.Recv(d_dst + (size_t)c * total + off,
+                                                 (size_t)counts[r], ncclDouble,
+                                                 r, ctx->comm,
+                                                 ctx->comm_stream));
+                }
+                off += counts[r];
+            }
+        } else {
+            for (int c = 0; c < nc; ++c)
+                RT_NCCL(ctx, g_rccl.Send(stage + (size_t)c * ctx->n,
+                                         (size_t)ctx->n, ncclDouble, root,
+                                         ctx->comm, ctx->comm_stream));
+        }
+        RT_NCCL(ctx, g_rccl.GroupEnd());
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->gathered[p], ctx->comm_stream));
+    ctx->gather_pending[p] = 1;
+    return RT_OK;
+}
+
+int rt_comm_sync(rt_ctx *ctx)
+{
+    if (!ctx)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_comm_sync: NULL context");
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+    return RT_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,314 @@
+/*
+ * rt_math.h -- per-ray surface arithmetic of the sequential trace, FP64.
+ *
+ * One call of rt_step<R>() is one "ray-surface op" for R rays held in
+ * registers: transfer into the element frame -> intercept (plane / closed
+ * form sphere+conic / Newton for even aspheres) -> clip -> Snell refraction
+ * or reflection.  It follows, operation for operation and in the same
+ * association order, what the reference evaluates with numpy:
+ *
+ *   System.propagate            rayopt/system.py:459-464
+ *   TransformMixin._do_rotate   rayopt/elements.py:156-175
+ *   Interface.propagate         rayopt/elements.py:306-315
+ *   Element.clip                rayopt/elements.py:206-209
+ *   Spheroid.intercept          rayopt/elements.py:477-501
+ *   Interface.intercept         rayopt/elements.py:333-349  (+ scipy newton)
+ *   Spheroid.surface_sag        rayopt/elements.py:440-455
+ *   Spheroid.surface_normal     rayopt/elements.py:457-475
+ *   Interface.refract           rayopt/elements.py:351-369
+ *
+ * numpy never contracts a*b+c into an FMA and adds the three terms of a
+ * length-3 .sum(1) left to right, so this file must be compiled with
+ * -ffp-contract=off; sqrt and / are IEEE correctly rounded on gfx950 FP64
+ * (and in numpy), which makes the spherical path reproduce the reference to
+ * the last bit or two.
+ *
+ * Everything that depends only on the surface (flags, curvature, mu ...) is
+ * wave-uniform: the kernel reads it through scalar loads into SGPRs and the
+ * branches below are scalar branches, never divergence.  The only divergent
+ * construct is the Newton loop, whose trip count is decided per wave with a
+ * ballot (RT_WAVE_ANY).
+ *
+ * The header is also compiled for the host by tests/hostemu (g++), purely so
+ * the arithmetic can be checked in a container without a GPU; the product
+ * never runs it on the CPU.
+ */
+#ifndef RT_MATH_H
+#define RT_MATH_H
+
+#include <math.h>
+#include "../../include/rt_mi355.h"
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+/* true if the predicate holds on any lane of the 64-wide wavefront */
+#define RT_WAVE_ANY(p) (__ballot(p) != 0ull)
+#define RT_NAN __builtin_nan("")
+#else
+#define RT_WAVE_ANY(p) (p)
+#define RT_NAN __builtin_nan("")
+#endif
+
+/* y @ R.T : to_normal (elements.py:174-175), row vector times R transposed */
+RT_HD void rt_rot_to(const double *__restrict__ r, double (&v)[3])
+{
+    const double a = v[0], b = v[1], c = v[2];
+    v[0] = (a * r[0] + b * r[1]) + c * r[2];
+    v[1] = (a * r[3] + b * r[4]) + c * r[5];
+    v[2] = (a * r[6] + b * r[7]) + c * r[8];
+}
+
+/* y @ R : from_normal (elements.py:171-172) */
+RT_HD void rt_rot_from(const double *__restrict__ r, double (&v)[3])
+{
+    const double a = v[0], b = v[1], c = v[2];
+    v[0] = (a * r[0] + b * r[3]) + c * r[6];
+    v[1] = (a * r[1] + b * r[4]) + c * r[7];
+    v[2] = (a * r[2] + b * r[5]) + c * r[8];
+}
+
+/* Spheroid.surface_sag(p) residual, elements.py:440-455 */
+RT_HD double rt_sag(const rt_surface *__restrict__ S, unsigned flags,
+                    double px, double py, double pz)
+{
+    double e = pz;
+    if (!(flags & (RT_F_CURVED | RT_F_ASPH)))
+        return e;
+    const double r2 = px * px + py * py;
+    if (flags & RT_F_CURVED)
+        e -= (S->c * r2) / (1. + sqrt(1. - S->kc2 * r2));
+    if (flags & RT_F_ASPH) {
+        double d = 0.;
+        for (int i = S->nasph - 1; i >= 0; --i) {
+            d += S->asph[i];
+            d *= r2;
+        }
+        e -= d;
+    }
+    return e;
+}
+
+/* x,y scale factor e of Spheroid.surface_normal, q = (x e, y e, 1), :457-475 */
+RT_HD double rt_normal_e(const rt_surface *__restrict__ S, unsigned flags,
+                         double r2)
+{
+    double e = 0.;
+    if (flags & RT_F_CURVED)
+        e -= S->c / sqrt(1. - S->kc2 * r2);
+    if (flags & RT_F_ASPH) {
+        double d = 0.;
+        for (int i = S->nasph - 1; i >= 0; --i) {
+            d *= r2;
+            d += S->dasph[i];
+        }
+        e -= d;
+    }
+    return e;
+}
+
+/* np.isclose(p, p0, rtol=0, atol=tol) as scipy's newton uses it */
+RT_HD bool rt_isclose(double p, double p0, double tol)
+{
+    if (isfinite(p) && isfinite(p0))
+        return fabs(p - p0) <= tol;
+    return p == p0; /* equal infinities are close, NaN never is */
+}
+
+/*
+ * Interface.intercept (elements.py:333-349): per-ray scipy.optimize.newton,
+ * scalar Newton-Raphson branch (scipy/optimize/_zeros_py.py, 1.15.3) with
+ * x0 = plane intercept, tol = 1e-7 (absolute, rtol = 0), maxiter = 5:
+ *   fval == 0            -> return current iterate
+ *   fder == 0            -> RuntimeError -> NaN
+ *   p = p0 - fval/fder;  isclose(p, p0) -> return p
+ *   5 iterations without convergence -> RuntimeError -> NaN
+ * All R rays of the lane iterate together; the wave leaves the loop when no
+ * lane of the wavefront has a ray still iterating (ballot).
+ */
+template <int R>
+RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
+                     const double (&y)[R][3], const double (&u)[R][3],
+                     double (&s)[R])
+{
+    bool live[R];
+    double res[R];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s[r] = -y[r][2] / u[r][2];
+        res[r] = RT_NAN;
+        live[r] = true;
+        any = true;
+    }
+    for (int itr = 0; itr < 5; ++itr) {
+        if (!RT_WAVE_ANY(any))
+            break;
+        any = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!live[r])
+                continue;
+            const double px = y[r][0] + s[r] * u[r][0];
+            const double py = y[r][1] + s[r] * u[r][1];
+            const double pz = y[r][2] + s[r] * u[r][2];
+            const double fval = rt_sag(S, flags, px, py, pz);
+            if (fval == 0.) {
+                res[r] = s[r];
+                live[r] = false;
+                continue;
+            }
+            const double r2 = px * px + py * py;
+            const double e = rt_normal_e(S, flags, r2);
+            const double fder =
+                ((px * e) * u[r][0] + (py * e) * u[r][1]) + 1. * u[r][2];
+            if (fder == 0.) {
+                live[r] = false; /* "Derivative was zero" -> NaN */
+                continue;
+            }
+            const double p = s[r] - fval / fder;
+            if (rt_isclose(p, s[r], 1e-7)) {
+                res[r] = p;
+                live[r] = false;
+                continue;
+            }
+            s[r] = p;
+            any = true;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        s[r] = res[r];
+}
+
+/*
+ * One element for R rays.  In: y,u in the global orientation relative to the
+ * previous vertex (what System.propagate carries between elements).  Out:
+ * y = intercept, u = outgoing direction, iv = incoming direction, t = OPL,
+ * all in the element-normal frame (the tuple System.propagate yields).
+ */
+template <int R>
+RT_HD void rt_step(const rt_surface *__restrict__ S, unsigned flags, int clip,
+                   double (&y)[R][3], double (&u)[R][3], double (&iv)[R][3],
+                   double (&t)[R])
+{
+    /* transfer: y - e.offset, then to_normal (system.py:461) */
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        y[r][0] -= S->offset[0];
+        y[r][1] -= S->offset[1];
+        y[r][2] -= S->offset[2];
+        iv[r][0] = u[r][0];
+        iv[r][1] = u[r][1];
+        iv[r][2] = u[r][2];
+        if (flags & RT_F_ROTATED) {
+            rt_rot_to(S->rot, y[r]);
+            rt_rot_to(S->rot, iv[r]);
+        }
+    }
+
+    /* intercept */
+    double s[R];
+    if (flags & RT_F_ASPH) {
+        rt_newton<R>(S, flags, y, iv, s);
+    } else if (!(flags & RT_F_CURVED)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            s[r] = -y[r][2] / iv[r][2];
+    } else {
+        const double c = S->c;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double uy, uu, yy;
+            if (!(flags & RT_F_CONIC)) {
+                uy = (iv[r][0] * y[r][0] + iv[r][1] * y[r][1]) +
+                     iv[r][2] * y[r][2];
+                uu = 1.;
+                yy = (y[r][0] * y[r][0] + y[r][1] * y[r][1]) +
+                     y[r][2] * y[r][2];
+            } else {
+                const double kw = S->kw;
+                uy = ((iv[r][0] * y[r][0]) * 1. + (iv[r][1] * y[r][1]) * 1.) +
+                     (iv[r][2] * y[r][2]) * kw;
+                uu = ((iv[r][0] * iv[r][0]) * 1. +
+                      (iv[r][1] * iv[r][1]) * 1.) +
+                     (iv[r][2] * iv[r][2]) * kw;
+                yy = ((y[r][0] * y[r][0]) * 1. + (y[r][1] * y[r][1]) * 1.) +
+                     (y[r][2] * y[r][2]) * kw;
+            }
+            const double d = c * uy - iv[r][2];
+            const double e = c * uu;
+            const double f = c * yy - 2. * y[r][2];
+            double g = sqrt(d * d - e * f);
+            if (flags & RT_F_ALT)
+                g *= -1.;
+            s[r] = -(d + g) / e;
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        /* y = y0 + t*u0 */
+        y[r][0] = y[r][0] + s[r] * iv[r][0];
+        y[r][1] = y[r][1] + s[r] * iv[r][1];
+        y[r][2] = y[r][2] + s[r] * iv[r][2];
+        u[r][0] = iv[r][0];
+        u[r][1] = iv[r][1];
+        u[r][2] = iv[r][2];
+        const double rxy = y[r][0] * y[r][0] + y[r][1] * y[r][1];
+        if (clip) {
+            /* Element.clip: NaN-poison the direction outside the aperture;
+             * NaN coordinates compare false and are poisoned as well */
+            if (!(rxy <= S->radius2))
+                u[r][0] = u[r][1] = u[r][2] = RT_NAN;
+        }
+        if (flags & RT_F_REFRACT) {
+            /* Spencer & Murty; q = (x e, y e, 1) un-normalised normal */
+            double qx, qy;
+            if (flags & (RT_F_CURVED | RT_F_ASPH)) {
+                const double e = rt_normal_e(S, flags, rxy);
+                qx = y[r][0] * e;
+                qy = y[r][1] * e;
+            } else {
+                qx = 0.;
+                qy = 0.;
+            }
+            const double r2 = (qx * qx + qy * qy) + 1.;
+            const double dot = (u[r][0] * qx + u[r][1] * qy) + u[r][2] * 1.;
+            const double a = S->muf * dot / r2;
+            if (flags & RT_F_MIRROR) {
+                const double a2 = 2. * a;
+                u[r][0] = u[r][0] - a2 * qx;
+                u[r][1] = u[r][1] - a2 * qy;
+                u[r][2] = u[r][2] - a2 * 1.;
+            } else {
+                const double b = S->mu2m1 / r2;
+                const double g = -a + S->smu * sqrt(a * a - b);
+                u[r][0] = S->muf * u[r][0] + g * qx;
+                u[r][1] = S->muf * u[r][1] + g * qy;
+                u[r][2] = S->muf * u[r][2] + g * 1.;
+            }
+        }
+        t[r] = s[r] * S->n0;
+    }
+}
+
+/* from_normal of the element just left (system.py:464); y,u copies */
+template <int R>
+RT_HD void rt_leave(const rt_surface *__restrict__ S, unsigned flags,
+                    double (&y)[R][3], double (&u)[R][3])
+{
+    if (flags & RT_F_ROTATED) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            rt_rot_from(S->rot, y[r]);
+            rt_rot_from(S->rot, u[r]);
+        }
+    }
+}
+
+#endif /* RT_MATH_H */

@@ -1,0 +1,227 @@
+"""Python face of one ``rt_ctx``: a device context of the HIP engine.
+
+All ray arithmetic happens in librt_mi355.so on the GPU; this module only
+moves arrays across the ctypes boundary.  Nothing here computes on the CPU
+and nothing falls back to the CPU: without the library or without a GPU every
+entry point raises :class:`EngineError`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import EngineError, RT_Y, RT_U, RT_I, RT_T, LAYOUT_AOS, LAYOUT_SOA
+from .pack import pack_system, resolve_range
+
+
+def _default_device():
+    for key in ("RT_DEVICE", "LOCAL_RANK"):
+        if key in os.environ:
+            return int(os.environ[key])
+    return 0
+
+
+class Engine:
+    """Owns one device context (stream, events, result arrays in HBM)."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        self.device = _default_device() if device is None else int(device)
+        ctx = ctypes.c_void_p()
+        rc = self.lib.rt_create(self.device, ctypes.byref(ctx))
+        if rc != 0:
+            raise EngineError("rt_create(device=%d) failed (%d): %s" % (
+                self.device, rc,
+                (self.lib.rt_last_error(None) or b"").decode()))
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.rt_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError("%s failed (%d): %s" % (
+                what, rc, (self.lib.rt_last_error(self.ctx) or b"").decode()))
+
+    # -- system / rays ----------------------------------------------------
+    def upload_system(self, table):
+        table = np.ascontiguousarray(table, dtype=_lib.SURFACE_DTYPE)
+        self._check(self.lib.rt_upload_system(
+            self.ctx, table.ctypes.data, len(table)), "rt_upload_system")
+        self.nsurf = len(table)
+
+    def reserve(self, nrays):
+        self._check(self.lib.rt_reserve(self.ctx, int(nrays)), "rt_reserve")
+
+    @property
+    def nrays(self):
+        return int(self.lib.rt_nrays(self.ctx))
+
+    @property
+    def ld(self):
+        return int(self.lib.rt_ld(self.ctx))
+
+    def set_rays(self, y, u):
+        """Seed row 0 from host arrays, (N,3) ray-major or (3,N) via
+        ``set_rays_soa``."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        if y.shape != u.shape or y.ndim != 2 or y.shape[1] != 3:
+            raise ValueError("y and u must both be (N,3)")
+        self._check(self.lib.rt_set_rays(
+            self.ctx, y.ctypes.data, u.ctypes.data, y.shape[0], LAYOUT_AOS),
+            "rt_set_rays")
+
+    def set_rays_soa(self, y, u):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        if y.shape != u.shape or y.ndim != 2 or y.shape[0] != 3:
+            raise ValueError("y and u must both be (3,N)")
+        self._check(self.lib.rt_set_rays(
+            self.ctx, y.ctypes.data, u.ctypes.data, y.shape[1], LAYOUT_SOA),
+            "rt_set_rays")
+
+    def set_rays_device(self, d_y, d_u, n, layout=LAYOUT_SOA):
+        self._check(self.lib.rt_set_rays_device(
+            self.ctx, ctypes.c_void_p(d_y), ctypes.c_void_p(d_u), int(n),
+            layout), "rt_set_rays_device")
+
+    def upload_row(self, which, surf, src_soa):
+        src = np.ascontiguousarray(src_soa, dtype=np.float64)
+        self._check(self.lib.rt_upload_row(self.ctx, which, surf,
+                                           src.ctypes.data), "rt_upload_row")
+
+    # -- trace ------------------------------------------------------------
+    def trace(self, start=1, stop=0, clip=False):
+        self._check(self.lib.rt_trace(self.ctx, int(start), int(stop),
+                                      1 if clip else 0), "rt_trace")
+
+    def sync(self):
+        self._check(self.lib.rt_sync(self.ctx), "rt_sync")
+
+    def kernel_ms(self):
+        ms = ctypes.c_double()
+        self._check(self.lib.rt_kernel_ms(self.ctx, ctypes.byref(ms)),
+                    "rt_kernel_ms")
+        return ms.value
+
+    def event_record(self, slot):
+        self._check(self.lib.rt_event_record(self.ctx, slot),
+                    "rt_event_record")
+
+    def event_elapsed(self, a, b):
+        ms = ctypes.c_double()
+        self._check(self.lib.rt_event_elapsed(self.ctx, a, b,
+                                              ctypes.byref(ms)),
+                    "rt_event_elapsed")
+        return ms.value
+
+    def set_option(self, key, value):
+        self._check(self.lib.rt_set_option(self.ctx, key.encode(), int(value)),
+                    "rt_set_option(%s)" % key)
+
+    # -- results ----------------------------------------------------------
+    def download(self, which, lo, hi):
+        """Rows [lo,hi) of one array as a compact SoA host array:
+        (rows,3,N) for y/u/i, (rows,N) for t."""
+        n = self.nrays
+        shape = (hi - lo, n) if which == RT_T else (hi - lo, 3, n)
+        out = np.empty(shape, dtype=np.float64)
+        self._check(self.lib.rt_download(self.ctx, which, lo, hi,
+                                         out.ctypes.data), "rt_download")
+        return out
+
+    def device_ptr(self, which, surf):
+        p = ctypes.c_void_p()
+        self._check(self.lib.rt_device_ptr(self.ctx, which, surf,
+                                           ctypes.byref(p)), "rt_device_ptr")
+        return p.value
+
+    def scratch(self, nbytes):
+        p = ctypes.c_void_p()
+        self._check(self.lib.rt_scratch(self.ctx, int(nbytes),
+                                        ctypes.byref(p)), "rt_scratch")
+        return p.value
+
+    def copy_to_host(self, d_src, nbytes, dtype=np.float64):
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._check(self.lib.rt_copy_to_host(
+            self.ctx, out.ctypes.data, ctypes.c_void_p(d_src), int(nbytes)),
+            "rt_copy_to_host")
+        return out
+
+    # -- multi GPU ----------------------------------------------------------
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        rc = self.lib.rt_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError("rt_comm_unique_id failed (%d): %s" % (
+                rc, (self.lib.rt_last_error(None) or b"").decode()))
+        return buf.raw
+
+    def comm_init(self, unique_id, nranks, rank):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.lib.rt_comm_init(self.ctx, buf, nranks, rank),
+                    "rt_comm_init")
+
+    def gather_final(self, which, surf, counts, root, d_dst):
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        self._check(self.lib.rt_gather_final(
+            self.ctx, which, surf,
+            counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), root,
+            ctypes.c_void_p(d_dst)), "rt_gather_final")
+
+    def comm_sync(self):
+        self._check(self.lib.rt_comm_sync(self.ctx), "rt_comm_sync")
+
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """Process-wide engine per device (contexts are not thread safe)."""
+    dev = _default_device() if device is None else int(device)
+    eng = _engines.get(dev)
+    if eng is None or eng.ctx is None:
+        eng = _engines[dev] = Engine(dev)
+    return eng
+
+
+def march_rows(system, y, u, n, l, start=1, stop=None, clip=False,
+               engine=None):
+    """System.propagate (rayopt/system.py:459-464) as one fused GPU trace.
+
+    ``y, u``: (N,3) in the global orientation relative to the vertex of
+    element ``start-1`` (the caller has already applied that element's
+    ``from_normal``, as geometric_trace.py:76 does), so the seed row is
+    packed as unrotated.  Yields ``(y, u, n, i, t)`` per element.
+    """
+    eng = engine or get_engine()
+    y, u = np.atleast_2d(y, u)
+    y, u = np.broadcast_arrays(np.asarray(y, float), np.asarray(u, float))
+    a, b = resolve_range(len(system), start, stop)
+    if a < 1:
+        raise ValueError("start must be >= 1")
+    table, ns = pack_system(system, l, n, a, b)
+    table["flags"][a - 1] &= ~np.uint32(_lib.F_ROTATED)
+    eng.upload_system(table)
+    eng.set_rays(y, u)
+    if a > 1:   # seed row is start-1, not 0
+        eng.upload_row(RT_Y, a - 1, np.ascontiguousarray(y.T))
+        eng.upload_row(RT_U, a - 1, np.ascontiguousarray(u.T))
+    eng.trace(a, b, clip)
+    for j in range(a, b):
+        yj = eng.download(RT_Y, j, j + 1)[0].T
+        uj = eng.download(RT_U, j, j + 1)[0].T
+        ij = eng.download(RT_I, j, j + 1)[0].T
+        tj = eng.download(RT_T, j, j + 1)[0]
+        yield yj, uj, ns[j], ij, tj

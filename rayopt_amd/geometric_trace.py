@@ -1,0 +1,252 @@
+"""Drop-in ``GeometricTrace`` whose ``propagate()`` runs on the MI355X.
+
+Interface and result arrays follow rayopt (rayopt/geometric_trace.py:29-80,
+rayopt/raytrace.py:24-36):
+
+    ``y[j]``  intercept at element j          (L,N,3)
+    ``u[j]``  direction after element j       (L,N,3)
+    ``i[j]``  direction before element j      (L,N,3)
+    ``t[j]``  optical path of segment j       (L,N)
+    ``n[j]``  refractive index after j        (L,)
+
+all in the element-normal frame relative to the vertex; dead rays are NaN.
+The arrays live in HBM (SoA ``[surface][component][ray]``) and are exposed
+as lazy host views with the reference's shapes: a surface row is copied over
+PCIe only when it is first touched (``trace.y[-1]``), and the view is a
+strided transpose of the SoA buffer, not a re-layout.
+
+``system`` may be a :class:`rayopt_amd.model.System` or an unmodified
+reference ``rayopt.System``: only public element attributes are read
+(rayopt_amd/pack.py).
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import RT_Y, RT_U, RT_I, RT_T
+from .engine import Engine
+from .pack import pack_system, resolve_range
+
+
+class Trace:
+    """rayopt/raytrace.py:24-36."""
+    def __init__(self, system):
+        self.system = system
+
+    def allocate(self):
+        self.length = len(self.system)
+
+    def propagate(self):
+        self.path = self.system.path
+        self.track = self.system.track
+        self.origins = self.system.origins
+        self.mirrored = self.system.mirrored
+
+
+class DeviceRows:
+    """Lazy host view of one device-resident result array.
+
+    Behaves like the reference's ``np.ndarray`` of shape (L,N,3) / (L,N) for
+    reading: indexing the first axis with an int or a unit-step slice copies
+    just those surface rows from the GPU (once); anything else, and
+    ``np.asarray``, materialises the whole array.
+    """
+    __array_priority__ = 100.
+
+    def __init__(self, trace, which):
+        self._trace = trace
+        self._which = which
+        self._host = None       # (L,3,N) or (L,N), allocated on first touch
+        self._valid = np.zeros(trace.length, dtype=bool)
+        self.dtype = np.dtype(np.float64)
+
+    @property
+    def shape(self):
+        t = self._trace
+        return ((t.length, t.nrays) if self._which == RT_T
+                else (t.length, t.nrays, 3))
+
+    ndim = property(lambda self: len(self.shape))
+    size = property(lambda self: int(np.prod(self.shape)))
+
+    def __len__(self):
+        return self._trace.length
+
+    def _buffer(self):
+        if self._host is None:
+            t = self._trace
+            shape = ((t.length, t.nrays) if self._which == RT_T
+                     else (t.length, 3, t.nrays))
+            self._host = np.empty(shape)
+        return self._host
+
+    def invalidate(self, lo, hi):
+        self._valid[lo:hi] = False
+
+    def put_row(self, j, soa):
+        """Host already knows this row (rays_given)."""
+        self._buffer()[j] = soa
+        self._valid[j] = True
+
+    def _ensure(self, lo, hi):
+        host = self._buffer()
+        j = lo
+        while j < hi:           # fetch maximal runs of missing rows
+            if self._valid[j]:
+                j += 1
+                continue
+            k = j
+            while k < hi and not self._valid[k]:
+                k += 1
+            host[j:k] = self._trace._engine.download(self._which, j, k)
+            self._valid[j:k] = True
+            j = k
+        return host
+
+    def _view(self, lo, hi):
+        host = self._ensure(lo, hi)[lo:hi]
+        return host if self._which == RT_T else host.transpose(0, 2, 1)
+
+    def __getitem__(self, key):
+        first, rest = (key[0], key[1:]) if isinstance(key, tuple) else (key, ())
+        length = self._trace.length
+        if isinstance(first, (int, np.integer)):
+            j = int(first)
+            if j < 0:
+                j += length
+            if not 0 <= j < length:
+                raise IndexError("surface index %d out of range" % first)
+            out = self._view(j, j + 1)[0]
+        elif isinstance(first, slice) and first.step in (None, 1):
+            idx = range(length)[first]
+            lo, hi = idx.start, max(idx.start, idx.stop)
+            out = self._view(lo, hi) if hi > lo else \
+                np.empty((0,) + self.shape[1:])
+        else:
+            out = self._view(0, length)[first]
+        return out[rest] if rest else out
+
+    def __array__(self, dtype=None, copy=None):
+        out = self._view(0, self._trace.length)
+        if dtype is not None and np.dtype(dtype) != out.dtype:
+            return out.astype(dtype)
+        return np.array(out) if copy else out
+
+    def __setitem__(self, key, value):
+        raise TypeError(
+            "result arrays are device resident and read-only from the host; "
+            "seed rays with rays_given()")
+
+    def __iter__(self):
+        for j in range(self._trace.length):
+            yield self[j]
+
+    def __repr__(self):
+        return "<DeviceRows %s shape=%s valid=%d/%d>" % (
+            "yuit"[self._which], self.shape, self._valid.sum(),
+            len(self._valid))
+
+
+class GeometricTrace(Trace):
+    """
+    y[i]: intercept at surface
+    i[i]: incoming/incidence direction before surface
+    u[i]: outgoing/excidence direction after surface
+    all in i-surface normal coordinates relative to vertex
+    """
+    def __init__(self, system, engine=None, device=None):
+        super().__init__(system)
+        self._engine = engine
+        self._device = device
+
+    # -- storage ----------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = Engine(self._device)   # raises without GPU/.so
+        return self._engine
+
+    def allocate(self, nrays):
+        super().allocate()
+        self.nrays = nrays
+        self.n = np.empty(self.length)
+        self.w = None
+        self.ref = None
+        self.l = 1.
+        self.y = DeviceRows(self, RT_Y)
+        self.u = DeviceRows(self, RT_U)
+        self.i = DeviceRows(self, RT_I)
+        self.t = DeviceRows(self, RT_T)
+
+    def _upload_table(self, start, stop, n_init):
+        table, ns = pack_system(self.system, self.l, n_init, start, stop)
+        self.engine.upload_system(table)
+        return table, ns
+
+    # -- seeding ------------------------------------------------------------
+    def rays_given(self, y, u, l=None, w=None, ref=0):
+        """Seed surface 0 (rayopt/geometric_trace.py:49-70)."""
+        y, u = np.atleast_2d(y, u)
+        y, u = np.broadcast_arrays(y, u)
+        n, m = y.shape
+        if not hasattr(self, "y") or self.nrays != n \
+                or self.length != len(self.system):
+            self.allocate(n)
+        if l is None:
+            l = self.system.wavelengths[0]
+        if w is None:
+            w = np.ones(n)/n
+        self.w = w
+        self.ref = ref
+        self.l = l
+        y0 = np.zeros((n, 3))
+        y0[:, :m] = y
+        u0 = np.empty((n, 3))
+        u0[:, :m] = u
+        if m < 3:  # assumes forward rays
+            u2 = np.square(u0[:, :2]).sum(-1)
+            u0[:, 2] = np.sqrt(1 - u2)
+        self.n[0] = self.system.refractive_index(l, 0)
+        self._upload_table(1, None, self.n[0])
+        self.engine.set_rays(y0, u0)
+        for rows in (self.y, self.u, self.i, self.t):
+            rows.invalidate(0, self.length)
+        self.y.put_row(0, y0.T)
+        self.u.put_row(0, u0.T)
+        self.i.put_row(0, u0.T)
+        self.t.put_row(0, 0.)
+
+    def rays_given_device(self, d_y, d_u, nrays, l=None, w=None, ref=0,
+                          layout=_lib.LAYOUT_SOA):
+        """Seed surface 0 from arrays already in device memory (raw device
+        pointers, float64, (3,N) SoA or (N,3) AoS): no PCIe transfer."""
+        if not hasattr(self, "y") or self.nrays != nrays \
+                or self.length != len(self.system):
+            self.allocate(nrays)
+        self.l = self.system.wavelengths[0] if l is None else l
+        self.w = w
+        self.ref = ref
+        self.n[0] = self.system.refractive_index(self.l, 0)
+        self._upload_table(1, None, self.n[0])
+        self.engine.set_rays_device(d_y, d_u, nrays, layout)
+        for rows in (self.y, self.u, self.i, self.t):
+            rows.invalidate(0, self.length)
+
+    # -- the hot path ---------------------------------------------------------
+    def propagate(self, start=1, stop=None, clip=False):
+        """Trace elements ``start .. stop-1`` for all rays on the GPU
+        (rayopt/geometric_trace.py:72-80 + rayopt/system.py:459-464)."""
+        super().propagate()
+        if len(self.system) != self.length:
+            raise ValueError("the system changed length since rays_given()")
+        a, b = resolve_range(self.length, start, stop)
+        if a < 1:
+            raise ValueError("start must be >= 1")
+        _, ns = self._upload_table(a, b, self.n[a - 1])
+        self.engine.trace(a, b, clip)
+        self.n[a:b] = ns[a:b]
+        for rows in (self.y, self.u, self.i, self.t):
+            rows.invalidate(a, b)
+
+    def kernel_ms(self):
+        """HIP-event duration of the last propagate() kernel."""
+        return self.engine.kernel_ms()

@@ -1,0 +1,458 @@
+"""Host-side optical model: the objects GeometricTrace walks.
+
+This is the host mirror of the reference's public interface for the hot path
+(SURVEY.md section 8b): a ``System`` is a ``list`` of elements whose public
+attributes carry the prescription; names, argument meaning and conventions
+follow rayopt so prescriptions (YAML dicts) and user code carry over:
+
+  =====================  ==================================================
+  here                   reference
+  =====================  ==================================================
+  ``Pose``               ``TransformMixin``      rayopt/elements.py:29-175
+  ``Element``            ``Element``             rayopt/elements.py:178-272
+  ``Interface``          ``Interface``           rayopt/elements.py:275-330
+  ``Spheroid``           ``Spheroid``            rayopt/elements.py:411-438
+  ``Material.make``      ``Material.make``       rayopt/material.py:84-115
+  ``System``             ``System``              rayopt/system.py:34-68,
+                                                 193-199, 413-442, 459-464
+  =====================  ==================================================
+
+Only state and O(L) scalar geometry live here.  The per-ray arithmetic
+(intercept, clip, refract, frame changes) is *not* implemented on the host:
+it runs in the HIP kernel (csrc/rt_math.h) and nowhere else in this package.
+"""
+import math
+
+import numpy as np
+
+# Fraunhofer lines used as default wavelengths (d, C, F), metres.
+LAMBDA_D, LAMBDA_C, LAMBDA_F = 587.56e-9, 656.27e-9, 486.13e-9
+
+
+# --------------------------------------------------------------------------
+# materials: scalar n(lambda), evaluated on the host once per (element, l)
+# --------------------------------------------------------------------------
+
+class Material:
+    """Refractive medium; ``mirror`` marks a reflecting coating."""
+    solid = True
+    mirror = False
+
+    def __init__(self, name="-", solid=True, mirror=False):
+        self.name = name
+        self.solid = solid
+        self.mirror = mirror
+
+    def refractive_index(self, wavelength):
+        return 1.
+
+    def __str__(self):
+        return self.name
+
+    @staticmethod
+    def make(spec):
+        """Same dispatch as rayopt's Material.make for the forms that need no
+        catalogue database: ``None``, a Material, a float (constant index), an
+        ``(nd, vd)`` tuple or ``"nd/vd"`` string (Abbe model), and the basic
+        names ``vacuum``, ``air``, ``mirror`` (optionally ``basic/<name>``).
+        """
+        if spec is None or isinstance(spec, Material):
+            return spec
+        if hasattr(spec, "refractive_index"):   # foreign material object
+            return spec
+        if type(spec) is float:
+            return ConstantIndex(spec)
+        if type(spec) is tuple:
+            return AbbeGlass(spec[0], spec[1])
+        text = str(spec)
+        parts = text.split("/")
+        if len(parts) == 2:
+            try:
+                return AbbeGlass(float(parts[0]), float(parts[1]))
+            except ValueError:
+                pass
+        key = parts[-1].lower()
+        if (len(parts) == 1 or parts[-2].lower() == "basic") and key in BASIC:
+            return BASIC[key]
+        raise KeyError("material %r needs a glass catalogue; give a numeric "
+                       "index or an 'nd/vd' pair" % (spec,))
+
+
+class ConstantIndex(Material):
+    def __init__(self, n=1., **kw):
+        super().__init__(**kw)
+        self.n = n
+
+    def refractive_index(self, wavelength):
+        return self.n
+
+    def __str__(self):
+        return repr(self.n)
+
+
+class AbbeGlass(Material):
+    """Linear dispersion model from (n_ref, Abbe number)."""
+    def __init__(self, n=1., v=math.inf, lambda_ref=LAMBDA_D,
+                 lambda_long=LAMBDA_C, lambda_short=LAMBDA_F, **kw):
+        super().__init__(**kw)
+        self.n, self.v = n, v
+        self.lambda_ref = lambda_ref
+        self.lambda_long, self.lambda_short = lambda_long, lambda_short
+
+    def refractive_index(self, wavelength):
+        return (self.n + (wavelength - self.lambda_ref) /
+                (self.lambda_long - self.lambda_short)*(1 - self.n)/self.v)
+
+    def __str__(self):
+        return "%r/%r" % (self.n, self.v)
+
+
+class GasFormula(Material):
+    """n = 1 + sum(B_i / (C_i - w^-2)), w in micrometres (standard air)."""
+    def __init__(self, b, c, **kw):
+        super().__init__(**kw)
+        self.b = np.asarray(b, dtype=float)
+        self.c = np.asarray(c, dtype=float)
+
+    def refractive_index(self, wavelength):
+        w = wavelength/1e-6
+        return 1. + (self.b/(self.c - w**-2)).sum()
+
+
+BASIC = {
+    "vacuum": ConstantIndex(1., name="vacuum", solid=False),
+    "mirror": Material(name="mirror", solid=False, mirror=True),
+    "air": GasFormula([.05792105, .00167917], [238.0185, 57.362],
+                      name="air", solid=False),
+}
+
+
+# --------------------------------------------------------------------------
+# element pose
+# --------------------------------------------------------------------------
+
+def _axis_angle(angle, axis):
+    """Rodrigues rotation matrix about ``axis`` (right-handed, 3x3)."""
+    d = np.asarray(axis, dtype=float)
+    d = d/np.linalg.norm(d)
+    ca, sa = math.cos(angle), math.sin(angle)
+    cross = np.array([[0., -d[2], d[1]], [d[2], 0., -d[0]], [-d[1], d[0], 0.]])
+    return ca*np.eye(3) + (1. - ca)*np.outer(d, d) + sa*cross
+
+
+def _euler_rxyz(ax, ay, az):
+    """Rotating-frame x-y-z Euler matrix: Rx(ax) Ry(ay) Rz(az)."""
+    cx, sx = math.cos(ax), math.sin(ax)
+    cy, sy = math.cos(ay), math.sin(ay)
+    cz, sz = math.cos(az), math.sin(az)
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return rx @ ry @ rz
+
+
+class Pose:
+    """Placement of an element relative to the previous one.
+
+    ``offset = distance*direction`` is expressed in the global, unrotated
+    frame and accumulates along the system; ``angles`` (rotating x-y-z Euler)
+    tilt the element normal relative to ``direction``.  A negative distance
+    flips the direction (used after mirrors).  ``rot_normal`` maps the
+    element-normal frame to the global one for row vectors:
+    ``from_normal(v) = v @ rot_normal``, ``to_normal(v) = v @ rot_normal.T``.
+    """
+    def __init__(self, distance=0., direction=(0, 0, 1.), angles=(0, 0, 0),
+                 offset=None):
+        self.update(distance, direction, angles)
+        if offset is not None:
+            self.offset = offset
+
+    def update(self, distance, direction, angles):
+        u = np.array(direction, dtype=float)
+        norm = np.linalg.norm(u)
+        u = u/norm if norm else np.array([0., 0., 1.])
+        if distance < 0:
+            distance, u = -distance, -u
+        self._distance, self._direction = distance, u
+        self._offset = distance*u
+        self._angles = np.array(angles, dtype=float)
+        self.straight = bool(np.allclose(u, (0, 0, 1.)))
+        self.normal = bool(np.allclose(self._angles, 0.))
+        self.rotated = not (self.straight and self.normal)
+        self.rot_axis = self.rot_normal = None
+        if not self.rotated:
+            return
+        rot = np.eye(3)
+        if not self.straight:
+            axis = np.cross(u, (0, 0, 1.))
+            angle = math.asin(min(1., float(np.linalg.norm(axis))))
+            if u[2] < 0:
+                angle = math.pi - angle
+            if np.allclose(axis, 0):
+                axis = (1., 0, 0)
+            self.rot_axis = _axis_angle(angle, axis)
+            rot = rot @ self.rot_axis
+        if not self.normal:
+            rot = rot @ _euler_rxyz(*self._angles)
+        self.rot_normal = rot
+
+    distance = property(lambda self: self._distance,
+                        lambda self, d: self.update(d, self._direction,
+                                                    self._angles))
+    direction = property(lambda self: self._direction,
+                         lambda self, d: self.update(self._distance, d,
+                                                     self._angles))
+    angles = property(lambda self: self._angles,
+                      lambda self, a: self.update(self._distance,
+                                                  self._direction, a))
+
+    @property
+    def offset(self):
+        return self._offset
+
+    @offset.setter
+    def offset(self, offset):
+        offset = np.asarray(offset, dtype=float)
+        d = float(np.linalg.norm(offset))
+        self.update(d, offset/d if d else (0, 0, 1.), self._angles)
+
+    # O(1) frame changes of a few host vectors (origins, axis directions);
+    # ray batches are rotated in the kernel, not here.
+    @staticmethod
+    def _apply(rot, active, vectors):
+        if active:
+            vectors = tuple(np.dot(v, rot) for v in vectors)
+        return vectors[0] if len(vectors) == 1 else vectors
+
+    def from_axis(self, *v):
+        return self._apply(self.rot_axis, not self.straight, v)
+
+    def to_axis(self, *v):
+        return self._apply(None if self.straight else self.rot_axis.T,
+                           not self.straight, v)
+
+    def from_normal(self, *v):
+        return self._apply(self.rot_normal, self.rotated, v)
+
+    def to_normal(self, *v):
+        return self._apply(None if not self.rotated else self.rot_normal.T,
+                           self.rotated, v)
+
+    @property
+    def incidence(self):
+        return self.to_normal(self._direction)
+
+
+class Element(Pose):
+    """A reference plane with a circular clear aperture of ``radius``."""
+    typeletter = "E"
+
+    def __init__(self, radius=math.inf, diameter=None, **kw):
+        super().__init__(**kw)
+        self.radius = diameter/2 if diameter is not None else radius
+
+    def dict(self):
+        dat = {}
+        if self.distance:
+            dat["distance"] = float(self.distance)
+        if not self.straight:
+            dat["direction"] = [float(x) for x in self.direction]
+        if not self.normal:
+            dat["angles"] = [float(x) for x in self.angles]
+        if np.isfinite(self.radius):
+            dat["radius"] = float(self.radius)
+        return dat
+
+    def rescale(self, scale):
+        self.distance *= scale
+        self.radius *= scale
+
+
+class Interface(Element):
+    """An element separating two media."""
+    typeletter = "I"
+
+    def __init__(self, material=None, **kw):
+        super().__init__(**kw)
+        self.material = Material.make(material) if material else None
+
+    def refractive_index(self, wavelength):
+        return self.material.refractive_index(wavelength)
+
+    def get_n_mu(self, n0, l):
+        """(index behind the element, mu = n0/n); mu = -1 marks a mirror."""
+        if self.material is None:
+            return n0, 1.
+        if self.material.mirror:
+            return n0, -1.
+        n = self.refractive_index(l)
+        return n, n0/n
+
+    def dict(self):
+        dat = super().dict()
+        if self.material is not None:
+            dat["material"] = str(self.material)
+        return dat
+
+
+class Spheroid(Interface):
+    """Rotationally symmetric conic + even-asphere surface.
+
+    sag(r) = c r^2 / (1 + sqrt(1 - (1+k) c^2 r^2)) + sum_i a_i r^(2(i+1)),
+    ``aspherics[0]`` multiplies r^2 (Zemax EVENASPH PARM 1).
+    """
+    typeletter = "S"
+
+    def __init__(self, curvature=0., conic=0., aspherics=None, roc=None,
+                 alternate_intersection=False, **kw):
+        super().__init__(**kw)
+        if roc is not None:
+            curvature = 1./roc
+        self.curvature = curvature
+        self.conic = conic
+        self.aspherics = list(aspherics) if aspherics is not None else None
+        self.alternate_intersection = alternate_intersection
+        if curvature and np.isfinite(self.radius) and conic > -1:
+            if self.radius**2 > 1/((1 + conic)*curvature**2):
+                raise ValueError("aperture radius %g exceeds the conic's "
+                                 "extent" % self.radius)
+
+    def dict(self):
+        dat = super().dict()
+        if self.curvature:
+            dat["curvature"] = float(self.curvature)
+        if self.conic:
+            dat["conic"] = float(self.conic)
+        if self.aspherics is not None:
+            dat["aspherics"] = [float(a) for a in self.aspherics]
+        if self.alternate_intersection:
+            dat["alternate_intersection"] = True
+        return dat
+
+    def rescale(self, scale):
+        super().rescale(scale)
+        self.curvature /= scale
+        if self.aspherics is not None:
+            self.aspherics = [a/scale**(2*i + 1)
+                              for i, a in enumerate(self.aspherics)]
+
+
+ELEMENT_TYPES = {"spheroid": Spheroid, "interface": Interface,
+                 "element": Element}
+
+
+def make_element(spec):
+    """Element from a prescription dict (default type: spheroid)."""
+    if isinstance(spec, Pose):
+        return spec
+    spec = dict(spec)
+    cls = ELEMENT_TYPES[spec.pop("type", "spheroid")]
+    return cls(**spec)
+
+
+# --------------------------------------------------------------------------
+# system
+# --------------------------------------------------------------------------
+
+class Conjugate:
+    """Object/image specification, kept as data for ray generation."""
+    def __init__(self, spec, finite_default):
+        spec = dict(spec or {})
+        typ = spec.pop("type", None)
+        if typ is None:
+            typ = "finite" if finite_default else "infinite"
+        self.type = typ
+        self.finite = typ == "finite"
+        self.pupil = dict(spec.pop("pupil", {}) or {})
+        if "angle_deg" in spec:
+            spec["angle"] = math.radians(spec.pop("angle_deg"))
+        self.angle = spec.pop("angle", 0.)
+        self.radius = spec.pop("radius", 0.)
+        self.extra = spec
+
+    def dict(self):
+        dat = {"type": self.type, "pupil": dict(self.pupil)}
+        if self.finite:
+            dat["radius"] = self.radius
+        else:
+            dat["angle"] = self.angle
+        dat.update(self.extra)
+        return dat
+
+
+class System(list):
+    """Sequential optical system: a list of elements, object first, image
+    last.  Mutating elements between traces is allowed; the surface table is
+    re-packed on every propagate()."""
+
+    def __init__(self, elements=None, description="", scale=1e-3,
+                 wavelengths=None, stop=1, fields=None, object=None,
+                 image=None, pickups=None, validators=None, solves=None):
+        super().__init__(make_element(e) for e in (elements or []))
+        self.description = description
+        self.scale = scale
+        self.wavelengths = list(wavelengths or
+                                [LAMBDA_D, LAMBDA_C, LAMBDA_F])
+        self.stop = stop
+        self.object = Conjugate(object, finite_default=False)
+        self.image = Conjugate(image, finite_default=True)
+        self.fields = fields if fields is not None else [0., .7, 1.]
+        self.pickups = pickups or []
+        self.validators = validators or []
+        self.solves = solves or []
+        self._engine = None
+
+    def dict(self):
+        return {"description": self.description, "stop": self.stop,
+                "scale": float(self.scale),
+                "wavelengths": [float(w) for w in self.wavelengths],
+                "object": self.object.dict(), "image": self.image.dict(),
+                "elements": [e.dict() for e in self]}
+
+    def update(self):
+        """Nothing to solve: pickups/solves/paraxial data are host-side
+        design tools outside the accelerated path."""
+        return self
+
+    @property
+    def aperture(self):
+        return self[self.stop]
+
+    def refractive_index(self, wavelength, index):
+        """Index of the medium behind element ``index``: the last material
+        at or before it (1. if none)."""
+        if index < 0:
+            index += len(self)
+        for el in reversed(self[:index + 1]):
+            mat = getattr(el, "material", None)
+            if mat is not None:
+                return mat.refractive_index(wavelength)
+        return 1.
+
+    @property
+    def origins(self):
+        """Vertex positions in the global frame, (L,3)."""
+        return np.cumsum([el.offset for el in self], axis=0)
+
+    @property
+    def path(self):
+        return np.cumsum([el.distance for el in self])
+
+    @property
+    def track(self):
+        return self.origins[:, 2]
+
+    @property
+    def mirrored(self):
+        return np.cumprod([-1 if getattr(getattr(el, "material", None),
+                                         "mirror", False) else 1
+                           for el in self])
+
+    def propagate(self, y, u, n, l, start=1, stop=None, clip=False):
+        """Generator with the reference's contract (system.py:459-464):
+        yields ``(y, u, n, i, t)`` per element of ``self[start:stop]``.
+        ``y, u`` are in the global orientation relative to the vertex of
+        element ``start-1``.  The whole march runs as one fused GPU trace;
+        the tuples are then handed out surface by surface."""
+        from .engine import march_rows
+        yield from march_rows(self, y, u, n, l, start, stop, clip)

@@ -1,0 +1,105 @@
+import ctypes
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# tolerances of the parity contract (BASELINE.json north_star)
+RTOL_SPHERICAL = 1e-10   # plane / sphere / conic closed form
+RTOL_ASPHERE = 1e-8      # iterated even aspheres
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        "markers", "gpu: needs a real MI355X (run by gpurun / the driver)")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4]
+                  for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+                  if not os.path.basename(p).startswith("kat_"))
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        g = {k: z[k] for k in z.files}
+    g["yaml"] = str(g["yaml"])
+    g["l"] = float(g["l"])
+    g["clip"] = bool(g["clip"])
+    g["start"] = int(g["start"])
+    g["stop"] = None if int(g["stop"]) == -999 else int(g["stop"])
+    return g
+
+
+def case_rtol(g):
+    return RTOL_ASPHERE if "aspherics" in g["yaml"] else RTOL_SPHERICAL
+
+
+def assert_parity(got, want, rtol, what=""):
+    """NaN masks must be identical; finite entries must agree to ``rtol``
+    relative, with an absolute floor of ``rtol`` x the largest finite
+    magnitude of the same surface row (components that are ~0 by symmetry
+    have no meaningful relative error)."""
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    for j in range(want.shape[0]):
+        a, b = got[j], want[j]
+        nan_a, nan_b = np.isnan(a), np.isnan(b)
+        assert np.array_equal(nan_a, nan_b), \
+            "%s row %d: NaN mask differs at %d entries" % (
+                what, j, (nan_a != nan_b).sum())
+        inf_b = np.isinf(b)
+        assert np.array_equal(a[inf_b], b[inf_b]), "%s row %d: inf" % (what, j)
+        fin = np.isfinite(b)
+        if not fin.any():
+            continue
+        scale = np.abs(b[fin]).max()
+        err = np.abs(a[fin] - b[fin])
+        tol = rtol*np.maximum(np.abs(b[fin]), scale)
+        worst = (err/np.maximum(np.abs(b[fin]), scale)).max()
+        assert (err <= tol).all(), "%s row %d: rel err %.3g > %.1g" % (
+            what, j, worst, rtol)
+
+
+@pytest.fixture(scope="session")
+def hostemu():
+    """g++ build of the kernel's arithmetic header (tests/hostemu)."""
+    src = os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")
+    lib = os.path.join(ROOT, "tests", "hostemu", "libhostemu.so")
+    hdr = os.path.join(ROOT, "rayopt_amd", "csrc", "rt_math.h")
+    if (not os.path.exists(lib) or
+            os.path.getmtime(lib) < max(os.path.getmtime(src),
+                                        os.path.getmtime(hdr))):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
+                               "-fPIC", "-shared", "-o", lib, src])
+    dll = ctypes.CDLL(lib)
+    dll.emu_trace.restype = ctypes.c_int
+
+    def trace(table, y0, u0, start, stop, clip, rays_per_lane=2):
+        y0 = np.ascontiguousarray(y0, dtype=float)
+        u0 = np.ascontiguousarray(u0, dtype=float)
+        table = np.ascontiguousarray(table)
+        n = y0.shape[0]
+        rows = stop - start
+        Y = np.full((rows, n, 3), -7.)
+        U = np.full((rows, n, 3), -7.)
+        I = np.full((rows, n, 3), -7.)
+        T = np.full((rows, n), -7.)
+        rc = dll.emu_trace(
+            ctypes.c_void_p(table.ctypes.data), start, stop, int(clip),
+            rays_per_lane, ctypes.c_void_p(y0.ctypes.data),
+            ctypes.c_void_p(u0.ctypes.data), ctypes.c_int64(n),
+            ctypes.c_void_p(Y.ctypes.data), ctypes.c_void_p(U.ctypes.data),
+            ctypes.c_void_p(I.ctypes.data), ctypes.c_void_p(T.ctypes.data))
+        assert rc == 0
+        return Y, U, I, T
+    return trace

@@ -1,0 +1,100 @@
+"""Golden-vector cases: (system, input rays, propagate arguments).
+
+Shared by ``make_golden.py`` (which runs the unmodified reference on them and
+stores its outputs) and by the tests (which feed the same inputs to the
+oracle and to the HIP engine).  Inputs are stored in the .npz next to the
+outputs, so the tests do not depend on this module reproducing them
+bit-for-bit.
+"""
+import numpy as np
+
+from rayopt_amd import prescriptions as P
+from rayopt_amd.bundles import disc_bundle, multi_field_bundle
+
+D, C, F = 587.56e-9, 656.27e-9, 486.13e-9
+
+
+def _edge_rays():
+    """Hand-picked rays for failure modes: axial, grazing, missing the first
+    sphere entirely, travelling sideways (u_z = 0) and backwards."""
+    y = np.array([[0, 0, 0], [0, 9.9, 0], [0, 60., 0], [70., 0, 0],
+                  [1., 1., 0], [0, 2., 0], [0, 0, 0], [3., -4., 0]])
+    u = np.array([[0, 0, 1.], [0, 0, 1.], [0, 0, 1.], [0, 0, 1.],
+                  [0, 1., 0.], [0, .6, .8], [.8, 0, .6], [0, 0, -1.]])
+    return y, u
+
+
+def cases():
+    out = []
+
+    def add(name, yaml_text, y, u, l=D, clip=True, start=1, stop=None):
+        out.append(dict(name=name, yaml=yaml_text, y=np.array(y, float),
+                        u=np.array(u, float), l=l, clip=clip, start=start,
+                        stop=stop))
+
+    # C1 singlet
+    add("singlet_axis", P.SINGLET, *disc_bundle(400, 8.0, 0., 1))
+    add("singlet_vignetted", P.SINGLET, *disc_bundle(400, 11.5, 3., 2))
+    add("singlet_noclip", P.SINGLET, *disc_bundle(400, 11.5, 3., 2),
+        clip=False)
+    add("singlet_edge_rays", P.SINGLET, *_edge_rays())
+    add("singlet_edge_rays_noclip", P.SINGLET, *_edge_rays(), clip=False)
+    # C2 cooke, three wavelengths (three index sets)
+    for tag, l in (("d", D), ("C", C), ("F", F)):
+        add("cooke_" + tag, P.cooke(l), *disc_bundle(300, 5.5, 5., 3), l=l)
+    # SURVEY section 8c anchor rays
+    ya = [(0, 5, 0), (1, -2, 0), (0, 0, 0)]
+    ua = [(0, 0, 1), (0, np.sin(np.radians(10)), np.cos(np.radians(10))),
+          (.05, -.02, np.sqrt(1 - .05**2 - .02**2))]
+    add("cooke_anchor", P.cooke(D), ya, ua)
+    # C3 double gauss, five fields in one batch + partial ranges
+    zp = P.DOUBLE_GAUSS_PUPIL_Z
+    th = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in (0, .35, .5, .7, 1.)]
+    add("dgauss_fields", P.DOUBLE_GAUSS,
+        *multi_field_bundle(500, 17., th, 4, zp))
+    add("dgauss_fields_noclip", P.DOUBLE_GAUSS,
+        *multi_field_bundle(500, 19., th, 5, zp), clip=False)
+    add("dgauss_stop_at_7", P.DOUBLE_GAUSS,
+        *multi_field_bundle(200, 17., th, 6, zp), stop=7)
+    add("dgauss_neg_stop", P.DOUBLE_GAUSS,
+        *multi_field_bundle(200, 17., th, 6, zp), stop=-1)
+    # C4 aspheres (Newton intercept)
+    for k, deg in enumerate((0., 12., 25.)):
+        y, u = disc_bundle(300, 0.6, deg, 7 + k)
+        y[:, 1] -= 0.5*np.tan(np.radians(deg))
+        add("asphere_%02d" % deg, P.ASPHERE_PHONE, y, u)
+    y, u = disc_bundle(300, 1.4, 30., 11)     # forces Newton failures / clip
+    y[:, 1] -= 0.5*np.tan(np.radians(30.))
+    add("asphere_overfill", P.ASPHERE_PHONE, y, u)
+    add("asphere_overfill_noclip", P.ASPHERE_PHONE, y, u, clip=False)
+    # torture: rotations, conics, mirror, alternate intersection
+    add("torture", P.TORTURE, *disc_bundle(400, 9., 2., 12))
+    add("torture_overfill", P.TORTURE, *disc_bundle(400, 16., 4., 13))
+    add("torture_noclip", P.TORTURE, *disc_bundle(400, 16., 4., 13),
+        clip=False)
+    # total internal reflection: glass -> air at a steep plane
+    tir = """
+wavelengths: [587.56e-9]
+elements:
+- {material: 1.8}
+- {distance: 5, material: 1.0, radius: 50, angles: [0.45, 0, 0]}
+- {roc: -80, distance: 10, material: 1.5, radius: 50}
+- {distance: 20, radius: 100}
+"""
+    y, u = disc_bundle(300, 4., 0., 14)
+    u[:, 1] = np.linspace(-.3, .3, 300)
+    u[:, 2] = np.sqrt(1 - u[:, 1]**2)
+    add("tir_tilted_plane", tir, y, u, clip=False)
+    # paraboloid, axis-parallel rays: the reference returns NaN (0/0), and a
+    # near-paraboloid k=-0.999 stays finite
+    para = """
+wavelengths: [587.56e-9]
+elements:
+- {material: 1.0}
+- {roc: -200, conic: %r, distance: 50, material: mirror, radius: 30}
+- {distance: -100, radius: 30}
+"""
+    add("paraboloid_axial", para % -1.0, *disc_bundle(100, 20., 0., 15))
+    add("paraboloid_tilted", para % -1.0, *disc_bundle(100, 20., 1., 15))
+    add("near_paraboloid", para % -0.9, *disc_bundle(100, 20., 0., 15))
+    return out

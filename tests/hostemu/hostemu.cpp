@@ -1,0 +1,56 @@
+/*
+ * TEST INFRASTRUCTURE ONLY.  Compiles the kernel's per-ray arithmetic
+ * (rayopt_amd/csrc/rt_math.h, the very header the gfx950 kernel inlines) for
+ * the host with g++, so the arithmetic can be checked against the golden
+ * vectors in a container that has no GPU.  The product never loads this.
+ */
+#include <stdint.h>
+#include "../../rayopt_amd/csrc/rt_math.h"
+
+template <int R>
+static void run(const rt_surface *surf, int start, int stop, int clip,
+                const double *y0, const double *u0, int64_t n, double *Y,
+                double *U, double *I, double *T)
+{
+    for (int64_t j0 = 0; j0 < n; j0 += R) {
+        double y[R][3], u[R][3], iv[R][3], t[R];
+        for (int r = 0; r < R; ++r) {
+            const int64_t j = j0 + r < n ? j0 + r : n - 1; /* pad: repeat */
+            for (int c = 0; c < 3; ++c) {
+                y[r][c] = y0[j * 3 + c];
+                u[r][c] = u0[j * 3 + c];
+            }
+        }
+        rt_leave<R>(surf + (start - 1), surf[start - 1].flags, y, u);
+        for (int s = start; s < stop; ++s) {
+            const rt_surface *S = surf + s;
+            rt_step<R>(S, S->flags, clip, y, u, iv, t);
+            for (int r = 0; r < R; ++r) {
+                const int64_t j = j0 + r;
+                if (j >= n)
+                    continue;
+                const int64_t row = (int64_t)(s - start) * n + j;
+                for (int c = 0; c < 3; ++c) {
+                    Y[row * 3 + c] = y[r][c];
+                    U[row * 3 + c] = u[r][c];
+                    I[row * 3 + c] = iv[r][c];
+                }
+                T[row] = t[r];
+            }
+            rt_leave<R>(S, S->flags, y, u);
+        }
+    }
+}
+
+extern "C" int emu_trace(const rt_surface *surf, int start, int stop, int clip,
+                         int rays_per_lane, const double *y0, const double *u0,
+                         int64_t n, double *Y, double *U, double *I, double *T)
+{
+    switch (rays_per_lane) {
+    case 1: run<1>(surf, start, stop, clip, y0, u0, n, Y, U, I, T); break;
+    case 2: run<2>(surf, start, stop, clip, y0, u0, n, Y, U, I, T); break;
+    case 4: run<4>(surf, start, stop, clip, y0, u0, n, Y, U, I, T); break;
+    default: return -1;
+    }
+    return 0;
+}
