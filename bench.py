@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""Headline benchmark: ray-surface-ops/s of GeometricTrace.propagate().
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one fused pass of the hot path (all S = len(system)-1 elements)
+over one batch of synthetic rays that is already resident in HBM.  Workload
+at every N: BASELINE.json configs[2] -- the double-Gauss (L=13, S=12,
+spherical + stop), 10^7 rays per GPU in five field bundles, clip=True (weak
+scaling: each rank traces its own 10^7-ray shard, different seeds).  For N>1
+(one process per GPU, launched by torch.distributed.run) every step also
+gathers the last-surface intercepts y[L-1] of all ranks to rank 0 with RCCL
+send/recv over xGMI, pipelined against the next step's trace.
+
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+
+  roofline      achieved/peak HBM GB/s of the trace kernel; achieved =
+                algorithmic bytes N*(80*S + 48) per launch / average launch
+                duration from HIP events on the kernel's own stream
+  cpu_baseline  the numpy port of the reference path (oracle/trace_numpy.py,
+                same whole-array numpy operations as rayopt) timed on this
+                host, one core, on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.  # same guide: measured float4 copy
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def workload_rays(n, rank):
+    from rayopt_amd import prescriptions as P
+    from rayopt_amd.bundles import multi_field_bundle
+    fields = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in (0, .35, .5, .7, 1.)]
+    return multi_field_bundle(n, 17., fields, seed=1000*rank,
+                              z_pupil=P.DOUBLE_GAUSS_PUPIL_Z)
+
+
+def traffic_from_profile():
+    """HBM bytes per launch from the committed PMC profile, if one exists
+    for this workload (profiles/traffic.json, written by
+    scripts/pmc_traffic.py on the GPU box); otherwise null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=10_000_000,
+                    help="rays per GPU")
+    ap.add_argument("--no-clip", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000,
+                    help="rays of the workload timed on the host (0: skip)")
+    ap.add_argument("--option", action="append", default=[],
+                    help="kernel variant key=value (rt_set_option)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(
+                "--gpus %d needs one process per GPU: launch with python -m "
+                "torch.distributed.run --nproc-per-node %d ..." % (
+                    args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(
+            "cuda", local_rank))
+
+    import rayopt_amd as ra
+    from rayopt_amd import prescriptions as P
+    from rayopt_amd._lib import RT_Y
+
+    clip = not args.no_clip
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    L = len(system)
+    S = L - 1
+    n = args.rays
+
+    t0 = time.perf_counter()
+    y, u = workload_rays(n, rank)
+    g = ra.GeometricTrace(system, device=local_rank)
+    eng = g.engine
+    for kv in args.option:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+    g.rays_given(y, u)          # rays resident in HBM from here on
+    log("[rank %d] %d rays generated + uploaded in %.2f s" % (
+        rank, n, time.perf_counter() - t0))
+
+    # RCCL gather of the final intercepts (only where there is an exchange)
+    counts = None
+    d_dst = 0
+    if world > 1:
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0], world, rank)
+        counts = np.full(world, n, dtype=np.int64)
+        if rank == 0:
+            d_dst = eng.scratch(int(counts.sum())*3*8)
+
+    from rayopt_amd.pack import pack_system
+    table, ns = pack_system(system, g.l, g.n[0])
+    eng.upload_system(table)
+
+    def step():
+        eng.trace(1, 0, clip)
+        if world > 1:
+            eng.gather_final(RT_Y, L - 1, counts, 0, d_dst)
+
+    def fence():
+        eng.sync()
+        if world > 1:
+            eng.comm_sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    eng.event_record(0)
+    for _ in range(args.steps):
+        step()
+    eng.event_record(1)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ev_ms = eng.event_elapsed(0, 1)
+    last_kernel_ms = eng.kernel_ms()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity on the result of the last step (not timed): a few per cent of
+    # the rays vignette, everything else reaches the image
+    ylast = np.asarray(g.y[L - 1])
+    ulast = np.asarray(g.u[L - 1])
+    finite = float(np.isfinite(ulast[:, 0]).mean())
+    if world > 1 and rank == 0:
+        gathered = eng.copy_to_host(d_dst, int(counts.sum())*3*8)
+        gathered = gathered.reshape(3, -1)
+        mine = gathered[:, :n].T
+        assert np.array_equal(mine, ylast, equal_nan=True), \
+            "gathered shard 0 differs from the local result"
+        assert np.isfinite(gathered).mean() > 0.9
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    total_rays = n*world
+    ms_per_step = elapsed*1e3/args.steps
+    value = total_rays*S*args.steps/elapsed
+    alg_bytes = n*(80*S + 48)               # per launch (one GPU's shard)
+    kernel_ms = ev_ms/args.steps if world == 1 else last_kernel_ms
+    achieved = alg_bytes/(kernel_ms*1e-3)/1e9
+    prof = traffic_from_profile()
+    traffic = None
+    if prof and prof.get("rays") == n and prof.get("clip") == clip:
+        traffic = prof.get("hbm_bytes_per_launch")
+
+    out = {
+        "metric": "ray-surface-ops/sec",
+        "value": value,
+        "unit": "ray-surface-ops/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "double-Gauss (BASELINE configs[2]): L=%d elements, "
+                        "S=%d propagated surfaces, %d rays/GPU in 5 field "
+                        "bundles, clip=%s" % (L, S, n, clip),
+            "rays_per_gpu": n,
+            "surfaces": S,
+            "clip": clip,
+            "finite_fraction_at_image": finite,
+            "parallelism": "ray shards x%d%s" % (
+                world, ", RCCL gather of y[L-1] to rank 0 each step"
+                if world > 1 else ""),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved/HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel": "rt_trace_kernel",
+            "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "frac_of_achievable_6290": achieved/HBM_ACHIEVABLE_GBS,
+        },
+    }
+
+    if world == 1 and args.cpu_sample > 0:
+        from oracle import trace_numpy as tn
+        m = min(args.cpu_sample, n)
+        ys, us = y[:m], u[:m]
+        tn.propagate(table, ys[:100000], us[:100000], clip=clip)   # warm
+        t0 = time.perf_counter()
+        Y, U, I, T = tn.propagate(table, ys, us, clip=clip)
+        dt = time.perf_counter() - t0
+        # the sample doubles as a parity check of the bench run itself
+        got = np.asarray(g.y[L - 1])[:m]
+        ref = Y[-1]
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        fin = np.isfinite(ref)
+        assert (np.abs(got[fin] - ref[fin]) <=
+                1e-10*np.maximum(np.abs(ref[fin]), 1.)).all()
+        out["cpu_baseline"] = {
+            "value": m*S/dt,
+            "unit": "ray-surface-ops/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": "first %d rays of the same workload, one "
+                      "propagate() of the numpy port (%.1f s); host has %d "
+                      "cores" % (m, dt, os.cpu_count()),
+        }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,298 @@
+"""Parity of the HIP engine with the reference, on a real MI355X.
+
+Every test goes through the C ABI (librt_mi355.so via ctypes) and compares
+with (a) the committed golden vectors produced by the unmodified reference
+and (b) the numpy oracle run on the same seeded inputs.  Tolerances are the
+contract's: 1e-10 relative for plane/sphere/conic surfaces, 1e-8 for iterated
+aspheres, identical NaN masks for y, u, i, t separately.
+"""
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd import prescriptions as P
+from rayopt_amd.bundles import disc_bundle, multi_field_bundle
+from rayopt_amd.pack import pack_system, resolve_range
+from oracle import trace_numpy as tn
+
+from conftest import (golden_names, load_golden, assert_parity, case_rtol,
+                      RTOL_SPHERICAL, RTOL_ASPHERE)
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_trace(system, y, u, l, clip, start=1, stop=None):
+    a, b = resolve_range(len(system), start, stop)
+    table, ns = pack_system(system, l, system.refractive_index(l, 0), a, b)
+    return tn.propagate(table, y, u, a, b, clip), ns
+
+
+def gpu_trace(system, y, u, l, clip, start=1, stop=None, **options):
+    g = ra.GeometricTrace(system)
+    for k, v in options.items():
+        g.engine.set_option(k, v)
+    g.rays_given(y, u, l)
+    g.propagate(start=start, stop=stop, clip=clip)
+    return g
+
+
+def compare(g, want, a, b, rtol, what):
+    for label, rows, ref in (("y", g.y, want[0]), ("u", g.u, want[1]),
+                             ("i", g.i, want[2]), ("t", g.t, want[3])):
+        assert_parity(np.asarray(rows[a:b]), ref, rtol,
+                      "%s.%s" % (what, label))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_matches_reference_golden(name):
+    gold = load_golden(name)
+    system = ra.system_from_yaml(gold["yaml"])
+    a, b = resolve_range(len(system), gold["start"], gold["stop"])
+    g = gpu_trace(system, gold["y0"], gold["u0"], gold["l"], gold["clip"],
+                  gold["start"], gold["stop"])
+    want = [gold[k][a:b] for k in "yuit"]
+    compare(g, want, a, b, case_rtol(gold), name)
+    assert np.array_equal(g.n[:b], gold["n"][:b])
+    # row 0 is what rays_given stored
+    assert np.array_equal(g.y[0], gold["y0"])
+    assert np.array_equal(g.u[0], gold["u0"])
+    assert np.array_equal(g.i[0], gold["u0"])
+    assert not np.asarray(g.t[0]).any()
+
+
+@pytest.mark.parametrize("options", [
+    dict(rays_per_thread=1), dict(rays_per_thread=4),
+    dict(nontemporal=1), dict(xcd_remap=1), dict(block=64), dict(block=512),
+    dict(rays_per_thread=4, nontemporal=1, xcd_remap=1, block=128)])
+@pytest.mark.parametrize("key", ["double_gauss", "asphere_phone", "torture"])
+def test_kernel_variants_are_bit_identical(key, options):
+    system = ra.system_from_yaml(P.ALL[key])
+    rad = min(float(e.radius) for e in system[1:-1])*1.1
+    y, u = disc_bundle(10007, rad, 2., 21)     # ragged: not a multiple of 64
+    base = gpu_trace(system, y, u, None, True)
+    var = gpu_trace(system, y, u, None, True, **options)
+    for a, b in ((base.y, var.y), (base.u, var.u), (base.i, var.i),
+                 (base.t, var.t)):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def test_kat_reference_rms():
+    """The reference's pinned known answer (test_raytrace.py:189-199)."""
+    with np.load("tests/golden/kat_cooke_quadrature.npz") as z:
+        k = {key: z[key] for key in z.files}
+    system = ra.system_from_yaml(P.cooke())
+    for el, n in zip(system, k["n"]):
+        if el.material is not None:
+            el.material = ra.ConstantIndex(float(n))
+    g = ra.GeometricTrace(system)
+    g.rays_given(k["y0"], k["u0"], float(k["l"]), k["w"], int(k["ref"]))
+    g.propagate(clip=False)
+    assert_parity(np.asarray(g.y), k["y"], RTOL_SPHERICAL, "kat.y")
+    y = g.y[-1][:, :2]
+    rms = np.sqrt((np.square(y - y.mean(0)).sum(1)*g.w).sum())
+    assert rms == pytest.approx(float(k["rms"]), rel=1e-10)
+    np.testing.assert_allclose(rms, .052, rtol=1e-2)
+
+
+# ---- BASELINE.json configs against the oracle on the same seeded rays ----
+
+def test_config_c1_singlet_1e4():
+    system = ra.system_from_yaml(P.SINGLET)
+    y, u = disc_bundle(10**4, 8.0, 0., 0)
+    g = gpu_trace(system, y, u, None, True)
+    want, ns = oracle_trace(system, y, u, g.l, True)
+    compare(g, want, 1, 4, RTOL_SPHERICAL, "C1")
+    assert np.isfinite(np.asarray(g.y)).all()
+
+
+@pytest.mark.parametrize("l", [587.56e-9, 656.27e-9, 486.13e-9])
+def test_config_c2_cooke_1e6(l):
+    system = ra.system_from_yaml(P.cooke(l))
+    y, u = disc_bundle(10**6, 5.5, 5., 0)
+    g = gpu_trace(system, y, u, l, True)
+    want, ns = oracle_trace(system, y, u, l, True)
+    compare(g, want, 1, 9, RTOL_SPHERICAL, "C2")
+    assert np.array_equal(g.n[1:], ns[1:])
+
+
+def _c3_rays(n, seed=0):
+    th = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in (0, .35, .5, .7, 1.)]
+    return multi_field_bundle(n, 17., th, seed, P.DOUBLE_GAUSS_PUPIL_Z)
+
+
+def test_config_c3_double_gauss_1e6_vs_oracle():
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = _c3_rays(10**6)
+    g = gpu_trace(system, y, u, None, True)
+    want, ns = oracle_trace(system, y, u, g.l, True)
+    compare(g, want, 1, 13, RTOL_SPHERICAL, "C3")
+    frac = np.isnan(np.asarray(g.u[-1])[:, 0]).mean()
+    assert 0.001 < frac < 0.1      # a few per cent vignetted, as designed
+
+
+def test_config_c4_asphere_2e5_vs_oracle():
+    system = ra.system_from_yaml(P.ASPHERE_PHONE)
+    ys, us = [], []
+    for k, deg in enumerate((0., 17.5)):
+        y, u = disc_bundle(10**5, 0.6, deg, k)
+        y[:, 1] -= 0.5*np.tan(np.radians(deg))
+        ys.append(y)
+        us.append(u)
+    y, u = np.concatenate(ys), np.concatenate(us)
+    g = gpu_trace(system, y, u, None, True)
+    want, ns = oracle_trace(system, y, u, g.l, True)
+    compare(g, want, 1, 9, RTOL_ASPHERE, "C4")
+    assert np.isfinite(np.asarray(g.y[-1])).mean() > 0.99
+
+
+# ---- full size (10^7 rays): size-independent properties -----------------
+
+def _subsample_check(system, g, y, u, clip, rtol, step):
+    """Every ``step``-th ray of the full-size device result against the
+    oracle run on just those rays (rays are independent)."""
+    sel = slice(0, None, step)
+    want, ns = oracle_trace(system, y[sel], u[sel], g.l, clip)
+    L = len(system)
+    for label, rows, ref in (("y", g.y, want[0]), ("u", g.u, want[1]),
+                             ("i", g.i, want[2]), ("t", g.t, want[3])):
+        for j in range(1, L):
+            assert_parity(np.asarray(rows[j])[sel][None], ref[j - 1][None],
+                          rtol, "full.%s[%d]" % (label, j))
+
+
+def test_full_size_c3_properties():
+    n = 10**7
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = _c3_rays(n)
+    g = gpu_trace(system, y, u, None, True)
+    L = len(system)
+    # (1) subsample against the oracle
+    _subsample_check(system, g, y, u, True, RTOL_SPHERICAL, 97)
+    # (2) shard invariance: tracing a contiguous shard alone gives the same
+    # bits as the same rays inside the big batch (rays are independent)
+    lo, hi = 3_000_001, 3_200_000
+    part = gpu_trace(system, y[lo:hi], u[lo:hi], None, True)
+    for rows, prow in ((g.y, part.y), (g.u, part.u), (g.i, part.i)):
+        assert np.array_equal(np.asarray(rows[-1])[lo:hi],
+                              np.asarray(prow[-1]), equal_nan=True)
+    assert np.array_equal(np.asarray(g.t[5])[lo:hi], np.asarray(part.t[5]),
+                          equal_nan=True)
+    # (3) physics invariants on the full arrays of a few rows
+    dead_before = np.zeros(n, dtype=bool)
+    for j in range(1, L):
+        uj = np.asarray(g.u[j])
+        dead = np.isnan(uj[:, 0])
+        assert not (dead_before & ~dead).any()      # NaN is absorbing
+        norm = np.square(uj[~dead]).sum(1)
+        assert np.abs(norm - 1).max() < 1e-13       # directions stay unit
+        if j in (1, 6, L - 1):
+            ij = np.asarray(g.i[j])
+            prev = np.asarray(g.u[j - 1])
+            # unrotated system: incoming direction == previous outgoing
+            assert np.array_equal(ij, prev, equal_nan=True)
+        dead_before = dead
+    t = np.asarray(g.t[1:])
+    assert (t[np.isfinite(t)] > -1e-9).all()        # forward propagation
+
+
+def test_full_size_c4_asphere_subsample():
+    n = 10**7
+    system = ra.system_from_yaml(P.ASPHERE_PHONE)
+    y, u = disc_bundle(n, 0.6, 0.7*25, 3)
+    y[:, 1] -= 0.5*np.tan(np.radians(0.7*25))
+    g = gpu_trace(system, y, u, None, True)
+    _subsample_check(system, g, y, u, True, RTOL_ASPHERE, 997)
+
+
+# ---- API behaviour ---------------------------------------------------------
+
+def test_partial_repropagate_like_refocus():
+    """refocus() edits system[-1].distance and re-propagates
+    (geometric_trace.py:98-99); re-running only the last element from the
+    stored row L-2 must equal a full trace of the edited system."""
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = _c3_rays(20000)
+    g = gpu_trace(system, y, u, None, True)
+    system[-1].distance += 0.37
+    full = gpu_trace(system, y, u, None, True)
+    g.propagate(start=len(system) - 1, clip=True)
+    for a, b in ((g.y, full.y), (g.u, full.u), (g.i, full.i), (g.t, full.t)):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def test_start_from_rotated_element():
+    """start > 1 seeds from a row in a tilted element's frame: the kernel
+    applies that element's from_normal first (geometric_trace.py:75-76)."""
+    system = ra.system_from_yaml(P.TORTURE)
+    y, u = disc_bundle(5000, 9., 2., 5)
+    g = gpu_trace(system, y, u, None, True)
+    want, _ = oracle_trace(system, y, u, g.l, True)
+    before = [np.array(np.asarray(r)) for r in (g.y, g.u, g.i, g.t)]
+    g.propagate(start=4, stop=8, clip=True)
+    for rows, old in zip((g.y, g.u, g.i, g.t), before):
+        assert np.array_equal(np.asarray(rows), old, equal_nan=True)
+    compare(g, want, 1, 9, RTOL_SPHERICAL, "torture")
+
+
+def test_system_propagate_generator():
+    """System.propagate yields (y,u,n,i,t) per element (system.py:459-464)."""
+    system = ra.system_from_yaml(P.TORTURE)
+    y, u = disc_bundle(3000, 12., 3., 8)
+    l = system.wavelengths[0]
+    table, ns = pack_system(system, l, 1.0)
+    Y, U, I, T = tn.propagate(table, y, u, clip=True)
+    rows = list(system.propagate(y, u, 1.0, l, clip=True))
+    assert len(rows) == len(system) - 1
+    for j, (yj, uj, nj, ij, tj) in enumerate(rows):
+        assert_parity(yj[None], Y[j][None], RTOL_SPHERICAL, "gen.y")
+        assert_parity(uj[None], U[j][None], RTOL_SPHERICAL, "gen.u")
+        assert_parity(ij[None], I[j][None], RTOL_SPHERICAL, "gen.i")
+        assert_parity(tj[None], T[j][None], RTOL_SPHERICAL, "gen.t")
+        assert nj == ns[j + 1]
+
+
+def test_rays_given_two_components_and_broadcast():
+    system = ra.system_from_yaml(P.SINGLET)
+    y = np.array([[0., 1.], [2., -3.], [0.5, 0.25]])
+    u = np.array([[0., .01]])                       # broadcast, u_z completed
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    g.propagate()
+    assert g.y.shape == (4, 3, 3) and g.t.shape == (4, 3)
+    u0 = np.asarray(g.u[0])
+    assert np.allclose(u0[:, 2], np.sqrt(1 - .01**2))
+    y3 = np.zeros((3, 3))
+    y3[:, :2] = y
+    want, _ = oracle_trace(system, y3, u0, g.l, False)
+    compare(g, want, 1, 4, RTOL_SPHERICAL, "2comp")
+    assert np.allclose(g.w, 1/3) and g.ref == 0
+
+
+def test_lazy_rows_views():
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = _c3_rays(1000)
+    g = gpu_trace(system, y, u, None, True)
+    full = np.asarray(g.y)
+    assert full.shape == (13, 1000, 3)
+    assert np.array_equal(g.y[-1], full[-1], equal_nan=True)
+    assert np.array_equal(g.y[2:5], full[2:5], equal_nan=True)
+    assert np.array_equal(g.y[-1, :, :2], full[-1, :, :2], equal_nan=True)
+    assert np.array_equal(g.t[:-1].sum(0), np.asarray(g.t)[:-1].sum(0),
+                          equal_nan=True)
+    assert len(g.y) == 13 and g.t.ndim == 2
+
+
+def test_errors_are_loud():
+    system = ra.system_from_yaml(P.SINGLET)
+    g = ra.GeometricTrace(system)
+    g.rays_given(np.zeros((4, 3)), np.array([[0, 0, 1.]]))
+    with pytest.raises(ValueError):
+        g.propagate(start=0)
+    system.append(ra.Spheroid(distance=1.))
+    with pytest.raises(ValueError):
+        g.propagate()
+    with pytest.raises(ra.EngineError):
+        ra.Engine(device=4096)
+    big = ra.Spheroid(aspherics=[0.]*11, distance=1.)
+    with pytest.raises(ValueError):
+        pack_system(ra.System([ra.Spheroid(), big]), 5e-7, 1.)
