@@ -120,10 +120,9 @@ def main():
     counts = None
     d_dst = 0
     if world > 1:
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(uid[0], world, rank)
-        counts = np.full(world, n, dtype=np.int64)
+        from rayopt_amd.distributed import init_engine_comm, shard_counts
+        init_engine_comm(eng, dist)
+        counts = shard_counts(n*world, world)   # weak scaling: n per rank
         if rank == 0:
             d_dst = eng.scratch(int(counts.sum())*3*8)
 

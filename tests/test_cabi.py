@@ -1,0 +1,84 @@
+"""The C-ABI shared library: loads, exports every symbol the header declares,
+agrees on the struct layout, and refuses to work without a GPU (no CPU
+fallback).  No compute is issued here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rayopt_amd import _lib, _build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rt_mi355.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def dll():
+    _build.build()
+    return _lib.load()
+
+
+def test_header_and_binding_agree(dll):
+    names = declared_symbols()
+    assert len(names) >= 25
+    assert set(names) == set(_lib.SIGNATURES), \
+        set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_every_declared_symbol_is_exported(dll):
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(raw, name), name
+
+
+def test_struct_layout(dll):
+    assert dll.rt_abi_version() == 1
+    assert dll.rt_sizeof_surface() == _lib.SURFACE_DTYPE.itemsize == 344
+    text = open(HEADER).read()
+    assert int(re.search(r"#define RT_MAX_ASPH (\d+)", text).group(1)) == \
+        _lib.RT_MAX_ASPH
+    assert int(re.search(r"#define RT_MAX_SURFACES (\d+)", text).group(1)) \
+        == _lib.RT_MAX_SURFACES
+    for flag in ("ROTATED", "CURVED", "CONIC", "ASPH", "ALT", "REFRACT",
+                 "MIRROR"):
+        val = int(re.search(r"#define RT_F_%s\s+0x([0-9a-f]+)u" % flag,
+                            text).group(1), 16)
+        assert val == getattr(_lib, "F_" + flag)
+
+
+def test_no_cpu_fallback_without_gpu(dll):
+    count = ctypes.c_int(-1)
+    rc = dll.rt_device_count(ctypes.byref(count))
+    if rc == 0 and count.value > 0:
+        pytest.skip("a GPU is visible")
+    import rayopt_amd as ra
+    with pytest.raises(ra.EngineError, match="rt_create"):
+        ra.Engine()
+    g = ra.GeometricTrace(ra.system_from_yaml(ra.prescriptions.SINGLET))
+    with pytest.raises(ra.EngineError):
+        g.rays_given(np.zeros((2, 3)), np.array([[0, 0, 1.]]))
+    with pytest.raises(ra.EngineError):
+        list(ra.system_from_yaml(ra.prescriptions.SINGLET).propagate(
+            np.zeros((2, 3)), np.array([[0, 0, 1.]]), 1., 5e-7))
+    assert b"ROCm" in dll.rt_last_error(None) or dll.rt_last_error(None)
+
+
+def test_product_does_not_import_oracle():
+    """oracle/ is test infrastructure: nothing under rayopt_amd/ may
+    reference it."""
+    pkg = os.path.join(ROOT, "rayopt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text,
+                                     flags=re.M), f
+                assert "trace_numpy" not in text, f

@@ -1,0 +1,124 @@
+"""Host model + packer: conventions pinned by the reference's element tests
+(rayopt/test/test_elements.py:29-58) and SURVEY section 8c anchors."""
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd import _lib
+from rayopt_amd.pack import pack_system, resolve_range
+from oracle import refshim
+
+
+def test_rotation_anchor():
+    e = ra.Spheroid(angles=(.1, .2, .3))
+    np.testing.assert_allclose(
+        e.rot_normal[0],
+        (0.9362933635841992, -0.28962947762551555, 0.19866933079506122),
+        rtol=0, atol=2e-16)
+
+
+def test_from_normal_convention():
+    # test_elements.py:48-58: from_normal of (0,0,3) with angles (.1,0,0)
+    e = ra.Spheroid(angles=(.1, 0, 0))
+    np.testing.assert_allclose(e.from_normal(np.array([0, 0, 3.])),
+                               (0, 3*np.sin(.1), 3*np.cos(.1)), atol=1e-15)
+    y = np.random.default_rng(0).normal(size=(5, 3))
+    np.testing.assert_allclose(e.to_normal(e.from_normal(y)), y, atol=1e-15)
+    np.testing.assert_allclose(e.to_axis(e.from_axis(y)), y, atol=1e-15)
+    assert not ra.Spheroid().rotated and ra.Spheroid().rot_normal is None
+
+
+def test_negative_distance_flips_direction():
+    e = ra.Spheroid(distance=-100.)
+    assert e.distance == 100. and e.rotated
+    np.testing.assert_allclose(e.offset, (0, 0, -100.))
+    np.testing.assert_allclose(np.diag(e.rot_normal), (1, -1, -1))
+    e.distance = 7.
+    np.testing.assert_allclose(e.offset, (0, 0, -7.))
+
+
+def test_material_make():
+    assert ra.Material.make(1.5).refractive_index(5e-7) == 1.5
+    assert ra.Material.make(None) is None
+    abbe = ra.Material.make("1.5168/64.17")
+    assert abbe.refractive_index(587.56e-9) == pytest.approx(1.5168)
+    assert abbe.refractive_index(486.13e-9) > abbe.refractive_index(656.27e-9)
+    assert ra.Material.make((1.5, 60.)).n == 1.5
+    assert ra.Material.make("mirror").mirror
+    assert ra.Material.make("basic/air").refractive_index(587.56e-9) == \
+        pytest.approx(1.000277, abs=2e-6)
+    with pytest.raises(KeyError):
+        ra.Material.make("SCHOTT-SK|N-SK16")
+
+
+def test_get_n_mu_and_system_index():
+    s = ra.system_from_yaml(ra.prescriptions.SINGLET)
+    assert s[1].get_n_mu(1., 5e-7) == (1.5168, 1/1.5168)
+    assert s[3].get_n_mu(1.3, 5e-7) == (1.3, 1.)        # no material
+    assert ra.Spheroid(material="mirror").get_n_mu(1.2, 5e-7) == (1.2, -1.)
+    assert s.refractive_index(5e-7, 1) == 1.5168
+    assert s.refractive_index(5e-7, 3) == 1.0           # walks back
+    assert s.refractive_index(5e-7, -1) == 1.0
+    np.testing.assert_allclose(s.path, [0, 10, 15, 63.2])
+    np.testing.assert_allclose(s.track, [0, 10, 15, 63.2])
+    assert list(s.mirrored) == [1, 1, 1, 1]
+
+
+def test_pack_flags_and_scalars():
+    s = ra.system_from_yaml(ra.prescriptions.TORTURE)
+    t, n = pack_system(s, 587.56e-9, 1.0)
+    f = t["flags"]
+    assert f[1] & _lib.F_ROTATED and f[1] & _lib.F_CONIC and \
+        f[1] & _lib.F_CURVED and f[1] & _lib.F_REFRACT
+    assert not f[4] & _lib.F_ROTATED and not f[3] & _lib.F_CURVED
+    assert f[5] & _lib.F_MIRROR and t["mu"][5] == -1.
+    assert f[7] & _lib.F_ALT
+    assert not f[8] & _lib.F_REFRACT and t["mu"][8] == 1.
+    np.testing.assert_array_equal(n, [1, 1.5168, 1, 1.7, 1, 1, 1.5168, 1, 1])
+    assert t["kc2"][1] == (1 + -0.6)*(1/80.)**2
+    assert t["radius2"][8] == 1600. and t["n0"][2] == 1.5168
+    a = ra.system_from_yaml(ra.prescriptions.ASPHERE_PHONE)
+    t, n = pack_system(a, 587.56e-9, 1.0)
+    assert t["nasph"][2] == 4 and t["flags"][2] & _lib.F_ASPH
+    np.testing.assert_array_equal(t["dasph"][2][:4],
+                                  [0., 4*-0.010, 6*-0.020, 8*0.010])
+    assert np.isinf(t["radius2"][0])
+
+
+def test_resolve_range_matches_python_slicing():
+    for L in (4, 9):
+        for start in (1, 2, 3):
+            for stop in (None, -1, 3, L, L + 5, 0):
+                a, b = resolve_range(L, start, stop)
+                assert list(range(a, b)) == list(range(L))[start:stop]
+
+
+def test_partial_pack_threads_index():
+    s = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    full, n_full = pack_system(s, 587.56e-9, 1.0)
+    part, n_part = pack_system(s, 587.56e-9, n_full[6], 7, None)
+    np.testing.assert_array_equal(n_part[6:], n_full[6:])
+    np.testing.assert_array_equal(part["mu"][7:], full["mu"][7:])
+    assert np.isnan(n_part[:6]).all()
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+def test_model_matches_reference_geometry():
+    ro = refshim.load()
+    for kw in (dict(angles=(.1, .2, .3)), dict(distance=-3.),
+               dict(distance=4., direction=(.1, -.2, 1.), angles=(0, .3, 0)),
+               dict(offset=(1., -2., 5.)), dict(distance=2., direction=(0, 0, -1))):
+        a, b = ra.Spheroid(**kw), ro.Spheroid(**kw)
+        assert a.rotated == b.rotated and a.straight == b.straight
+        np.testing.assert_allclose(a.offset, b.offset, atol=1e-15)
+        np.testing.assert_allclose(a.rot_normal, b.rot_normal, atol=1e-15)
+        if not a.straight:
+            np.testing.assert_allclose(a.rot_axis, b.rot_axis, atol=1e-15)
+    for key, text in ra.prescriptions.ALL.items():
+        a, b = ra.system_from_yaml(text), ro.system_from_yaml(text)
+        np.testing.assert_allclose(a.origins, b.origins, atol=1e-13)
+        np.testing.assert_allclose(a.path, b.path)
+        np.testing.assert_array_equal(a.mirrored, b.mirrored)
+        for j in range(len(a)):
+            assert a.refractive_index(5.5e-7, j) == \
+                b.refractive_index(5.5e-7, j)
