@@ -86,9 +86,12 @@ def main():
                     args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    # RT_BENCH_FORCE_DIST=1 exercises the whole multi-process path (torch
+    # rendezvous, RCCL communicator, pipelined gather) with a single rank
+    dist_mode = world > 1 or bool(os.environ.get("RT_BENCH_FORCE_DIST"))
     dist = None
     torch = None
-    if world > 1:
+    if dist_mode:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -119,7 +122,7 @@ def main():
     # RCCL gather of the final intercepts (only where there is an exchange)
     counts = None
     d_dst = 0
-    if world > 1:
+    if dist_mode:
         from rayopt_amd.distributed import init_engine_comm, shard_counts
         init_engine_comm(eng, dist)
         counts = shard_counts(n*world, world)   # weak scaling: n per rank
@@ -132,12 +135,12 @@ def main():
 
     def step():
         eng.trace(1, 0, clip)
-        if world > 1:
+        if dist_mode:
             eng.gather_final(RT_Y, L - 1, counts, 0, d_dst)
 
     def fence():
         eng.sync()
-        if world > 1:
+        if dist_mode:
             eng.comm_sync()
             torch.cuda.synchronize()
             dist.barrier()
@@ -154,7 +157,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ev_ms = eng.event_elapsed(0, 1)
     last_kernel_ms = eng.kernel_ms()
-    if world > 1:
+    if dist_mode:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -164,7 +167,7 @@ def main():
     ylast = np.asarray(g.y[L - 1])
     ulast = np.asarray(g.u[L - 1])
     finite = float(np.isfinite(ulast[:, 0]).mean())
-    if world > 1 and rank == 0:
+    if dist_mode and rank == 0:
         gathered = eng.copy_to_host(d_dst, int(counts.sum())*3*8)
         gathered = gathered.reshape(3, -1)
         mine = gathered[:, :n].T
@@ -173,7 +176,7 @@ def main():
         assert np.isfinite(gathered).mean() > 0.9
 
     if rank != 0:
-        if world > 1:
+        if dist_mode:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -182,7 +185,7 @@ def main():
     ms_per_step = elapsed*1e3/args.steps
     value = total_rays*S*args.steps/elapsed
     alg_bytes = n*(80*S + 48)               # per launch (one GPU's shard)
-    kernel_ms = ev_ms/args.steps if world == 1 else last_kernel_ms
+    kernel_ms = ev_ms/args.steps if not dist_mode else last_kernel_ms
     achieved = alg_bytes/(kernel_ms*1e-3)/1e9
     prof = traffic_from_profile()
     traffic = None
@@ -212,7 +215,7 @@ def main():
             "finite_fraction_at_image": finite,
             "parallelism": "ray shards x%d%s" % (
                 world, ", RCCL gather of y[L-1] to rank 0 each step"
-                if world > 1 else ""),
+                if dist_mode else ""),
         },
         "roofline": {
             "bound": "hbm",
@@ -253,7 +256,7 @@ def main():
                       "cores" % (m, dt, os.cpu_count()),
         }
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_mode:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -168,6 +168,13 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * (0,1), "block" (64..1024).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
+/*
+ * Memory-system calibration on the context's own result arrays (row 0 is
+ * preserved): mode 0 = the trace kernel's store pattern without arithmetic,
+ * 1 = linear 16-byte fill, 2 = 16-byte copy.  Returns kernel time and the
+ * bytes moved.  Overwrites rows >= 1.
+ */
+int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes);
 
 /*
  * Lazy D2H of surface rows [surf_lo, surf_hi) of one array into a caller

@@ -64,6 +64,7 @@ SIGNATURES = {
     "rt_event_elapsed": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                         _c_double_p]),
     "rt_set_option": (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int]),
+    "rt_probe": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p, _c_double_p]),
     "rt_download": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_void_p]),
     "rt_device_ptr": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,

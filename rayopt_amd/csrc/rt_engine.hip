@@ -195,6 +195,60 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
     T[j] = 0.;
 }
 
+
+/*
+ * Bandwidth probes (measurement only): the store pattern of the trace kernel
+ * without its arithmetic, a linear fill and a 16-byte copy.  They calibrate
+ * the memory-system ceiling the trace kernel is judged against.
+ */
+__global__ void rt_probe_pattern_kernel(int start, int stop,
+                                        double *__restrict__ Y,
+                                        double *__restrict__ U,
+                                        double *__restrict__ I,
+                                        double *__restrict__ T, int64_t ld)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (j >= ld)
+        return;
+    v2 y[3], u[3];
+    const int64_t row0 = (int64_t)(start - 1) * 3;
+    for (int c = 0; c < 3; ++c) {
+        y[c] = *reinterpret_cast<const v2 *>(Y + (row0 + c) * ld + j);
+        u[c] = *reinterpret_cast<const v2 *>(U + (row0 + c) * ld + j);
+    }
+    for (int s = start; s < stop; ++s) {
+        const int64_t row = (int64_t)s * 3;
+        for (int c = 0; c < 3; ++c) {
+            y[c] += u[c];
+            *reinterpret_cast<v2 *>(Y + (row + c) * ld + j) = y[c];
+            *reinterpret_cast<v2 *>(U + (row + c) * ld + j) = u[c];
+            *reinterpret_cast<v2 *>(I + (row + c) * ld + j) = u[c];
+        }
+        *reinterpret_cast<v2 *>(T + (int64_t)s * ld + j) = y[2];
+    }
+}
+
+__global__ void rt_probe_fill_kernel(double *__restrict__ dst, int64_t n2)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    v2 v = {1., 2.};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+         i += stride)
+        reinterpret_cast<v2 *>(dst)[i] = v;
+}
+
+__global__ void rt_probe_copy_kernel(const double *__restrict__ src,
+                                     double *__restrict__ dst, int64_t n2)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+         i += stride)
+        reinterpret_cast<v2 *>(dst)[i] = reinterpret_cast<const v2 *>(src)[i];
+}
+
 /* ------------------------------------------------------------------ */
 /* context                                                            */
 /* ------------------------------------------------------------------ */
@@ -668,6 +722,56 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
     } else {
         return rt_fail(ctx, RT_ERR_ARG, "rt_set_option: unknown key '%s'", key);
     }
+    return RT_OK;
+}
+
+
+int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
+{
+    if (!ctx || !ms || !bytes)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_probe: NULL argument");
+    if (!ctx->d_buf || ctx->nsurf < 2)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_probe: set rays first");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int L = ctx->buf_nsurf;
+    const int64_t ld = ctx->ld;
+    /* rows 1..L-1 of the four arrays; row 0 (the input rays) is preserved */
+    RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
+    if (mode == 0) {
+        const int block = 256;
+        const unsigned grid = (unsigned)((ld / 2 + block - 1) / block);
+        hipLaunchKernelGGL(rt_probe_pattern_kernel, dim3(grid), dim3(block), 0,
+                           ctx->stream, 1, L, rt_arr(ctx, RT_Y),
+                           rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
+                           rt_arr(ctx, RT_T), ld);
+        *bytes = (double)ld * (80. * (L - 1) + 48.);
+    } else if (mode == 1) {
+        double total = 0.;
+        for (int w = RT_Y; w <= RT_T; ++w) {
+            const int nc = rt_ncomp(w);
+            const int64_t n2 = (int64_t)(L - 1) * nc * ld / 2;
+            hipLaunchKernelGGL(rt_probe_fill_kernel, dim3(2048), dim3(256), 0,
+                               ctx->stream, rt_arr(ctx, w) + (size_t)nc * ld,
+                               n2);
+            total += (double)n2 * 16.;
+        }
+        *bytes = total;
+    } else if (mode == 2) {
+        /* copy rows 1..h of Y -> rows 1..h of U, h = L-1: read + write */
+        const int64_t n2 = (int64_t)(L - 1) * 3 * ld / 2;
+        hipLaunchKernelGGL(rt_probe_copy_kernel, dim3(2048), dim3(256), 0,
+                           ctx->stream, rt_arr(ctx, RT_Y) + (size_t)3 * ld,
+                           rt_arr(ctx, RT_I) + (size_t)3 * ld, n2);
+        *bytes = (double)n2 * 32.;
+    } else {
+        return rt_fail(ctx, RT_ERR_ARG, "rt_probe: mode %d", mode);
+    }
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
+    RT_HIP(ctx, hipEventSynchronize(ctx->k1));
+    float f = 0.f;
+    RT_HIP(ctx, hipEventElapsedTime(&f, ctx->k0, ctx->k1));
+    *ms = f;
     return RT_OK;
 }
 

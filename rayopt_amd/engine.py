@@ -129,6 +129,13 @@ class Engine:
         self._check(self.lib.rt_set_option(self.ctx, key.encode(), int(value)),
                     "rt_set_option(%s)" % key)
 
+    def probe(self, mode):
+        """(ms, bytes) of a bandwidth probe kernel (rt_probe)."""
+        ms, nbytes = ctypes.c_double(), ctypes.c_double()
+        self._check(self.lib.rt_probe(self.ctx, mode, ctypes.byref(ms),
+                                      ctypes.byref(nbytes)), "rt_probe")
+        return ms.value, nbytes.value
+
     # -- results ----------------------------------------------------------
     def download(self, which, lo, hi):
         """Rows [lo,hi) of one array as a compact SoA host array:

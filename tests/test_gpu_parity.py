@@ -296,3 +296,33 @@ def test_errors_are_loud():
     big = ra.Spheroid(aspherics=[0.]*11, distance=1.)
     with pytest.raises(ValueError):
         pack_system(ra.System([ra.Spheroid(), big]), 5e-7, 1.)
+
+
+def test_rccl_gather_single_rank_pipeline():
+    """rt_comm_* / rt_gather_final with a one-rank communicator: exercises the
+    RCCL load, communicator creation, the staged snapshot pipeline (two
+    steps, so both parities and the event chain are used) and the root's
+    [component][global ray] layout."""
+    from rayopt_amd._lib import RT_Y, RT_T
+    from rayopt_amd.distributed import split_gathered
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = _c3_rays(100003)
+    g = gpu_trace(system, y, u, None, True)
+    eng = g.engine
+    eng.comm_init(eng.comm_unique_id(), 1, 0)
+    counts = np.array([g.nrays], dtype=np.int64)
+    d_dst = eng.scratch(g.nrays*3*8)
+    L = len(system)
+    for step in range(3):
+        eng.trace(1, 0, True)
+        eng.gather_final(RT_Y, L - 1, counts, 0, d_dst)
+    eng.comm_sync()
+    got = eng.copy_to_host(d_dst, g.nrays*3*8)
+    parts = split_gathered(got, counts)
+    assert np.array_equal(parts[0], np.asarray(g.y[-1]), equal_nan=True)
+    eng.gather_final(RT_T, L - 2, counts, 0, d_dst)
+    eng.comm_sync()
+    got = eng.copy_to_host(d_dst, g.nrays*8)
+    assert np.array_equal(got, np.asarray(g.t[-2]), equal_nan=True)
+    with pytest.raises(ra.EngineError):
+        eng.gather_final(RT_Y, L - 1, np.array([5], dtype=np.int64), 0, d_dst)
