@@ -15,8 +15,16 @@ send/recv over xGMI, pipelined against the next step's trace.
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
 
   roofline      achieved/peak HBM GB/s of the trace kernel; achieved =
-                algorithmic bytes N*(80*S + 48) per launch / average launch
-                duration from HIP events on the kernel's own stream
+                algorithmic bytes per launch / average launch duration from
+                HIP events on the kernel's own stream.  Algorithmic bytes:
+                48 B read per ray + per ray-surface op 56 B written (y 24,
+                u 24, t 8) + 24 B for i where it has to be materialised.
+                i[j] is bit-identical to u[j-1] unless element j or j-1 is
+                tilted (rayopt/system.py:461,464), so by default the engine
+                serves those rows of `i` from `u` instead of writing them
+                again; the double-Gauss has no tilted element -> 56 B.
+  full_i        the same timed loop with every row of `i` materialised
+                (rt_set_option alias_i=0): the 80 B/op figure of SURVEY 8(d)
   cpu_baseline  the numpy port of the reference path (oracle/trace_numpy.py,
                 same whole-array numpy operations as rayopt) timed on this
                 host, one core, on a bounded sample of the same workload
@@ -145,18 +153,30 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    eng.event_record(0)
-    for _ in range(args.steps):
-        step()
-    eng.event_record(1)
-    fence()
-    elapsed = time.perf_counter() - t0
-    ev_ms = eng.event_elapsed(0, 1)
-    last_kernel_ms = eng.kernel_ms()
+    def timed_loop():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        eng.event_record(0)
+        for _ in range(args.steps):
+            step()
+        eng.event_record(1)
+        fence()
+        return (time.perf_counter() - t0, eng.event_elapsed(0, 1),
+                eng.kernel_ms())
+
+    full_i = None
+    if not dist_mode and not any(kv.startswith("alias_i")
+                                 for kv in args.option):
+        # reference point: every row of `i` written (80 B per op)
+        eng.set_option("alias_i", 0)
+        eng.upload_system(table)
+        e_full, ev_full, _ = timed_loop()
+        full_i = (e_full, ev_full/args.steps)
+        eng.set_option("alias_i", 1)
+        eng.upload_system(table)
+    elapsed, ev_ms, last_kernel_ms = timed_loop()
     if dist_mode:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -184,12 +204,18 @@ def main():
     total_rays = n*world
     ms_per_step = elapsed*1e3/args.steps
     value = total_rays*S*args.steps/elapsed
-    alg_bytes = n*(80*S + 48)               # per launch (one GPU's shard)
+    from rayopt_amd._lib import F_ROTATED
+    rot = (table["flags"] & F_ROTATED) != 0
+    alias_on = not any(kv == "alias_i=0" for kv in args.option)
+    stored_i = sum(1 for j in range(1, L)
+                   if not alias_on or rot[j] or rot[j - 1])
+    alg_bytes = n*(56*S + 24*stored_i + 48)  # per launch (one GPU's shard)
     kernel_ms = ev_ms/args.steps if not dist_mode else last_kernel_ms
     achieved = alg_bytes/(kernel_ms*1e-3)/1e9
     prof = traffic_from_profile()
     traffic = None
-    if prof and prof.get("rays") == n and prof.get("clip") == clip:
+    if prof and prof.get("rays") == n and prof.get("clip") == clip and \
+            prof.get("alias_i", 0) == int(alias_on):
         traffic = prof.get("hbm_bytes_per_launch")
 
     out = {
@@ -227,11 +253,24 @@ def main():
             "kernel": "rt_trace_kernel",
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
+            "bytes_per_ray_surface_op": (56*S + 24*stored_i)/S,
             "frac_of_achievable_6290": achieved/HBM_ACHIEVABLE_GBS,
         },
     }
 
-    if world == 1 and args.cpu_sample > 0:
+    if full_i is not None:
+        e_full, k_full = full_i
+        b_full = n*(80*S + 48)
+        out["full_i"] = {
+            "value": total_rays*S*args.steps/e_full,
+            "kernel_ms": k_full,
+            "algorithmic_bytes_per_launch": b_full,
+            "achieved": b_full/(k_full*1e-3)/1e9,
+            "frac": b_full/(k_full*1e-3)/1e9/HBM_PEAK_GBS,
+            "note": "every row of i materialised (alias_i=0): 80 B per op",
+        }
+
+    if world == 1 and not dist_mode and args.cpu_sample > 0:
         from oracle import trace_numpy as tn
         m = min(args.cpu_sample, n)
         ys, us = y[:m], u[:m]

@@ -48,6 +48,10 @@ extern "C" {
 #define RT_F_ALT     0x10u /* alternate_intersection (elements.py:497) */
 #define RT_F_REFRACT 0x20u /* mu != 0 and mu != 1: Snell (elements.py:313,356) */
 #define RT_F_MIRROR  0x40u /* mu == -1: reflection (elements.py:363) */
+/* set by the library, not by the caller: row I[j] must be materialised
+ * because element j or j-1 is rotated; otherwise i[j] == u[j-1] bit for bit
+ * (system.py:461,464 with rot None) and I[j] is served from U[j-1] */
+#define RT_F_STORE_I 0x80u
 
 /* which array (rt_download / rt_upload_row / rt_device_ptr) */
 #define RT_Y 0 /* intercepts, element-normal frame, relative to vertex */
@@ -165,7 +169,8 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
 /*
  * Kernel variant selection for A/B measurements (defaults are the tuned
  * ones): key "rays_per_thread" (1,2,4), "nontemporal" (0,1), "xcd_remap"
- * (0,1), "block" (64..1024).
+ * (0,1), "block" (64..1024), "alias_i" (1 = do not write I[j] where it is
+ * identical to U[j-1], the default; 0 = materialise every row of I).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
 /*

@@ -141,7 +141,8 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
             }
             rt_store<R, NT>(Y + (row + c) * ld + j, a);
             rt_store<R, NT>(U + (row + c) * ld + j, b);
-            rt_store<R, NT>(I + (row + c) * ld + j, d);
+            if (flags & RT_F_STORE_I)
+                rt_store<R, NT>(I + (row + c) * ld + j, d);
         }
         rt_store<R, NT>(T + (int64_t)s * ld + j, t);
 
@@ -155,7 +156,8 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
                                    int64_t n, double *__restrict__ Y,
                                    double *__restrict__ U,
                                    double *__restrict__ I,
-                                   double *__restrict__ T, int64_t ld)
+                                   double *__restrict__ T, int64_t ld,
+                                   int store_i)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
@@ -167,7 +169,8 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
         const double b = in ? u_aos[j * 3 + c] : 0.;
         Y[c * ld + j] = a;
         U[c * ld + j] = b;
-        I[c * ld + j] = b;
+        if (store_i)
+            I[c * ld + j] = b;
     }
     T[j] = 0.;
 }
@@ -178,7 +181,8 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
                                    int64_t n, double *__restrict__ Y,
                                    double *__restrict__ U,
                                    double *__restrict__ I,
-                                   double *__restrict__ T, int64_t ld)
+                                   double *__restrict__ T, int64_t ld,
+                                   int store_i)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
@@ -190,7 +194,8 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
         const double b = in ? u_soa[c * n + j] : 0.;
         Y[c * ld + j] = a;
         U[c * ld + j] = b;
-        I[c * ld + j] = b;
+        if (store_i)
+            I[c * ld + j] = b;
     }
     T[j] = 0.;
 }
@@ -236,6 +241,20 @@ __global__ void rt_probe_fill_kernel(double *__restrict__ dst, int64_t n2)
     v2 v = {1., 2.};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
          i += stride)
+        reinterpret_cast<v2 *>(dst)[i] = v;
+}
+
+template <bool NT>
+__global__ void rt_probe_fill_once_kernel(double *__restrict__ dst, int64_t n2)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2)
+        return;
+    v2 v = {1., 2.};
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, reinterpret_cast<v2 *>(dst) + i);
+    else
         reinterpret_cast<v2 *>(dst)[i] = v;
 }
 
@@ -292,7 +311,9 @@ struct rt_ctx {
     size_t user_bytes;
 
     /* kernel variant */
-    int opt_r, opt_nt, opt_xcd, opt_block;
+    int opt_r, opt_nt, opt_xcd, opt_block, opt_alias;
+    /* per row of I: 0 = materialised, 1 = identical to U[j-1], 2 = to U[j] */
+    unsigned char i_alias[RT_MAX_SURFACES];
 
     /* multi GPU */
     ncclComm_t comm;
@@ -345,6 +366,16 @@ static inline double *rt_arr(const rt_ctx *c, int which)
 }
 
 static inline int rt_ncomp(int which) { return which == RT_T ? 1 : 3; }
+
+/* device address of one surface row, resolving the I -> U aliasing */
+static inline double *rt_row(const rt_ctx *c, int which, int surf)
+{
+    if (which == RT_I && c->i_alias[surf]) {
+        const int src = c->i_alias[surf] == 1 ? surf - 1 : surf;
+        return rt_arr(c, RT_U) + (size_t)src * 3 * c->ld;
+    }
+    return rt_arr(c, which) + (size_t)surf * rt_ncomp(which) * c->ld;
+}
 
 template <int R, bool NT, bool XCD>
 static void rt_launch(rt_ctx *c, int start, int stop, int clip)
@@ -401,6 +432,7 @@ int rt_create(int device, rt_ctx **out)
     c->opt_nt = 0;
     c->opt_xcd = 0;
     c->opt_block = 256;
+    c->opt_alias = 1;
 #define RT_HIP_C(call)                                                        \
     do {                                                                      \
         hipError_t e_ = (call);                                               \
@@ -483,6 +515,14 @@ int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf)
      * pageable host copy must be stable until the DMA is done */
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(ctx->h_surf, surf, sizeof(rt_surface) * nsurf);
+    for (int j = 0; j < nsurf; ++j) {
+        const bool rot = (surf[j].flags & RT_F_ROTATED) ||
+                         (j > 0 && (surf[j - 1].flags & RT_F_ROTATED));
+        if (!ctx->opt_alias || rot || j == 0)
+            ctx->h_surf[j].flags |= RT_F_STORE_I;
+        else
+            ctx->h_surf[j].flags &= ~RT_F_STORE_I;
+    }
     RT_HIP(ctx, hipMemcpyAsync(ctx->d_surf, ctx->h_surf,
                                sizeof(rt_surface) * nsurf,
                                hipMemcpyHostToDevice, ctx->stream));
@@ -524,6 +564,7 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     ctx->ld = ld;
     ctx->buf_nsurf = ctx->nsurf;
     ctx->traced = 0;
+    memset(ctx->i_alias, 0, sizeof ctx->i_alias);
     return RT_OK;
 }
 
@@ -559,11 +600,14 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
            *I = rt_arr(ctx, RT_I), *T = rt_arr(ctx, RT_T);
     if (layout == RT_LAYOUT_AOS)
         hipLaunchKernelGGL(rt_seed_aos_kernel, dim3(grid), dim3(block), 0,
-                           ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld);
+                           ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld,
+                           !ctx->opt_alias);
     else
         hipLaunchKernelGGL(rt_seed_soa_kernel, dim3(grid), dim3(block), 0,
-                           ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld);
+                           ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld,
+                           !ctx->opt_alias);
     RT_HIP(ctx, hipGetLastError());
+    ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
     return RT_OK;
 }
 
@@ -614,7 +658,9 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
         return rt_fail(ctx, RT_ERR_STATE, "rt_upload_row: no such row %d",
                        surf);
     const int nc = rt_ncomp(which);
-    double *dst = rt_arr(ctx, which) + (size_t)surf * nc * ctx->ld;
+    if (which == RT_I)
+        ctx->i_alias[surf] = 0; /* now holds its own data */
+    double *dst = rt_row(ctx, which, surf);
     RT_HIP(ctx, hipMemcpy2DAsync(dst, ctx->ld * sizeof(double), src_soa,
                                  ctx->n * sizeof(double),
                                  ctx->n * sizeof(double), nc,
@@ -659,6 +705,9 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
         RT_HIP(ctx, hipGetLastError());
     }
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
+    for (int sidx = start; sidx < stop; ++sidx)
+        ctx->i_alias[sidx] =
+            (ctx->h_surf[sidx].flags & RT_F_STORE_I) ? 0 : 1;
     ctx->traced = 1;
     return RT_OK;
 }
@@ -715,6 +764,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         ctx->opt_nt = value ? 1 : 0;
     } else if (!strcmp(key, "xcd_remap")) {
         ctx->opt_xcd = value ? 1 : 0;
+    } else if (!strcmp(key, "alias_i")) {
+        ctx->opt_alias = value ? 1 : 0;
     } else if (!strcmp(key, "block")) {
         if (value < 64 || value > 1024 || value % 64)
             return rt_fail(ctx, RT_ERR_ARG, "block must be k*64 in [64,1024]");
@@ -756,6 +807,23 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
             total += (double)n2 * 16.;
         }
         *bytes = total;
+    } else if (mode == 3 || mode == 4) {
+        double total = 0.;
+        for (int w = RT_Y; w <= RT_T; ++w) {
+            const int nc = rt_ncomp(w);
+            const int64_t n2 = (int64_t)(L - 1) * nc * ld / 2;
+            const unsigned grid = (unsigned)((n2 + 255) / 256);
+            if (mode == 3)
+                hipLaunchKernelGGL(rt_probe_fill_once_kernel<false>,
+                                   dim3(grid), dim3(256), 0, ctx->stream,
+                                   rt_arr(ctx, w) + (size_t)nc * ld, n2);
+            else
+                hipLaunchKernelGGL(rt_probe_fill_once_kernel<true>,
+                                   dim3(grid), dim3(256), 0, ctx->stream,
+                                   rt_arr(ctx, w) + (size_t)nc * ld, n2);
+            total += (double)n2 * 16.;
+        }
+        *bytes = total;
     } else if (mode == 2) {
         /* copy rows 1..h of Y -> rows 1..h of U, h = L-1: read + write */
         const int64_t n2 = (int64_t)(L - 1) * 3 * ld / 2;
@@ -784,13 +852,22 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
         return rt_fail(ctx, RT_ERR_STATE, "rt_download: rows [%d,%d) of %d",
                        surf_lo, surf_hi, ctx->buf_nsurf);
     const int nc = rt_ncomp(which);
-    const double *src = rt_arr(ctx, which) + (size_t)surf_lo * nc * ctx->ld;
-    const size_t rows = (size_t)(surf_hi - surf_lo) * nc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipMemcpy2DAsync(dst, ctx->n * sizeof(double), src,
-                                 ctx->ld * sizeof(double),
-                                 ctx->n * sizeof(double), rows,
-                                 hipMemcpyDeviceToHost, ctx->stream));
+    if (which != RT_I) {
+        const double *src = rt_row(ctx, which, surf_lo);
+        const size_t rows = (size_t)(surf_hi - surf_lo) * nc;
+        RT_HIP(ctx, hipMemcpy2DAsync(dst, ctx->n * sizeof(double), src,
+                                     ctx->ld * sizeof(double),
+                                     ctx->n * sizeof(double), rows,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        for (int j = surf_lo; j < surf_hi; ++j)
+            RT_HIP(ctx, hipMemcpy2DAsync(
+                            dst + (size_t)(j - surf_lo) * nc * ctx->n,
+                            ctx->n * sizeof(double), rt_row(ctx, which, j),
+                            ctx->ld * sizeof(double), ctx->n * sizeof(double),
+                            nc, hipMemcpyDeviceToHost, ctx->stream));
+    }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -801,7 +878,7 @@ int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
         return rt_fail(ctx, RT_ERR_ARG, "rt_device_ptr: bad argument");
     if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
         return rt_fail(ctx, RT_ERR_STATE, "rt_device_ptr: no such row %d", surf);
-    *out = rt_arr(ctx, which) + (size_t)surf * rt_ncomp(which) * ctx->ld;
+    *out = rt_row(ctx, which, surf);
     return RT_OK;
 }
 
@@ -958,7 +1035,7 @@ int rt_gather_final(rt_ctx *ctx, int which, int surf, const int64_t *counts,
      * snapshot of step k+2 must wait for the gather of step k. */
     if (ctx->gather_pending[p])
         RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gathered[p], 0));
-    const double *src = rt_arr(ctx, which) + (size_t)surf * nc * ctx->ld;
+    const double *src = rt_row(ctx, which, surf);
     RT_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage[p], ctx->n * sizeof(double), src,
                                  ctx->ld * sizeof(double),
                                  ctx->n * sizeof(double), nc,

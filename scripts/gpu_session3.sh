@@ -1,0 +1,27 @@
+#!/bin/bash
+# tests + probes + bench + kernel-trace stats + FETCH/WRITE PMC
+set -u
+TAG=${1:-r01c}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$REPO"
+timeout 1200 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+echo "pytest rc=$?" | tee -a "$OUT/summary.txt"; tail -3 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"
+timeout 300 python scripts/probe.py > "$OUT/probe.json" 2> "$OUT/probe.err"
+echo "probe rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/probe.json" | tee -a "$OUT/summary.txt"
+timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+echo "bench rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench.json" | tee -a "$OUT/summary.txt"
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- \
+    python "$REPO/bench.py" --steps 10 --warmup 2 --cpu-sample 0 > "$OUT/prof_stats.log" 2>&1
+echo "rocprof stats rc=$?" | tee -a "$OUT/summary.txt"
+find "$OUT/prof_stats" -name "*kernel_stats*.csv" | head -1 | xargs -r head -8 | tee -a "$OUT/summary.txt"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/prof_pmc_$c" -- \
+      python "$REPO/bench.py" --steps 3 --warmup 1 --cpu-sample 0 --option alias_i=1 > "$OUT/prof_pmc_$c.log" 2>&1
+  echo "rocprof pmc $c rc=$?" | tee -a "$OUT/summary.txt"
+done
+cd "$REPO"
+python scripts/pmc_traffic.py "$OUT" 2>&1 | tee -a "$OUT/summary.txt"
+du -sh "$OUT"

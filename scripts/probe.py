@@ -27,9 +27,20 @@ def main():
     for rep in range(10):
         g.propagate(clip=True)
         ms.append(eng.kernel_ms())
+    alg = n*(56*12 + 48)
+    res["trace_alias_i"] = dict(ms=float(np.median(ms)),
+                                GBs=alg/np.median(ms)/1e6)
+    eng.set_option("alias_i", 0)
+    ms = []
+    for rep in range(10):
+        g.propagate(clip=True)
+        ms.append(eng.kernel_ms())
     alg = n*(80*12 + 48)
-    res["trace"] = dict(ms=float(np.median(ms)), GBs=alg/np.median(ms)/1e6)
-    for mode, name in ((0, "store_pattern"), (1, "linear_fill"), (2, "copy")):
+    res["trace_full_i"] = dict(ms=float(np.median(ms)),
+                               GBs=alg/np.median(ms)/1e6)
+    for mode, name in ((0, "store_pattern_80B"), (1, "linear_fill"),
+                       (3, "fill_one_store_per_lane"),
+                       (4, "fill_one_store_per_lane_nt"), (2, "copy")):
         t = []
         for rep in range(8):
             m, b = eng.probe(mode)

@@ -63,6 +63,7 @@ def test_matches_reference_golden(name):
 @pytest.mark.parametrize("options", [
     dict(rays_per_thread=1), dict(rays_per_thread=4),
     dict(nontemporal=1), dict(xcd_remap=1), dict(block=64), dict(block=512),
+    dict(alias_i=0),
     dict(rays_per_thread=4, nontemporal=1, xcd_remap=1, block=128)])
 @pytest.mark.parametrize("key", ["double_gauss", "asphere_phone", "torture"])
 def test_kernel_variants_are_bit_identical(key, options):
@@ -326,3 +327,21 @@ def test_rccl_gather_single_rank_pipeline():
     assert np.array_equal(got, np.asarray(g.t[-2]), equal_nan=True)
     with pytest.raises(ra.EngineError):
         eng.gather_final(RT_Y, L - 1, np.array([5], dtype=np.int64), 0, d_dst)
+
+
+def test_i_rows_alias_u_only_where_identical():
+    """i[j] is served from u[j-1] when neither element is tilted; the
+    device pointers show which rows were materialised."""
+    from rayopt_amd._lib import RT_U, RT_I
+    system = ra.system_from_yaml(P.TORTURE)   # rotated: 1,2,3,5,6,7,8
+    y, u = disc_bundle(4096, 9., 2., 5)
+    g = gpu_trace(system, y, u, None, True)
+    eng = g.engine
+    rotated = [bool(e.rotated) for e in system]
+    for j in range(1, len(system)):
+        aliased = eng.device_ptr(RT_I, j) == eng.device_ptr(RT_U, j - 1)
+        assert aliased == (not rotated[j] and not rotated[j - 1]), j
+    assert eng.device_ptr(RT_I, 0) == eng.device_ptr(RT_U, 0)
+    full = gpu_trace(system, y, u, None, True, alias_i=0)
+    assert full.engine.device_ptr(RT_I, 4) != full.engine.device_ptr(RT_U, 3)
+    assert np.array_equal(np.asarray(g.i), np.asarray(full.i), equal_nan=True)
