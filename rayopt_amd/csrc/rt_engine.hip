@@ -94,36 +94,43 @@ __device__ __forceinline__ int64_t rt_chunk(int64_t nblocks)
     return c; /* may be >= nblocks for the ragged tail: caller checks */
 }
 
-template <int R, bool NT, bool XCD>
-__global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
-                                int stop, int clip, double *__restrict__ Y,
-                                double *__restrict__ U, double *__restrict__ I,
-                                double *__restrict__ T, int64_t ld,
-                                int64_t nblocks)
+/* read rows start-1 of Y,U for the R rays at offset j */
+template <int R>
+__device__ __forceinline__ void rt_load_state(const double *__restrict__ Y,
+                                              const double *__restrict__ U,
+                                              int64_t row, int64_t ld,
+                                              int64_t j, double (&y)[R][3],
+                                              double (&u)[R][3])
 {
-    const int64_t chunk = rt_chunk<XCD>(nblocks);
-    const int64_t j = (chunk * blockDim.x + threadIdx.x) * R;
-    if (j >= ld)
-        return;
-
-    double y[R][3], u[R][3], iv[R][3], t[R];
-    {
-        const int64_t row = (int64_t)(start - 1) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double a[R], b[R];
-            rt_load<R>(Y + (row + c) * ld + j, a);
-            rt_load<R>(U + (row + c) * ld + j, b);
+    for (int c = 0; c < 3; ++c) {
+        double a[R], b[R];
+        rt_load<R>(Y + (row + c) * ld + j, a);
+        rt_load<R>(U + (row + c) * ld + j, b);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                y[r][c] = a[r];
-                u[r][c] = b[r];
-            }
+        for (int r = 0; r < R; ++r) {
+            y[r][c] = a[r];
+            u[r][c] = b[r];
         }
+    }
+}
+
+/* all elements start..stop-1 for the R rays of this lane; state in VGPRs */
+template <int R, bool NT>
+__device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
+                                         int start, int stop, int clip,
+                                         double *__restrict__ Y,
+                                         double *__restrict__ U,
+                                         double *__restrict__ I,
+                                         double *__restrict__ T, int64_t ld,
+                                         int64_t j, double (&y)[R][3],
+                                         double (&u)[R][3])
+{
+    double iv[R][3], t[R];
+    {
         const rt_surface *S0 = surf + (start - 1);
         rt_leave<R>(S0, S0->flags, y, u);
     }
-
     for (int s = start; s < stop; ++s) {
         const rt_surface *S = surf + s;
         const unsigned flags = S->flags;
@@ -148,6 +155,22 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
 
         rt_leave<R>(S, flags, y, u);
     }
+}
+
+template <int R, bool NT, bool XCD>
+__global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
+                                int stop, int clip, double *__restrict__ Y,
+                                double *__restrict__ U, double *__restrict__ I,
+                                double *__restrict__ T, int64_t ld,
+                                int64_t nblocks)
+{
+    const int64_t chunk = rt_chunk<XCD>(nblocks);
+    const int64_t j = (chunk * blockDim.x + threadIdx.x) * R;
+    if (j >= ld)
+        return;
+    double y[R][3], u[R][3];
+    rt_load_state<R>(Y, U, (int64_t)(start - 1) * 3, ld, j, y, u);
+    rt_march<R, NT>(surf, start, stop, clip, Y, U, I, T, ld, j, y, u);
 }
 
 /* rays_given: AoS (n,3) staging -> SoA row 0 of Y,U,I and T[0] = 0 */
@@ -428,7 +451,7 @@ int rt_create(int device, rt_ctx **out)
     if (!c)
         return rt_fail(NULL, RT_ERR_NOMEM, "rt_create: host allocation");
     c->device = device;
-    c->opt_r = 2;
+    c->opt_r = 1;
     c->opt_nt = 0;
     c->opt_xcd = 0;
     c->opt_block = 256;
