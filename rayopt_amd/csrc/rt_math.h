@@ -72,16 +72,24 @@ RT_HD void rt_rot_from(const double *__restrict__ r, double (&v)[3])
     v[2] = (a * r[2] + b * r[5]) + c * r[8];
 }
 
+/*
+ * sqrt(1 - (1+k) c^2 r^2): the one square root surface_sag (:451) and
+ * surface_normal (:468) both evaluate at the same point; computed once per
+ * point and handed to both (identical bits, half the sqrt sequences).
+ */
+RT_HD double rt_conic_root(const rt_surface *__restrict__ S, unsigned flags,
+                           double r2)
+{
+    return (flags & RT_F_CURVED) ? sqrt(1. - S->kc2 * r2) : 1.;
+}
+
 /* Spheroid.surface_sag(p) residual, elements.py:440-455 */
 RT_HD double rt_sag(const rt_surface *__restrict__ S, unsigned flags,
-                    double px, double py, double pz)
+                    double r2, double pz, double root)
 {
     double e = pz;
-    if (!(flags & (RT_F_CURVED | RT_F_ASPH)))
-        return e;
-    const double r2 = px * px + py * py;
     if (flags & RT_F_CURVED)
-        e -= (S->c * r2) / (1. + sqrt(1. - S->kc2 * r2));
+        e -= (S->c * r2) / (1. + root);
     if (flags & RT_F_ASPH) {
         double d = 0.;
         for (int i = S->nasph - 1; i >= 0; --i) {
@@ -95,11 +103,11 @@ RT_HD double rt_sag(const rt_surface *__restrict__ S, unsigned flags,
 
 /* x,y scale factor e of Spheroid.surface_normal, q = (x e, y e, 1), :457-475 */
 RT_HD double rt_normal_e(const rt_surface *__restrict__ S, unsigned flags,
-                         double r2)
+                         double r2, double root)
 {
     double e = 0.;
     if (flags & RT_F_CURVED)
-        e -= S->c / sqrt(1. - S->kc2 * r2);
+        e -= S->c / root;
     if (flags & RT_F_ASPH) {
         double d = 0.;
         for (int i = S->nasph - 1; i >= 0; --i) {
@@ -145,6 +153,7 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
         live[r] = true;
         any = true;
     }
+#pragma unroll 1
     for (int itr = 0; itr < 5; ++itr) {
         if (!RT_WAVE_ANY(any))
             break;
@@ -156,14 +165,15 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
             const double px = y[r][0] + s[r] * u[r][0];
             const double py = y[r][1] + s[r] * u[r][1];
             const double pz = y[r][2] + s[r] * u[r][2];
-            const double fval = rt_sag(S, flags, px, py, pz);
+            const double r2 = px * px + py * py;
+            const double root = rt_conic_root(S, flags, r2);
+            const double fval = rt_sag(S, flags, r2, pz, root);
             if (fval == 0.) {
                 res[r] = s[r];
                 live[r] = false;
                 continue;
             }
-            const double r2 = px * px + py * py;
-            const double e = rt_normal_e(S, flags, r2);
+            const double e = rt_normal_e(S, flags, r2, root);
             const double fder =
                 ((px * e) * u[r][0] + (py * e) * u[r][1]) + 1. * u[r][2];
             if (fder == 0.) {
@@ -270,7 +280,8 @@ RT_HD void rt_step(const rt_surface *__restrict__ S, unsigned flags, int clip,
             /* Spencer & Murty; q = (x e, y e, 1) un-normalised normal */
             double qx, qy;
             if (flags & (RT_F_CURVED | RT_F_ASPH)) {
-                const double e = rt_normal_e(S, flags, rxy);
+                const double e = rt_normal_e(S, flags, rxy,
+                                             rt_conic_root(S, flags, rxy));
                 qx = y[r][0] * e;
                 qy = y[r][1] * e;
             } else {

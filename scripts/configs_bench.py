@@ -1,0 +1,59 @@
+"""Kernel time of every BASELINE.json config on one GPU (documentation table;
+the headline bench line is bench.py).  Prints one JSON object per config."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rayopt_amd as ra
+from rayopt_amd import prescriptions as P
+from rayopt_amd._lib import F_ROTATED
+from rayopt_amd.bundles import disc_bundle, multi_field_bundle
+from rayopt_amd.pack import pack_system
+
+
+def run(name, system, y, u, l, clip, reps=8):
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u, l)
+    ms = []
+    for k in range(reps + 2):
+        g.propagate(clip=clip)
+        ms.append(g.kernel_ms())
+    ms = float(np.median(ms[2:]))
+    n, S = y.shape[0], len(system) - 1
+    table, _ = pack_system(system, g.l, g.n[0])
+    rot = (table["flags"] & F_ROTATED) != 0
+    stored_i = sum(1 for j in range(1, S + 1) if rot[j] or rot[j - 1])
+    nbytes = n*(56*S + 24*stored_i + 48)
+    dead = float(np.isnan(np.asarray(g.u[-1])[:, 0]).mean())
+    print(json.dumps(dict(config=name, rays=n, surfaces=S, clip=clip,
+                          kernel_ms=ms, ops_per_s=n*S/ms*1e3,
+                          GBs=nbytes/ms/1e6, dead_fraction=dead)), flush=True)
+
+
+def main():
+    s = ra.system_from_yaml(P.SINGLET)
+    run("C1 singlet 1e4", s, *disc_bundle(10**4, 8., 0., 0), None, True)
+    for l in (587.56e-9, 656.27e-9, 486.13e-9):
+        s = ra.system_from_yaml(P.cooke(l))
+        run("C2 cooke 1e6 l=%.0fnm" % (l*1e9), s,
+            *disc_bundle(10**6, 5.5, 5., 0), l, True)
+    s = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    th = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in (0, .35, .5, .7, 1.)]
+    y, u = multi_field_bundle(10**7, 17., th, 0, P.DOUBLE_GAUSS_PUPIL_Z)
+    run("C3 double-gauss 1e7 clip", s, y, u, None, True)
+    run("C3 double-gauss 1e7 noclip", s, y, u, None, False)
+    s = ra.system_from_yaml(P.ASPHERE_PHONE)
+    for deg in (0., 17.5):
+        y, u = disc_bundle(10**7, 0.6, deg, 3)
+        y[:, 1] -= 0.5*np.tan(np.radians(deg))
+        run("C4 asphere 1e7 field %.1f deg" % deg, s, y, u, None, True)
+    s = ra.system_from_yaml(P.TORTURE)
+    run("torture (tilts, conics, mirror) 1e7", s, *disc_bundle(10**7, 9., 2., 1),
+        None, True)
+
+
+if __name__ == "__main__":
+    main()
