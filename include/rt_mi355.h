@@ -190,6 +190,46 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes);
  */
 int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst);
 
+/* all surfaces of ONE ray: dst[L][ncomp] (print_trace, reference-ray terms) */
+int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst);
+
+/*
+ * Device-side consumers of the result arrays: the
+ * O(N) reductions GeometricTrace offers on top of a trace, so that only a few
+ * scalars (or 24 B/ray for opd) cross PCIe instead of whole rows.
+ *
+ * rt_set_weights: GeometricTrace.w (geometric_trace.py:57-59); NULL = 1/N.
+ * rt_rms:     GeometricTrace.rms(i, ref) (:171-183): sqrt(sum_k w_k |y_k -
+ *             y0|^2) over x,y of row `surf`; ref < 0: y0 = unweighted mean.
+ * rt_refocus_shift: the least-squares focus shift of refocus(at) (:82-97):
+ *             u = i_xy/i_z, rays with finite u, centred y and u,
+ *             t = -<w y, u>/<w u, u>.  Does not touch the system.
+ * rt_opd_rays: per-ray part of GeometricTrace.opd (:101-131, the rows the
+ *             reference returns for resample=0): out[3][n] = (x, y, t) on the
+ *             reference sphere, t in waves.
+ */
+int rt_set_weights(rt_ctx *ctx, const double *w);
+int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms);
+int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift);
+
+typedef struct rt_opd_args {
+    int32_t nrows;      /* t rows 0..nrows-1 are summed (t[:after + 1]) */
+    int32_t after;      /* element in front of the reference sphere */
+    int32_t image;      /* image element */
+    int32_t finite;     /* system.object.finite */
+    int32_t rot_after;  /* element `after` is rotated: apply r_after */
+    int32_t rot_image;  /* element `image` is rotated: apply r_image */
+    int64_t ref;        /* reference ray index */
+    double n0, n_after; /* n[0], n[after] */
+    double radius;      /* reference sphere radius */
+    double lscale;      /* l / system.scale */
+    double shift[3];    /* origins[after] - origins[image] */
+    double r_after[9];  /* rot_normal of element after (from_normal) */
+    double r_image[9];  /* rot_normal of element image (to_normal) */
+} rt_opd_args;
+int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa);
+int rt_sizeof_opd_args(void);
+
 /* raw device pointer to row `surf` of an array (interop, collectives) */
 int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out);
 

@@ -1,0 +1,83 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the consumers of a trace.
+
+numpy restatements of the O(N) post-processing GeometricTrace offers on the
+result arrays (quartiq/rayopt), used to check the device-side reductions
+``rt_rms``, ``rt_refocus_shift`` and ``rt_opd_rays``.  Same whole-array numpy
+operations as the reference; pinned against the unmodified reference by the
+``consumers_*.npz`` goldens (tests/golden/make_golden.py) and, when
+/root/reference is present, live (tests/test_consumers.py).  Never imported
+by the product.
+"""
+import numpy as np
+
+
+def rms(y_row, w=None, ref=None):
+    """GeometricTrace.rms (rayopt/geometric_trace.py:171-183); ``y_row`` is
+    ``trace.y[i]`` (N,3)."""
+    y = y_row[:, :2]
+    y0 = y.mean(0) if ref is None else y[ref]
+    r = np.square(y - y0).sum(1)
+    if w is None:
+        w = np.ones_like(r)/r.shape[0]
+    return np.sqrt((r*w).sum())
+
+
+def refocus_shift(y_row, i_row, w=None):
+    """The shift ``t`` GeometricTrace.refocus adds to ``system[at].distance``
+    (rayopt/geometric_trace.py:82-97)."""
+    y = y_row[:, :2]
+    u = i_row[:, :2]/i_row[:, 2:]          # tanarcsin, rayopt/utils.py:47-50
+    good = np.all(np.isfinite(u), axis=1)
+    y, u = y[good], u[good]
+    w = w[good] if w is not None else np.ones(y.shape[0])
+    y = y - y.mean(0)
+    u = u - u.mean(0)
+    wy = (w[:, None]*y).ravel()
+    wu = (w[:, None]*u).ravel()
+    u = u.ravel()
+    return -np.dot(wy, u)/np.dot(wu, u)
+
+
+def sphere_intercept(curvature, y, u):
+    """Spheroid(curvature=c).intercept, k=0 (rayopt/elements.py:477-501)."""
+    c = curvature
+    if c == 0:
+        return -y[:, 2]/u[:, 2]
+    uy = (u*y).sum(1)
+    yy = np.square(y).sum(1)
+    d = c*uy - u[:, 2]
+    e = c*1.
+    f = c*yy - 2*y[:, 2]
+    g = np.sqrt(np.square(d) - e*f)
+    return -(d + g)/e
+
+
+def opd_rays(Y, U, T, n, ref, origins, frames, finite, radius, lscale,
+             after=-2, image=-1):
+    """GeometricTrace.opd up to (not including) the resampling
+    (rayopt/geometric_trace.py:101-131).  ``Y,U`` (L,N,3), ``T`` (L,N), ``n``
+    (L,), ``frames[j]`` = rot_normal of element j or None, ``lscale`` =
+    l/system.scale.  Returns x, y, t per ray."""
+    def from_normal(j, v):
+        return v if frames[j] is None else np.dot(v, frames[j])
+
+    def to_normal(j, v):
+        return v if frames[j] is None else np.dot(v, frames[j].T)
+
+    t = (T[:after + 1] - T[:after + 1, (ref,)]).sum(0)
+    if not finite:
+        tj = np.dot(U[0, ref], (Y[0, ref] - Y[0]).T)
+        t -= tj*n[0]
+    y = from_normal(after, Y[after])
+    y = y + (origins[after] - origins[image])
+    y = to_normal(image, y) - Y[image, ref]
+    u = to_normal(image, from_normal(after, U[after]))
+    y[:, 2] += radius
+    ti = sphere_intercept(1./radius, y, u)
+    t += (ti - ti[ref])*n[after]
+    t = -t/lscale
+    py = y + ti[:, None]*u
+    py[:, 2] -= radius
+    py -= py[ref]
+    x, yy, z = py.T
+    return x, yy, t

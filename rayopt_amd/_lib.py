@@ -29,6 +29,13 @@ SURFACE_DTYPE = np.dtype([
     ("nasph", "i4"), ("flags", "u4"),
 ], align=True)
 
+OPD_ARGS_DTYPE = np.dtype([
+    ("nrows", "i4"), ("after", "i4"), ("image", "i4"), ("finite", "i4"),
+    ("rot_after", "i4"), ("rot_image", "i4"), ("ref", "i8"),
+    ("n0", "f8"), ("n_after", "f8"), ("radius", "f8"), ("lscale", "f8"),
+    ("shift", "f8", (3,)), ("r_after", "f8", (9,)), ("r_image", "f8", (9,)),
+], align=True)
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
                         "librt_mi355.so")
 
@@ -40,6 +47,7 @@ _ctx = ctypes.c_void_p
 SIGNATURES = {
     "rt_abi_version": (ctypes.c_int, []),
     "rt_sizeof_surface": (ctypes.c_int, []),
+    "rt_sizeof_opd_args": (ctypes.c_int, []),
     "rt_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "rt_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_ctx)]),
     "rt_destroy": (ctypes.c_int, [_ctx]),
@@ -67,6 +75,13 @@ SIGNATURES = {
     "rt_probe": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p, _c_double_p]),
     "rt_download": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_void_p]),
+    "rt_download_ray": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,
+                                       ctypes.c_void_p]),
+    "rt_set_weights": (ctypes.c_int, [_ctx, ctypes.c_void_p]),
+    "rt_rms": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,
+                              _c_double_p]),
+    "rt_refocus_shift": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p]),
+    "rt_opd_rays": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p]),
     "rt_device_ptr": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_void_p)]),
     "rt_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
@@ -108,5 +123,7 @@ def load():
         raise EngineError("struct rt_surface is %d bytes in the library but "
                           "%d in SURFACE_DTYPE" % (lib.rt_sizeof_surface(),
                                                    SURFACE_DTYPE.itemsize))
+    if lib.rt_sizeof_opd_args() != OPD_ARGS_DTYPE.itemsize:
+        raise EngineError("struct rt_opd_args layout mismatch")
     _lib = lib
     return lib

@@ -291,6 +291,211 @@ __global__ void rt_probe_copy_kernel(const double *__restrict__ src,
         reinterpret_cast<v2 *>(dst)[i] = reinterpret_cast<const v2 *>(src)[i];
 }
 
+
+/* ------------------------------------------------------------------ */
+/* device-side consumers: rms, refocus sums, opd rays                 */
+/* ------------------------------------------------------------------ */
+
+#define RT_RED_BLOCKS 1024
+#define RT_RED_THREADS 256
+
+/* deterministic two-level sum of K accumulators: wave shuffle -> LDS ->
+ * one partial per workgroup; the host adds the RT_RED_BLOCKS partials in
+ * index order (no atomics, run-to-run identical) */
+template <int K>
+__device__ __forceinline__ void rt_block_reduce(double (&acc)[K],
+                                                double *__restrict__ partials)
+{
+    __shared__ double sm[RT_RED_THREADS / 64][K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        for (int off = 32; off > 0; off >>= 1)
+            acc[k] += __shfl_down(acc[k], off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            sm[wave][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double v = sm[0][k];
+            for (int w = 1; w < RT_RED_THREADS / 64; ++w)
+                v += sm[w][k];
+            partials[(int64_t)blockIdx.x * K + k] = v;
+        }
+}
+
+/* sum of x and y of one row (rms: y.mean(0)) */
+__global__ void rt_sum_xy_kernel(const double *__restrict__ Yrow, int64_t n,
+                                 int64_t ld, double *__restrict__ partials)
+{
+    double acc[2] = {0., 0.};
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        acc[0] += Yrow[j];
+        acc[1] += Yrow[ld + j];
+    }
+    rt_block_reduce<2>(acc, partials);
+}
+
+/* sum_k w_k ((x-x0)^2 + (y-y0)^2) */
+__global__ void rt_rms_kernel(const double *__restrict__ Yrow,
+                              const double *__restrict__ w, double wconst,
+                              double x0, double y0, int64_t n, int64_t ld,
+                              double *__restrict__ partials)
+{
+    double acc[1] = {0.};
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        const double dx = Yrow[j] - x0, dy = Yrow[ld + j] - y0;
+        const double r = dx * dx + dy * dy;
+        acc[0] += r * (w ? w[j] : wconst);
+    }
+    rt_block_reduce<1>(acc, partials);
+}
+
+/* refocus pass A: over rays with finite u = i_xy/i_z: count, sum y, sum u */
+__global__ void rt_refocus_sums_kernel(const double *__restrict__ Yrow,
+                                       const double *__restrict__ Irow,
+                                       int64_t n, int64_t ld,
+                                       double *__restrict__ partials)
+{
+    double acc[5] = {0., 0., 0., 0., 0.};
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        const double iz = Irow[2 * ld + j];
+        const double ux = Irow[j] / iz, uy = Irow[ld + j] / iz;
+        if (isfinite(ux) && isfinite(uy)) {
+            acc[0] += 1.;
+            acc[1] += Yrow[j];
+            acc[2] += Yrow[ld + j];
+            acc[3] += ux;
+            acc[4] += uy;
+        }
+    }
+    rt_block_reduce<5>(acc, partials);
+}
+
+/* refocus pass B: <w yc, uc> and <w uc, uc> with centred y, u */
+__global__ void rt_refocus_dots_kernel(const double *__restrict__ Yrow,
+                                       const double *__restrict__ Irow,
+                                       const double *__restrict__ w,
+                                       double wconst, double my0, double my1,
+                                       double mu0, double mu1, int64_t n,
+                                       int64_t ld,
+                                       double *__restrict__ partials)
+{
+    double acc[2] = {0., 0.};
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        const double iz = Irow[2 * ld + j];
+        const double ux = Irow[j] / iz, uy = Irow[ld + j] / iz;
+        if (isfinite(ux) && isfinite(uy)) {
+            const double wk = w ? w[j] : wconst;
+            const double y0 = Yrow[j] - my0, y1 = Yrow[ld + j] - my1;
+            const double u0 = ux - mu0, u1 = uy - mu1;
+            acc[0] += (wk * y0) * u0 + (wk * y1) * u1;
+            acc[1] += (wk * u0) * u0 + (wk * u1) * u1;
+        }
+    }
+    rt_block_reduce<2>(acc, partials);
+}
+
+/* reference-ray columns the opd kernel needs, all wave-uniform */
+struct rt_opd_ref {
+    double t[RT_MAX_SURFACES]; /* T[row][ref] */
+    double y0[3], u0[3];       /* Y[0][ref], U[0][ref] */
+    double ya[3], ua[3];       /* Y[after][ref], U[after][ref] */
+    double yi[3];              /* Y[image][ref] */
+};
+
+/* transform + reference-sphere intercept of one ray (opd, :118-131) */
+__device__ __forceinline__ void rt_opd_point(const rt_opd_args &a,
+                                             const double (&yi_ref)[3],
+                                             double (&y)[3], double (&u)[3],
+                                             double &ti, double (&py)[3])
+{
+    if (a.rot_after) { /* ea.from_normal */
+        rt_rot_from(a.r_after, y);
+        rt_rot_from(a.r_after, u);
+    }
+    y[0] = y[0] + a.shift[0];
+    y[1] = y[1] + a.shift[1];
+    y[2] = y[2] + a.shift[2];
+    if (a.rot_image) { /* ei.to_normal */
+        rt_rot_to(a.r_image, y);
+        rt_rot_to(a.r_image, u);
+    }
+    y[0] -= yi_ref[0];
+    y[1] -= yi_ref[1];
+    y[2] -= yi_ref[2];
+    y[2] += a.radius;
+    /* Spheroid(curvature=1/radius).intercept(y, u), elements.py:477-501 */
+    const double c = 1. / a.radius;
+    if (c == 0.) {
+        ti = -y[2] / u[2];
+    } else {
+        const double uy = (u[0] * y[0] + u[1] * y[1]) + u[2] * y[2];
+        const double yy = (y[0] * y[0] + y[1] * y[1]) + y[2] * y[2];
+        const double d = c * uy - u[2];
+        const double e = c * 1.;
+        const double f = c * yy - 2. * y[2];
+        const double g = sqrt(d * d - e * f);
+        ti = -(d + g) / e;
+    }
+    py[0] = y[0] + ti * u[0];
+    py[1] = y[1] + ti * u[1];
+    py[2] = y[2] + ti * u[2];
+    py[2] -= a.radius;
+}
+
+__global__ void rt_opd_kernel(rt_opd_args a, const rt_opd_ref *__restrict__ ref,
+                              const double *__restrict__ Y,
+                              const double *__restrict__ U,
+                              const double *__restrict__ T, int64_t n,
+                              int64_t ld, double *__restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    /* t = (t[:after+1] - t[:after+1, ref]).sum(0): row by row */
+    double t = 0.;
+    for (int s = 0; s < a.nrows; ++s) {
+        const double d = T[(int64_t)s * ld + j] - ref->t[s];
+        t = s ? t + d : d;
+    }
+    if (!a.finite) { /* input reference sphere is a tilted plane (:104-109) */
+        const double tj =
+            (ref->u0[0] * (ref->y0[0] - Y[j]) +
+             ref->u0[1] * (ref->y0[1] - Y[ld + j])) +
+            ref->u0[2] * (ref->y0[2] - Y[2 * ld + j]);
+        t -= tj * a.n0;
+    }
+    double y[3], u[3], py[3], ti;
+    const int64_t ra = (int64_t)a.after * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        y[c] = Y[(ra + c) * ld + j];
+        u[c] = U[(ra + c) * ld + j];
+    }
+    rt_opd_point(a, ref->yi, y, u, ti, py);
+    /* the same for the reference ray (uniform; every lane recomputes it) */
+    double yr[3], ur[3], pr[3], tr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        yr[c] = ref->ya[c];
+        ur[c] = ref->ua[c];
+    }
+    rt_opd_point(a, ref->yi, yr, ur, tr, pr);
+    t += (ti - tr) * a.n_after;
+    t = -t / a.lscale;
+    out[j] = py[0] - pr[0];
+    out[n + j] = py[1] - pr[1];
+    out[2 * n + j] = t;
+}
+
 /* ------------------------------------------------------------------ */
 /* context                                                            */
 /* ------------------------------------------------------------------ */
@@ -332,6 +537,10 @@ struct rt_ctx {
     size_t scratch_bytes;
     void *d_user; /* rt_scratch */
     size_t user_bytes;
+    double *d_w;  /* ray weights, NULL = uniform 1/n */
+    size_t w_cap;
+    double *d_partials; /* RT_RED_BLOCKS x 8 doubles */
+    rt_opd_ref *d_opd_ref;
 
     /* kernel variant */
     int opt_r, opt_nt, opt_xcd, opt_block, opt_alias;
@@ -417,6 +626,7 @@ extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
 int rt_sizeof_surface(void) { return (int)sizeof(rt_surface); }
+int rt_sizeof_opd_args(void) { return (int)sizeof(rt_opd_args); }
 
 int rt_device_count(int *count)
 {
@@ -500,6 +710,12 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_scratch);
     if (ctx->d_user)
         (void)hipFree(ctx->d_user);
+    if (ctx->d_w)
+        (void)hipFree(ctx->d_w);
+    if (ctx->d_partials)
+        (void)hipFree(ctx->d_partials);
+    if (ctx->d_opd_ref)
+        (void)hipFree(ctx->d_opd_ref);
     if (ctx->d_surf)
         (void)hipFree(ctx->d_surf);
     for (int i = 0; i < 2; ++i) {
@@ -891,6 +1107,208 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
                             ctx->ld * sizeof(double), ctx->n * sizeof(double),
                             nc, hipMemcpyDeviceToHost, ctx->stream));
     }
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+
+int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
+{
+    if (!ctx || !dst || which < RT_Y || which > RT_T)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_download_ray: bad argument");
+    if (!ctx->d_buf || ray < 0 || ray >= ctx->n)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_download_ray: ray %lld of %lld",
+                       (long long)ray, (long long)ctx->n);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int nc = rt_ncomp(which);
+    for (int j = 0; j < ctx->buf_nsurf; ++j)
+        RT_HIP(ctx, hipMemcpy2DAsync(dst + (size_t)j * nc, sizeof(double),
+                                     rt_row(ctx, which, j) + ray,
+                                     ctx->ld * sizeof(double), sizeof(double),
+                                     nc, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_set_weights(rt_ctx *ctx, const double *w)
+{
+    if (!ctx)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_set_weights: NULL context");
+    if (ctx->n < 1)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_set_weights: set rays first");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!w) {
+        if (ctx->d_w)
+            RT_HIP(ctx, hipFree(ctx->d_w));
+        ctx->d_w = NULL;
+        ctx->w_cap = 0;
+        return RT_OK;
+    }
+    if ((size_t)ctx->n > ctx->w_cap) {
+        if (ctx->d_w)
+            RT_HIP(ctx, hipFree(ctx->d_w));
+        ctx->d_w = NULL;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_w, ctx->n * sizeof(double)));
+        ctx->w_cap = (size_t)ctx->n;
+    }
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_w, w, ctx->n * sizeof(double),
+                               hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+/* fetch and add the per-workgroup partials in index order */
+static int rt_collect(rt_ctx *ctx, int k, double *out)
+{
+    double host[RT_RED_BLOCKS * 8];
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(host, ctx->d_partials,
+                               sizeof(double) * RT_RED_BLOCKS * k,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < k; ++c) {
+        double v = 0.;
+        for (int b = 0; b < RT_RED_BLOCKS; ++b)
+            v += host[b * k + c];
+        out[c] = v;
+    }
+    return RT_OK;
+}
+
+static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
+{
+    if (!ctx)
+        return rt_fail(ctx, RT_ERR_ARG, "%s: NULL context", who);
+    if (!ctx->d_buf || ctx->n < 1 || surf < 0 || surf >= ctx->buf_nsurf)
+        return rt_fail(ctx, RT_ERR_STATE, "%s: no row %d", who, surf);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_partials)
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_partials,
+                              sizeof(double) * RT_RED_BLOCKS * 8));
+    return RT_OK;
+}
+
+int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
+{
+    int rc = rt_consumer_ready(ctx, surf, "rt_rms");
+    if (rc != RT_OK)
+        return rc;
+    if (!rms || ref >= ctx->n)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_rms: bad argument");
+    const double *Yrow = rt_row(ctx, RT_Y, surf);
+    double x0, y0;
+    if (ref < 0) {
+        double sums[2];
+        hipLaunchKernelGGL(rt_sum_xy_kernel, dim3(RT_RED_BLOCKS),
+                           dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, ctx->n,
+                           ctx->ld, ctx->d_partials);
+        rc = rt_collect(ctx, 2, sums);
+        if (rc != RT_OK)
+            return rc;
+        x0 = sums[0] / (double)ctx->n;
+        y0 = sums[1] / (double)ctx->n;
+    } else {
+        double xy[2];
+        RT_HIP(ctx, hipMemcpy2DAsync(xy, sizeof(double), Yrow + ref,
+                                     ctx->ld * sizeof(double), sizeof(double),
+                                     2, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        x0 = xy[0];
+        y0 = xy[1];
+    }
+    double sum;
+    hipLaunchKernelGGL(rt_rms_kernel, dim3(RT_RED_BLOCKS),
+                       dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, ctx->d_w,
+                       1. / (double)ctx->n, x0, y0, ctx->n, ctx->ld,
+                       ctx->d_partials);
+    rc = rt_collect(ctx, 1, &sum);
+    if (rc != RT_OK)
+        return rc;
+    *rms = sqrt(sum);
+    return RT_OK;
+}
+
+int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
+{
+    int rc = rt_consumer_ready(ctx, surf, "rt_refocus_shift");
+    if (rc != RT_OK)
+        return rc;
+    if (!shift)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_refocus_shift: NULL");
+    const double *Yrow = rt_row(ctx, RT_Y, surf);
+    const double *Irow = rt_row(ctx, RT_I, surf);
+    double a[5], d[2];
+    hipLaunchKernelGGL(rt_refocus_sums_kernel, dim3(RT_RED_BLOCKS),
+                       dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow, ctx->n,
+                       ctx->ld, ctx->d_partials);
+    rc = rt_collect(ctx, 5, a);
+    if (rc != RT_OK)
+        return rc;
+    const double cnt = a[0];
+    hipLaunchKernelGGL(rt_refocus_dots_kernel, dim3(RT_RED_BLOCKS),
+                       dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow,
+                       ctx->d_w, 1. / (double)ctx->n, a[1] / cnt, a[2] / cnt,
+                       a[3] / cnt,
+                       a[4] / cnt, ctx->n, ctx->ld, ctx->d_partials);
+    rc = rt_collect(ctx, 2, d);
+    if (rc != RT_OK)
+        return rc;
+    *shift = -d[0] / d[1];
+    return RT_OK;
+}
+
+int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa)
+{
+    if (!ctx || !args || !out_soa)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_opd_rays: NULL argument");
+    int rc = rt_consumer_ready(ctx, 0, "rt_opd_rays");
+    if (rc != RT_OK)
+        return rc;
+    const int L = ctx->buf_nsurf;
+    if (args->nrows < 0 || args->nrows > L || args->after < 0 ||
+        args->after >= L || args->image < 0 || args->image >= L ||
+        args->ref < 0 || args->ref >= ctx->n)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_opd_rays: index out of range");
+    /* reference-ray columns: small strided D2H, then one struct upload */
+    rt_opd_ref href;
+    memset(&href, 0, sizeof href);
+    double col[RT_MAX_SURFACES * 3];
+    rc = rt_download_ray(ctx, RT_T, args->ref, col);
+    if (rc != RT_OK)
+        return rc;
+    memcpy(href.t, col, sizeof(double) * L);
+    rc = rt_download_ray(ctx, RT_Y, args->ref, col);
+    if (rc != RT_OK)
+        return rc;
+    memcpy(href.y0, col, sizeof(double) * 3);
+    memcpy(href.ya, col + 3 * args->after, sizeof(double) * 3);
+    memcpy(href.yi, col + 3 * args->image, sizeof(double) * 3);
+    rc = rt_download_ray(ctx, RT_U, args->ref, col);
+    if (rc != RT_OK)
+        return rc;
+    memcpy(href.u0, col, sizeof(double) * 3);
+    memcpy(href.ua, col + 3 * args->after, sizeof(double) * 3);
+    if (!ctx->d_opd_ref)
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_opd_ref, sizeof(rt_opd_ref)));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_opd_ref, &href, sizeof href,
+                               hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t bytes = (size_t)ctx->n * 3 * sizeof(double);
+    rc = rt_need_scratch(ctx, bytes);
+    if (rc != RT_OK)
+        return rc;
+    const unsigned grid = (unsigned)((ctx->n + 255) / 256);
+    RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
+    hipLaunchKernelGGL(rt_opd_kernel, dim3(grid), dim3(256), 0, ctx->stream,
+                       *args, ctx->d_opd_ref, rt_arr(ctx, RT_Y),
+                       rt_arr(ctx, RT_U), rt_arr(ctx, RT_T), ctx->n, ctx->ld,
+                       (double *)ctx->d_scratch);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
+    ctx->traced = 1;
+    RT_HIP(ctx, hipMemcpyAsync(out_soa, ctx->d_scratch, bytes,
+                               hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }

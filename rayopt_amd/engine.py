@@ -147,6 +147,48 @@ class Engine:
                                          out.ctypes.data), "rt_download")
         return out
 
+    def download_ray(self, which, ray):
+        """One ray across all surfaces: (L,3) for y/u/i, (L,) for t."""
+        L = self.nsurf
+        out = np.empty(L if which == RT_T else (L, 3))
+        self._check(self.lib.rt_download_ray(self.ctx, which, int(ray),
+                                             out.ctypes.data),
+                    "rt_download_ray")
+        return out
+
+    # -- device-side consumers ---------------------------------------------
+    def set_weights(self, w):
+        if w is None:
+            self._check(self.lib.rt_set_weights(self.ctx, None),
+                        "rt_set_weights")
+            return
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        if w.shape != (self.nrays,):
+            raise ValueError("weights must have shape (nrays,)")
+        self._check(self.lib.rt_set_weights(self.ctx, w.ctypes.data),
+                    "rt_set_weights")
+
+    def rms(self, surf, ref=-1):
+        out = ctypes.c_double()
+        self._check(self.lib.rt_rms(self.ctx, int(surf), int(ref),
+                                    ctypes.byref(out)), "rt_rms")
+        return out.value
+
+    def refocus_shift(self, surf):
+        out = ctypes.c_double()
+        self._check(self.lib.rt_refocus_shift(self.ctx, int(surf),
+                                              ctypes.byref(out)),
+                    "rt_refocus_shift")
+        return out.value
+
+    def opd_rays(self, args):
+        """(3, n): x, y on the reference sphere and t in waves."""
+        args = np.ascontiguousarray(args, dtype=_lib.OPD_ARGS_DTYPE)
+        out = np.empty((3, self.nrays))
+        self._check(self.lib.rt_opd_rays(self.ctx, args.ctypes.data,
+                                         out.ctypes.data), "rt_opd_rays")
+        return out
+
     def device_ptr(self, which, surf):
         p = ctypes.c_void_p()
         self._check(self.lib.rt_device_ptr(self.ctx, which, surf,

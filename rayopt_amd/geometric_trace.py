@@ -20,6 +20,7 @@ reference ``rayopt.System``: only public element attributes are read
 (rayopt_amd/pack.py).
 """
 import numpy as np
+from scipy.interpolate import griddata
 
 from . import _lib
 from ._lib import RT_Y, RT_U, RT_I, RT_T
@@ -193,6 +194,7 @@ class GeometricTrace(Trace):
             self.allocate(n)
         if l is None:
             l = self.system.wavelengths[0]
+        self._uniform_w = w is None
         if w is None:
             w = np.ones(n)/n
         self.w = w
@@ -208,6 +210,7 @@ class GeometricTrace(Trace):
         self.n[0] = self.system.refractive_index(l, 0)
         self._upload_table(1, None, self.n[0])
         self.engine.set_rays(y0, u0)
+        self.engine.set_weights(None if self._uniform_w else w)
         for rows in (self.y, self.u, self.i, self.t):
             rows.invalidate(0, self.length)
         self.y.put_row(0, y0.T)
@@ -250,3 +253,94 @@ class GeometricTrace(Trace):
     def kernel_ms(self):
         """HIP-event duration of the last propagate() kernel."""
         return self.engine.kernel_ms()
+
+    # -- consumers: O(N) reductions on the device ---------------------------
+    def rms(self, i=-1, ref=None):
+        """RMS spot radius at surface ``i`` about the centroid (or ray
+        ``ref``), weighted with ``w`` (rayopt/geometric_trace.py:171-183);
+        reduced on the GPU, two scalars cross PCIe."""
+        return self.engine.rms(range(self.length)[i],
+                               -1 if ref is None else range(self.nrays)[ref])
+
+    def refocus(self, at=-1):
+        """Least-squares refocus: moves element ``at`` along the axis so the
+        weighted spot is smallest and re-traces
+        (rayopt/geometric_trace.py:82-99).  The sums are reduced on the GPU."""
+        t = self.engine.refocus_shift(range(self.length)[at])
+        self.system[at].distance += t
+        self.propagate()
+        return t
+
+    def _image_pupil(self):
+        pupil = self.system.image.pupil
+        if isinstance(pupil, dict):
+            return bool(pupil.get("telecentric", False)), pupil.get("distance")
+        return bool(pupil.telecentric), pupil.distance
+
+    def opd_rays(self, radius=None, after=-2, image=-1):
+        """Per-ray optical path difference on the reference sphere centred
+        on the image of ray ``ref``: ``x, y`` (exit-pupil coordinates) and
+        ``t`` in waves -- what the reference's ``opd(resample=0)`` returns
+        (rayopt/geometric_trace.py:101-131), computed by one fused kernel."""
+        L = self.length
+        nrows = len(range(L)[:after + 1])
+        after, image = range(L)[after], range(L)[image]
+        if radius is None:
+            telecentric, distance = self._image_pupil()
+            if telecentric:
+                radius = self.track[image] - self.track[after]
+            else:
+                if distance is None:
+                    raise ValueError("opd: give `radius` or an image pupil "
+                                     "distance")
+                radius = -distance
+        ea, ei = self.system[after], self.system[image]
+        args = np.zeros((), dtype=_lib.OPD_ARGS_DTYPE)
+        args["nrows"], args["after"], args["image"] = nrows, after, image
+        args["finite"] = bool(self.system.object.finite)
+        args["ref"] = range(self.nrays)[self.ref]
+        args["n0"], args["n_after"] = self.n[0], self.n[after]
+        args["radius"] = radius
+        args["lscale"] = self.l/self.system.scale
+        args["shift"] = self.origins[after] - self.origins[image]
+        eye = np.eye(3)
+        args["rot_after"] = bool(ea.rotated)
+        args["rot_image"] = bool(ei.rotated)
+        args["r_after"] = (ea.rot_normal if ea.rotated else eye).reshape(9)
+        args["r_image"] = (ei.rot_normal if ei.rotated else eye).reshape(9)
+        x, y, t = self.engine.opd_rays(args)
+        return x, y, t
+
+    def opd(self, radius=None, after=-2, image=-1, resample=4):
+        x, y, t = self.opd_rays(radius, after, image)
+        if resample:
+            pyt = np.vstack((x, y, t))
+            x, y, t = pyt[:, np.all(np.isfinite(pyt), axis=0)]
+            if not t.size:
+                raise ValueError("no rays made it through")
+            n = int(resample*self.nrays**.5)
+            h = np.fabs((x, y)).max()
+            xs, ys = np.mgrid[-1:1:1j*n, -1:1:1j*n]*h
+            ts = griddata((x, y), t, (xs, ys), method="linear",
+                          fill_value=np.nan)
+            x, y, t = xs, ys, ts
+        return x, y, t
+
+    def psf(self, pad=4, resample=4, **kwargs):
+        """Point spread function from the resampled pupil OPD (FFT on the
+        host grid, rayopt/geometric_trace.py:146-169)."""
+        if not resample:
+            raise NotImplementedError
+        radius = self.system[-1].distance
+        x, y, o = self.opd(resample=resample, radius=radius, **kwargs)
+        good = np.isfinite(o)
+        n = np.count_nonzero(good)
+        o = np.where(good, np.exp(-2j*np.pi*o), 0)/n**.5
+        nx, ny = (k*pad for k in o.shape)
+        apsf = np.fft.fft2(o, (nx, ny))
+        psf = (apsf*apsf.conj()).real/apsf.size
+        dx = x[1, 0] - x[0, 0]
+        k = 1/(self.l/self.system.scale)
+        f = np.fft.fftfreq(nx, dx*k/radius)
+        p, q = np.broadcast_arrays(f[:, None], f)
+        return p, q, psf

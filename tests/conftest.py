@@ -25,7 +25,27 @@ def pytest_configure(config):
 def golden_names():
     return sorted(os.path.basename(p)[:-4]
                   for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                  if not os.path.basename(p).startswith("kat_"))
+                  if not os.path.basename(p).startswith(("kat_",
+                                                         "consumers_")))
+
+
+def consumer_golden_names():
+    return sorted(os.path.basename(p)[:-4]
+                  for p in glob.glob(os.path.join(GOLDEN, "consumers_*.npz")))
+
+
+def load_consumer_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        g = {k: z[k] for k in z.files}
+    g["yaml"] = str(g["yaml"])
+    for k in ("l", "radius", "rms_mean", "rms_ref", "rms_mid",
+              "refocus_shift"):
+        g[k] = float(g[k])
+    g["ref"] = int(g["ref"])
+    g["clip"] = bool(g["clip"])
+    g["finite_object"] = bool(g["finite_object"])
+    g["w"] = g["w"] if g["w"].size else None
+    return g
 
 
 def load_golden(name):

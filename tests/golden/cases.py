@@ -98,3 +98,31 @@ elements:
     add("paraboloid_tilted", para % -1.0, *disc_bundle(100, 20., 1., 15))
     add("near_paraboloid", para % -0.9, *disc_bundle(100, 20., 0., 15))
     return out
+
+
+def consumer_cases():
+    """Inputs for the rms / refocus / opd goldens."""
+    out = []
+    zp = P.DOUBLE_GAUSS_PUPIL_Z
+    rng = np.random.default_rng(99)
+    y, u = disc_bundle(500, 14., 7., 21, zp)
+    out.append(dict(name="dgauss", yaml=P.DOUBLE_GAUSS, y=y, u=u, l=D, w=None,
+                    ref=0, clip=True, radius=120.))
+    w = rng.random(500)
+    w /= w.sum()
+    out.append(dict(name="dgauss_weighted", yaml=P.DOUBLE_GAUSS, y=y, u=u,
+                    l=D, w=w, ref=17, clip=False, radius=-75.5))
+    y, u = disc_bundle(400, 6.2, 5., 22)
+    out.append(dict(name="cooke_clipped", yaml=P.cooke(D), y=y, u=u, l=D,
+                    w=None, ref=3, clip=True, radius=45.))
+    y, u = disc_bundle(400, 8., 2., 23)
+    out.append(dict(name="torture", yaml=P.TORTURE, y=y, u=u, l=D, w=None,
+                    ref=5, clip=True, radius=-33.))
+    out.append(dict(name="torture_finite_object", yaml=P.TORTURE, y=y, u=u,
+                    l=D, w=None, ref=5, clip=True, radius=-33.,
+                    finite_object=True))
+    y, u = disc_bundle(300, 0.55, 12., 24)
+    y[:, 1] -= 0.5*np.tan(np.radians(12.))
+    out.append(dict(name="asphere", yaml=P.ASPHERE_PHONE, y=y, u=u, l=D,
+                    w=None, ref=1, clip=True, radius=2.5))
+    return out

@@ -62,6 +62,34 @@ def main():
             case["name"], g.y.shape[0], g.y.shape[1],
             np.isnan(g.u[1:, :, 0]).mean()))
 
+    # --- consumers: rms / refocus / opd(resample=0) from the reference ---
+    from cases import consumer_cases
+    for case in consumer_cases():
+        s = ro.system_from_yaml(case["yaml"])
+        if case.get("finite_object"):
+            s.object = ro.FiniteConjugate(radius=1.)
+        g = ro.GeometricTrace(s)
+        g.rays_given(case["y"], case["u"], case["l"], case["w"], case["ref"])
+        with np.errstate(all="ignore"):
+            g.propagate(clip=case["clip"])
+            out = dict(rms_mean=g.rms(), rms_ref=g.rms(ref=case["ref"]),
+                       rms_mid=g.rms(i=2))
+            x, y, t = g.opd(radius=case["radius"], resample=0)
+            d0 = float(s[-1].distance)
+            g.refocus()
+            out["refocus_shift"] = float(s[-1].distance) - d0
+            out["y_after_refocus"] = g.y[-1].copy()
+        np.savez_compressed(
+            os.path.join(HERE, "consumers_" + case["name"] + ".npz"),
+            yaml=case["yaml"], y0=case["y"], u0=case["u"], l=case["l"],
+            w=case["w"] if case["w"] is not None else np.zeros(0),
+            ref=case["ref"], clip=case["clip"], radius=case["radius"],
+            finite_object=bool(case.get("finite_object")),
+            opd_x=x, opd_y=y, opd_t=t, meta=meta, **out)
+        print("consumers_%-20s rms=%.6g shift=%.6g opd rms=%.4g waves" % (
+            case["name"], out["rms_mean"], out["refocus_shift"],
+            np.nanstd(t)))
+
     # --- the reference's own known-answer test -------------------------
     sys.path.insert(0, refshim.REFERENCE_ROOT)
     db = os.path.join(tempfile.mkdtemp(), "library.sqlite")

@@ -1,0 +1,131 @@
+"""rms / refocus / opd: the oracle (oracle/consumers_numpy.py) against the
+reference's own outputs, and the device-side reductions against both."""
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd.pack import pack_system
+from oracle import trace_numpy as tn
+from oracle import consumers_numpy as cn
+
+from conftest import (consumer_golden_names, load_consumer_golden,
+                      assert_parity)
+
+
+def make_system(g):
+    system = ra.system_from_yaml(g["yaml"])
+    if g["finite_object"]:
+        system.object = ra.Conjugate({"type": "finite", "radius": 1.}, True)
+    return system
+
+
+def oracle_arrays(system, g):
+    n0 = system.refractive_index(g["l"], 0)
+    table, ns = pack_system(system, g["l"], n0)
+    Y, U, I, T = tn.propagate(table, g["y0"], g["u0"], clip=g["clip"])
+    L, N = len(system), g["y0"].shape[0]
+    full = lambda a, first: np.concatenate([first[None], a])   # noqa: E731
+    return (full(Y, g["y0"]), full(U, g["u0"]), full(I, g["u0"]),
+            full(T, np.zeros(N)), ns)
+
+
+def close(a, b, rtol):
+    if np.isnan(b):
+        return np.isnan(a)
+    return abs(a - b) <= rtol*abs(b)
+
+
+@pytest.mark.parametrize("name", consumer_golden_names())
+def test_oracle_consumers_match_reference(name):
+    g = load_consumer_golden(name)
+    system = make_system(g)
+    Y, U, I, T, ns = oracle_arrays(system, g)
+    with np.errstate(all="ignore"):
+        assert close(cn.rms(Y[-1], g["w"]), g["rms_mean"], 1e-14)
+        assert close(cn.rms(Y[-1], g["w"], g["ref"]), g["rms_ref"], 1e-14)
+        assert close(cn.rms(Y[2], g["w"]), g["rms_mid"], 1e-14)
+        w = g["w"] if g["w"] is not None else np.ones(len(g["y0"]))/len(g["y0"])
+        assert close(cn.refocus_shift(Y[-1], I[-1], w), g["refocus_shift"],
+                     1e-10)
+        frames = [e.rot_normal if e.rotated else None for e in system]
+        x, y, t = cn.opd_rays(Y, U, T, ns, g["ref"], system.origins, frames,
+                              system.object.finite, g["radius"],
+                              g["l"]/system.scale)
+    assert_parity(x[None], g["opd_x"][None], 1e-12, name + ".x")
+    assert_parity(y[None], g["opd_y"][None], 1e-12, name + ".y")
+    assert_parity(t[None], g["opd_t"][None], 1e-9, name + ".t")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", consumer_golden_names())
+def test_device_consumers_match_reference(name):
+    """rt_rms / rt_refocus_shift / rt_opd_rays against the reference's
+    numbers.  Tolerances: reductions 1e-12 (different summation order), the
+    refocus ratio 1e-9 (centred sums cancel), OPD in waves 1e-9 (a ~70 mm
+    path difference expressed in units of 0.6 um: condition ~1e5)."""
+    g = load_consumer_golden(name)
+    system = make_system(g)
+    tr = ra.GeometricTrace(system)
+    tr.rays_given(g["y0"], g["u0"], g["l"], g["w"], g["ref"])
+    tr.propagate(clip=g["clip"])
+    assert close(tr.rms(), g["rms_mean"], 1e-12)
+    assert close(tr.rms(ref=g["ref"]), g["rms_ref"], 1e-12)
+    assert close(tr.rms(i=2), g["rms_mid"], 1e-12)
+    x, y, t = tr.opd(radius=g["radius"], resample=0)
+    assert_parity(x[None], g["opd_x"][None], 1e-10, name + ".x")
+    assert_parity(y[None], g["opd_y"][None], 1e-10, name + ".y")
+    assert_parity(t[None], g["opd_t"][None], 1e-9, name + ".t")
+    d0 = float(system[-1].distance)
+    shift = tr.refocus()
+    assert close(shift, g["refocus_shift"], 1e-9)
+    assert float(system[-1].distance) == pytest.approx(d0 + shift, rel=1e-15)
+    # refocus re-traced with the reference's defaults (clip=False)
+    assert_parity(np.asarray(tr.y[-1])[None], g["y_after_refocus"][None],
+                  1e-8, name + ".refocused")
+
+
+@pytest.mark.gpu
+def test_device_consumers_large_n_vs_oracle():
+    """10^6 rays: device reductions against the numpy oracle on the arrays
+    the device itself produced (isolates the reductions)."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    y, u = ra.bundles.disc_bundle(10**6, 16., 5., 3,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    rng = np.random.default_rng(5)
+    w = rng.random(10**6)
+    w /= w.sum()
+    tr = ra.GeometricTrace(system)
+    tr.rays_given(y, u, None, w, 11)
+    tr.propagate(clip=True)
+    Y, I = np.asarray(tr.y[-1]), np.asarray(tr.i[-1])
+    with np.errstate(all="ignore"):
+        good = np.isfinite(Y[:, 0])
+        assert 0.9 < good.mean() < 1.
+        assert np.isnan(tr.rms())                       # NaN rays poison it
+        assert tr.rms(i=3) == pytest.approx(
+            cn.rms(np.asarray(tr.y[3]), w), rel=1e-12)
+        assert tr.engine.refocus_shift(12) == pytest.approx(
+            cn.refocus_shift(Y, I, w), rel=1e-9)
+    x, yy, t = tr.opd(radius=100., resample=0)
+    frames = [None]*len(system)
+    xo, yo, to = cn.opd_rays(np.asarray(tr.y), np.asarray(tr.u),
+                             np.asarray(tr.t), tr.n, 11, system.origins,
+                             frames, False, 100., tr.l/system.scale)
+    assert_parity(x[None], xo[None], 1e-12, "x")
+    assert_parity(t[None], to[None], 1e-9, "t")
+    xs, ys, ts = tr.opd(radius=100., resample=1)        # griddata path runs
+    assert ts.shape == (1000, 1000) and np.isfinite(ts).any()
+
+
+@pytest.mark.gpu
+def test_psf_runs_and_is_normalised():
+    system = ra.system_from_yaml(ra.prescriptions.SINGLET)
+    y, u = ra.bundles.disc_bundle(2000, 4., 0., 1)
+    tr = ra.GeometricTrace(system)
+    tr.rays_given(y, u)
+    tr.propagate()
+    tr.refocus()
+    p, q, psf = tr.psf(pad=2, resample=2)
+    assert psf.shape == p.shape == q.shape
+    assert np.isfinite(psf).all() and psf.max() > 0
+    assert psf.sum() == pytest.approx(1., rel=0.2)
