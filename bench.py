@@ -166,6 +166,16 @@ def main():
         return (time.perf_counter() - t0, eng.event_elapsed(0, 1),
                 eng.kernel_ms())
 
+    image_only = None
+    if not dist_mode and not args.option:
+        # extension: keep only the image row (merit-function use): the
+        # kernel leaves the HBM roofline for the FP64 one
+        mask = np.zeros(L, dtype=np.uint8)
+        mask[0] = mask[L - 1] = 1
+        eng.set_keep_rows(mask)
+        e_img, ev_img, _ = timed_loop()
+        image_only = (e_img, ev_img/args.steps)
+        eng.set_keep_rows(None)
     full_i = None
     if not dist_mode and not any(kv.startswith("alias_i")
                                  for kv in args.option):
@@ -268,6 +278,15 @@ def main():
             "achieved": b_full/(k_full*1e-3)/1e9,
             "frac": b_full/(k_full*1e-3)/1e9/HBM_PEAK_GBS,
             "note": "every row of i materialised (alias_i=0): 80 B per op",
+        }
+
+    if image_only is not None:
+        e_img, k_img = image_only
+        out["image_row_only"] = {
+            "value": total_rays*S*args.steps/e_img,
+            "kernel_ms": k_img,
+            "note": "propagate(keep=[-1]): all %d surfaces traced, only the "
+                    "image row stored (80 B/ray); FP64-VALU bound" % S,
         }
 
     if world == 1 and not dist_mode and args.cpu_sample > 0:

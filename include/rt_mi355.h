@@ -52,6 +52,8 @@ extern "C" {
  * because element j or j-1 is rotated; otherwise i[j] == u[j-1] bit for bit
  * (system.py:461,464 with rot None) and I[j] is served from U[j-1] */
 #define RT_F_STORE_I 0x80u
+/* set by the library: this row is not stored (rt_set_keep_rows) */
+#define RT_F_NOSTORE 0x100u
 
 /* which array (rt_download / rt_upload_row / rt_device_ptr) */
 #define RT_Y 0 /* intercepts, element-normal frame, relative to vertex */
@@ -157,6 +159,15 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa);
  * Y,U,I,T.  stop <= 0 or stop > nsurf means nsurf.  Asynchronous.
  */
 int rt_trace(rt_ctx *ctx, int start, int stop, int clip);
+/*
+ * Extension over the reference: choose which surface rows propagate()
+ * stores.  keep[j] != 0 keeps row j; NULL restores the reference behaviour
+ * (every row).  Rows that are not kept are still traced (the ray state lives
+ * in registers) but cost no HBM traffic; reading them afterwards is an error.
+ * A merit function that only needs the image-plane intercepts keeps one row
+ * and the kernel moves from the HBM roofline to the FP64 one.
+ */
+int rt_set_keep_rows(rt_ctx *ctx, const unsigned char *keep, int n);
 int rt_sync(rt_ctx *ctx);
 /* HIP-event time of the last rt_trace kernel in ms (synchronises) */
 int rt_kernel_ms(rt_ctx *ctx, double *ms);

@@ -66,6 +66,7 @@ SIGNATURES = {
                                      ctypes.c_void_p]),
     "rt_trace": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_int]),
+    "rt_set_keep_rows": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_int]),
     "rt_sync": (ctypes.c_int, [_ctx]),
     "rt_kernel_ms": (ctypes.c_int, [_ctx, _c_double_p]),
     "rt_event_record": (ctypes.c_int, [_ctx, ctypes.c_int]),

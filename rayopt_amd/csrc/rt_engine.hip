@@ -136,22 +136,24 @@ __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
         const unsigned flags = S->flags;
         rt_step<R>(S, flags, clip, y, u, iv, t);
 
-        const int64_t row = (int64_t)s * 3;
+        if (!(flags & RT_F_NOSTORE)) {
+            const int64_t row = (int64_t)s * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double a[R], b[R], d[R];
+            for (int c = 0; c < 3; ++c) {
+                double a[R], b[R], d[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                a[r] = y[r][c];
-                b[r] = u[r][c];
-                d[r] = iv[r][c];
+                for (int r = 0; r < R; ++r) {
+                    a[r] = y[r][c];
+                    b[r] = u[r][c];
+                    d[r] = iv[r][c];
+                }
+                rt_store<R, NT>(Y + (row + c) * ld + j, a);
+                rt_store<R, NT>(U + (row + c) * ld + j, b);
+                if (flags & RT_F_STORE_I)
+                    rt_store<R, NT>(I + (row + c) * ld + j, d);
             }
-            rt_store<R, NT>(Y + (row + c) * ld + j, a);
-            rt_store<R, NT>(U + (row + c) * ld + j, b);
-            if (flags & RT_F_STORE_I)
-                rt_store<R, NT>(I + (row + c) * ld + j, d);
+            rt_store<R, NT>(T + (int64_t)s * ld + j, t);
         }
-        rt_store<R, NT>(T + (int64_t)s * ld + j, t);
 
         rt_leave<R>(S, flags, y, u);
     }
@@ -526,7 +528,12 @@ struct rt_ctx {
 
     rt_surface *d_surf;
     int nsurf;
-    rt_surface h_surf[RT_MAX_SURFACES];
+    rt_surface h_surf[RT_MAX_SURFACES]; /* as given by the caller */
+    rt_surface *h_stage;                /* pinned: flags finalised */
+    int table_dirty;
+    int table_start;
+    unsigned char keep[RT_MAX_SURFACES];  /* rows propagate() stores */
+    unsigned char valid[RT_MAX_SURFACES]; /* rows that hold data */
 
     double *d_buf; /* Y | U | I | T */
     size_t cap_doubles;
@@ -689,6 +696,9 @@ int rt_create(int device, rt_ctx **out)
     }
     RT_HIP_C(hipMalloc((void **)&c->d_surf,
                        sizeof(rt_surface) * RT_MAX_SURFACES));
+    RT_HIP_C(hipHostMalloc((void **)&c->h_stage,
+                           sizeof(rt_surface) * RT_MAX_SURFACES));
+    memset(c->keep, 1, sizeof c->keep);
 #undef RT_HIP_C
     *out = c;
     return RT_OK;
@@ -718,6 +728,8 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_opd_ref);
     if (ctx->d_surf)
         (void)hipFree(ctx->d_surf);
+    if (ctx->h_stage)
+        (void)hipHostFree(ctx->h_stage);
     for (int i = 0; i < 2; ++i) {
         if (ctx->d_stage[i])
             (void)hipFree(ctx->d_stage[i]);
@@ -749,23 +761,8 @@ int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf)
                            "terms, limit %d",
                            j, surf[j].nasph, RT_MAX_ASPH);
     }
-    RT_HIP(ctx, hipSetDevice(ctx->device));
-    /* the previous table may still be read by a kernel in flight and the
-     * pageable host copy must be stable until the DMA is done */
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(ctx->h_surf, surf, sizeof(rt_surface) * nsurf);
-    for (int j = 0; j < nsurf; ++j) {
-        const bool rot = (surf[j].flags & RT_F_ROTATED) ||
-                         (j > 0 && (surf[j - 1].flags & RT_F_ROTATED));
-        if (!ctx->opt_alias || rot || j == 0)
-            ctx->h_surf[j].flags |= RT_F_STORE_I;
-        else
-            ctx->h_surf[j].flags &= ~RT_F_STORE_I;
-    }
-    RT_HIP(ctx, hipMemcpyAsync(ctx->d_surf, ctx->h_surf,
-                               sizeof(rt_surface) * nsurf,
-                               hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->table_dirty = 1; /* finalised and sent by the next rt_trace */
     ctx->nsurf = nsurf;
     return RT_OK;
 }
@@ -804,6 +801,7 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     ctx->buf_nsurf = ctx->nsurf;
     ctx->traced = 0;
     memset(ctx->i_alias, 0, sizeof ctx->i_alias);
+    memset(ctx->valid, 0, sizeof ctx->valid);
     return RT_OK;
 }
 
@@ -847,6 +845,7 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
                            !ctx->opt_alias);
     RT_HIP(ctx, hipGetLastError());
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
+    ctx->valid[0] = 1;
     return RT_OK;
 }
 
@@ -899,6 +898,7 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
     const int nc = rt_ncomp(which);
     if (which == RT_I)
         ctx->i_alias[surf] = 0; /* now holds its own data */
+    ctx->valid[surf] = 1;
     double *dst = rt_row(ctx, which, surf);
     RT_HIP(ctx, hipMemcpy2DAsync(dst, ctx->ld * sizeof(double), src_soa,
                                  ctx->n * sizeof(double),
@@ -925,7 +925,41 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
     if (start < 1 || start > stop)
         return rt_fail(ctx, RT_ERR_ARG, "rt_trace: start=%d stop=%d nsurf=%d",
                        start, stop, ctx->nsurf);
+    if (!ctx->valid[start - 1])
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_trace: seed row %d holds no data (not stored by "
+                       "the previous trace)", start - 1);
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->table_dirty) {
+        /* a kernel in flight may still read the device table, and the pinned
+         * staging copy must not change under a pending DMA */
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(ctx->h_stage, ctx->h_surf, sizeof(rt_surface) * ctx->nsurf);
+        for (int j = 0; j < ctx->nsurf; ++j) {
+            unsigned f = ctx->h_stage[j].flags &
+                         ~(RT_F_STORE_I | RT_F_NOSTORE);
+            if (!ctx->keep[j])
+                f |= RT_F_NOSTORE;
+            /* i[j] == u[j-1] bit for bit unless j or j-1 is tilted; it can
+             * only be served from U[j-1] if that row exists */
+            const bool rot = (f & RT_F_ROTATED) ||
+                             (j > 0 && (ctx->h_stage[j - 1].flags &
+                                        RT_F_ROTATED));
+            const bool prev_kept =
+                j > 0 && (j - 1 < start ? ctx->valid[j - 1] : ctx->keep[j - 1]);
+            if (!ctx->opt_alias || rot || j == 0 || !prev_kept)
+                f |= RT_F_STORE_I;
+            ctx->h_stage[j].flags = f;
+        }
+        RT_HIP(ctx, hipMemcpyAsync(ctx->d_surf, ctx->h_stage,
+                                   sizeof(rt_surface) * ctx->nsurf,
+                                   hipMemcpyHostToDevice, ctx->stream));
+        ctx->table_dirty = 0;
+        ctx->table_start = start;
+    } else if (ctx->table_start != start) {
+        ctx->table_dirty = 1; /* alias decisions depend on start */
+        return rt_trace(ctx, start, stop, clip);
+    }
     RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
     if (start < stop) {
         const int key = ctx->opt_r * 4 + ctx->opt_nt * 2 + ctx->opt_xcd;
@@ -944,10 +978,24 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
         RT_HIP(ctx, hipGetLastError());
     }
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
-    for (int sidx = start; sidx < stop; ++sidx)
-        ctx->i_alias[sidx] =
-            (ctx->h_surf[sidx].flags & RT_F_STORE_I) ? 0 : 1;
+    for (int sidx = start; sidx < stop; ++sidx) {
+        const unsigned f = ctx->h_stage[sidx].flags;
+        ctx->valid[sidx] = !(f & RT_F_NOSTORE);
+        ctx->i_alias[sidx] = (f & (RT_F_STORE_I | RT_F_NOSTORE)) ? 0 : 1;
+    }
     ctx->traced = 1;
+    return RT_OK;
+}
+
+int rt_set_keep_rows(rt_ctx *ctx, const unsigned char *keep, int n)
+{
+    if (!ctx || (keep && (n < 1 || n > RT_MAX_SURFACES)))
+        return rt_fail(ctx, RT_ERR_ARG, "rt_set_keep_rows: bad argument");
+    memset(ctx->keep, 1, sizeof ctx->keep);
+    if (keep)
+        for (int j = 0; j < n; ++j)
+            ctx->keep[j] = keep[j] ? 1 : 0;
+    ctx->table_dirty = 1;
     return RT_OK;
 }
 
@@ -1005,6 +1053,7 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         ctx->opt_xcd = value ? 1 : 0;
     } else if (!strcmp(key, "alias_i")) {
         ctx->opt_alias = value ? 1 : 0;
+        ctx->table_dirty = 1;
     } else if (!strcmp(key, "block")) {
         if (value < 64 || value > 1024 || value % 64)
             return rt_fail(ctx, RT_ERR_ARG, "block must be k*64 in [64,1024]");
@@ -1091,6 +1140,11 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
         return rt_fail(ctx, RT_ERR_STATE, "rt_download: rows [%d,%d) of %d",
                        surf_lo, surf_hi, ctx->buf_nsurf);
     const int nc = rt_ncomp(which);
+    for (int j = surf_lo; j < surf_hi; ++j)
+        if (!ctx->valid[j])
+            return rt_fail(ctx, RT_ERR_STATE,
+                           "rt_download: row %d holds no data (not kept by "
+                           "rt_set_keep_rows, or not traced yet)", j);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (which != RT_I) {
         const double *src = rt_row(ctx, which, surf_lo);
@@ -1121,11 +1175,17 @@ int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
                        (long long)ray, (long long)ctx->n);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int nc = rt_ncomp(which);
-    for (int j = 0; j < ctx->buf_nsurf; ++j)
+    for (int j = 0; j < ctx->buf_nsurf; ++j) {
+        if (!ctx->valid[j]) { /* row not stored: NaN, like a dead ray */
+            for (int c = 0; c < nc; ++c)
+                dst[(size_t)j * nc + c] = __builtin_nan("");
+            continue;
+        }
         RT_HIP(ctx, hipMemcpy2DAsync(dst + (size_t)j * nc, sizeof(double),
                                      rt_row(ctx, which, j) + ray,
                                      ctx->ld * sizeof(double), sizeof(double),
                                      nc, hipMemcpyDeviceToHost, ctx->stream));
+    }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -1180,8 +1240,10 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
 {
     if (!ctx)
         return rt_fail(ctx, RT_ERR_ARG, "%s: NULL context", who);
-    if (!ctx->d_buf || ctx->n < 1 || surf < 0 || surf >= ctx->buf_nsurf)
-        return rt_fail(ctx, RT_ERR_STATE, "%s: no row %d", who, surf);
+    if (!ctx->d_buf || ctx->n < 1 || surf < 0 || surf >= ctx->buf_nsurf ||
+        !ctx->valid[surf])
+        return rt_fail(ctx, RT_ERR_STATE, "%s: row %d holds no data", who,
+                       surf);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_partials)
         RT_HIP(ctx, hipMalloc((void **)&ctx->d_partials,
@@ -1270,6 +1332,11 @@ int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa)
         args->after >= L || args->image < 0 || args->image >= L ||
         args->ref < 0 || args->ref >= ctx->n)
         return rt_fail(ctx, RT_ERR_ARG, "rt_opd_rays: index out of range");
+    for (int j = 0; j < L; ++j)
+        if (!ctx->valid[j] &&
+            (j < args->nrows || j == args->after || j == args->image))
+            return rt_fail(ctx, RT_ERR_STATE,
+                           "rt_opd_rays: row %d holds no data", j);
     /* reference-ray columns: small strided D2H, then one struct upload */
     rt_opd_ref href;
     memset(&href, 0, sizeof href);
@@ -1319,6 +1386,9 @@ int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
         return rt_fail(ctx, RT_ERR_ARG, "rt_device_ptr: bad argument");
     if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
         return rt_fail(ctx, RT_ERR_STATE, "rt_device_ptr: no such row %d", surf);
+    if (!ctx->valid[surf])
+        return rt_fail(ctx, RT_ERR_STATE, "rt_device_ptr: row %d holds no data",
+                       surf);
     *out = rt_row(ctx, which, surf);
     return RT_OK;
 }
@@ -1444,6 +1514,9 @@ int rt_gather_final(rt_ctx *ctx, int which, int surf, const int64_t *counts,
         return rt_fail(ctx, RT_ERR_ARG, "rt_gather_final: root %d", root);
     if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
         return rt_fail(ctx, RT_ERR_STATE, "rt_gather_final: no row %d", surf);
+    if (!ctx->valid[surf])
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_gather_final: row %d holds no data", surf);
     if (counts[ctx->rank] != ctx->n)
         return rt_fail(ctx, RT_ERR_ARG,
                        "rt_gather_final: counts[%d]=%lld but this rank holds "

@@ -105,6 +105,17 @@ class Engine:
         self._check(self.lib.rt_trace(self.ctx, int(start), int(stop),
                                       1 if clip else 0), "rt_trace")
 
+    def set_keep_rows(self, keep):
+        """Rows propagate() stores: boolean sequence per element, or None
+        for all rows (the reference behaviour)."""
+        if keep is None:
+            self._check(self.lib.rt_set_keep_rows(self.ctx, None, 0),
+                        "rt_set_keep_rows")
+            return
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        self._check(self.lib.rt_set_keep_rows(self.ctx, keep.ctypes.data,
+                                              len(keep)), "rt_set_keep_rows")
+
     def sync(self):
         self._check(self.lib.rt_sync(self.ctx), "rt_sync")
 

@@ -235,9 +235,14 @@ class GeometricTrace(Trace):
             rows.invalidate(0, self.length)
 
     # -- the hot path ---------------------------------------------------------
-    def propagate(self, start=1, stop=None, clip=False):
+    def propagate(self, start=1, stop=None, clip=False, keep=None):
         """Trace elements ``start .. stop-1`` for all rays on the GPU
-        (rayopt/geometric_trace.py:72-80 + rayopt/system.py:459-464)."""
+        (rayopt/geometric_trace.py:72-80 + rayopt/system.py:459-464).
+
+        ``keep`` (extension, default None = every row as in the reference):
+        iterable of surface indices whose rows are stored, e.g. ``keep=[-1]``
+        for the image-plane intercepts only.  The other rows are traced but
+        not written (no HBM traffic); reading them raises."""
         super().propagate()
         if len(self.system) != self.length:
             raise ValueError("the system changed length since rays_given()")
@@ -245,6 +250,13 @@ class GeometricTrace(Trace):
         if a < 1:
             raise ValueError("start must be >= 1")
         _, ns = self._upload_table(a, b, self.n[a - 1])
+        if keep is None:
+            self.engine.set_keep_rows(None)
+        else:
+            mask = np.zeros(self.length, dtype=np.uint8)
+            mask[[range(self.length)[k] for k in keep]] = 1
+            mask[:a] = 1        # rows before `start` are not touched
+            self.engine.set_keep_rows(mask)
         self.engine.trace(a, b, clip)
         self.n[a:b] = ns[a:b]
         for rows in (self.y, self.u, self.i, self.t):

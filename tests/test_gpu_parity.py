@@ -345,3 +345,40 @@ def test_i_rows_alias_u_only_where_identical():
     full = gpu_trace(system, y, u, None, True, alias_i=0)
     assert full.engine.device_ptr(RT_I, 4) != full.engine.device_ptr(RT_U, 3)
     assert np.array_equal(np.asarray(g.i), np.asarray(full.i), equal_nan=True)
+
+
+def test_keep_rows_extension():
+    """propagate(keep=...) stores only the chosen rows; they are bit-identical
+    to the full trace, the others raise on access."""
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = _c3_rays(30011)
+    full = gpu_trace(system, y, u, None, True)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    g.propagate(clip=True, keep=[-1])
+    for a, b in ((g.y, full.y), (g.u, full.u), (g.i, full.i), (g.t, full.t)):
+        assert np.array_equal(a[-1], b[-1], equal_nan=True)
+        assert np.array_equal(a[0], b[0], equal_nan=True)
+    assert np.array_equal(g.n, full.n)
+    with pytest.raises(ra.EngineError, match="holds no data"):
+        g.y[3]
+    with pytest.raises(ra.EngineError, match="holds no data"):
+        g.rms(i=5)
+    assert np.isnan(g.rms()) == np.isnan(full.rms())
+    with pytest.raises(ra.EngineError, match="seed row"):
+        g.propagate(start=6, clip=True)
+    # a sparse selection; i[6] must be materialised because row 5 is absent,
+    # i[3] may alias u[2]
+    g.propagate(clip=True, keep=[2, 3, 6, -1])
+    for j in (2, 3, 6, 12):
+        for a, b in ((g.y, full.y), (g.u, full.u), (g.i, full.i),
+                     (g.t, full.t)):
+            assert np.array_equal(a[j], b[j], equal_nan=True), j
+    # restart from a kept row reproduces the tail
+    g.propagate(start=7, clip=True)
+    for a, b in ((g.y, full.y), (g.u, full.u), (g.i, full.i), (g.t, full.t)):
+        assert np.array_equal(a[7:], b[7:], equal_nan=True)
+    # and the default restores the reference behaviour
+    g.propagate(clip=True)
+    assert np.array_equal(np.asarray(g.y), np.asarray(full.y), equal_nan=True)
+    assert np.array_equal(np.asarray(g.i), np.asarray(full.i), equal_nan=True)

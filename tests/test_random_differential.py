@@ -1,0 +1,85 @@
+"""Randomised differential tests.
+
+CPU (here, with /root/reference): oracle == unmodified reference on random
+systems (pins the oracle far beyond the hand-written fixtures), and the
+kernel arithmetic (host build of rt_math.h) agrees with the reference at the
+contract tolerances.  GPU: the HIP engine against the oracle on the same
+seeds.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd.pack import pack_system
+from oracle import trace_numpy as tn
+from oracle import refshim
+
+from conftest import assert_parity, RTOL_SPHERICAL, RTOL_ASPHERE
+from random_systems import random_prescription, random_rays
+
+SEEDS = list(range(60))
+
+
+def has_asphere(p):
+    return any("aspherics" in e for e in p["elements"])
+
+
+def tilted(p):
+    return any("angles" in e or "direction" in e for e in p["elements"])
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+@pytest.mark.parametrize("seed", SEEDS)
+def test_oracle_and_kernel_math_vs_live_reference(seed, hostemu):
+    ro = refshim.load()
+    p = random_prescription(seed)
+    n = 48 if has_asphere(p) else 400
+    y, u = random_rays(seed, n, p)
+    ref_sys = ro.System(**copy.deepcopy(p))
+    mine = ra.system_from_dict(copy.deepcopy(p))
+    for clip in (True, False):
+        g = ro.GeometricTrace(ref_sys)
+        g.rays_given(y, u)
+        with np.errstate(all="ignore"):
+            g.propagate(clip=clip)
+        want = (g.y[1:], g.u[1:], g.i[1:], g.t[1:])
+        # (1) oracle on the reference's own System object
+        table, ns = pack_system(ref_sys, g.l, g.n[0])
+        got = tn.propagate(table, y, u, clip=clip)
+        assert np.array_equal(ns[1:], g.n[1:])
+        for a, b in zip(got, want):
+            if has_asphere(p):
+                assert_parity(a, b, 1e-11, "oracle seed %d" % seed)
+            else:
+                assert np.array_equal(a, b, equal_nan=True), seed
+        # (2) this package's host model packs the same system
+        table2, _ = pack_system(mine, g.l, g.n[0])
+        for f in table.dtype.names:
+            np.testing.assert_allclose(table2[f], table[f], rtol=0,
+                                       atol=1e-15)
+        # (3) the kernel's arithmetic at the contract tolerance
+        emu = hostemu(table2, y, u, 1, len(table2), clip, 1)
+        rtol = RTOL_ASPHERE if has_asphere(p) else RTOL_SPHERICAL
+        for a, b in zip(emu, want):
+            assert_parity(a, b, rtol, "kernel math seed %d" % seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_gpu_vs_oracle_random_systems(seed):
+    p = random_prescription(seed)
+    system = ra.system_from_dict(copy.deepcopy(p))
+    n = 20011
+    y, u = random_rays(seed, n, p)
+    for clip in (True, False):
+        g = ra.GeometricTrace(system)
+        g.rays_given(y, u)
+        g.propagate(clip=clip)
+        table, ns = pack_system(system, g.l, g.n[0])
+        want = tn.propagate(table, y, u, clip=clip)
+        rtol = RTOL_ASPHERE if has_asphere(p) else RTOL_SPHERICAL
+        for rows, b in zip((g.y, g.u, g.i, g.t), want):
+            assert_parity(np.asarray(rows[1:]), b, rtol, "seed %d" % seed)
+        assert np.array_equal(g.n[1:], ns[1:])
