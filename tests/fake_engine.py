@@ -1,0 +1,75 @@
+"""TEST DOUBLE for rayopt_amd.engine.Engine backed by the numpy oracle.
+
+Lets the host-side glue of the drop-in (GeometricTrace, DeviceRows, packer,
+dropin.accelerate) run end to end in a container without a GPU.  Lives in
+tests/ only; the product never sees it.
+"""
+import numpy as np
+
+from oracle import trace_numpy as tn
+from oracle import consumers_numpy as cn
+from rayopt_amd._lib import RT_Y, RT_U, RT_I, RT_T
+
+
+class OracleEngine:
+    def __init__(self):
+        self.table = None
+        self.rows = None
+        self.keep = None
+        self.w = None
+        self.ms = 0.
+
+    def upload_system(self, table):
+        self.table = np.array(table)
+        self.nsurf = len(table)
+
+    def set_rays(self, y, u):
+        L, n = self.nsurf, y.shape[0]
+        self.nrays = n
+        self.rows = {RT_Y: np.full((L, n, 3), np.nan),
+                     RT_U: np.full((L, n, 3), np.nan),
+                     RT_I: np.full((L, n, 3), np.nan),
+                     RT_T: np.full((L, n), np.nan)}
+        self.rows[RT_Y][0], self.rows[RT_U][0] = y, u
+        self.rows[RT_I][0], self.rows[RT_T][0] = u, 0.
+        self.valid = np.zeros(L, dtype=bool)
+        self.valid[0] = True
+
+    def set_weights(self, w):
+        self.w = None if w is None else np.array(w)
+
+    def set_keep_rows(self, keep):
+        self.keep = None if keep is None else np.array(keep, dtype=bool)
+
+    def set_option(self, key, value):
+        pass
+
+    def trace(self, start=1, stop=0, clip=False):
+        if stop <= 0:
+            stop = self.nsurf
+        assert self.valid[start - 1]
+        Y, U, I, T = tn.propagate(self.table, self.rows[RT_Y][start - 1],
+                                  self.rows[RT_U][start - 1], start, stop,
+                                  clip)
+        for which, arr in ((RT_Y, Y), (RT_U, U), (RT_I, I), (RT_T, T)):
+            self.rows[which][start:stop] = arr
+        keep = np.ones(self.nsurf, bool) if self.keep is None else self.keep
+        self.valid[start:stop] = keep[start:stop]
+
+    def download(self, which, lo, hi):
+        assert self.valid[lo:hi].all(), "row holds no data"
+        a = self.rows[which][lo:hi]
+        return a if which == RT_T else np.ascontiguousarray(
+            a.transpose(0, 2, 1))
+
+    def kernel_ms(self):
+        return self.ms
+
+    def rms(self, surf, ref=-1):
+        return cn.rms(self.rows[RT_Y][surf], self.w, None if ref < 0 else ref)
+
+    def refocus_shift(self, surf):
+        w = self.w if self.w is not None else \
+            np.ones(self.nrays)/self.nrays
+        return cn.refocus_shift(self.rows[RT_Y][surf], self.rows[RT_I][surf],
+                                w)

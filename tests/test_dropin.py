@@ -1,0 +1,93 @@
+"""The drop-in glue (GeometricTrace + DeviceRows + dropin.accelerate) driven
+end to end on CPU through a test double of the engine (tests/fake_engine.py,
+oracle backed), against the unmodified reference on its own System objects
+and its own ray generators."""
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd import dropin
+from oracle import refshim
+
+from fake_engine import OracleEngine
+
+pytestmark = pytest.mark.skipif(not refshim.available(),
+                                reason="no /root/reference")
+
+
+@pytest.fixture()
+def ro():
+    mod = refshim.load()
+    yield mod
+    dropin.restore(mod)
+
+
+def test_geometric_trace_on_reference_system(ro):
+    s = ro.system_from_yaml(ra.prescriptions.TORTURE)
+    y, u = ra.bundles.disc_bundle(500, 12., 3., 4)
+    ref = ro.GeometricTrace(s)
+    ref.rays_given(y[:, :2], u[:, :2])        # 2-component launch data
+    mine = ra.GeometricTrace(s, engine=OracleEngine())
+    mine.rays_given(y[:, :2], u[:, :2])
+    for kw in (dict(clip=True), dict(clip=False), dict(clip=True, stop=-2)):
+        with np.errstate(all="ignore"):
+            ref.propagate(**kw)
+        mine.propagate(**kw)
+        b = range(len(s))[1:kw.get("stop")].stop
+        for name in "yuit":
+            assert np.array_equal(np.asarray(getattr(mine, name))[:b],
+                                  getattr(ref, name)[:b], equal_nan=True)
+        assert np.array_equal(mine.n[:b], ref.n[:b])
+    for attr in ("path", "track", "origins", "mirrored"):
+        assert np.array_equal(getattr(mine, attr), getattr(ref, attr))
+    assert mine.y.shape == ref.y.shape and mine.t.shape == ref.t.shape
+    assert np.array_equal(mine.y[-1, :, :2], ref.y[-1, :, :2], equal_nan=True)
+    assert np.array_equal(mine.t[:4].sum(0), ref.t[:4].sum(0), equal_nan=True)
+
+
+def test_accelerate_runs_reference_ray_generators(ro):
+    """rays_point / rays_clipping / rays_line (aiming, pupils: rayopt's own
+    host code) feeding the swapped-in propagate; reproduces the reference's
+    known answer rms = 0.052 (test_raytrace.py:189-199) on numeric indices."""
+    cls = dropin.accelerate(ro, engine_factory=OracleEngine)
+    assert ro.GeometricTrace is cls and ro.analysis.GeometricTrace is cls
+    text = ra.prescriptions.cooke().replace("radius: 20.", "radius: 0.364")
+    s = ro.system_from_yaml(text)
+    s.update()
+    p = ro.ParaxialTrace(s)
+    p.update_conjugates()
+    g = ro.GeometricTrace(s)
+    assert type(g).__mro__[1] is ra.GeometricTrace
+    g.rays_point((0, 1.), nrays=13, distribution="radau", filter=False)
+    np.testing.assert_allclose(g.rms(), .052, rtol=1e-2)
+    ref = cls._reference_class(s)
+    ref.rays_point((0, 1.), nrays=13, distribution="radau", filter=False)
+    assert np.array_equal(np.asarray(g.y), ref.y, equal_nan=True)
+    assert g.rms() == pytest.approx(ref.rms(), rel=1e-14)
+    g.rays_clipping((0, 1.))
+    g.rays_line((0, 1.))
+    ref.rays_line((0, 1.))
+    assert np.array_equal(np.asarray(g.u), ref.u, equal_nan=True)
+    d0 = float(s[-1].distance)
+    g.rays_point((0, 0.), nrays=21, distribution="hexapolar")
+    shift = g.refocus()
+    d1 = float(s[-1].distance)
+    assert d1 == pytest.approx(d0 + shift) and abs(shift) < 1.
+    s[-1].distance = d0
+    ref.rays_point((0, 0.), nrays=21, distribution="hexapolar")
+    ref.refocus()
+    assert float(s[-1].distance) == pytest.approx(d1, rel=1e-12)
+    assert np.array_equal(np.asarray(g.y), ref.y, equal_nan=True)
+    dropin.restore(ro)
+    assert ro.GeometricTrace is cls._reference_class
+
+
+def test_keep_rows_glue(ro):
+    s = ro.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    y, u = ra.bundles.disc_bundle(100, 10., 0., 1)
+    g = ra.GeometricTrace(s, engine=OracleEngine())
+    g.rays_given(y, u)
+    g.propagate(keep=[-1, 4])
+    assert np.isfinite(g.y[-1]).all() and np.isfinite(g.y[4]).all()
+    with pytest.raises(AssertionError):
+        g.y[5]
