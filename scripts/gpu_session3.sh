@@ -12,6 +12,16 @@ timeout 300 python scripts/probe.py > "$OUT/probe.json" 2> "$OUT/probe.err"
 echo "probe rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/probe.json" | tee -a "$OUT/summary.txt"
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench.json" | tee -a "$OUT/summary.txt"
+timeout 300 python scripts/configs_bench.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
+echo "configs rc=$?" | tee -a "$OUT/summary.txt"
+RT_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
+   --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 2 --cpu-sample 0 \
+   > "$OUT/bench_forced_dist.json" 2> "$OUT/bench_forced_dist.err"
+echo "forced-dist bench rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench_forced_dist.json" | tee -a "$OUT/summary.txt"
+RT_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
+   --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 10 --warmup 2 --cpu-sample 0 --gather-every-step \
+   > "$OUT/bench_forced_dist_every.json" 2> "$OUT/bench_forced_dist_every.err"
+echo "forced-dist (gather every step) rc=$?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench_forced_dist_every.json" | tee -a "$OUT/summary.txt"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- \
     python "$REPO/bench.py" --steps 10 --warmup 2 --cpu-sample 0 > "$OUT/prof_stats.log" 2>&1
