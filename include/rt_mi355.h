@@ -148,6 +148,35 @@ int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
 /* same, y/u already in device memory (rays generated on the device) */
 int rt_set_rays_device(rt_ctx *ctx, const double *d_y, const double *d_u,
                        int64_t n, int layout);
+/*
+ * On-device ray generation: the launch rays of
+ * nfields field points x npupil pupil coordinates, ray r = f*npupil + p, as
+ * System.aim(yo, yp, z, a, filter=False) builds them one field at a time on
+ * the host (rayopt/system.py:504, Infinite/FiniteConjugate.aim,
+ * rayopt/conjugates.py:137-166,236-255, Pupil.map rayopt/pupils.py:97-107,
+ * rectilinear projection).  Only npupil*16 B + nfields*sizeof(rt_field) cross
+ * PCIe instead of 48 B per ray; seeds row 0 like rt_set_rays.  The per-field
+ * frame is evaluated by the host (O(nfields)):
+ *   infinite: u = direction, base = (0,0,z) - z u, y = base + am px s + am py m,
+ *             then projected onto element 0 along u
+ *   finite:   base = object point, u = (0,0,z) [- base],
+ *             dir = u + z tan(am px) s + z tan(am py) m, normalised (flipped
+ *             if z < 0)
+ */
+typedef struct rt_field {
+    int32_t finite;
+    int32_t flip;
+    double am;
+    double z;
+    double base[3];
+    double u[3];
+    double s[3];
+    double m[3];
+} rt_field;
+int rt_sizeof_field(void);
+int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
+                     const double *pupil_xy, int64_t npupil);
+
 /* overwrite one surface row of one array from a host SoA buffer */
 int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa);
 

@@ -36,6 +36,12 @@ OPD_ARGS_DTYPE = np.dtype([
     ("shift", "f8", (3,)), ("r_after", "f8", (9,)), ("r_image", "f8", (9,)),
 ], align=True)
 
+FIELD_DTYPE = np.dtype([
+    ("finite", "i4"), ("flip", "i4"), ("am", "f8"), ("z", "f8"),
+    ("base", "f8", (3,)), ("u", "f8", (3,)), ("s", "f8", (3,)),
+    ("m", "f8", (3,)),
+], align=True)
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
                         "librt_mi355.so")
 
@@ -62,6 +68,9 @@ SIGNATURES = {
     "rt_set_rays_device": (ctypes.c_int, [_ctx, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_int64,
                                           ctypes.c_int]),
+    "rt_sizeof_field": (ctypes.c_int, []),
+    "rt_generate_rays": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_int64]),
     "rt_upload_row": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_void_p]),
     "rt_trace": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
@@ -124,6 +133,8 @@ def load():
         raise EngineError("struct rt_surface is %d bytes in the library but "
                           "%d in SURFACE_DTYPE" % (lib.rt_sizeof_surface(),
                                                    SURFACE_DTYPE.itemsize))
+    if lib.rt_sizeof_field() != FIELD_DTYPE.itemsize:
+        raise EngineError("struct rt_field layout mismatch")
     if lib.rt_sizeof_opd_args() != OPD_ARGS_DTYPE.itemsize:
         raise EngineError("struct rt_opd_args layout mismatch")
     _lib = lib

@@ -294,6 +294,36 @@ __global__ void rt_probe_copy_kernel(const double *__restrict__ src,
 }
 
 
+
+/* rays of field f x pupil point p, see rt_generate_rays in rt_mi355.h */
+__global__ void rt_generate_kernel(const rt_field *__restrict__ fields,
+                                   const double *__restrict__ pupil,
+                                   int64_t npupil, int64_t n, rt_surface S0,
+                                   double *__restrict__ Y,
+                                   double *__restrict__ U,
+                                   double *__restrict__ I,
+                                   double *__restrict__ T, int64_t ld,
+                                   int store_i)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ld)
+        return;
+    double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
+    if (r < n) {
+        const int64_t p = r % npupil;
+        rt_generate_ray(fields + r / npupil, pupil[2 * p], pupil[2 * p + 1],
+                        &S0, y, u);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Y[c * ld + r] = y[0][c];
+        U[c * ld + r] = u[0][c];
+        if (store_i)
+            I[c * ld + r] = u[0][c];
+    }
+    T[r] = 0.;
+}
+
 /* ------------------------------------------------------------------ */
 /* device-side consumers: rms, refocus sums, opd rays                 */
 /* ------------------------------------------------------------------ */
@@ -886,6 +916,49 @@ int rt_set_rays_device(rt_ctx *ctx, const double *d_y, const double *d_u,
     if (rc != RT_OK)
         return rc;
     return rt_seed(ctx, d_y, d_u, n, layout);
+}
+
+
+int rt_sizeof_field(void) { return (int)sizeof(rt_field); }
+
+int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
+                     const double *pupil_xy, int64_t npupil)
+{
+    if (!ctx || !fields || !pupil_xy || nfields < 1 || npupil < 1)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_generate_rays: bad argument");
+    if (ctx->nsurf < 2)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_generate_rays: rt_upload_system must come first");
+    const int64_t n = (int64_t)nfields * npupil;
+    int rc = rt_reserve(ctx, n);
+    if (rc != RT_OK)
+        return rc;
+    const size_t fbytes = sizeof(rt_field) * (size_t)nfields;
+    const size_t fpad = (fbytes + 255) / 256 * 256;
+    const size_t pbytes = sizeof(double) * 2 * (size_t)npupil;
+    rc = rt_need_scratch(ctx, fpad + pbytes);
+    if (rc != RT_OK)
+        return rc;
+    rt_field *d_fields = (rt_field *)ctx->d_scratch;
+    double *d_pupil = (double *)((char *)ctx->d_scratch + fpad);
+    RT_HIP(ctx, hipMemcpyAsync(d_fields, fields, fbytes, hipMemcpyHostToDevice,
+                               ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(d_pupil, pupil_xy, pbytes,
+                               hipMemcpyHostToDevice, ctx->stream));
+    const unsigned grid = (unsigned)((ctx->ld + 255) / 256);
+    rt_surface s0 = ctx->h_surf[0];
+    RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
+    hipLaunchKernelGGL(rt_generate_kernel, dim3(grid), dim3(256), 0,
+                       ctx->stream, d_fields, d_pupil, npupil, n, s0,
+                       rt_arr(ctx, RT_Y), rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
+                       rt_arr(ctx, RT_T), ctx->ld, !ctx->opt_alias);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
+    ctx->traced = 1;
+    ctx->i_alias[0] = ctx->opt_alias ? 2 : 0;
+    ctx->valid[0] = 1;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
 }
 
 int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)

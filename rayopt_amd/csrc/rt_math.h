@@ -196,33 +196,14 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
 }
 
 /*
- * One element for R rays.  In: y,u in the global orientation relative to the
- * previous vertex (what System.propagate carries between elements).  Out:
- * y = intercept, u = outgoing direction, iv = incoming direction, t = OPL,
- * all in the element-normal frame (the tuple System.propagate yields).
+ * Ray length to the element's surface: Spheroid.intercept (elements.py:
+ * 477-501) -- Newton for aspheres, plane, or the closed-form conic root.
  */
 template <int R>
-RT_HD void rt_step(const rt_surface *__restrict__ S, unsigned flags, int clip,
-                   double (&y)[R][3], double (&u)[R][3], double (&iv)[R][3],
-                   double (&t)[R])
+RT_HD void rt_intercept(const rt_surface *__restrict__ S, unsigned flags,
+                        const double (&y)[R][3], const double (&iv)[R][3],
+                        double (&s)[R])
 {
-    /* transfer: y - e.offset, then to_normal (system.py:461) */
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        y[r][0] -= S->offset[0];
-        y[r][1] -= S->offset[1];
-        y[r][2] -= S->offset[2];
-        iv[r][0] = u[r][0];
-        iv[r][1] = u[r][1];
-        iv[r][2] = u[r][2];
-        if (flags & RT_F_ROTATED) {
-            rt_rot_to(S->rot, y[r]);
-            rt_rot_to(S->rot, iv[r]);
-        }
-    }
-
-    /* intercept */
-    double s[R];
     if (flags & RT_F_ASPH) {
         rt_newton<R>(S, flags, y, iv, s);
     } else if (!(flags & RT_F_CURVED)) {
@@ -259,6 +240,77 @@ RT_HD void rt_step(const rt_surface *__restrict__ S, unsigned flags, int clip,
             s[r] = -(d + g) / e;
         }
     }
+}
+
+/*
+ * One launch ray of field F through pupil coordinates (px, py):
+ * Infinite/FiniteConjugate.aim after the per-field frame has been built by
+ * the host (conjugates.py:137-166, 236-255; Pupil.map pupils.py:97-107).
+ */
+RT_HD void rt_generate_ray(const rt_field *__restrict__ F, double px,
+                           double py, const rt_surface *__restrict__ S0,
+                           double (&y)[1][3], double (&u)[1][3])
+{
+    px *= F->am;
+    py *= F->am;
+    if (!F->finite) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u[0][c] = F->u[c];
+            y[0][c] = F->base[c] + (px * F->s[c] + py * F->m[c]);
+        }
+        double t[1]; /* y += surface.intercept(y, u) u  (:253-254) */
+        rt_intercept<1>(S0, S0->flags, y, u, t);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            y[0][c] = y[0][c] + t[0] * u[0][c];
+    } else {
+        const double qx = F->z * tan(px), qy = F->z * tan(py);
+        double d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            y[0][c] = F->base[c];
+            d[c] = F->u[c] + (qx * F->s[c] + qy * F->m[c]);
+        }
+        const double nrm = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u[0][c] = d[c] / nrm;
+            if (F->flip)
+                u[0][c] *= -1.;
+        }
+    }
+}
+
+/*
+ * One element for R rays.  In: y,u in the global orientation relative to the
+ * previous vertex (what System.propagate carries between elements).  Out:
+ * y = intercept, u = outgoing direction, iv = incoming direction, t = OPL,
+ * all in the element-normal frame (the tuple System.propagate yields).
+ */
+template <int R>
+RT_HD void rt_step(const rt_surface *__restrict__ S, unsigned flags, int clip,
+                   double (&y)[R][3], double (&u)[R][3], double (&iv)[R][3],
+                   double (&t)[R])
+{
+    /* transfer: y - e.offset, then to_normal (system.py:461) */
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        y[r][0] -= S->offset[0];
+        y[r][1] -= S->offset[1];
+        y[r][2] -= S->offset[2];
+        iv[r][0] = u[r][0];
+        iv[r][1] = u[r][1];
+        iv[r][2] = u[r][2];
+        if (flags & RT_F_ROTATED) {
+            rt_rot_to(S->rot, y[r]);
+            rt_rot_to(S->rot, iv[r]);
+        }
+    }
+
+    /* intercept */
+    double s[R];
+    rt_intercept<R>(S, flags, y, iv, s);
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {

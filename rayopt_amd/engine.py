@@ -95,6 +95,18 @@ class Engine:
             self.ctx, ctypes.c_void_p(d_y), ctypes.c_void_p(d_u), int(n),
             layout), "rt_set_rays_device")
 
+    def generate_rays(self, fields, pupil_xy):
+        """Seed row 0 with len(fields) x len(pupil_xy) rays built on the
+        device (rt_generate_rays); returns the ray count."""
+        fields = np.ascontiguousarray(fields, dtype=_lib.FIELD_DTYPE)
+        pupil = np.ascontiguousarray(pupil_xy, dtype=np.float64)
+        if pupil.ndim != 2 or pupil.shape[1] != 2:
+            raise ValueError("pupil coordinates must be (P,2)")
+        self._check(self.lib.rt_generate_rays(
+            self.ctx, fields.ctypes.data, len(fields), pupil.ctypes.data,
+            pupil.shape[0]), "rt_generate_rays")
+        return len(fields)*pupil.shape[0]
+
     def upload_row(self, which, surf, src_soa):
         src = np.ascontiguousarray(src_soa, dtype=np.float64)
         self._check(self.lib.rt_upload_row(self.ctx, which, surf,

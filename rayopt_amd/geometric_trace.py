@@ -234,6 +234,32 @@ class GeometricTrace(Trace):
         for rows in (self.y, self.u, self.i, self.t):
             rows.invalidate(0, self.length)
 
+    def rays_fields(self, yo, yp, z, a, l=None, ref=0):
+        """Launch ``len(yo) x len(yp)`` rays built on the GPU: for every
+        field point ``yo[f]`` (fractional object coordinates) the bundle
+        through the pupil coordinates ``yp`` (P,2), as
+        ``system.aim(yo[f], yp, z[f], a[f], filter=False)`` + ``rays_given``
+        would (rayopt/system.py:504, rayopt/conjugates.py:137-166,236-255)
+        -- ray ``f*P + p`` -- without the 48 B/ray host transfer.  ``z, a``:
+        pupil distance and aperture per field (e.g. from ``system.pupil``)."""
+        from .launch import field_frames
+        yp = np.atleast_2d(np.asarray(yp, dtype=float))
+        fields = field_frames(self.system, yo, z, a)
+        nrays = len(fields)*yp.shape[0]
+        if not hasattr(self, "y") or self.nrays != nrays \
+                or self.length != len(self.system):
+            self.allocate(nrays)
+        self.l = self.system.wavelengths[0] if l is None else l
+        self._uniform_w = True
+        self.w = np.ones(nrays)/nrays
+        self.ref = ref
+        self.n[0] = self.system.refractive_index(self.l, 0)
+        self._upload_table(1, None, self.n[0])
+        self.engine.generate_rays(fields, yp)
+        self.engine.set_weights(None)
+        for rows in (self.y, self.u, self.i, self.t):
+            rows.invalidate(0, self.length)
+
     # -- the hot path ---------------------------------------------------------
     def propagate(self, start=1, stop=None, clip=False, keep=None):
         """Trace elements ``start .. stop-1`` for all rays on the GPU

@@ -1,0 +1,102 @@
+"""Per-field launch frames for on-device ray generation.
+
+For every field point the host evaluates the O(1) frame that the reference's
+``Conjugate.aim`` builds before it broadcasts over the pupil coordinates
+(rayopt/conjugates.py:137-166 finite, :236-255 infinite; sagittal/meridional
+unit vectors rayopt/utils.py:106-114); the GPU expands it over the pupil
+grid (``rt_generate_rays``).  ``system.object`` may be this package's
+``Conjugate`` or a reference conjugate object (``finite``, ``angle`` /
+``radius``, ``projection``, ``pupil.telecentric`` are read).
+"""
+import numpy as np
+
+from ._lib import FIELD_DTYPE
+
+
+def _unit(v):
+    return v/np.sqrt(np.square(v).sum(-1))
+
+
+def _frame(u, z):
+    """Sagittal and meridional unit vectors of direction ``u`` about the
+    axis ``(0,0,z)``."""
+    axis = np.array((0., 0., z))
+    s = np.cross(u, axis)
+    if np.all(s == 0):
+        s = np.array((1., 0., 0.))
+    m = np.cross(u, s)
+    return _unit(s), _unit(m)
+
+
+def _sag0(element, y):
+    """-surface_sag of element 0 at the object point (z of the object
+    surface), Spheroid.surface_sag rayopt/elements.py:440-455."""
+    c = getattr(element, "curvature", 0.)
+    asph = getattr(element, "aspherics", None)
+    if not c and asph is None:
+        return -y[2]
+    r2 = y[0]*y[0] + y[1]*y[1]
+    e = y[2]
+    if c:
+        k = getattr(element, "conic", 0.)
+        e = e - c*r2/(1 + np.sqrt(1 - (1 + k)*c**2*r2))
+    if asph is not None:
+        d = 0.
+        for ai in reversed(asph):
+            d += ai
+            d *= r2
+        e = e - d
+    return -e
+
+
+def _telecentric(obj):
+    pupil = obj.pupil
+    if isinstance(pupil, dict):
+        return bool(pupil.get("telecentric", False))
+    return bool(pupil.telecentric)
+
+
+def field_frames(system, yo, z, a):
+    """``FIELD_DTYPE`` array, one entry per row of ``yo`` (F,2) fractional
+    object coordinates.  ``z``: pupil distance(s) from the vertex of element
+    0, scalar or (F,); ``a``: pupil aperture(s): scalar radius, (2,2)
+    ``[[-sag,-mer],[+sag,+mer]]`` or (F,2,2)."""
+    obj = system.object
+    projection = getattr(obj, "projection", "rectilinear")
+    if projection != "rectilinear":
+        raise NotImplementedError("projection %r" % projection)
+    yo = np.atleast_2d(np.asarray(yo, dtype=float))
+    nf = yo.shape[0]
+    z = np.broadcast_to(np.asarray(z, dtype=float), (nf,))
+    a = np.asarray(a, dtype=float)
+    if a.ndim == 0:
+        a = a*np.array(((-1., -1.), (1., 1.)))
+    a = np.broadcast_to(a, (nf, 2, 2))
+    out = np.zeros(nf, dtype=FIELD_DTYPE)
+    for f in range(nf):
+        zf = float(z[f])
+        row = out[f]
+        row["z"] = zf
+        if not obj.finite:
+            yt = yo[f]*np.tan(obj.angle)
+            u = np.array((yt[0], yt[1], 1.))
+            u /= np.sqrt(np.square(u).sum(-1))
+            s, m = _frame(u, zf)
+            row["finite"] = 0
+            row["am"] = np.fabs(a[f]).max()
+            row["u"] = u
+            row["base"] = np.array((0., 0., zf)) - zf*u
+        else:
+            y = np.zeros(3)
+            y[:2] = -yo[f]*obj.radius
+            y[2] = _sag0(system[0], y)
+            uz = np.array((0., 0., zf))
+            u = uz if _telecentric(obj) else uz - y
+            s, m = _frame(u, zf)
+            row["finite"] = 1
+            row["flip"] = zf < 0
+            row["am"] = np.fabs(np.arctan2(a[f], zf)).max()
+            row["u"] = u
+            row["base"] = y
+        row["s"], row["m"] = s, m
+    return out

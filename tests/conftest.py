@@ -122,4 +122,19 @@ def hostemu():
             ctypes.c_void_p(I.ctypes.data), ctypes.c_void_p(T.ctypes.data))
         assert rc == 0
         return Y, U, I, T
+
+    def generate(fields, pupil, s0):
+        fields = np.ascontiguousarray(fields)
+        pupil = np.ascontiguousarray(pupil, dtype=float)
+        s0 = np.ascontiguousarray(s0)
+        n = len(fields)*len(pupil)
+        Y, U = np.empty((n, 3)), np.empty((n, 3))
+        rc = dll.emu_generate(
+            ctypes.c_void_p(fields.ctypes.data), len(fields),
+            ctypes.c_void_p(pupil.ctypes.data), ctypes.c_int64(len(pupil)),
+            ctypes.c_void_p(s0.ctypes.data), ctypes.c_void_p(Y.ctypes.data),
+            ctypes.c_void_p(U.ctypes.data))
+        assert rc == 0
+        return Y, U
+    trace.generate = generate
     return trace

@@ -54,3 +54,21 @@ extern "C" int emu_trace(const rt_surface *surf, int start, int stop, int clip,
     }
     return 0;
 }
+
+extern "C" int emu_generate(const rt_field *fields, int nfields,
+                            const double *pupil, int64_t npupil,
+                            const rt_surface *s0, double *Y, double *U)
+{
+    for (int f = 0; f < nfields; ++f)
+        for (int64_t p = 0; p < npupil; ++p) {
+            double y[1][3], u[1][3];
+            rt_generate_ray(fields + f, pupil[2 * p], pupil[2 * p + 1], s0, y,
+                            u);
+            const int64_t r = (int64_t)f * npupil + p;
+            for (int c = 0; c < 3; ++c) {
+                Y[r * 3 + c] = y[0][c];
+                U[r * 3 + c] = u[0][c];
+            }
+        }
+    return 0;
+}

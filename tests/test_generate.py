@@ -1,0 +1,109 @@
+"""On-device ray generation (rt_generate_rays): host frames + the generation
+arithmetic (compiled for the host) against the reference's System.aim here;
+the kernel against the oracle on the GPU."""
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd.launch import field_frames
+from rayopt_amd.pack import pack_system
+from oracle import aim_numpy as an
+from oracle import trace_numpy as tn
+from oracle import refshim
+
+from conftest import assert_parity, RTOL_SPHERICAL
+
+FINITE_OBJECT = ("object: {type: finite, radius: 25., "
+                 "pupil: {radius: 16.0, distance: 120}}")
+CURVED_OBJECT = "- {material: 1.0, roc: -300., conic: -0.4}\n"
+
+
+def systems():
+    base = ra.prescriptions.DOUBLE_GAUSS
+    fin = base.replace("object: {angle_deg: 14, pupil: {radius: 16.0}}",
+                       FINITE_OBJECT)
+    out = {"infinite": base, "finite": fin,
+           "finite_telecentric": fin.replace(
+               "distance: 120}", "distance: 120, telecentric: true}"),
+           "finite_curved_object": fin.replace("- {material: 1.0}\n",
+                                               CURVED_OBJECT, 1),
+           "infinite_curved_first": base.replace("- {material: 1.0}\n",
+                                                 CURVED_OBJECT, 1)}
+    return out
+
+
+FIELDS = np.array([(0., 0.), (0., 1.), (0.3, -0.7), (-1., 0.2)])
+ZA = [(68.94, 16.0), (-20., np.array(((-3., -5.), (3.5, 5.)))),
+      (150., np.array(((-9., -9.), (9., 9.))))]
+
+
+def pupil_points(n=200, seed=3):
+    rng = np.random.default_rng(seed)
+    return np.vstack([[(0., 0.)], rng.uniform(-1, 1, (n - 1, 2))])
+
+
+def oracle_rays(system, yo, yp, z, a):
+    obj = system.object
+    if not obj.finite:
+        return an.aim_infinite(obj.angle, yo, yp, z, a,
+                               getattr(system[0], "curvature", 0.),
+                               getattr(system[0], "conic", 0.))
+    from rayopt_amd.launch import _sag0, _telecentric
+
+    def sag(y):
+        return np.array([_sag0(system[0], yi) for yi in y])
+    return an.aim_finite(obj.radius, _telecentric(obj), yo, yp, z, a, sag)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+@pytest.mark.parametrize("key", sorted(systems()))
+def test_frames_and_generation_math_vs_reference_aim(key, hostemu):
+    ro = refshim.load()
+    ref_sys = ro.system_from_yaml(systems()[key])
+    mine = ra.system_from_yaml(systems()[key])
+    yp = pupil_points()
+    for z, a in ZA:
+        a2 = a if np.ndim(a) else a*np.array(((-1., -1.), (1., 1.)))
+        for s in (ref_sys, mine):     # frames from either kind of System
+            frames = field_frames(s, FIELDS, z, a)
+            table, _ = pack_system(s, 587.56e-9, 1.0)
+            Y, U = hostemu.generate(frames, yp, table[:1])
+            for f, yo in enumerate(FIELDS):
+                with np.errstate(all="ignore"):
+                    yr, ur = ref_sys.aim(yo, yp, z, a2, filter=False)
+                yo_, uo_ = oracle_rays(mine, yo, yp, z, a2)
+                assert np.array_equal(yr, yo_) and np.array_equal(ur, uo_)
+                sl = slice(f*len(yp), (f + 1)*len(yp))
+                assert_parity(Y[sl][None], yr[None], 1e-13, key + ".y")
+                assert_parity(U[sl][None], ur[None], 1e-13, key + ".u")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", sorted(systems()))
+def test_device_generation_vs_oracle(key):
+    system = ra.system_from_yaml(systems()[key])
+    yp = pupil_points(5003, 9)
+    z, a = ZA[0] if not system.object.finite else ZA[2]
+    a2 = a if np.ndim(a) else a*np.array(((-1., -1.), (1., 1.)))
+    g = ra.GeometricTrace(system)
+    g.rays_fields(FIELDS, yp, z, a)
+    assert g.nrays == len(FIELDS)*len(yp)
+    y0, u0 = np.asarray(g.y[0]), np.asarray(g.u[0])
+    for f, yo in enumerate(FIELDS):
+        with np.errstate(all="ignore"):
+            yr, ur = oracle_rays(system, yo, yp, z, a2)
+        sl = slice(f*len(yp), (f + 1)*len(yp))
+        assert_parity(y0[sl][None], yr[None], 1e-13, key + ".y")
+        assert_parity(u0[sl][None], ur[None], 1e-13, key + ".u")
+    assert np.array_equal(np.asarray(g.i[0]), u0, equal_nan=True)
+    assert not np.asarray(g.t[0]).any()
+    # and the trace that follows equals the oracle's on the generated rays
+    g.propagate(clip=True)
+    table, ns = pack_system(system, g.l, g.n[0])
+    with np.errstate(all="ignore"):
+        want = tn.propagate(table, y0, u0, clip=True)
+    for rows, b in zip((g.y, g.u, g.i, g.t), want):
+        assert_parity(np.asarray(rows[1:]), b, RTOL_SPHERICAL, key)
+    assert g.rms(i=1) == pytest.approx(
+        np.sqrt((np.square(np.asarray(g.y[1])[:, :2] - np.asarray(
+            g.y[1])[:, :2].mean(0)).sum(1)/g.nrays).sum()), rel=1e-12)
