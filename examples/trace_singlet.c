@@ -66,7 +66,7 @@ int main(int argc, char **argv)
     }
     /* paraxial check: a ray at height h crosses the axis near the focus */
     const int64_t mid = n / 2 + n / 20;
-    printf("rays %lld kernel_ms %.4f rms %.6f y_image[mid] %.9f\n",
+    printf("rays %lld kernel_ms %.4f rms %.6f y_image[mid] %.17g\n",
            (long long)n, ms, rms, img[n + mid]);
     rt_destroy(ctx);
     free(y); free(u); free(img);
