@@ -13,7 +13,7 @@ from .formats import (system_from_yaml, system_from_json, system_from_dict,
 from .geometric_trace import GeometricTrace, Trace, DeviceRows
 from .engine import Engine, get_engine
 from ._lib import EngineError
-from . import prescriptions, bundles
+from . import prescriptions, bundles, pupil
 
 __all__ = [
     "System", "Element", "Interface", "Spheroid", "Pose", "Material",

@@ -1,0 +1,177 @@
+"""Batched ray aiming on the GPU.
+
+The reference aims one field point at a time: ``System.pupil`` ->
+``_aim_pupil`` -> ``aim_chief`` (secant on the chief ray's stop intercept) and
+four ``aim_marginal`` solves (Brent on the marginal rays' aperture margin),
+each evaluation a trace of ONE ray (rayopt/system.py:507-593; ~130 serial
+N=1 traces per field).  Here every solver iteration is ONE trace of all F
+field points at once (rays built on the device by ``rays_fields``), so the
+cost is ~5 solves x ~30 launches independent of F.  The roots are the same
+(the chief ray through the centre of the stop; marginal rays grazing the stop
+edge, or the first limiting aperture for ``rim=True``); the reference stops
+at ``tol=1e-3``, this solver iterates to ``tol`` (default 1e-9), so the two
+agree to the reference's tolerance.
+
+``entrance_pupil`` gives the first-order starting values the reference takes
+from its paraxial trace (``ParaxialTrace.update_conjugates``,
+rayopt/paraxial_trace.py:326-334): the paraxial image of the stop in object
+space.
+"""
+import numpy as np
+
+from .geometric_trace import GeometricTrace
+
+
+def entrance_pupil(system, l=None):
+    """(distance from the vertex of element 0, radius) of the paraxial image
+    of the stop in object space: y-nu trace of two rays through elements
+    1..stop (untilted, no mirror in front of the stop)."""
+    if l is None:
+        l = system.wavelengths[0]
+    stop = system.stop
+    n0 = system.refractive_index(l, 0)
+    rays = np.array([[1., 0.], [0., 1.]])        # (y, n u) for two rays
+    n_prev = n0
+    for el in system[1:stop + 1]:
+        if getattr(getattr(el, "material", None), "mirror", False):
+            raise NotImplementedError("mirror in front of the stop")
+        rays[:, 0] += el.distance*rays[:, 1]/n_prev
+        c = getattr(el, "curvature", 0.)
+        asph = getattr(el, "aspherics", None)
+        if asph:
+            c = c + 2*asph[0]
+        n_next, _ = el.get_n_mu(n_prev, l)
+        rays[:, 1] -= rays[:, 0]*c*(n_next - n_prev)
+        n_prev = n_next
+    a, b = rays[0, 0], rays[1, 0]*n0
+    return b/a, system[stop].radius/a
+
+
+class FieldAimer:
+    """Aims F field points at once.  ``engine`` is injectable (tests)."""
+
+    def __init__(self, system, l=None, engine=None, tol=1e-9, maxiter=60):
+        self.system = system
+        self.l = system.wavelengths[0] if l is None else l
+        self.trace = GeometricTrace(system, engine=engine)
+        self.tol = tol
+        self.maxiter = maxiter
+
+    # one trace of F rays: field f through pupil point yp with (z_f, a_f)
+    def _stop_xy(self, yo, yp, z, a, last):
+        t = self.trace
+        t.rays_fields(yo, [yp], z, a, self.l)
+        t.propagate(stop=last + 1)
+        return t
+
+    def chief(self, yo, z0, p, stop=None):
+        """Pupil distance per field such that the chief ray crosses the
+        centre of the stop (aim_chief, rayopt/system.py:507-526)."""
+        yo = np.atleast_2d(np.asarray(yo, dtype=float))
+        stop = self.system.stop if stop in (-1, None) else stop
+        rad = self.system[stop].radius
+        z0 = np.broadcast_to(np.asarray(z0, dtype=float), (len(yo),))
+        todo = ~np.all(np.isclose(yo, 0), axis=1)   # on-axis: nothing to aim
+        if not todo.any():
+            return z0.copy()
+
+        def miss(alpha):
+            t = self._stop_xy(yo, (0., 0.), z0 + alpha*p, p, stop)
+            y = np.asarray(t.y[stop])[:, :2]
+            return (yo*y).sum(1)/rad
+
+        a0 = np.zeros(len(yo))
+        f0 = miss(a0)
+        a1 = a0 + 1e-4
+        f1 = miss(a1)
+        for _ in range(self.maxiter):
+            with np.errstate(all="ignore"):
+                step = np.where(todo & (f1 != f0),
+                                f1*(a1 - a0)/(f1 - f0), 0.)
+            a0, f0 = a1, f1
+            a1 = a1 - step
+            if np.all(np.abs(step) <= self.tol):
+                break
+            f1 = miss(a1)
+        else:
+            raise ValueError("chief-ray aiming did not converge")
+        return np.where(todo, z0 + a1*p, z0)
+
+    def marginal(self, yo, yp, z, p, rim=False, stop=None):
+        """Signed aperture per field such that the ray through pupil
+        coordinate ``yp`` grazes the stop edge -- or, ``rim=True``, the first
+        limiting aperture of the whole system (aim_marginal,
+        rayopt/system.py:528-555).  Bracketing + regula falsi (Illinois),
+        vectorised over fields."""
+        yo = np.atleast_2d(np.asarray(yo, dtype=float))
+        nf = len(yo)
+        last = len(self.system) - 2 if rim else \
+            (self.system.stop if stop is None else stop)
+        r2 = np.square([e.radius for e in self.system[1:last + 1]])
+        p = np.broadcast_to(np.asarray(p, dtype=float), (nf,))
+
+        def margin(scale):
+            t = self._stop_xy(yo, yp, z, np.abs(scale*p), last)
+            if rim:
+                ys = np.asarray(t.y[1:last + 1])[:, :, :2]
+                return (np.square(ys).sum(2)/r2[:, None] - 1).max(0)
+            y = np.asarray(t.y[last])[:, :2]
+            return np.square(y).sum(1)/r2[-1] - 1
+
+        lo = np.zeros(nf)
+        flo = margin(np.full(nf, 1e-9))       # ~ chief ray: inside, < 0
+        hi = np.ones(nf)
+        for _ in range(self.maxiter):         # expand until outside
+            fhi = margin(hi)
+            bad = np.isnan(fhi)
+            inside = ~bad & (fhi < 0)
+            if not (bad | inside).any():
+                break
+            lo = np.where(inside, hi, lo)
+            flo = np.where(inside, fhi, flo)
+            hi = np.where(bad, hi/2, np.where(inside, hi*(1 - fhi), hi))
+        else:
+            raise ValueError("no viable marginal-ray interval")
+        side = np.zeros(nf)
+        for _ in range(self.maxiter):
+            with np.errstate(all="ignore"):
+                x = (lo*fhi - hi*flo)/(fhi - flo)
+            x = np.where(np.isfinite(x), x, (lo + hi)/2)
+            fx = margin(x)
+            neg = fx < 0
+            # Illinois: halve the retained end's value when it is kept twice
+            flo = np.where(neg, fx, np.where(side == 1, flo/2, flo))
+            fhi = np.where(neg, np.where(side == -1, fhi/2, fhi), fx)
+            lo = np.where(neg, x, lo)
+            hi = np.where(neg, hi, x)
+            side = np.where(neg, -1., 1.)
+            if np.all(np.abs(fx) <= self.tol):
+                break
+        else:
+            raise ValueError("marginal-ray aiming did not converge")
+        return x*p
+
+    def pupil(self, yo, z0=None, a0=None, rim=False):
+        """(z (F,), a (F,2,2)) for every field: chief aiming, then the four
+        marginal rays -sag, -mer, +sag, +mer (_aim_pupil,
+        rayopt/system.py:557-583; a = [[-sag,-mer],[+sag,+mer]])."""
+        yo = np.atleast_2d(np.asarray(yo, dtype=float))
+        nf = len(yo)
+        if z0 is None or a0 is None:
+            zp, ap = entrance_pupil(self.system, self.l)
+            spec = getattr(self.system.object, "pupil", None)
+            given = spec.get("radius") if isinstance(spec, dict) else \
+                getattr(spec, "radius", None)
+            z0 = zp if z0 is None else z0
+            # a specified object pupil radius is the starting aperture, as in
+            # the reference (Pupil.update only tracks it if update_radius)
+            a0 = (given or ap) if a0 is None else a0
+        z = self.chief(yo, z0, np.fabs(a0))
+        a = np.empty((nf, 2, 2))
+        for axis in (1, 0):
+            for sign in (1, 0):
+                yp = [0., 0.]
+                yp[axis] = 2*sign - 1.
+                a[:, sign, axis] = (2*sign - 1.)*np.fabs(
+                    self.marginal(yo, yp, z, a0, rim=rim))
+        return z, a

@@ -59,8 +59,8 @@ def _telecentric(obj):
 def field_frames(system, yo, z, a):
     """``FIELD_DTYPE`` array, one entry per row of ``yo`` (F,2) fractional
     object coordinates.  ``z``: pupil distance(s) from the vertex of element
-    0, scalar or (F,); ``a``: pupil aperture(s): scalar radius, (2,2)
-    ``[[-sag,-mer],[+sag,+mer]]`` or (F,2,2)."""
+    0, scalar or (F,); ``a``: pupil aperture(s): scalar radius, (F,) radii,
+    (2,2) ``[[-sag,-mer],[+sag,+mer]]`` or (F,2,2)."""
     obj = system.object
     projection = getattr(obj, "projection", "rectilinear")
     if projection != "rectilinear":
@@ -69,8 +69,8 @@ def field_frames(system, yo, z, a):
     nf = yo.shape[0]
     z = np.broadcast_to(np.asarray(z, dtype=float), (nf,))
     a = np.asarray(a, dtype=float)
-    if a.ndim == 0:
-        a = a*np.array(((-1., -1.), (1., 1.)))
+    if a.ndim <= 1:     # scalar radius, or one radius per field
+        a = a[..., None, None]*np.array(((-1., -1.), (1., 1.)))
     a = np.broadcast_to(a, (nf, 2, 2))
     out = np.zeros(nf, dtype=FIELD_DTYPE)
     for f in range(nf):

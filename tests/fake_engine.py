@@ -73,3 +73,28 @@ class OracleEngine:
             np.ones(self.nrays)/self.nrays
         return cn.refocus_shift(self.rows[RT_Y][surf], self.rows[RT_I][surf],
                                 w)
+
+
+def _generate_rays(self, fields, pupil_xy):
+    """Test double of rt_generate_rays: the generation arithmetic compiled
+    for the host (tests/hostemu)."""
+    import ctypes
+    import os
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                   "hostemu", "libhostemu.so"))
+    fields = np.ascontiguousarray(fields)
+    pupil = np.ascontiguousarray(pupil_xy, dtype=float)
+    n = len(fields)*len(pupil)
+    Y, U = np.empty((n, 3)), np.empty((n, 3))
+    s0 = np.ascontiguousarray(self.table[:1])
+    lib.emu_generate(ctypes.c_void_p(fields.ctypes.data), len(fields),
+                     ctypes.c_void_p(pupil.ctypes.data),
+                     ctypes.c_int64(len(pupil)),
+                     ctypes.c_void_p(s0.ctypes.data),
+                     ctypes.c_void_p(Y.ctypes.data),
+                     ctypes.c_void_p(U.ctypes.data))
+    self.set_rays(Y, U)
+    return n
+
+
+OracleEngine.generate_rays = _generate_rays
