@@ -25,7 +25,7 @@ def pytest_configure(config):
 def golden_names():
     return sorted(os.path.basename(p)[:-4]
                   for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                  if not os.path.basename(p).startswith(("kat_",
+                  if not os.path.basename(p).startswith(("kat_", "aim_",
                                                          "consumers_")))
 
 
