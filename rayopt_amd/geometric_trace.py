@@ -260,6 +260,34 @@ class GeometricTrace(Trace):
         for rows in (self.y, self.u, self.i, self.t):
             rows.invalidate(0, self.length)
 
+    def rays_points(self, fields, wavelength=None, nrays=11,
+                    distribution="meridional", clip=False, aim=True,
+                    rim=False):
+        """Bundles for many field points in one go -- the batched counterpart
+        of ``rays_point`` (rayopt/geometric_trace.py:204-209): pupil pattern
+        (``pupil_distribution``), aiming of every field on the GPU
+        (:class:`rayopt_amd.aiming.FieldAimer`; ``aim=False`` uses the
+        paraxial entrance pupil), ray construction on the GPU, trace.  Ray
+        ``f*P + p`` belongs to field ``f``; ``self.w`` carries the quadrature
+        weights of the pattern, normalised per field."""
+        from .aiming import FieldAimer, entrance_pupil
+        from .pupil import pupil_distribution
+        fields = np.atleast_2d(np.asarray(fields, dtype=float))
+        ref, yp, weight = pupil_distribution(distribution, nrays)
+        l = self.system.wavelengths[0] if wavelength is None else wavelength
+        if aim:
+            z, a = FieldAimer(self.system, l).pupil(fields, rim=rim)
+        else:
+            z, a = entrance_pupil(self.system, l)
+        self.rays_fields(fields, yp, z, a, l, ref=ref)
+        if weight is not None:
+            self.w = np.tile(weight, len(fields))
+            self._uniform_w = False
+            self.engine.set_weights(self.w)
+        self.fields = fields
+        self.rays_per_field = len(yp)
+        self.propagate(clip=clip)
+
     # -- the hot path ---------------------------------------------------------
     def propagate(self, start=1, stop=None, clip=False, keep=None):
         """Trace elements ``start .. stop-1`` for all rays on the GPU

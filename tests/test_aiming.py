@@ -101,3 +101,27 @@ def test_batched_aiming_on_device():
     rad = system[system.stop].radius
     assert np.isfinite(r).all() and r.max() > 0.95*rad
     assert (r <= rad*1.02).mean() > 0.8
+
+
+@pytest.mark.gpu
+def test_rays_points_chain():
+    """pattern -> batched aiming -> device generation -> trace -> device
+    reduction, for a fan of fields; per-field spot sizes are finite and grow
+    off axis for the Cooke triplet."""
+    system = ra.system_from_yaml(COOKE)
+    fields = np.c_[np.zeros(6), np.linspace(0, 1, 6)]
+    g = ra.GeometricTrace(system)
+    g.rays_points(fields, nrays=200, distribution="hexapolar")
+    P = g.rays_per_field
+    assert g.nrays == 6*P and g.y.shape == (9, 6*P, 3)
+    spots = np.asarray(g.y[-1])[:, :2].reshape(6, P, 2)
+    rms = np.sqrt(np.square(spots - spots.mean(1, keepdims=True)).sum(2)
+                  .mean(1))
+    assert np.isfinite(rms).all() and rms[-1] > rms[0]
+    # chief rays (pattern point 0) cross the stop centre
+    stop = np.asarray(g.y[system.stop]).reshape(6, P, 3)[:, 0, :2]
+    assert np.abs(stop).max() < 1e-6*system[system.stop].radius
+    # unaimed variant runs from the paraxial pupil
+    g.rays_points(fields[:2], nrays=50, distribution="square", aim=False,
+                  clip=True)
+    assert g.nrays == 2*g.rays_per_field
