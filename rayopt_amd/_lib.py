@@ -42,8 +42,8 @@ FIELD_DTYPE = np.dtype([
     ("m", "f8", (3,)),
 ], align=True)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                        "librt_mi355.so")
+LIB_PATH = os.environ.get("RT_MI355_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "librt_mi355.so")
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int64_p = ctypes.POINTER(ctypes.c_int64)

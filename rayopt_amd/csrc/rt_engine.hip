@@ -136,6 +136,10 @@ __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
         const unsigned flags = S->flags;
         rt_step<R>(S, flags, clip, y, u, iv, t);
 
+        /* all rows of the element leave in one burst: measured 3 % faster
+         * than sending y,t,i ahead of the refraction, and aligning the waves
+         * of a workgroup with a barrier first does not help
+         * (profiles/r01_probes/ab_store_order.log) */
         if (!(flags & RT_F_NOSTORE)) {
             const int64_t row = (int64_t)s * 3;
 #pragma unroll

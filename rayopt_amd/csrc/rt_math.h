@@ -289,9 +289,9 @@ RT_HD void rt_generate_ray(const rt_field *__restrict__ F, double px,
  * all in the element-normal frame (the tuple System.propagate yields).
  */
 template <int R>
-RT_HD void rt_step(const rt_surface *__restrict__ S, unsigned flags, int clip,
-                   double (&y)[R][3], double (&u)[R][3], double (&iv)[R][3],
-                   double (&t)[R])
+RT_HD void rt_step_hit(const rt_surface *__restrict__ S, unsigned flags,
+                       double (&y)[R][3], const double (&u)[R][3],
+                       double (&iv)[R][3], double (&t)[R])
 {
     /* transfer: y - e.offset, then to_normal (system.py:461) */
 #pragma unroll
@@ -318,6 +318,18 @@ RT_HD void rt_step(const rt_surface *__restrict__ S, unsigned flags, int clip,
         y[r][0] = y[r][0] + s[r] * iv[r][0];
         y[r][1] = y[r][1] + s[r] * iv[r][1];
         y[r][2] = y[r][2] + s[r] * iv[r][2];
+        t[r] = s[r] * S->n0;
+    }
+}
+
+/* clip + refract/reflect at the intercept y: iv -> u (elements.py:309-314) */
+template <int R>
+RT_HD void rt_step_bend(const rt_surface *__restrict__ S, unsigned flags,
+                        int clip, const double (&y)[R][3],
+                        const double (&iv)[R][3], double (&u)[R][3])
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
         u[r][0] = iv[r][0];
         u[r][1] = iv[r][1];
         u[r][2] = iv[r][2];
@@ -356,8 +368,16 @@ RT_HD void rt_step(const rt_surface *__restrict__ S, unsigned flags, int clip,
                 u[r][2] = S->muf * u[r][2] + g * 1.;
             }
         }
-        t[r] = s[r] * S->n0;
     }
+}
+
+template <int R>
+RT_HD void rt_step(const rt_surface *__restrict__ S, unsigned flags, int clip,
+                   double (&y)[R][3], double (&u)[R][3], double (&iv)[R][3],
+                   double (&t)[R])
+{
+    rt_step_hit<R>(S, flags, y, u, iv, t);
+    rt_step_bend<R>(S, flags, clip, y, iv, u);
 }
 
 /* from_normal of the element just left (system.py:464); y,u copies */
