@@ -115,6 +115,34 @@ __device__ __forceinline__ void rt_load_state(const double *__restrict__ Y,
     }
 }
 
+/* the rows of one element for the R rays at offset j */
+template <int R, bool NT>
+__device__ __forceinline__ void rt_store_rows(
+    unsigned flags, int s, double *__restrict__ Y, double *__restrict__ U,
+    double *__restrict__ I, double *__restrict__ T, int64_t ld, int64_t j,
+    const double (&y)[R][3], const double (&u)[R][3],
+    const double (&iv)[R][3], const double (&t)[R])
+{
+    if (flags & RT_F_NOSTORE)
+        return;
+    const int64_t row = (int64_t)s * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double a[R], b[R], d[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            a[r] = y[r][c];
+            b[r] = u[r][c];
+            d[r] = iv[r][c];
+        }
+        rt_store<R, NT>(Y + (row + c) * ld + j, a);
+        rt_store<R, NT>(U + (row + c) * ld + j, b);
+        if (flags & RT_F_STORE_I)
+            rt_store<R, NT>(I + (row + c) * ld + j, d);
+    }
+    rt_store<R, NT>(T + (int64_t)s * ld + j, t);
+}
+
 /* all elements start..stop-1 for the R rays of this lane; state in VGPRs */
 template <int R, bool NT>
 __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
@@ -140,24 +168,7 @@ __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
          * than sending y,t,i ahead of the refraction, and aligning the waves
          * of a workgroup with a barrier first does not help
          * (profiles/r01_probes/ab_store_order.log) */
-        if (!(flags & RT_F_NOSTORE)) {
-            const int64_t row = (int64_t)s * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double a[R], b[R], d[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    a[r] = y[r][c];
-                    b[r] = u[r][c];
-                    d[r] = iv[r][c];
-                }
-                rt_store<R, NT>(Y + (row + c) * ld + j, a);
-                rt_store<R, NT>(U + (row + c) * ld + j, b);
-                if (flags & RT_F_STORE_I)
-                    rt_store<R, NT>(I + (row + c) * ld + j, d);
-            }
-            rt_store<R, NT>(T + (int64_t)s * ld + j, t);
-        }
+        rt_store_rows<R, NT>(flags, s, Y, U, I, T, ld, j, y, u, iv, t);
 
         rt_leave<R>(S, flags, y, u);
     }
