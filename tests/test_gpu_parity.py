@@ -382,3 +382,17 @@ def test_keep_rows_extension():
     g.propagate(clip=True)
     assert np.array_equal(np.asarray(g.y), np.asarray(full.y), equal_nan=True)
     assert np.array_equal(np.asarray(g.i), np.asarray(full.i), equal_nan=True)
+
+
+def test_optimiser_as_caller():
+    """examples/optimize_spot.py: the merit function (image row only + device
+    rms) drives scipy's Nelder-Mead; the spot must shrink."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "examples", "optimize_spot.py")
+    spec = importlib.util.spec_from_file_location("optimize_spot", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    f0, f1, nfev = mod.main(nrays=200_000, verbose=False)
+    assert f1 < 0.5*f0 and nfev > 20
