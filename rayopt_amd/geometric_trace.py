@@ -20,7 +20,6 @@ reference ``rayopt.System``: only public element attributes are read
 (rayopt_amd/pack.py).
 """
 import numpy as np
-from scipy.interpolate import griddata
 
 from . import _lib
 from ._lib import RT_Y, RT_U, RT_I, RT_T
@@ -378,35 +377,21 @@ class GeometricTrace(Trace):
         return x, y, t
 
     def opd(self, radius=None, after=-2, image=-1, resample=4):
+        """OPD map: the per-ray values (device) optionally resampled onto a
+        regular ``resample*sqrt(N)`` grid (host, scipy griddata) --
+        rayopt/geometric_trace.py:101-144."""
+        from .wavefront import resample_pupil
         x, y, t = self.opd_rays(radius, after, image)
         if resample:
-            pyt = np.vstack((x, y, t))
-            x, y, t = pyt[:, np.all(np.isfinite(pyt), axis=0)]
-            if not t.size:
-                raise ValueError("no rays made it through")
-            n = int(resample*self.nrays**.5)
-            h = np.fabs((x, y)).max()
-            xs, ys = np.mgrid[-1:1:1j*n, -1:1:1j*n]*h
-            ts = griddata((x, y), t, (xs, ys), method="linear",
-                          fill_value=np.nan)
-            x, y, t = xs, ys, ts
+            return resample_pupil(x, y, t, int(resample*self.nrays**.5))
         return x, y, t
 
     def psf(self, pad=4, resample=4, **kwargs):
-        """Point spread function from the resampled pupil OPD (FFT on the
-        host grid, rayopt/geometric_trace.py:146-169)."""
+        """Point spread function from the resampled pupil OPD (host FFT of
+        the n x n grid) -- rayopt/geometric_trace.py:146-169."""
+        from .wavefront import psf_from_opd
         if not resample:
             raise NotImplementedError
         radius = self.system[-1].distance
         x, y, o = self.opd(resample=resample, radius=radius, **kwargs)
-        good = np.isfinite(o)
-        n = np.count_nonzero(good)
-        o = np.where(good, np.exp(-2j*np.pi*o), 0)/n**.5
-        nx, ny = (k*pad for k in o.shape)
-        apsf = np.fft.fft2(o, (nx, ny))
-        psf = (apsf*apsf.conj()).real/apsf.size
-        dx = x[1, 0] - x[0, 0]
-        k = 1/(self.l/self.system.scale)
-        f = np.fft.fftfreq(nx, dx*k/radius)
-        p, q = np.broadcast_arrays(f[:, None], f)
-        return p, q, psf
+        return psf_from_opd(x, o, pad, radius, self.l/self.system.scale)
