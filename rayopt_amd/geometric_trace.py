@@ -195,27 +195,29 @@ class GeometricTrace(Trace):
             l = self.system.wavelengths[0]
         self._uniform_w = w is None
         if w is None:
-            w = np.ones(n)/n
+            # same values as the reference's np.ones(n)/n, without the
+            # 8 B/ray allocation (read-only broadcast view)
+            w = np.broadcast_to(np.ones(1)/n, (n,))
         self.w = w
         self.ref = ref
         self.l = l
-        y0 = np.zeros((n, 3))
-        y0[:, :m] = y
-        u0 = np.empty((n, 3))
-        u0[:, :m] = u
-        if m < 3:  # assumes forward rays
-            u2 = np.square(u0[:, :2]).sum(-1)
-            u0[:, 2] = np.sqrt(1 - u2)
+        if m == 3 and y.dtype == np.float64 and u.dtype == np.float64 \
+                and y.flags.c_contiguous and u.flags.c_contiguous:
+            y0, u0 = y, u                    # hand over as is, no host copy
+        else:
+            y0 = np.zeros((n, 3))
+            y0[:, :m] = y
+            u0 = np.empty((n, 3))
+            u0[:, :m] = u
+            if m < 3:  # assumes forward rays
+                u2 = np.square(u0[:, :2]).sum(-1)
+                u0[:, 2] = np.sqrt(1 - u2)
         self.n[0] = self.system.refractive_index(l, 0)
         self._upload_table(1, None, self.n[0])
         self.engine.set_rays(y0, u0)
         self.engine.set_weights(None if self._uniform_w else w)
         for rows in (self.y, self.u, self.i, self.t):
-            rows.invalidate(0, self.length)
-        self.y.put_row(0, y0.T)
-        self.u.put_row(0, u0.T)
-        self.i.put_row(0, u0.T)
-        self.t.put_row(0, 0.)
+            rows.invalidate(0, self.length)   # row 0 is read back on demand
 
     def rays_given_device(self, d_y, d_u, nrays, l=None, w=None, ref=0,
                           layout=_lib.LAYOUT_SOA):
@@ -250,7 +252,7 @@ class GeometricTrace(Trace):
             self.allocate(nrays)
         self.l = self.system.wavelengths[0] if l is None else l
         self._uniform_w = True
-        self.w = np.ones(nrays)/nrays
+        self.w = np.broadcast_to(np.ones(1)/nrays, (nrays,))
         self.ref = ref
         self.n[0] = self.system.refractive_index(self.l, 0)
         self._upload_table(1, None, self.n[0])

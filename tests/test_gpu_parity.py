@@ -396,3 +396,68 @@ def test_optimiser_as_caller():
     spec.loader.exec_module(mod)
     f0, f1, nfev = mod.main(nrays=200_000, verbose=False)
     assert f1 < 0.5*f0 and nfev > 20
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129])
+def test_ragged_small_batches(n):
+    """N not a multiple of the 64-ray padding, down to a single ray."""
+    system = ra.system_from_yaml(P.TORTURE)
+    y, u = disc_bundle(n, 9., 2., n)
+    g = gpu_trace(system, y, u, None, True)
+    want, _ = oracle_trace(system, y, u, g.l, True)
+    compare(g, want, 1, 9, RTOL_SPHERICAL, "n=%d" % n)
+    assert g.y.shape == (9, n, 3)
+
+
+def test_maximum_elements_and_aspheric_terms():
+    """RT_MAX_SURFACES = 256 elements, RT_MAX_ASPH = 10 terms."""
+    rng = np.random.default_rng(3)
+    els = [{"material": 1.0}]
+    for j in range(254):
+        el = {"distance": 0.4, "radius": 6.0,
+              "material": float(1.0 + 0.5*(j % 2))}
+        if j % 3 == 0:
+            el["roc"] = float(rng.choice([-1, 1])*rng.uniform(40, 300))
+        if j % 50 == 7:
+            el["aspherics"] = [float(rng.normal()*1e-4/6.**(2*i + 1))
+                               for i in range(10)]
+        els.append(el)
+    els.append({"distance": 5.0, "radius": 50.})
+    system = ra.System(elements=els, wavelengths=[587.56e-9])
+    assert len(system) == 256
+    y, u = disc_bundle(3000, 4., 1., 2)
+    g = gpu_trace(system, y, u, None, True)
+    want, ns = oracle_trace(system, y, u, g.l, True)
+    compare(g, want, 1, 256, RTOL_ASPHERE, "L=256")
+    assert np.array_equal(g.n[1:], ns[1:])
+    with pytest.raises(ValueError):
+        pack_system(ra.System(elements=els + [{"distance": 1.}]), 5e-7, 1.)
+
+
+def test_huge_batch_64bit_indexing():
+    """6*10^7 rays x 13 elements: 62 GB of results, element offsets beyond
+    2^31 -- rays are built on the device, single rays are read back across
+    all surfaces (rt_download_ray) and compared with the oracle."""
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    per_field = 10_000_000
+    fields = np.c_[np.zeros(6), np.linspace(0, 1, 6)]
+    rng = np.random.default_rng(1)
+    r, phi = np.sqrt(rng.random(per_field)), 2*np.pi*rng.random(per_field)
+    yp = np.c_[r*np.cos(phi), r*np.sin(phi)]
+    g = ra.GeometricTrace(system)
+    g.rays_fields(fields, yp, P.DOUBLE_GAUSS_PUPIL_Z, 17.)
+    n = g.nrays
+    assert n == 60_000_000 and 13*3*g.engine.ld > 2**31
+    g.propagate(clip=True)
+    from rayopt_amd._lib import RT_Y, RT_U, RT_I, RT_T
+    picks = [0, 1, 63, 12_345_678, 35_791_394, 35_791_395, 47_721_858,
+             n - 65, n - 1]
+    cols = {w: np.array([g.engine.download_ray(w, k) for k in picks])
+            for w in (RT_Y, RT_U, RT_I, RT_T)}
+    y0, u0 = cols[RT_Y][:, 0], cols[RT_U][:, 0]
+    want, _ = oracle_trace(system, y0, u0, g.l, True)
+    for w, ref in zip((RT_Y, RT_U, RT_I, RT_T), want):
+        got = np.moveaxis(cols[w], 0, 1)[1:]       # (L-1, rays[, 3])
+        assert_parity(got, ref, RTOL_SPHERICAL, "huge")
+    assert np.isfinite(cols[RT_T][:, 1:]).any()
+    assert g.rms(i=1) > 0
