@@ -297,3 +297,30 @@ def march_rows(system, y, u, n, l, start=1, stop=None, clip=False,
         ij = eng.download(RT_I, j, j + 1)[0].T
         tj = eng.download(RT_T, j, j + 1)[0]
         yield yj, uj, ns[j], ij, tj
+
+
+def element_propagate(element, y0, u0, n0, l, clip=True, engine=None):
+    """``Element.propagate(y0, u0, n0, l, clip)`` (rayopt/elements.py:230-236,
+    306-315) for one element on the GPU: ``y0, u0`` (N,3) already in the
+    element's normal frame relative to its vertex (no transfer, no rotation:
+    those belong to System.propagate).  Returns ``(y, u, n, t*n0)``."""
+    from .model import Spheroid
+    eng = engine or get_engine()
+    y0, u0 = np.atleast_2d(y0, u0)
+    y0, u0 = np.broadcast_arrays(np.asarray(y0, float), np.asarray(u0, float))
+    intercept_only = l is None
+    table, ns = pack_system([Spheroid(), element],
+                            5.8756e-7 if intercept_only else l, n0)
+    if intercept_only:      # geometry only: no index change, no bending
+        table["flags"][1] &= ~np.uint32(_lib.F_REFRACT | _lib.F_MIRROR)
+    table["offset"][1] = 0.
+    table["rot"][1] = np.eye(3).reshape(9)
+    table["flags"][1] &= ~np.uint32(_lib.F_ROTATED)
+    eng.upload_system(table)
+    eng.set_rays(np.ascontiguousarray(y0), np.ascontiguousarray(u0))
+    eng.set_keep_rows(None)
+    eng.trace(1, 2, clip)
+    y = eng.download(RT_Y, 1, 2)[0].T
+    u = eng.download(RT_U, 1, 2)[0].T
+    t = eng.download(RT_T, 1, 2)[0]
+    return y, u, ns[1], t

@@ -267,6 +267,20 @@ class Element(Pose):
         self.distance *= scale
         self.radius *= scale
 
+    # per-ray arithmetic of a single element: runs on the GPU like the
+    # system trace (same kernel, a two-row table)
+    def propagate(self, y0, u0, n0, l, clip=True):
+        """(y, u, n, t*n0) for rays given in this element's normal frame
+        relative to its vertex (rayopt/elements.py:230-236, 306-315)."""
+        from .engine import element_propagate
+        return element_propagate(self, y0, u0, n0, l, clip)
+
+    def intercept(self, y, u):
+        """Ray length to the surface (rayopt/elements.py:195-201, 333-349,
+        477-501)."""
+        from .engine import element_propagate
+        return element_propagate(self, y, u, 1., None, False)[3]
+
 
 class Interface(Element):
     """An element separating two media."""

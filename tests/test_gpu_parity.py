@@ -461,3 +461,31 @@ def test_huge_batch_64bit_indexing():
         assert_parity(got, ref, RTOL_SPHERICAL, "huge")
     assert np.isfinite(cols[RT_T][:, 1:]).any()
     assert g.rms(i=1) > 0
+
+
+def test_element_level_methods():
+    """Spheroid.propagate / .intercept on the device vs the oracle's
+    element_propagate (rayopt/elements.py:306-315, 477-501)."""
+    rng = np.random.default_rng(8)
+    y = np.c_[rng.uniform(-4, 4, (500, 2)), rng.uniform(-3, -1, 500)]
+    u = rng.normal(size=(500, 3))*[.05, .05, 0] + [0, 0, 1.]
+    u /= np.sqrt(np.square(u).sum(1))[:, None]
+    for kw in (dict(roc=30., material=1.6, radius=3.5),
+               dict(roc=-40., conic=-1.7, material="mirror", radius=5.),
+               dict(roc=25., conic=.2, aspherics=[0, 1e-5, -2e-7],
+                    material=1.5, radius=3.),
+               dict(material=1.33, radius=2., angles=(.2, 0, 0))):
+        el = ra.Spheroid(**kw)
+        table, ns = pack_system([ra.Spheroid(), el], 5.5e-7, 1.1)
+        table["offset"][1] = 0.
+        table["flags"][1] &= ~np.uint32(1)
+        for clip in (True, False):
+            yo, uo, to = tn.element_propagate(table[1], y, u, clip)
+            yg, ug, ng, tg = el.propagate(y, u, 1.1, 5.5e-7, clip)
+            rtol = RTOL_ASPHERE if "aspherics" in kw else RTOL_SPHERICAL
+            assert_parity(yg[None], yo[None], rtol, "el.y")
+            assert_parity(ug[None], uo[None], rtol, "el.u")
+            assert_parity(tg[None], to[None], rtol, "el.t")
+            assert ng == ns[1]
+        s = el.intercept(y, u)
+        assert_parity((s*1.1)[None], to[None], 1e-12, "el.intercept")
