@@ -84,8 +84,9 @@ def main():
     ap.add_argument("--rays", type=int, default=10_000_000,
                     help="rays per GPU")
     ap.add_argument("--no-clip", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000,
-                    help="rays of the workload timed on the host (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
+                    help="rays of the workload timed on the host (0: skip); "
+                         "the default is the whole batch, ~10 s on one core")
     ap.add_argument("--extras", action="store_true",
                     help="also time the full_i (80 B/op) and image-row-only "
                          "modes (separate timed loops, reported as extra "
