@@ -589,6 +589,8 @@ struct rt_ctx {
     size_t scratch_bytes;
     void *d_user; /* rt_scratch */
     size_t user_bytes;
+    void *h_pin[2]; /* pinned staging for large pageable H2D copies */
+    hipEvent_t pin_done[2];
     double *d_w;  /* ray weights, NULL = uniform 1/n */
     size_t w_cap;
     double *d_partials; /* RT_RED_BLOCKS x 8 doubles */
@@ -765,6 +767,11 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_scratch);
     if (ctx->d_user)
         (void)hipFree(ctx->d_user);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->h_pin[i]) {
+            (void)hipHostFree(ctx->h_pin[i]);
+            (void)hipEventDestroy(ctx->pin_done[i]);
+        }
     if (ctx->d_w)
         (void)hipFree(ctx->d_w);
     if (ctx->d_partials)
@@ -894,6 +901,41 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
     return RT_OK;
 }
 
+#define RT_PIN_CHUNK ((size_t)32 << 20)
+
+/*
+ * Host -> device copy of a pageable buffer through two pinned staging
+ * buffers: the CPU fills one while the DMA engine drains the other.  A plain
+ * hipMemcpyAsync from pageable memory is staged by the runtime in small
+ * pieces and reaches ~5 GB/s; this path is bound by the host memcpy.
+ */
+static int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes < RT_PIN_CHUNK / 8) {
+        RT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        return RT_OK;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->h_pin[i]) {
+            RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK));
+            RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
+                                                hipEventDisableTiming));
+        }
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += RT_PIN_CHUNK, k ^= 1) {
+        const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
+                                                      : RT_PIN_CHUNK;
+        if (off >= 2 * RT_PIN_CHUNK) /* buffer k was used two chunks ago */
+            RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[k]));
+        memcpy(ctx->h_pin[k], (const char *)src + off, len);
+        RT_HIP(ctx, hipMemcpyAsync((char *)dst + off, ctx->h_pin[k], len,
+                                   hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipEventRecord(ctx->pin_done[k], ctx->stream));
+    }
+    return RT_OK;
+}
+
 int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
                 int layout)
 {
@@ -909,10 +951,11 @@ int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
         return rc;
     double *sy = (double *)ctx->d_scratch;
     double *su = sy + (size_t)n * 3;
-    RT_HIP(ctx, hipMemcpyAsync(sy, y, bytes, hipMemcpyHostToDevice,
-                               ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(su, u, bytes, hipMemcpyHostToDevice,
-                               ctx->stream));
+    rc = rt_h2d(ctx, sy, y, bytes);
+    if (rc == RT_OK)
+        rc = rt_h2d(ctx, su, u, bytes);
+    if (rc != RT_OK)
+        return rc;
     rc = rt_seed(ctx, sy, su, n, layout);
     if (rc != RT_OK)
         return rc;
