@@ -936,6 +936,64 @@ static int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
     return RT_OK;
 }
 
+/* device -> pageable host, same double-buffered staging; synchronous */
+static int rt_d2h(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes < RT_PIN_CHUNK / 8) {
+        RT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->h_pin[i]) {
+            RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK));
+            RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
+                                                hipEventDisableTiming));
+        }
+    const size_t nchunk = (bytes + RT_PIN_CHUNK - 1) / RT_PIN_CHUNK;
+    for (size_t i = 0; i <= nchunk; ++i) {
+        if (i < nchunk) { /* start the DMA of chunk i */
+            const size_t off = i * RT_PIN_CHUNK;
+            const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
+                                                          : RT_PIN_CHUNK;
+            RT_HIP(ctx, hipMemcpyAsync(ctx->h_pin[i & 1],
+                                       (const char *)src + off, len,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+            RT_HIP(ctx, hipEventRecord(ctx->pin_done[i & 1], ctx->stream));
+        }
+        if (i > 0) { /* drain chunk i-1 while chunk i is in flight */
+            const size_t off = (i - 1) * RT_PIN_CHUNK;
+            const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
+                                                          : RT_PIN_CHUNK;
+            RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[(i - 1) & 1]));
+            memcpy((char *)dst + off, ctx->h_pin[(i - 1) & 1], len);
+        }
+    }
+    return RT_OK;
+}
+
+/* nrow rows of ld doubles -> compact rows of n doubles on the host */
+static int rt_rows_to_host(rt_ctx *ctx, double *dst, const double *src,
+                           size_t nrow)
+{
+    const size_t rb = (size_t)ctx->n * sizeof(double);
+    if (ctx->ld == ctx->n) /* no padding: one contiguous block */
+        return rt_d2h(ctx, dst, src, rb * nrow);
+    if (rb >= RT_PIN_CHUNK / 8) {
+        for (size_t r = 0; r < nrow; ++r) {
+            int rc = rt_d2h(ctx, dst + r * ctx->n, src + r * ctx->ld, rb);
+            if (rc != RT_OK)
+                return rc;
+        }
+        return RT_OK;
+    }
+    RT_HIP(ctx, hipMemcpy2DAsync(dst, rb, src, ctx->ld * sizeof(double), rb,
+                                 nrow, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
                 int layout)
 {
@@ -1277,21 +1335,18 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
                            "rt_download: row %d holds no data (not kept by "
                            "rt_set_keep_rows, or not traced yet)", j);
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = RT_OK;
     if (which != RT_I) {
-        const double *src = rt_row(ctx, which, surf_lo);
-        const size_t rows = (size_t)(surf_hi - surf_lo) * nc;
-        RT_HIP(ctx, hipMemcpy2DAsync(dst, ctx->n * sizeof(double), src,
-                                     ctx->ld * sizeof(double),
-                                     ctx->n * sizeof(double), rows,
-                                     hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        for (int j = surf_lo; j < surf_hi; ++j)
-            RT_HIP(ctx, hipMemcpy2DAsync(
-                            dst + (size_t)(j - surf_lo) * nc * ctx->n,
-                            ctx->n * sizeof(double), rt_row(ctx, which, j),
-                            ctx->ld * sizeof(double), ctx->n * sizeof(double),
-                            nc, hipMemcpyDeviceToHost, ctx->stream));
+        rc = rt_rows_to_host(ctx, dst, rt_row(ctx, which, surf_lo),
+                             (size_t)(surf_hi - surf_lo) * nc);
+    } else { /* rows of I may live in U (aliasing): one by one */
+        for (int j = surf_lo; j < surf_hi && rc == RT_OK; ++j)
+            rc = rt_rows_to_host(ctx,
+                                 dst + (size_t)(j - surf_lo) * nc * ctx->n,
+                                 rt_row(ctx, which, j), nc);
     }
+    if (rc != RT_OK)
+        return rc;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -1505,10 +1560,7 @@ int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa)
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
     ctx->traced = 1;
-    RT_HIP(ctx, hipMemcpyAsync(out_soa, ctx->d_scratch, bytes,
-                               hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return RT_OK;
+    return rt_d2h(ctx, out_soa, ctx->d_scratch, bytes);
 }
 
 int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
@@ -1554,10 +1606,7 @@ int rt_copy_to_host(rt_ctx *ctx, void *dst, const void *d_src, int64_t bytes)
         return rt_fail(ctx, RT_ERR_ARG, "rt_copy_to_host: bad argument");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
-    RT_HIP(ctx, hipMemcpyAsync(dst, d_src, (size_t)bytes,
-                               hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return RT_OK;
+    return rt_d2h(ctx, dst, d_src, (size_t)bytes);
 }
 
 /* ------------------------------------------------------------------ */
