@@ -160,12 +160,17 @@ class Engine:
         return ms.value, nbytes.value
 
     # -- results ----------------------------------------------------------
-    def download(self, which, lo, hi):
+    def download(self, which, lo, hi, out=None):
         """Rows [lo,hi) of one array as a compact SoA host array:
-        (rows,3,N) for y/u/i, (rows,N) for t."""
+        (rows,3,N) for y/u/i, (rows,N) for t (into ``out`` if given)."""
         n = self.nrays
         shape = (hi - lo, n) if which == RT_T else (hi - lo, 3, n)
-        out = np.empty(shape, dtype=np.float64)
+        if out is None:
+            out = np.empty(shape, dtype=np.float64)
+        elif out.shape != shape or not out.flags.c_contiguous \
+                or out.dtype != np.float64:
+            raise ValueError("download: `out` must be C-contiguous float64 "
+                             "of shape %r" % (shape,))
         self._check(self.lib.rt_download(self.ctx, which, lo, hi,
                                          out.ctypes.data), "rt_download")
         return out

@@ -97,7 +97,7 @@ class DeviceRows:
             k = j
             while k < hi and not self._valid[k]:
                 k += 1
-            host[j:k] = self._trace._engine.download(self._which, j, k)
+            self._trace._engine.download(self._which, j, k, out=host[j:k])
             self._valid[j:k] = True
             j = k
         return host

@@ -56,11 +56,15 @@ class OracleEngine:
         keep = np.ones(self.nsurf, bool) if self.keep is None else self.keep
         self.valid[start:stop] = keep[start:stop]
 
-    def download(self, which, lo, hi):
+    def download(self, which, lo, hi, out=None):
         assert self.valid[lo:hi].all(), "row holds no data"
         a = self.rows[which][lo:hi]
-        return a if which == RT_T else np.ascontiguousarray(
+        a = a if which == RT_T else np.ascontiguousarray(
             a.transpose(0, 2, 1))
+        if out is not None:
+            out[...] = a
+            return out
+        return a
 
     def kernel_ms(self):
         return self.ms
