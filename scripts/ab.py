@@ -20,8 +20,13 @@ def main():
     n = 10_000_000
     variants = [dict(v) for v in json.loads(sys.argv[1])] if len(sys.argv) > 1 \
         else [{}]
-    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
-    y, u = workload_rays(n, 0)
+    if os.environ.get("RT_AB_CONFIG") == "asphere":
+        system = ra.system_from_yaml(P.ASPHERE_PHONE)
+        y, u = ra.bundles.disc_bundle(n, 0.6, 17.5, 3)
+        y[:, 1] -= 0.5*np.tan(np.radians(17.5))
+    else:
+        system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+        y, u = workload_rays(n, 0)
     g = ra.GeometricTrace(system)
     g.rays_given(y, u)
     eng = g.engine
