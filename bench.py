@@ -17,6 +17,11 @@ in HBM exactly as they stay in HBM at N=1).  `gather_ms` reports it alone;
 pipelined), which is bound by the root's xGMI ingest (24 B/ray over <= 7
 links), not by the engine.
 
+Setup (untimed, before the W warm-up steps): rays are generated and uploaded
+and the kernel is launched for --settle seconds (default 0.3 s) so the device
+reaches its sustained clocks -- short runs otherwise measure the clock ramp
+(first launches ~15 % slower).  Then exactly W untimed and K timed steps.
+
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
 
   roofline      achieved/peak HBM GB/s of the trace kernel; achieved =
@@ -87,6 +92,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="rays of the workload timed on the host (0: skip); "
                          "the default is the whole batch, ~10 s on one core")
+    ap.add_argument("--settle", type=float, default=0.3,
+                    help="seconds of untimed launches during setup so the "
+                         "device reaches its sustained clocks (boxes of the "
+                         "pool take ~50 launches); 0 disables")
     ap.add_argument("--extras", action="store_true",
                     help="also time the full_i (80 B/op) and image-row-only "
                          "modes (separate timed loops, reported as extra "
@@ -167,6 +176,13 @@ def main():
             eng.comm_sync()
             torch.cuda.synchronize()
             dist.barrier()
+
+    if args.settle > 0:         # setup, not part of W or K
+        t_end = time.perf_counter() + args.settle
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                eng.trace(1, 0, clip)
+            eng.sync()
 
     def timed_loop():
         for _ in range(args.warmup):
@@ -276,6 +292,7 @@ def main():
             "surfaces": S,
             "clip": clip,
             "finite_fraction_at_image": finite,
+            "settle_s": args.settle,
             "parallelism": "ray shards x%d%s" % (
                 world, (", RCCL gather of y[L-1] to rank 0 %s (gather alone: "
                         "%.2f ms)" % ("in every step" if args.gather_every_step
