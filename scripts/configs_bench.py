@@ -14,14 +14,14 @@ from rayopt_amd.bundles import disc_bundle, multi_field_bundle
 from rayopt_amd.pack import pack_system
 
 
-def run(name, system, y, u, l, clip, reps=8):
+def run(name, system, y, u, l, clip, reps=60):
     g = ra.GeometricTrace(system)
     g.rays_given(y, u, l)
     ms = []
-    for k in range(reps + 2):
+    for k in range(reps):       # the first ~50 launches ride the clock ramp
         g.propagate(clip=clip)
         ms.append(g.kernel_ms())
-    ms = float(np.median(ms[2:]))
+    ms = float(np.median(ms[-10:]))
     n, S = y.shape[0], len(system) - 1
     table, _ = pack_system(system, g.l, g.n[0])
     rot = (table["flags"] & F_ROTATED) != 0
