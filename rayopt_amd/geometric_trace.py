@@ -187,12 +187,17 @@ class GeometricTrace(Trace):
         """Seed surface 0 (rayopt/geometric_trace.py:49-70)."""
         y, u = np.atleast_2d(y, u)
         y, u = np.broadcast_arrays(y, u)
+        if y.ndim != 2 or y.shape[1] not in (2, 3) or y.shape[0] < 1:
+            raise ValueError("rays_given: y and u must broadcast to (N,2) or "
+                             "(N,3), got %r" % (y.shape,))
         n, m = y.shape
         if not hasattr(self, "y") or self.nrays != n \
                 or self.length != len(self.system):
             self.allocate(n)
         if l is None:
             l = self.system.wavelengths[0]
+        if w is not None and np.shape(w) != (n,):
+            raise ValueError("rays_given: w must have shape (%d,)" % n)
         self._uniform_w = w is None
         if w is None:
             # same values as the reference's np.ones(n)/n, without the
@@ -298,6 +303,8 @@ class GeometricTrace(Trace):
         iterable of surface indices whose rows are stored, e.g. ``keep=[-1]``
         for the image-plane intercepts only.  The other rows are traced but
         not written (no HBM traffic); reading them raises."""
+        if not hasattr(self, "y"):
+            raise ValueError("propagate: no rays; call rays_given() first")
         super().propagate()
         if len(self.system) != self.length:
             raise ValueError("the system changed length since rays_given()")

@@ -286,6 +286,12 @@ def test_lazy_rows_views():
 def test_errors_are_loud():
     system = ra.system_from_yaml(P.SINGLET)
     g = ra.GeometricTrace(system)
+    with pytest.raises(ValueError, match="rays_given"):
+        g.propagate()
+    with pytest.raises(ValueError):
+        g.rays_given(np.zeros((4, 1)), np.zeros((4, 1)))
+    with pytest.raises(ValueError):
+        g.rays_given(np.zeros((4, 3)), np.zeros((4, 3)), w=np.ones(3))
     g.rays_given(np.zeros((4, 3)), np.array([[0, 0, 1.]]))
     with pytest.raises(ValueError):
         g.propagate(start=0)
