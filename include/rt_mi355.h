@@ -126,6 +126,16 @@ const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: global */
  * propagate(); the copy is O(L) and tiny.
  */
 int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf);
+/*
+ * Extension: ngroups surface tables (surf[g*nsurf + j], typically the same
+ * geometry evaluated at ngroups wavelengths; <= 16).  The ray batch is then
+ * read as ngroups equal, contiguous groups and group g is traced through
+ * table g in the same launch; the group size must be a multiple of 64 rays
+ * so every wavefront stays inside one group and the table reads remain
+ * scalar.  BASELINE config C2 (10^6 rays x 3 wavelengths) is one launch.
+ */
+int rt_upload_system_groups(rt_ctx *ctx, const rt_surface *surf, int nsurf,
+                            int ngroups);
 
 /*
  * GeometricTrace.allocate(nrays) (geometric_trace.py:37-47): size the device
@@ -145,6 +155,9 @@ int rt_nsurf(const rt_ctx *ctx);
  */
 int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
                 int layout);
+/* same p rays replicated `copies` times on the device (one copy per group) */
+int rt_set_rays_repeat(rt_ctx *ctx, const double *y, const double *u,
+                       int64_t p, int copies, int layout);
 /* same, y/u already in device memory (rays generated on the device) */
 int rt_set_rays_device(rt_ctx *ctx, const double *d_y, const double *d_u,
                        int64_t n, int layout);

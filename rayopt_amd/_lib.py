@@ -59,6 +59,11 @@ SIGNATURES = {
     "rt_destroy": (ctypes.c_int, [_ctx]),
     "rt_last_error": (ctypes.c_char_p, [_ctx]),
     "rt_upload_system": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_int]),
+    "rt_upload_system_groups": (ctypes.c_int, [_ctx, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_int]),
+    "rt_set_rays_repeat": (ctypes.c_int, [_ctx, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_int64,
+                                          ctypes.c_int, ctypes.c_int]),
     "rt_reserve": (ctypes.c_int, [_ctx, ctypes.c_int64]),
     "rt_nrays": (ctypes.c_int64, [_ctx]),
     "rt_ld": (ctypes.c_int64, [_ctx]),

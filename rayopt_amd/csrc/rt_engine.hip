@@ -179,12 +179,21 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
                                 int stop, int clip, double *__restrict__ Y,
                                 double *__restrict__ U, double *__restrict__ I,
                                 double *__restrict__ T, int64_t ld,
-                                int64_t nblocks)
+                                int64_t nblocks, int64_t group_rays,
+                                int nsurf)
 {
     const int64_t chunk = rt_chunk<XCD>(nblocks);
     const int64_t j = (chunk * blockDim.x + threadIdx.x) * R;
     if (j >= ld)
         return;
+    if (group_rays) {
+        /* ray groups with their own surface table (one wavelength each):
+         * group boundaries are multiples of 64 R rays, so the group -- and
+         * with it every table read -- stays wave-uniform (SGPRs) */
+        const int64_t j0 = j - (int64_t)(threadIdx.x & 63) * R;
+        const int g = __builtin_amdgcn_readfirstlane((int)(j0 / group_rays));
+        surf += (int64_t)g * nsurf;
+    }
     double y[R][3], u[R][3];
     rt_load_state<R>(Y, U, (int64_t)(start - 1) * 3, ld, j, y, u);
     rt_march<R, NT>(surf, start, stop, clip, Y, U, I, T, ld, j, y, u);
@@ -197,16 +206,17 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
                                    double *__restrict__ U,
                                    double *__restrict__ I,
                                    double *__restrict__ T, int64_t ld,
-                                   int store_i)
+                                   int store_i, int64_t period)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
         return;
     const bool in = j < n;
+    const int64_t k = j % period; /* the same rays for every group */
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double a = in ? y_aos[j * 3 + c] : 0.;
-        const double b = in ? u_aos[j * 3 + c] : 0.;
+        const double a = in ? y_aos[k * 3 + c] : 0.;
+        const double b = in ? u_aos[k * 3 + c] : 0.;
         Y[c * ld + j] = a;
         U[c * ld + j] = b;
         if (store_i)
@@ -222,16 +232,17 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
                                    double *__restrict__ U,
                                    double *__restrict__ I,
                                    double *__restrict__ T, int64_t ld,
-                                   int store_i)
+                                   int store_i, int64_t period)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
         return;
     const bool in = j < n;
+    const int64_t k = j % period;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double a = in ? y_soa[c * n + j] : 0.;
-        const double b = in ? u_soa[c * n + j] : 0.;
+        const double a = in ? y_soa[c * period + k] : 0.;
+        const double b = in ? u_soa[c * period + k] : 0.;
         Y[c * ld + j] = a;
         U[c * ld + j] = b;
         if (store_i)
@@ -548,6 +559,7 @@ __global__ void rt_opd_kernel(rt_opd_args a, const rt_opd_ref *__restrict__ ref,
 /* ------------------------------------------------------------------ */
 
 #define RT_NEVENTS 8
+#define RT_MAX_GROUPS 16
 
 struct rt_rccl_api {
     void *lib;
@@ -573,7 +585,8 @@ struct rt_ctx {
 
     rt_surface *d_surf;
     int nsurf;
-    rt_surface h_surf[RT_MAX_SURFACES]; /* as given by the caller */
+    rt_surface *h_surf;                 /* [ngroups][nsurf] as given */
+    int ngroups;                        /* surface tables (wavelengths) */
     rt_surface *h_stage;                /* pinned: flags finalised */
     int table_dirty;
     int table_start;
@@ -673,7 +686,9 @@ static void rt_launch(rt_ctx *c, int start, int stop, int clip)
     hipLaunchKernelGGL((rt_trace_kernel<R, NT, XCD>), dim3((unsigned)grid),
                        dim3(block), 0, c->stream, c->d_surf, start, stop, clip,
                        rt_arr(c, RT_Y), rt_arr(c, RT_U), rt_arr(c, RT_I),
-                       rt_arr(c, RT_T), c->ld, nblocks);
+                       rt_arr(c, RT_T), c->ld, nblocks,
+                       c->ngroups > 1 ? c->n / c->ngroups : (int64_t)0,
+                       c->nsurf);
 }
 
 extern "C" {
@@ -741,10 +756,19 @@ int rt_create(int device, rt_ctx **out)
         RT_HIP_C(
             hipEventCreateWithFlags(&c->gathered[i], hipEventDisableTiming));
     }
-    RT_HIP_C(hipMalloc((void **)&c->d_surf,
-                       sizeof(rt_surface) * RT_MAX_SURFACES));
-    RT_HIP_C(hipHostMalloc((void **)&c->h_stage,
-                           sizeof(rt_surface) * RT_MAX_SURFACES));
+    c->ngroups = 1;
+    c->h_surf = (rt_surface *)calloc((size_t)RT_MAX_GROUPS * RT_MAX_SURFACES,
+                                     sizeof(rt_surface));
+    if (!c->h_surf) {
+        free(c);
+        return rt_fail(NULL, RT_ERR_NOMEM, "rt_create: host allocation");
+    }
+    RT_HIP_C(hipMalloc((void **)&c->d_surf, sizeof(rt_surface) *
+                                                RT_MAX_GROUPS *
+                                                RT_MAX_SURFACES));
+    RT_HIP_C(hipHostMalloc((void **)&c->h_stage, sizeof(rt_surface) *
+                                                     RT_MAX_GROUPS *
+                                                     RT_MAX_SURFACES));
     memset(c->keep, 1, sizeof c->keep);
 #undef RT_HIP_C
     *out = c;
@@ -782,6 +806,7 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_surf);
     if (ctx->h_stage)
         (void)hipHostFree(ctx->h_stage);
+    free(ctx->h_surf);
     for (int i = 0; i < 2; ++i) {
         if (ctx->d_stage[i])
             (void)hipFree(ctx->d_stage[i]);
@@ -798,7 +823,8 @@ int rt_destroy(rt_ctx *ctx)
     return RT_OK;
 }
 
-int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf)
+int rt_upload_system_groups(rt_ctx *ctx, const rt_surface *surf, int nsurf,
+                            int ngroups)
 {
     if (!ctx || !surf)
         return rt_fail(ctx, RT_ERR_ARG, "rt_upload_system: NULL argument");
@@ -806,17 +832,27 @@ int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf)
         return rt_fail(ctx, RT_ERR_ARG,
                        "rt_upload_system: nsurf=%d not in [2,%d]", nsurf,
                        RT_MAX_SURFACES);
-    for (int j = 0; j < nsurf; ++j) {
+    if (ngroups < 1 || ngroups > RT_MAX_GROUPS)
+        return rt_fail(ctx, RT_ERR_ARG,
+                       "rt_upload_system: ngroups=%d not in [1,%d]", ngroups,
+                       RT_MAX_GROUPS);
+    for (int j = 0; j < nsurf * ngroups; ++j) {
         if (surf[j].nasph < 0 || surf[j].nasph > RT_MAX_ASPH)
             return rt_fail(ctx, RT_ERR_ARG,
                            "rt_upload_system: element %d has %d aspheric "
                            "terms, limit %d",
-                           j, surf[j].nasph, RT_MAX_ASPH);
+                           j % nsurf, surf[j].nasph, RT_MAX_ASPH);
     }
-    memcpy(ctx->h_surf, surf, sizeof(rt_surface) * nsurf);
+    memcpy(ctx->h_surf, surf, sizeof(rt_surface) * nsurf * ngroups);
     ctx->table_dirty = 1; /* finalised and sent by the next rt_trace */
     ctx->nsurf = nsurf;
+    ctx->ngroups = ngroups;
     return RT_OK;
+}
+
+int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf)
+{
+    return rt_upload_system_groups(ctx, surf, nsurf, 1);
 }
 
 int rt_reserve(rt_ctx *ctx, int64_t nrays)
@@ -881,7 +917,7 @@ static int rt_need_scratch(rt_ctx *ctx, size_t bytes)
 }
 
 static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
-                   int64_t n, int layout)
+                   int64_t n, int layout, int64_t period)
 {
     const int block = 256;
     const unsigned grid = (unsigned)((ctx->ld + block - 1) / block);
@@ -890,11 +926,11 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
     if (layout == RT_LAYOUT_AOS)
         hipLaunchKernelGGL(rt_seed_aos_kernel, dim3(grid), dim3(block), 0,
                            ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld,
-                           !ctx->opt_alias);
+                           !ctx->opt_alias, period);
     else
         hipLaunchKernelGGL(rt_seed_soa_kernel, dim3(grid), dim3(block), 0,
                            ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld,
-                           !ctx->opt_alias);
+                           !ctx->opt_alias, period);
     RT_HIP(ctx, hipGetLastError());
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
     ctx->valid[0] = 1;
@@ -994,32 +1030,39 @@ static int rt_rows_to_host(rt_ctx *ctx, double *dst, const double *src,
     return RT_OK;
 }
 
-int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
-                int layout)
+int rt_set_rays_repeat(rt_ctx *ctx, const double *y, const double *u,
+                       int64_t p, int copies, int layout)
 {
-    if (!ctx || !y || !u || n < 1 ||
+    if (!ctx || !y || !u || p < 1 || copies < 1 ||
         (layout != RT_LAYOUT_AOS && layout != RT_LAYOUT_SOA))
         return rt_fail(ctx, RT_ERR_ARG, "rt_set_rays: bad argument");
+    const int64_t n = p * copies;
     int rc = rt_reserve(ctx, n);
     if (rc != RT_OK)
         return rc;
-    const size_t bytes = (size_t)n * 3 * sizeof(double);
+    const size_t bytes = (size_t)p * 3 * sizeof(double);
     rc = rt_need_scratch(ctx, 2 * bytes);
     if (rc != RT_OK)
         return rc;
     double *sy = (double *)ctx->d_scratch;
-    double *su = sy + (size_t)n * 3;
+    double *su = sy + (size_t)p * 3;
     rc = rt_h2d(ctx, sy, y, bytes);
     if (rc == RT_OK)
         rc = rt_h2d(ctx, su, u, bytes);
     if (rc != RT_OK)
         return rc;
-    rc = rt_seed(ctx, sy, su, n, layout);
+    rc = rt_seed(ctx, sy, su, n, layout, p);
     if (rc != RT_OK)
         return rc;
     /* caller's host arrays may be released as soon as we return */
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
+}
+
+int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
+                int layout)
+{
+    return rt_set_rays_repeat(ctx, y, u, n, 1, layout);
 }
 
 int rt_set_rays_device(rt_ctx *ctx, const double *d_y, const double *d_u,
@@ -1031,7 +1074,7 @@ int rt_set_rays_device(rt_ctx *ctx, const double *d_y, const double *d_u,
     int rc = rt_reserve(ctx, n);
     if (rc != RT_OK)
         return rc;
-    return rt_seed(ctx, d_y, d_u, n, layout);
+    return rt_seed(ctx, d_y, d_u, n, layout, n);
 }
 
 
@@ -1118,30 +1161,38 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
         return rt_fail(ctx, RT_ERR_STATE,
                        "rt_trace: seed row %d holds no data (not stored by "
                        "the previous trace)", start - 1);
+    if (ctx->ngroups > 1 && (ctx->n % ctx->ngroups ||
+                             (ctx->n / ctx->ngroups) % (64 * ctx->opt_r)))
+        return rt_fail(ctx, RT_ERR_ARG,
+                       "rt_trace: %lld rays do not split into %d groups of a "
+                       "multiple of %d rays", (long long)ctx->n, ctx->ngroups,
+                       64 * ctx->opt_r);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->table_dirty) {
         /* a kernel in flight may still read the device table, and the pinned
          * staging copy must not change under a pending DMA */
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        memcpy(ctx->h_stage, ctx->h_surf, sizeof(rt_surface) * ctx->nsurf);
-        for (int j = 0; j < ctx->nsurf; ++j) {
-            unsigned f = ctx->h_stage[j].flags &
+        const int ntab = ctx->nsurf * ctx->ngroups;
+        memcpy(ctx->h_stage, ctx->h_surf, sizeof(rt_surface) * ntab);
+        for (int jj = 0; jj < ntab; ++jj) {
+            const int j = jj % ctx->nsurf; /* element index in its group */
+            unsigned f = ctx->h_stage[jj].flags &
                          ~(RT_F_STORE_I | RT_F_NOSTORE);
             if (!ctx->keep[j])
                 f |= RT_F_NOSTORE;
             /* i[j] == u[j-1] bit for bit unless j or j-1 is tilted; it can
              * only be served from U[j-1] if that row exists */
             const bool rot = (f & RT_F_ROTATED) ||
-                             (j > 0 && (ctx->h_stage[j - 1].flags &
+                             (j > 0 && (ctx->h_stage[jj - 1].flags &
                                         RT_F_ROTATED));
             const bool prev_kept =
                 j > 0 && (j - 1 < start ? ctx->valid[j - 1] : ctx->keep[j - 1]);
             if (!ctx->opt_alias || rot || j == 0 || !prev_kept)
                 f |= RT_F_STORE_I;
-            ctx->h_stage[j].flags = f;
+            ctx->h_stage[jj].flags = f;
         }
         RT_HIP(ctx, hipMemcpyAsync(ctx->d_surf, ctx->h_stage,
-                                   sizeof(rt_surface) * ctx->nsurf,
+                                   sizeof(rt_surface) * ntab,
                                    hipMemcpyHostToDevice, ctx->stream));
         ctx->table_dirty = 0;
         ctx->table_start = start;

@@ -54,10 +54,16 @@ class Engine:
 
     # -- system / rays ----------------------------------------------------
     def upload_system(self, table):
+        """``table``: (L,) one surface table, or (G,L) one per ray group
+        (wavelength)."""
         table = np.ascontiguousarray(table, dtype=_lib.SURFACE_DTYPE)
-        self._check(self.lib.rt_upload_system(
-            self.ctx, table.ctypes.data, len(table)), "rt_upload_system")
-        self.nsurf = len(table)
+        if table.ndim == 1:
+            table = table[None]
+        groups, nsurf = table.shape
+        self._check(self.lib.rt_upload_system_groups(
+            self.ctx, table.ctypes.data, nsurf, groups), "rt_upload_system")
+        self.nsurf = nsurf
+        self.ngroups = groups
 
     def reserve(self, nrays):
         self._check(self.lib.rt_reserve(self.ctx, int(nrays)), "rt_reserve")
@@ -80,6 +86,17 @@ class Engine:
         self._check(self.lib.rt_set_rays(
             self.ctx, y.ctypes.data, u.ctypes.data, y.shape[0], LAYOUT_AOS),
             "rt_set_rays")
+
+    def set_rays_repeat(self, y, u, copies):
+        """The same (P,3) rays ``copies`` times in a row (one copy per ray
+        group); only P rays cross PCIe."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        if y.shape != u.shape or y.ndim != 2 or y.shape[1] != 3:
+            raise ValueError("y and u must both be (P,3)")
+        self._check(self.lib.rt_set_rays_repeat(
+            self.ctx, y.ctypes.data, u.ctypes.data, y.shape[0], int(copies),
+            LAYOUT_AOS), "rt_set_rays_repeat")
 
     def set_rays_soa(self, y, u):
         y = np.ascontiguousarray(y, dtype=np.float64)

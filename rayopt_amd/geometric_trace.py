@@ -178,7 +178,15 @@ class GeometricTrace(Trace):
         self.t = DeviceRows(self, RT_T)
 
     def _upload_table(self, start, stop, n_init):
-        table, ns = pack_system(self.system, self.l, n_init, start, stop)
+        """Pack + hand over the surface table(s): one per wavelength when
+        ``self.l`` is a sequence (ray groups), returns (tables, n)."""
+        if np.ndim(self.l) == 0:
+            table, ns = pack_system(self.system, self.l, n_init, start, stop)
+        else:
+            packed = [pack_system(self.system, l, n0, start, stop)
+                      for l, n0 in zip(self.l, n_init)]
+            table = np.stack([t for t, _ in packed])
+            ns = np.stack([n for _, n in packed])
         self.engine.upload_system(table)
         return table, ns
 
@@ -196,6 +204,8 @@ class GeometricTrace(Trace):
             self.allocate(n)
         if l is None:
             l = self.system.wavelengths[0]
+        if np.ndim(l) == 1:
+            return self._rays_given_groups(y, u, np.asarray(l, float), w, ref)
         if w is not None and np.shape(w) != (n,):
             raise ValueError("rays_given: w must have shape (%d,)" % n)
         self._uniform_w = w is None
@@ -223,6 +233,48 @@ class GeometricTrace(Trace):
         self.engine.set_weights(None if self._uniform_w else w)
         for rows in (self.y, self.u, self.i, self.t):
             rows.invalidate(0, self.length)   # row 0 is read back on demand
+
+    def _rays_given_groups(self, y, u, wavelengths, w, ref):
+        """``rays_given(y, u, l=[l1, l2, ...])`` (extension): the same P rays
+        at W wavelengths in ONE trace.  The batch holds W groups of P rays,
+        group g at ``wavelengths[g]``: ray ``g*P + p``; ``n`` becomes (W, L).
+        P must be a multiple of 64 so each wavefront stays inside one group
+        and keeps reading its surface table through scalar loads."""
+        p, m = y.shape
+        groups = len(wavelengths)
+        if p % 64:
+            raise ValueError("rays_given with several wavelengths needs a "
+                             "multiple of 64 rays per wavelength, got %d" % p)
+        n = p*groups
+        if not hasattr(self, "y") or self.nrays != n \
+                or self.length != len(self.system):
+            self.allocate(n)
+        y0 = np.zeros((p, 3))
+        y0[:, :m] = y
+        u0 = np.empty((p, 3))
+        u0[:, :m] = u
+        if m < 3:
+            u0[:, 2] = np.sqrt(1 - np.square(u0[:, :2]).sum(-1))
+        self.l = wavelengths
+        self.rays_per_group = p
+        self._uniform_w = w is None
+        if w is None:
+            w = np.broadcast_to(np.ones(1)/n, (n,))
+        elif np.shape(w) == (p,):
+            w = np.tile(np.asarray(w, float)/groups, groups)
+        elif np.shape(w) != (n,):
+            raise ValueError("rays_given: w must have shape (%d,) or (%d,)"
+                             % (p, n))
+        self.w = w
+        self.ref = ref
+        self.n = np.empty((groups, self.length))
+        self.n[:, 0] = [self.system.refractive_index(l, 0)
+                        for l in wavelengths]
+        self._upload_table(1, None, self.n[:, 0])
+        self.engine.set_rays_repeat(y0, u0, groups)
+        self.engine.set_weights(None if self._uniform_w else w)
+        for rows in (self.y, self.u, self.i, self.t):
+            rows.invalidate(0, self.length)
 
     def rays_given_device(self, d_y, d_u, nrays, l=None, w=None, ref=0,
                           layout=_lib.LAYOUT_SOA):
@@ -311,7 +363,9 @@ class GeometricTrace(Trace):
         a, b = resolve_range(self.length, start, stop)
         if a < 1:
             raise ValueError("start must be >= 1")
-        _, ns = self._upload_table(a, b, self.n[a - 1])
+        grouped = np.ndim(self.l) == 1
+        _, ns = self._upload_table(
+            a, b, self.n[:, a - 1] if grouped else self.n[a - 1])
         if keep is None:
             self.engine.set_keep_rows(None)
         else:
@@ -320,7 +374,10 @@ class GeometricTrace(Trace):
             mask[:a] = 1        # rows before `start` are not touched
             self.engine.set_keep_rows(mask)
         self.engine.trace(a, b, clip)
-        self.n[a:b] = ns[a:b]
+        if grouped:
+            self.n[:, a:b] = ns[:, a:b]
+        else:
+            self.n[a:b] = ns[a:b]
         for rows in (self.y, self.u, self.i, self.t):
             rows.invalidate(a, b)
 
@@ -356,6 +413,9 @@ class GeometricTrace(Trace):
         on the image of ray ``ref``: ``x, y`` (exit-pupil coordinates) and
         ``t`` in waves -- what the reference's ``opd(resample=0)`` returns
         (rayopt/geometric_trace.py:101-131), computed by one fused kernel."""
+        if np.ndim(self.l):
+            raise NotImplementedError("opd of a multi-wavelength batch: "
+                                      "trace one wavelength per trace")
         L = self.length
         nrows = len(range(L)[:after + 1])
         after, image = range(L)[after], range(L)[image]

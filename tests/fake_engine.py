@@ -20,8 +20,13 @@ class OracleEngine:
         self.ms = 0.
 
     def upload_system(self, table):
-        self.table = np.array(table)
-        self.nsurf = len(table)
+        table = np.array(table)
+        self.tables = table[None] if table.ndim == 1 else table
+        self.table = self.tables[0]
+        self.nsurf = self.tables.shape[1]
+
+    def set_rays_repeat(self, y, u, copies):
+        self.set_rays(np.tile(y, (copies, 1)), np.tile(u, (copies, 1)))
 
     def set_rays(self, y, u):
         L, n = self.nsurf, y.shape[0]
@@ -48,11 +53,15 @@ class OracleEngine:
         if stop <= 0:
             stop = self.nsurf
         assert self.valid[start - 1]
-        Y, U, I, T = tn.propagate(self.table, self.rows[RT_Y][start - 1],
-                                  self.rows[RT_U][start - 1], start, stop,
-                                  clip)
-        for which, arr in ((RT_Y, Y), (RT_U, U), (RT_I, I), (RT_T, T)):
-            self.rows[which][start:stop] = arr
+        groups = len(self.tables)
+        per = self.nrays//groups
+        for g in range(groups):
+            sl = slice(g*per, (g + 1)*per)
+            Y, U, I, T = tn.propagate(
+                self.tables[g], self.rows[RT_Y][start - 1][sl],
+                self.rows[RT_U][start - 1][sl], start, stop, clip)
+            for which, arr in ((RT_Y, Y), (RT_U, U), (RT_I, I), (RT_T, T)):
+                self.rows[which][start:stop, sl] = arr
         keep = np.ones(self.nsurf, bool) if self.keep is None else self.keep
         self.valid[start:stop] = keep[start:stop]
 

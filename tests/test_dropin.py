@@ -91,3 +91,32 @@ def test_keep_rows_glue(ro):
     assert np.isfinite(g.y[-1]).all() and np.isfinite(g.y[4]).all()
     with pytest.raises(AssertionError):
         g.y[5]
+
+
+def test_multi_wavelength_groups_glue(ro):
+    """rays_given(l=[...]): one batch, one table per wavelength; equals the
+    reference traced once per wavelength (catalogue-free Abbe glasses)."""
+    text = ra.prescriptions.SINGLET.replace("material: 1.5168",
+                                            "material: 1.5168/64.17")
+    s = ro.system_from_yaml(text)
+    mine = ra.system_from_yaml(text)
+    y, u = ra.bundles.disc_bundle(128, 7., 2., 3)
+    ls = [486.13e-9, 587.56e-9, 656.27e-9]
+    g = ra.GeometricTrace(mine, engine=OracleEngine())
+    g.rays_given(y, u, ls)
+    g.propagate(clip=True)
+    assert g.y.shape == (4, 384, 3) and g.n.shape == (3, 4)
+    for k, l in enumerate(ls):
+        ref = ro.GeometricTrace(s)
+        ref.rays_given(y, u, l)
+        with np.errstate(all="ignore"):
+            ref.propagate(clip=True)
+        sl = slice(k*128, (k + 1)*128)
+        for name in "yui":
+            assert np.array_equal(np.asarray(getattr(g, name))[:, sl],
+                                  getattr(ref, name), equal_nan=True)
+        assert np.array_equal(np.asarray(g.t)[:, sl], ref.t, equal_nan=True)
+        assert np.array_equal(g.n[k], ref.n)
+    assert g.n[0, 1] != g.n[2, 1]
+    with pytest.raises(ValueError, match="multiple of 64"):
+        g.rays_given(y[:100], u[:100], ls)

@@ -495,3 +495,47 @@ def test_element_level_methods():
             assert ng == ns[1]
         s = el.intercept(y, u)
         assert_parity((s*1.1)[None], to[None], 1e-12, "el.intercept")
+
+
+def test_config_c2_three_wavelengths_one_launch():
+    """BASELINE config C2 literally: 10^6 rays x 3 wavelengths in ONE trace
+    (ray groups, one surface table per wavelength); every group is
+    bit-identical to the same rays traced alone at that wavelength."""
+    ls = [587.56e-9, 656.27e-9, 486.13e-9]
+    p = 10**6 - 10**6 % 64
+    y, u = disc_bundle(p, 5.5, 5., 0)
+    # a system whose indices depend on the wavelength: Abbe models fitted to
+    # the catalogue values of the Cooke fixture
+    idx = P.COOKE_INDICES
+    def abbe(key):
+        nd, nf, nc = (idx[l][key] for l in (587.56e-9, 486.13e-9, 656.27e-9))
+        return "%r/%r" % (nd, (nd - 1)/(nf - nc))
+    text = P.COOKE % dict(air=1.0, sk16=0., f2=0.)
+    text = text.replace("material: 0.0,", "material: @,")
+    parts = text.split("@")
+    glasses = [abbe("sk16"), abbe("f2"), abbe("sk16")]
+    text = "".join(a + b for a, b in zip(parts, glasses + [""]))
+    system = ra.system_from_yaml(text)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u, ls)
+    g.propagate(clip=True)
+    assert g.nrays == 3*p and g.n.shape == (3, 9)
+    ms = g.kernel_ms()
+    for k, l in enumerate(ls):
+        single = gpu_trace(system, y, u, l, True)
+        sl = slice(k*p, (k + 1)*p)
+        for j in (1, 4, 8):
+            for a, b in ((g.y, single.y), (g.u, single.u), (g.i, single.i)):
+                assert np.array_equal(np.asarray(a[j])[sl], np.asarray(b[j]),
+                                      equal_nan=True)
+            assert np.array_equal(np.asarray(g.t[j])[sl],
+                                  np.asarray(single.t[j]), equal_nan=True)
+        assert np.array_equal(g.n[k], single.n)
+    assert g.n[0, 1] != g.n[1, 1] and ms > 0
+    want, _ = oracle_trace(system, y[:6400], u[:6400], ls[2], True)
+    sub = ra.GeometricTrace(system)
+    sub.rays_given(y[:6400], u[:6400], ls)
+    sub.propagate(clip=True)
+    for rows, b in zip((sub.y, sub.u, sub.i, sub.t), want):
+        assert_parity(np.asarray(rows[1:])[:, 2*6400:], b, RTOL_SPHERICAL,
+                      "group 2")
