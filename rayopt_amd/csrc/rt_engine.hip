@@ -602,8 +602,9 @@ struct rt_ctx {
     size_t scratch_bytes;
     void *d_user; /* rt_scratch */
     size_t user_bytes;
-    void *h_pin[2]; /* pinned staging for large pageable H2D copies */
+    void *h_pin[2]; /* pinned staging for large pageable copies */
     hipEvent_t pin_done[2];
+    int pin_busy[2]; /* a DMA recorded in pin_done[k] may still use h_pin[k] */
     double *d_w;  /* ray weights, NULL = uniform 1/n */
     size_t w_cap;
     double *d_partials; /* RT_RED_BLOCKS x 8 doubles */
@@ -962,12 +963,13 @@ static int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
     for (size_t off = 0; off < bytes; off += RT_PIN_CHUNK, k ^= 1) {
         const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
                                                       : RT_PIN_CHUNK;
-        if (off >= 2 * RT_PIN_CHUNK) /* buffer k was used two chunks ago */
+        if (ctx->pin_busy[k]) /* this call's or an earlier call's DMA */
             RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[k]));
         memcpy(ctx->h_pin[k], (const char *)src + off, len);
         RT_HIP(ctx, hipMemcpyAsync((char *)dst + off, ctx->h_pin[k], len,
                                    hipMemcpyHostToDevice, ctx->stream));
         RT_HIP(ctx, hipEventRecord(ctx->pin_done[k], ctx->stream));
+        ctx->pin_busy[k] = 1;
     }
     return RT_OK;
 }
@@ -993,6 +995,8 @@ static int rt_d2h(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
             const size_t off = i * RT_PIN_CHUNK;
             const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
                                                           : RT_PIN_CHUNK;
+            if (ctx->pin_busy[i & 1]) /* an upload may still read it */
+                RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[i & 1]));
             RT_HIP(ctx, hipMemcpyAsync(ctx->h_pin[i & 1],
                                        (const char *)src + off, len,
                                        hipMemcpyDeviceToHost, ctx->stream));
@@ -1004,6 +1008,7 @@ static int rt_d2h(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
                                                           : RT_PIN_CHUNK;
             RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[(i - 1) & 1]));
             memcpy((char *)dst + off, ctx->h_pin[(i - 1) & 1], len);
+            ctx->pin_busy[(i - 1) & 1] = 0;
         }
     }
     return RT_OK;

@@ -539,3 +539,20 @@ def test_config_c2_three_wavelengths_one_launch():
     for rows, b in zip((sub.y, sub.u, sub.i, sub.t), want):
         assert_parity(np.asarray(rows[1:])[:, 2*6400:], b, RTOL_SPHERICAL,
                       "group 2")
+
+
+@pytest.mark.parametrize("n", [100_000, 200_000, 1_400_000, 1_500_000,
+                               3_000_001])
+def test_upload_download_round_trip(n):
+    """Row 0 read back equals what rays_given was handed, across the direct
+    and the pinned double-buffered staging paths (one chunk, chunk boundary,
+    several chunks) -- y and u share the staging buffers back to back."""
+    rng = np.random.default_rng(n)
+    y = rng.normal(size=(n, 3))
+    u = rng.normal(size=(n, 3))
+    g = ra.GeometricTrace(ra.system_from_yaml(P.SINGLET))
+    for rep in range(2):
+        g.rays_given(y, u)
+        assert np.array_equal(g.y[0], y) and np.array_equal(g.u[0], u)
+        assert np.array_equal(g.i[0], u)
+        y, u = u, y
