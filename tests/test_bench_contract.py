@@ -1,0 +1,60 @@
+"""bench.py's output contract, on a small batch (GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int,
+            "steps": int, "warmup": int, "ms_per_step": float,
+            "higher_is_better": bool, "scaling": str, "dtype": str,
+            "data": str, "config": dict, "roofline": dict}
+
+
+def check_line(out, steps, warmup):
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must be ONE JSON line"
+    d = json.loads(lines[0])
+    for key, typ in REQUIRED.items():
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["steps"] == steps and d["warmup"] == warmup
+    assert d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.
+    assert r["frac"] == pytest.approx(r["achieved"]/r["peak"])
+    rays, S = d["config"]["rays_per_gpu"], d["config"]["surfaces"]
+    assert d["value"] == pytest.approx(
+        rays*S*d["n_gpus"]/(d["ms_per_step"]*1e-3), rel=1e-6)
+    return d
+
+
+def test_single_process_line():
+    out = subprocess.check_output(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--rays", "200000",
+         "--steps", "4", "--warmup", "1", "--cpu-sample", "50000",
+         "--settle", "0.05"], text=True, cwd=ROOT)
+    d = check_line(out, 4, 1)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+
+
+def test_torchrun_single_rank_multi_process_path():
+    """The whole N>1 code path (torch rendezvous, RCCL communicator, gather
+    of the final intercepts inside the timed region) with one rank."""
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus",
+         "1", "--rays", "200000", "--steps", "3", "--warmup", "1",
+         "--settle", "0"], text=True, cwd=ROOT, env=env,
+        stderr=subprocess.DEVNULL)
+    d = check_line(out, 3, 1)
+    assert "RCCL gather" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d
