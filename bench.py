@@ -82,6 +82,17 @@ def traffic_from_profile():
 
 
 def main():
+    # the contract is ONE JSON line on stdout: native libraries (RCCL prints a
+    # version banner) must not get at it, so fd 1 is pointed at stderr for the
+    # whole run and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(real_stdout, (line + "\n").encode())
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -360,7 +371,7 @@ def main():
                       "propagate() of the numpy port (%.1f s); host has %d "
                       "cores" % (m, dt, os.cpu_count()),
         }
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     if dist_mode:
         dist.barrier()
         dist.destroy_process_group()
