@@ -53,6 +53,28 @@ def main():
     s = ra.system_from_yaml(P.TORTURE)
     run("torture (tilts, conics, mirror) 1e7", s, *disc_bundle(10**7, 9., 2., 1),
         None, True)
+    # C5's whole batch on ONE GPU: 10^8 rays x 13 elements = 104 GB of result
+    # arrays in HBM; rays built on the device (5 fields x 2*10^7 pupil points)
+    s = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    rng = np.random.default_rng(0)
+    m = 2*10**7
+    r, phi = np.sqrt(rng.random(m)), 2*np.pi*rng.random(m)
+    yp = np.c_[r*np.cos(phi), r*np.sin(phi)]
+    fields = np.c_[np.zeros(5), [0, .35, .5, .7, 1.]]
+    g = ra.GeometricTrace(s)
+    g.rays_fields(fields, yp, P.DOUBLE_GAUSS_PUPIL_Z, 17.)
+    gen_ms = g.kernel_ms()
+    ms = []
+    for k in range(12):
+        g.propagate(clip=True)
+        ms.append(g.kernel_ms())
+    ms = float(np.median(ms[-5:]))
+    n, S = g.nrays, len(s) - 1
+    print(json.dumps(dict(config="C5 batch on one GPU: 1e8 rays, device-"
+                          "generated", rays=n, surfaces=S, clip=True,
+                          kernel_ms=ms, ops_per_s=n*S/ms*1e3,
+                          GBs=n*(56*S + 48)/ms/1e6, generate_ms=gen_ms,
+                          result_GB=n*13*80/1e9)), flush=True)
 
 
 if __name__ == "__main__":
