@@ -36,17 +36,43 @@ def plane_or_sphere_intercept(c, k, y, u):
     return -(d + g)/e
 
 
-def aim_infinite(angle, yo, yp, z, a, c0=0., k0=0.):
+def project(yo, a, p="rectilinear"):
+    """InfiniteConjugate.map (rayopt/conjugates.py:208-234)."""
+    n = yo.shape[0]
+    if p == "rectilinear":
+        y = yo*np.tan(a)
+        u = np.hstack((y, np.ones((n, 1))))
+        u /= np.sqrt(np.square(u).sum(-1))[:, None]
+    elif p == "stereographic":
+        y = yo*(2*np.tan(a/2))
+        r = np.square(y).sum(-1)[:, None]/4
+        u = np.hstack((y, 1 - r))/(r + 1)
+    elif p == "equisolid":
+        y = yo*(2*np.sin(a/2))
+        r = np.square(y).sum(-1)[:, None]
+        u = np.hstack((y*np.sqrt(1 - r/4), 1 - r/2))
+    elif p == "orthographic":
+        y = yo*np.sin(a)
+        r = np.square(y).sum(-1)[:, None]
+        u = np.hstack((y, np.sqrt(1 - r)))
+    elif p == "equidistant":
+        y = yo*a
+        b = np.square(y).sum(-1) > (np.pi/2)**2
+        y = np.sin(y)
+        z = np.sqrt(np.square(y).sum(-1))
+        z = np.where(b, -z, z)[:, None]
+        u = np.hstack((y, z))
+    return u
+
+
+def aim_infinite(angle, yo, yp, z, a, c0=0., k0=0., projection="rectilinear"):
     """InfiniteConjugate.aim(yo, yp, z, a, surface=system[0], filter=False);
     ``c0, k0``: curvature/conic of element 0."""
     yo = np.atleast_2d(yo)
     a = np.asarray(a, dtype=float)
     yp = np.atleast_2d(yp)*np.fabs(a).max()            # Pupil.map
     yo, yp = np.broadcast_arrays(yo, yp)
-    n = yo.shape[0]
-    y = yo*np.tan(angle)                               # map(): rectilinear
-    u = np.hstack((y, np.ones((n, 1))))
-    u /= np.sqrt(np.square(u).sum(-1))[:, None]
+    u = project(yo, angle, projection)
     yz = (0, 0, z)
     y = yz - z*u
     s, m = sagittal_meridional(u, yz)

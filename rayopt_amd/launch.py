@@ -2,7 +2,8 @@
 
 For every field point the host evaluates the O(1) frame that the reference's
 ``Conjugate.aim`` builds before it broadcasts over the pupil coordinates
-(rayopt/conjugates.py:137-166 finite, :236-255 infinite; sagittal/meridional
+(rayopt/conjugates.py:137-166 finite, :236-255 infinite, all five projections
+of InfiniteConjugate.map :208-234; sagittal/meridional
 unit vectors rayopt/utils.py:106-114); the GPU expands it over the pupil
 grid (``rt_generate_rays``).  ``system.object`` may be this package's
 ``Conjugate`` or a reference conjugate object (``finite``, ``angle`` /
@@ -49,6 +50,36 @@ def _sag0(element, y):
     return -e
 
 
+def _direction(yo, angle, projection):
+    """Unit direction of field ``yo`` (fractional, 2,) for an object at
+    infinity with semi-angle ``angle`` (InfiniteConjugate.map,
+    rayopt/conjugates.py:208-234)."""
+    if projection == "rectilinear":
+        y = yo*np.tan(angle)
+        u = np.array((y[0], y[1], 1.))
+        return u/np.sqrt(np.square(u).sum(-1))
+    if projection == "stereographic":
+        y = yo*(2*np.tan(angle/2))
+        r = np.square(y).sum(-1)/4
+        return np.array((y[0], y[1], 1 - r))/(r + 1)
+    if projection == "equisolid":
+        y = yo*(2*np.sin(angle/2))
+        r = np.square(y).sum(-1)
+        y = y*np.sqrt(1 - r/4)
+        return np.array((y[0], y[1], 1 - r/2))
+    if projection == "orthographic":
+        y = yo*np.sin(angle)
+        r = np.square(y).sum(-1)
+        return np.array((y[0], y[1], np.sqrt(1 - r)))
+    if projection == "equidistant":
+        y = yo*angle
+        behind = np.square(y).sum(-1) > (np.pi/2)**2
+        y = np.sin(y)
+        z = np.sqrt(np.square(y).sum(-1))
+        return np.array((y[0], y[1], -z if behind else z))
+    raise NotImplementedError("projection %r" % projection)
+
+
 def _telecentric(obj):
     pupil = obj.pupil
     if isinstance(pupil, dict):
@@ -62,9 +93,8 @@ def field_frames(system, yo, z, a):
     0, scalar or (F,); ``a``: pupil aperture(s): scalar radius, (F,) radii,
     (2,2) ``[[-sag,-mer],[+sag,+mer]]`` or (F,2,2)."""
     obj = system.object
-    projection = getattr(obj, "projection", "rectilinear")
-    if projection != "rectilinear":
-        raise NotImplementedError("projection %r" % projection)
+    projection = getattr(obj, "projection", None) or \
+        getattr(obj, "extra", {}).get("projection", "rectilinear")
     yo = np.atleast_2d(np.asarray(yo, dtype=float))
     nf = yo.shape[0]
     z = np.broadcast_to(np.asarray(z, dtype=float), (nf,))
@@ -78,9 +108,7 @@ def field_frames(system, yo, z, a):
         row = out[f]
         row["z"] = zf
         if not obj.finite:
-            yt = yo[f]*np.tan(obj.angle)
-            u = np.array((yt[0], yt[1], 1.))
-            u /= np.sqrt(np.square(u).sum(-1))
+            u = _direction(yo[f], obj.angle, projection)
             s, m = _frame(u, zf)
             row["finite"] = 0
             row["am"] = np.fabs(a[f]).max()

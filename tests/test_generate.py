@@ -29,6 +29,10 @@ def systems():
                                                CURVED_OBJECT, 1),
            "infinite_curved_first": base.replace("- {material: 1.0}\n",
                                                  CURVED_OBJECT, 1)}
+    for proj in ("stereographic", "equisolid", "orthographic", "equidistant"):
+        out["infinite_" + proj] = base.replace(
+            "object: {angle_deg: 14,",
+            "object: {projection: %s, angle_deg: 34," % proj)
     return out
 
 
@@ -47,7 +51,8 @@ def oracle_rays(system, yo, yp, z, a):
     if not obj.finite:
         return an.aim_infinite(obj.angle, yo, yp, z, a,
                                getattr(system[0], "curvature", 0.),
-                               getattr(system[0], "conic", 0.))
+                               getattr(system[0], "conic", 0.),
+                               obj.extra.get("projection", "rectilinear"))
     from rayopt_amd.launch import _sag0, _telecentric
 
     def sag(y):
@@ -72,7 +77,8 @@ def test_frames_and_generation_math_vs_reference_aim(key, hostemu):
                 with np.errstate(all="ignore"):
                     yr, ur = ref_sys.aim(yo, yp, z, a2, filter=False)
                 yo_, uo_ = oracle_rays(mine, yo, yp, z, a2)
-                assert np.array_equal(yr, yo_) and np.array_equal(ur, uo_)
+                assert np.array_equal(yr, yo_, equal_nan=True)
+                assert np.array_equal(ur, uo_, equal_nan=True)
                 sl = slice(f*len(yp), (f + 1)*len(yp))
                 assert_parity(Y[sl][None], yr[None], 1e-13, key + ".y")
                 assert_parity(U[sl][None], ur[None], 1e-13, key + ".u")
