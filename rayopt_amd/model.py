@@ -60,6 +60,12 @@ class Material:
             return spec
         if hasattr(spec, "refractive_index"):   # foreign material object
             return spec
+        if isinstance(spec, dict):               # {typ:, coefficients:, ...}
+            spec = dict(spec)
+            spec.pop("type", None)
+            return DispersionGlass(spec.pop("typ", "sellmeier"),
+                                   spec.pop("coefficients"), **{
+                k: spec[k] for k in ("name", "solid", "mirror") if k in spec})
         if type(spec) is float:
             return ConstantIndex(spec)
         if type(spec) is tuple:
@@ -117,6 +123,85 @@ class GasFormula(Material):
     def refractive_index(self, wavelength):
         w = wavelength/1e-6
         return 1. + (self.b/(self.c - w**-2)).sum()
+
+
+def _pairs(c):
+    return np.asarray(c, dtype=float).reshape(-1, 2).T
+
+
+def _laurent(head, tail, w):
+    """head + sum_i tail[i] w^(-2(i+1))"""
+    n = head
+    for i, ci in enumerate(tail):
+        n = n + ci*w**(-2*(i + 1))
+    return n
+
+
+# Published dispersion formulas, w = wavelength in micrometres, c = the
+# coefficient vector in the order the glass catalogues (Zemax .agf, OSLO
+# .glc, refractiveindex.info) list them; names as in rayopt
+# (rayopt/material.py:240-322).
+DISPERSION = {
+    "schott": lambda w, c: np.sqrt(_laurent(c[0] + c[1]*w**2, c[2:], w)),
+    "sellmeier": lambda w, c: np.sqrt(
+        1. + (_pairs(c)[0]*w**2/(w**2 - _pairs(c)[1]**2)).sum()),
+    "sellmeier_squared": lambda w, c: np.sqrt(
+        1. + (_pairs(c)[0]*w**2/(w**2 - _pairs(c)[1])).sum()),
+    "sellmeier_squared_transposed": lambda w, c: np.sqrt(
+        1. + (c.reshape(2, -1)[0]*w**2/(w**2 - c.reshape(2, -1)[1])).sum()),
+    "conrady": lambda w, c: c[0] + c[1]/w + c[2]/w**3.5,
+    "herzberger": lambda w, c: (
+        c[0] + c[1]/(w**2 - .028) + c[2]/(w**2 - .028)**2 + c[3]*w**2 +
+        c[4]*w**4 + c[5]*w**6),
+    "sellmeier_offset": lambda w, c: np.sqrt(
+        1. + c[0] + (_pairs(c[1:1 + (len(c) - 1)//2*2])[0]*w**2 /
+                     (w**2 - _pairs(c[1:1 + (len(c) - 1)//2*2])[1]**2)).sum()),
+    "sellmeier_squared_offset": lambda w, c: np.sqrt(
+        1. + c[0] + (_pairs(c[1:1 + (len(c) - 1)//2*2])[0]*w**2 /
+                     (w**2 - _pairs(c[1:1 + (len(c) - 1)//2*2])[1])).sum()),
+    "handbook_of_optics1": lambda w, c: np.sqrt(
+        c[0] + c[1]/(w**2 - c[2]) - c[3]*w**2),
+    "handbook_of_optics2": lambda w, c: np.sqrt(
+        c[0] + c[1]*w**2/(w**2 - c[2]) - c[3]*w**2),
+    "extended2": lambda w, c: np.sqrt(_laurent(
+        c[0] + c[1]*w**2 + c[6]*w**4 + c[7]*w**6, c[2:6], w)),
+    "hikari": lambda w, c: np.sqrt(_laurent(
+        c[0] + c[1]*w**2 + c[2]*w**4, c[3:], w)),
+    "gas": lambda w, c: 1. + (c.reshape(2, -1)[0] /
+                              (c.reshape(2, -1)[1] - w**-2)).sum(),
+    "gas_offset": lambda w, c: c[0] + 1. + (
+        c[1:].reshape(2, -1)[0]/(c[1:].reshape(2, -1)[1] - w**-2)).sum(),
+    "refractiveindex_info": lambda w, c: np.sqrt(
+        c[0] + c[1]*w**c[2]/(w**2 - c[3]**c[4]) +
+        c[5]*w**c[6]/(w**2 - c[7]**c[8]) +
+        (_pairs(c[9:])[0]*w**_pairs(c[9:])[1]).sum()),
+    "retro": lambda w, c: np.sqrt(
+        2 + 1/(c[0] + c[1]*w**2/(w**2 - c[2]) + c[3]*w**2 - 1)),
+    "cauchy": lambda w, c: c[0] + (_pairs(c[1:])[0]*w**_pairs(c[1:])[1]).sum(),
+    "polynomial": lambda w, c: np.sqrt(
+        c[0] + (_pairs(c[1:])[0]*w**_pairs(c[1:])[1]).sum()),
+    "exotic": lambda w, c: np.sqrt(
+        c[0] + c[1]/(w**2 - c[2]) +
+        c[3]*(w - c[4])/((w - c[4])**2 + c[5])),
+}
+
+
+class DispersionGlass(Material):
+    """Glass given by a catalogue dispersion formula and its coefficients,
+    e.g. ``DispersionGlass("sellmeier_squared", [B1, C1, B2, C2, B3, C3])``."""
+    def __init__(self, typ, coefficients, **kw):
+        super().__init__(**kw)
+        if typ not in DISPERSION:
+            raise KeyError("unknown dispersion formula %r" % typ)
+        self.typ = typ
+        self.coefficients = np.atleast_1d(np.asarray(coefficients, float))
+
+    def refractive_index(self, wavelength):
+        n = DISPERSION[self.typ](wavelength/1e-6, self.coefficients)
+        return -n if self.mirror else n
+
+    def __str__(self):
+        return "%s%r" % (self.typ, list(self.coefficients))
 
 
 BASIC = {

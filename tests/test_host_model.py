@@ -122,3 +122,32 @@ def test_model_matches_reference_geometry():
         for j in range(len(a)):
             assert a.refractive_index(5.5e-7, j) == \
                 b.refractive_index(5.5e-7, j)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+def test_dispersion_formulas_match_reference():
+    ro = refshim.load()
+    from rayopt_amd.model import DISPERSION, DispersionGlass
+    rng = np.random.default_rng(4)
+    sizes = {"schott": 6, "sellmeier": 6, "sellmeier_squared": 6,
+             "sellmeier_squared_transposed": 6, "conrady": 3, "herzberger": 6,
+             "sellmeier_offset": 7, "sellmeier_squared_offset": 7,
+             "handbook_of_optics1": 4, "handbook_of_optics2": 4,
+             "extended2": 8, "hikari": 8, "gas": 4, "gas_offset": 5,
+             "refractiveindex_info": 13, "retro": 4, "cauchy": 5,
+             "polynomial": 5, "exotic": 6}
+    assert set(sizes) == set(DISPERSION)
+    for typ, k in sizes.items():
+        c = rng.uniform(0.01, 0.9, k)
+        c[0] = rng.uniform(1.5, 2.5)
+        ref = ro.material.CoefficientsMaterial(c, typ=typ)
+        mine = DispersionGlass(typ, c)
+        for l in (0.45e-6, 0.5876e-6, 1.06e-6):
+            with np.errstate(all="ignore"):
+                a, b = mine.refractive_index(l), ref.refractive_index(l)
+            assert (np.isnan(a) and np.isnan(b)) or a == pytest.approx(
+                b, rel=1e-14), typ
+    bk7 = ra.Material.make({"typ": "sellmeier_squared", "coefficients": [
+        1.03961212, 0.00600069867, 0.231792344, 0.0200179144, 1.01046945,
+        103.560653], "name": "N-BK7"})
+    assert bk7.refractive_index(587.5618e-9) == pytest.approx(1.5168, abs=2e-5)
