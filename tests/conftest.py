@@ -90,18 +90,25 @@ def assert_parity(got, want, rtol, what=""):
             what, j, worst, rtol)
 
 
-@pytest.fixture(scope="session")
-def hostemu():
-    """g++ build of the kernel's arithmetic header (tests/hostemu)."""
+def build_hostemu():
+    """g++ build of the kernel's arithmetic header (tests/hostemu), rebuilt
+    when the sources are newer; returns the library path."""
     src = os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")
     lib = os.path.join(ROOT, "tests", "hostemu", "libhostemu.so")
-    hdr = os.path.join(ROOT, "rayopt_amd", "csrc", "rt_math.h")
+    hdrs = [os.path.join(ROOT, "rayopt_amd", "csrc", "rt_math.h"),
+            os.path.join(ROOT, "include", "rt_mi355.h")]
     if (not os.path.exists(lib) or
-            os.path.getmtime(lib) < max(os.path.getmtime(src),
-                                        os.path.getmtime(hdr))):
+            os.path.getmtime(lib) < max(os.path.getmtime(f)
+                                        for f in [src] + hdrs)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
                                "-fPIC", "-shared", "-o", lib, src])
-    dll = ctypes.CDLL(lib)
+    return lib
+
+
+@pytest.fixture(scope="session")
+def hostemu():
+    """The kernel arithmetic compiled for the host, as callables."""
+    dll = ctypes.CDLL(build_hostemu())
     dll.emu_trace.restype = ctypes.c_int
 
     def trace(table, y0, u0, start, stop, clip, rays_per_lane=2):

@@ -92,9 +92,8 @@ def _generate_rays(self, fields, pupil_xy):
     """Test double of rt_generate_rays: the generation arithmetic compiled
     for the host (tests/hostemu)."""
     import ctypes
-    import os
-    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                                   "hostemu", "libhostemu.so"))
+    from conftest import build_hostemu
+    lib = ctypes.CDLL(build_hostemu())
     fields = np.ascontiguousarray(fields)
     pupil = np.ascontiguousarray(pupil_xy, dtype=float)
     n = len(fields)*len(pupil)
