@@ -69,6 +69,41 @@ def workload_rays(n, rank):
                               z_pupil=P.DOUBLE_GAUSS_PUPIL_Z)
 
 
+_SHARD = {}
+
+
+def _shard_worker(k):
+    from oracle import trace_numpy as tn
+    table, y, u, clip, bounds = (_SHARD[key] for key in
+                                 ("table", "y", "u", "clip", "bounds"))
+    lo, hi = bounds[k]
+    Y, U, I, T = tn.propagate(table, y[lo:hi], u[lo:hi], clip=clip)
+    return float(np.nansum(Y[-1]))      # touch the result
+
+
+def cpu_port_on_processes(system, y, u, clip, procs):
+    """The numpy port on `procs` forked processes over contiguous shards of
+    the whole batch (must run before this process touches the GPU)."""
+    import multiprocessing as mp
+    from rayopt_amd.pack import pack_system
+    from rayopt_amd.distributed import shard_bounds
+    l = system.wavelengths[0]
+    table, _ = pack_system(system, l, system.refractive_index(l, 0))
+    _SHARD.update(table=table, y=y, u=u, clip=clip,
+                  bounds=shard_bounds(len(y), procs))
+    ctx = mp.get_context("fork")
+    with ctx.Pool(procs) as pool:
+        pool.map(_shard_worker, range(procs))          # warm the workers
+        t0 = time.perf_counter()
+        pool.map(_shard_worker, range(procs))
+        dt = time.perf_counter() - t0
+    S = len(system) - 1
+    return {"value": len(y)*S/dt, "unit": "ray-surface-ops/s",
+            "cores": procs, "kind": "port",
+            "sample": "the whole batch on %d processes, contiguous shards "
+                      "(%.2f s)" % (procs, dt)}
+
+
 def traffic_from_profile():
     """HBM bytes per launch from the committed PMC profile, if one exists
     for this workload (profiles/traffic.json, written by
@@ -114,6 +149,11 @@ def main():
                          "the default command is the headline kernel")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N>1: gather y[L-1] to rank 0 in every step")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="also time the numpy port on this many host "
+                         "processes over contiguous ray shards (forked "
+                         "before the GPU is touched); reported as "
+                         "cpu_baseline_procs")
     ap.add_argument("--option", action="append", default=[],
                     help="kernel variant key=value (rt_set_option)")
     args = ap.parse_args()
@@ -153,6 +193,9 @@ def main():
 
     t0 = time.perf_counter()
     y, u = workload_rays(n, rank)
+    cpu_procs = None
+    if args.cpu_procs > 1 and rank == 0 and not dist_mode:
+        cpu_procs = cpu_port_on_processes(system, y, u, clip, args.cpu_procs)
     g = ra.GeometricTrace(system, device=local_rank)
     eng = g.engine
     for kv in args.option:
@@ -371,6 +414,8 @@ def main():
                       "propagate() of the numpy port (%.1f s); host has %d "
                       "cores" % (m, dt, os.cpu_count()),
         }
+    if cpu_procs is not None:
+        out["cpu_baseline_procs"] = cpu_procs
     emit(json.dumps(out))
     if dist_mode:
         dist.barrier()
