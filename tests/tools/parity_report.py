@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import rayopt_amd as ra
 from rayopt_amd import prescriptions as P
 from rayopt_amd.bundles import disc_bundle, multi_field_bundle

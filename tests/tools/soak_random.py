@@ -1,12 +1,12 @@
 """One-off soak: many more random systems than the test suite (engine vs
-oracle at the contract tolerances).  python scripts/soak_random.py 60 400"""
+oracle at the contract tolerances).  python tests/tools/soak_random.py 60 400"""
 import copy
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rayopt_amd as ra
