@@ -264,6 +264,9 @@ int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst);
 int rt_set_weights(rt_ctx *ctx, const double *w);
 int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms);
 int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift);
+/* max over rays of hypot(x, y) on row `surf` (NaN if any ray is NaN):
+ * GeometricTrace.resize (geometric_trace.py:231-234) */
+int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax);
 
 typedef struct rt_opd_args {
     int32_t nrows;      /* t rows 0..nrows-1 are summed (t[:after + 1]) */

@@ -461,6 +461,42 @@ __global__ void rt_refocus_dots_kernel(const double *__restrict__ Yrow,
     rt_block_reduce<2>(acc, partials);
 }
 
+/* max over rays of x^2 + y^2 of one row; NaN if any ray is NaN (np.max) */
+__global__ void rt_r2max_kernel(const double *__restrict__ Yrow, int64_t n,
+                                int64_t ld, double *__restrict__ partials)
+{
+    __shared__ double sm[RT_RED_THREADS / 64][2];
+    double mx = 0., bad = 0.;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        const double x = Yrow[j], y = Yrow[ld + j];
+        const double r2 = x * x + y * y;
+        if (r2 != r2)
+            bad = 1.;
+        else
+            mx = r2 > mx ? r2 : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(mx, off), b = __shfl_down(bad, off);
+        mx = o > mx ? o : mx;
+        bad = b > bad ? b : bad;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sm[wave][0] = mx;
+        sm[wave][1] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RT_RED_THREADS / 64; ++w) {
+            mx = sm[w][0] > mx ? sm[w][0] : mx;
+            bad = sm[w][1] > bad ? sm[w][1] : bad;
+        }
+        partials[(int64_t)blockIdx.x * 2] = mx;
+        partials[(int64_t)blockIdx.x * 2 + 1] = bad;
+    }
+}
+
 /* reference-ray columns the opd kernel needs, all wave-uniform */
 struct rt_opd_ref {
     double t[RT_MAX_SURFACES]; /* T[row][ref] */
@@ -1530,6 +1566,31 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
     if (rc != RT_OK)
         return rc;
     *rms = sqrt(sum);
+    return RT_OK;
+}
+
+int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax)
+{
+    int rc = rt_consumer_ready(ctx, surf, "rt_row_rmax");
+    if (rc != RT_OK)
+        return rc;
+    if (!rmax)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_row_rmax: NULL");
+    hipLaunchKernelGGL(rt_r2max_kernel, dim3(RT_RED_BLOCKS),
+                       dim3(RT_RED_THREADS), 0, ctx->stream,
+                       rt_row(ctx, RT_Y, surf), ctx->n, ctx->ld,
+                       ctx->d_partials);
+    double host[RT_RED_BLOCKS * 2];
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(host, ctx->d_partials, sizeof host,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double mx = 0., bad = 0.;
+    for (int b = 0; b < RT_RED_BLOCKS; ++b) {
+        mx = host[2 * b] > mx ? host[2 * b] : mx;
+        bad = host[2 * b + 1] > bad ? host[2 * b + 1] : bad;
+    }
+    *rmax = bad ? __builtin_nan("") : sqrt(mx);
     return RT_OK;
 }
 

@@ -219,6 +219,12 @@ class Engine:
                                     ctypes.byref(out)), "rt_rms")
         return out.value
 
+    def row_rmax(self, surf):
+        out = ctypes.c_double()
+        self._check(self.lib.rt_row_rmax(self.ctx, int(surf),
+                                         ctypes.byref(out)), "rt_row_rmax")
+        return out.value
+
     def refocus_shift(self, surf):
         out = ctypes.c_double()
         self._check(self.lib.rt_refocus_shift(self.ctx, int(surf),

@@ -402,6 +402,40 @@ class GeometricTrace(Trace):
         self.propagate()
         return t
 
+    def resize(self, fn=lambda a, b: a):
+        """Set every element's aperture from the largest ray height on it:
+        ``radius = fn(max hypot(x, y), radius)``
+        (rayopt/geometric_trace.py:231-234); the maxima are reduced on the
+        GPU, one scalar per surface crosses PCIe."""
+        for j, el in enumerate(self.system[1:], 1):
+            el.radius = fn(self.engine.row_rmax(j), el.radius)
+
+    def print_trace(self, rays=None):
+        """Text table per ray (default: the first three): index, track,
+        path relative to the axial path, intercept, direction
+        (rayopt/geometric_trace.py:242-255)."""
+        if np.ndim(self.l):
+            raise NotImplementedError("one wavelength per table")
+        rays = range(min(3, self.nrays)) if rays is None else rays
+        labels = ("n/track z/rel path/height x/height y/height z/"
+                  "angle x/angle y/angle z").split("/")
+        head = ("%2s %1s" + "% 10s"*len(labels)) % (("#", "T") + tuple(labels))
+        for k in rays:
+            y = self.engine.download_ray(RT_Y, k)
+            u = self.engine.download_ray(RT_U, k)
+            t = np.cumsum(self.engine.download_ray(RT_T, k)) - self.path
+            yield "ray %i" % k
+            yield head
+            for j in range(self.length):
+                row = (self.n[j], self.path[j], t[j]) + tuple(y[j]) + \
+                    tuple(u[j])
+                letter = getattr(self.system[j], "typeletter", "S")
+                yield ("%2s %1s" + "% 10.4g"*len(row)) % ((j, letter) + row)
+            yield ""
+
+    def __str__(self):
+        return "\n".join(self.print_trace())
+
     def _image_pupil(self):
         pupil = self.system.image.pupil
         if isinstance(pupil, dict):

@@ -133,3 +133,29 @@ def test_psf_runs_and_is_normalised():
     assert psf.shape == p.shape == q.shape
     assert np.isfinite(psf).all() and psf.max() > 0
     assert psf.sum() == pytest.approx(1., rel=0.2)
+
+
+@pytest.mark.gpu
+def test_resize_and_print_trace():
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    y, u = ra.bundles.disc_bundle(50000, 12., 5., 2,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    tr = ra.GeometricTrace(system)
+    tr.rays_given(y, u)
+    tr.propagate()
+    want = [np.hypot(*np.asarray(tr.y[j])[:, :2].T).max()
+            for j in range(1, len(system))]
+    tr.resize()
+    got = [e.radius for e in system[1:]]
+    np.testing.assert_allclose(got, want, rtol=1e-15)
+    tr.resize(lambda a, b: max(a, b)*1.05)
+    assert system[3].radius == pytest.approx(want[2]*1.05)
+    text = str(tr)
+    assert text.count("ray ") == 3 and "height x" in text
+    lines = list(tr.print_trace(rays=[7]))
+    assert len(lines) == 2 + len(system) + 1
+    # clipped rays make the maximum NaN, as np.max does in the reference
+    system[5].radius = 1.0
+    tr.propagate(clip=True)
+    tr.resize()
+    assert np.isnan(system[8].radius)
