@@ -346,6 +346,38 @@ class GeometricTrace(Trace):
         self.rays_per_field = len(yp)
         self.propagate(clip=clip)
 
+    def rays_point(self, yo, wavelength=None, nrays=11,
+                   distribution="meridional", filter=None, stop=None,
+                   clip=False):
+        """One field point, as the reference's ``rays_point``
+        (rayopt/geometric_trace.py:204-209): pupil pattern, aiming
+        (``stop=-1``: to the rim of the limiting aperture), optional
+        filtering of the pattern to the aimed pupil ellipse
+        (``Pupil.map(filter=True)``, rayopt/pupils.py:97-107; default
+        ``not clip``), trace."""
+        from .aiming import FieldAimer
+        from .pupil import pupil_distribution
+        if filter is None:
+            filter = not clip
+        ref, yp, weight = pupil_distribution(distribution, nrays)
+        l = self.system.wavelengths[0] if wavelength is None else wavelength
+        z, a = FieldAimer(self.system, l).pupil([yo], rim=(stop == -1))
+        if filter:
+            am = np.fabs(a[0]).max()
+            c = np.sum(a[0], axis=0)/2
+            d = np.diff(a[0], axis=0)/2
+            inside = (np.square(yp*am - c)/np.square(d)).sum(1) <= 1
+            yp = yp[inside]
+            if weight is not None:
+                weight = weight[inside]
+            ref = int(np.count_nonzero(inside[:ref]))
+        self.rays_fields([yo], yp, z, a, l, ref=ref)
+        if weight is not None:
+            self.w = weight
+            self._uniform_w = False
+            self.engine.set_weights(weight)
+        self.propagate(clip=clip)
+
     # -- the hot path ---------------------------------------------------------
     def propagate(self, start=1, stop=None, clip=False, keep=None):
         """Trace elements ``start .. stop-1`` for all rays on the GPU

@@ -125,3 +125,35 @@ def test_rays_points_chain():
     g.rays_points(fields[:2], nrays=50, distribution="square", aim=False,
                   clip=True)
     assert g.nrays == 2*g.rays_per_field
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+def test_rays_point_matches_reference_quadrature():
+    """Native rays_point (pattern + batched aiming + device generation) on
+    the Cooke fixture reproduces the reference's pinned rms = 0.052 known
+    answer (rayopt/test/test_raytrace.py:189-199) -- through the oracle-backed
+    engine double on CPU."""
+    from fake_engine import OracleEngine
+    import rayopt_amd.aiming as aiming
+    ro = refshim.load()
+    text = COOKE.replace("radius: 20.", "radius: 0.364")
+    mine = ra.system_from_yaml(text)
+    real = aiming.GeometricTrace
+
+    class Doubled(real):
+        def __init__(self, system, engine=None, device=None):
+            super().__init__(system, engine=OracleEngine())
+    aiming.GeometricTrace = Doubled
+    try:
+        g = ra.GeometricTrace(mine, engine=OracleEngine())
+        g.rays_point((0, 1.), nrays=13, distribution="radau", filter=False)
+    finally:
+        aiming.GeometricTrace = real
+    np.testing.assert_allclose(g.rms(), .052, rtol=1e-2)
+    ref = ro.system_from_yaml(text)
+    ref.update()
+    ro.ParaxialTrace(ref).update_conjugates()
+    r = ro.GeometricTrace(ref)
+    r.rays_point((0, 1.), nrays=13, distribution="radau", filter=False)
+    assert g.rms() == pytest.approx(r.rms(), rel=2e-2)
+    assert g.nrays == r.nrays
