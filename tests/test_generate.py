@@ -117,6 +117,10 @@ def test_device_generation_vs_oracle(key):
         want = tn.propagate(table, y0, u0, clip=True)
     for rows, b in zip((g.y, g.u, g.i, g.t), want):
         assert_parity(np.asarray(rows[1:]), b, RTOL_SPHERICAL, key)
-    assert g.rms(i=1) == pytest.approx(
-        np.sqrt((np.square(np.asarray(g.y[1])[:, :2] - np.asarray(
-            g.y[1])[:, :2].mean(0)).sum(1)/g.nrays).sum()), rel=1e-12)
+    y1 = np.asarray(g.y[1])[:, :2]
+    want_rms = np.sqrt((np.square(y1 - y1.mean(0)).sum(1)/g.nrays).sum())
+    got_rms = g.rms(i=1)
+    # the reference's equidistant projection yields a zero direction on axis
+    # (NaN rays); NaN in, NaN out on both sides
+    assert (np.isnan(got_rms) and np.isnan(want_rms)) or \
+        got_rms == pytest.approx(want_rms, rel=1e-12)
