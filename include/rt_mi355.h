@@ -166,8 +166,8 @@ int rt_set_rays_device(rt_ctx *ctx, const double *d_y, const double *d_u,
  * nfields field points x npupil pupil coordinates, ray r = f*npupil + p, as
  * System.aim(yo, yp, z, a, filter=False) builds them one field at a time on
  * the host (rayopt/system.py:504, Infinite/FiniteConjugate.aim,
- * rayopt/conjugates.py:137-166,236-255, Pupil.map rayopt/pupils.py:97-107,
- * rectilinear projection).  Only npupil*16 B + nfields*sizeof(rt_field) cross
+ * rayopt/conjugates.py:137-166,236-255, Pupil.map rayopt/pupils.py:97-107;
+ * the object-space projection lives in the host-evaluated direction).  Only npupil*16 B + nfields*sizeof(rt_field) cross
  * PCIe instead of 48 B per ray; seeds row 0 like rt_set_rays.  The per-field
  * frame is evaluated by the host (O(nfields)):
  *   infinite: u = direction, base = (0,0,z) - z u, y = base + am px s + am py m,
