@@ -104,6 +104,51 @@ def cpu_port_on_processes(system, y, u, clip, procs):
                       "(%.2f s)" % (procs, dt)}
 
 
+class _DeviceView:
+    """numpy-style view of raw device memory for torch.as_tensor."""
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+            "version": 2, "strides": None}
+
+
+class TorchGather:
+    """Gather of row y[L-1] to rank 0 with torch.distributed send/recv on
+    views of the engine's buffers; used only if the engine's own RCCL
+    communicator cannot be created."""
+    def __init__(self, torch, dist, eng, n, world, rank, d_dst, L):
+        from rayopt_amd._lib import RT_Y
+        self.torch, self.dist, self.eng = torch, dist, eng
+        self.n, self.world, self.rank = n, world, rank
+        eng.sync()
+        ld = eng.ld
+        src = torch.as_tensor(_DeviceView(eng.device_ptr(RT_Y, L - 1),
+                                          (3, ld)), device="cuda")
+        self.src = src[:, :n]
+        self.dst = None
+        if rank == 0:
+            self.dst = torch.as_tensor(_DeviceView(d_dst, (3, n*world)),
+                                       device="cuda")
+
+    def __call__(self):
+        torch, dist = self.torch, self.dist
+        self.eng.sync()                  # the trace that produced the row
+        if self.rank == 0:
+            self.dst[:, :self.n].copy_(self.src)
+            ops = []
+            for r in range(1, self.world):
+                for c in range(3):
+                    ops.append(dist.P2POp(
+                        dist.irecv, self.dst[c, r*self.n:(r + 1)*self.n], r))
+        else:
+            stage = self.src.contiguous()
+            ops = [dist.P2POp(dist.isend, stage[c], 0) for c in range(3)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        torch.cuda.synchronize()
+
+
 def traffic_from_profile():
     """HBM bytes per launch from the committed PMC profile, if one exists
     for this workload (profiles/traffic.json, written by
@@ -208,21 +253,44 @@ def main():
     # RCCL gather of the final intercepts (only where there is an exchange)
     counts = None
     d_dst = 0
+    torch_gather = None
     if dist_mode:
         from rayopt_amd.distributed import init_engine_comm, shard_counts
-        init_engine_comm(eng, dist)
         counts = shard_counts(n*world, world)   # weak scaling: n per rank
         if rank == 0:
             d_dst = eng.scratch(int(counts.sum())*3*8)
+        try:
+            if os.environ.get("RT_BENCH_FORCE_TORCH_GATHER"):
+                raise ra.EngineError("forced")
+            init_engine_comm(eng, dist)
+            ok = 1
+        except ra.EngineError as exc:
+            log("[rank %d] engine RCCL communicator unavailable (%s)" % (
+                rank, exc))
+            ok = 0
+        flag = torch.tensor([ok], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            # safety net for the exchange only: the same RCCL send/recv
+            # through torch.distributed on views of the engine's device
+            # memory (no host staging, no CPU path)
+            torch_gather = TorchGather(torch, dist, eng, n, world, rank,
+                                       d_dst, L)
 
     from rayopt_amd.pack import pack_system
     table, ns = pack_system(system, g.l, g.n[0])
     eng.upload_system(table)
 
+    def gather():
+        if torch_gather is not None:
+            torch_gather()
+        else:
+            eng.gather_final(RT_Y, L - 1, counts, 0, d_dst)
+
     def step():
         eng.trace(1, 0, clip)
         if dist_mode and args.gather_every_step:
-            eng.gather_final(RT_Y, L - 1, counts, 0, d_dst)
+            gather()
 
     def fence():
         eng.sync()
@@ -249,7 +317,7 @@ def main():
         eng.event_record(1)
         if dist_mode and not args.gather_every_step:
             # the job's one exchange: final intercepts to rank 0
-            eng.gather_final(RT_Y, L - 1, counts, 0, d_dst)
+            gather()
         fence()
         return (time.perf_counter() - t0, eng.event_elapsed(0, 1),
                 eng.kernel_ms())
@@ -280,7 +348,7 @@ def main():
         # the exchange alone (not part of `value`'s timed region)
         fence()
         t0 = time.perf_counter()
-        eng.gather_final(RT_Y, L - 1, counts, 0, d_dst)
+        gather()
         fence()
         gather_ms = (time.perf_counter() - t0)*1e3
     if dist_mode:
@@ -349,9 +417,12 @@ def main():
             "settle_s": args.settle,
             "parallelism": "ray shards x%d%s" % (
                 world, (", RCCL gather of y[L-1] to rank 0 %s (gather alone: "
-                        "%.2f ms)" % ("in every step" if args.gather_every_step
-                                      else "once, after the last step, inside "
-                                      "the timed region", gather_ms))
+                        "%.2f ms%s)" % ("in every step"
+                                        if args.gather_every_step
+                                        else "once, after the last step, "
+                                        "inside the timed region", gather_ms,
+                                        ", via torch.distributed" if
+                                        torch_gather is not None else ""))
                 if dist_mode else ""),
         },
         "roofline": {

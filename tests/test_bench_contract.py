@@ -58,3 +58,19 @@ def test_torchrun_single_rank_multi_process_path():
     d = check_line(out, 3, 1)
     assert "RCCL gather" in d["config"]["parallelism"]
     assert "cpu_baseline" not in d
+
+
+def test_torchrun_torch_gather_safety_net():
+    """Same, with the engine's communicator declared unavailable: the
+    exchange goes through torch.distributed on views of the device memory."""
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1",
+               RT_BENCH_FORCE_TORCH_GATHER="1")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus",
+         "1", "--rays", "200000", "--steps", "3", "--warmup", "1",
+         "--settle", "0"], text=True, cwd=ROOT, env=env,
+        stderr=subprocess.DEVNULL)
+    d = check_line(out, 3, 1)
+    assert "via torch.distributed" in d["config"]["parallelism"]
