@@ -120,19 +120,23 @@ class TorchGather:
         from rayopt_amd._lib import RT_Y
         self.torch, self.dist, self.eng = torch, dist, eng
         self.n, self.world, self.rank = n, world, rank
-        eng.sync()
-        ld = eng.ld
-        src = torch.as_tensor(_DeviceView(eng.device_ptr(RT_Y, L - 1),
-                                          (3, ld)), device="cuda")
+        self.row, self.d_dst = (RT_Y, L - 1), d_dst
+        self.src = self.dst = None
+
+    def _views(self):
+        torch, n = self.torch, self.n
+        src = torch.as_tensor(_DeviceView(self.eng.device_ptr(*self.row),
+                                          (3, self.eng.ld)), device="cuda")
         self.src = src[:, :n]
-        self.dst = None
-        if rank == 0:
-            self.dst = torch.as_tensor(_DeviceView(d_dst, (3, n*world)),
-                                       device="cuda")
+        if self.rank == 0:
+            self.dst = torch.as_tensor(
+                _DeviceView(self.d_dst, (3, n*self.world)), device="cuda")
 
     def __call__(self):
         torch, dist = self.torch, self.dist
         self.eng.sync()                  # the trace that produced the row
+        if self.src is None:
+            self._views()
         if self.rank == 0:
             self.dst[:, :self.n].copy_(self.src)
             ops = []
