@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_mi355.so")
 SOURCES = [os.path.join(CSRC, "rt_engine.hip")]
-HEADERS = [os.path.join(CSRC, "rt_math.h"),
+HEADERS = [os.path.join(CSRC, "rt_math.h"), os.path.join(CSRC, "rt_kernels.h"),
            os.path.join(HERE, "..", "include", "rt_mi355.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
          "-fPIC", "-shared"]

@@ -30,565 +30,7 @@
 
 #include "rt_math.h"
 
-/* ------------------------------------------------------------------ */
-/* kernels                                                            */
-/* ------------------------------------------------------------------ */
-
-template <int R> struct rt_vec;
-template <> struct rt_vec<1> { typedef double type; };
-template <> struct rt_vec<2> {
-    typedef double type __attribute__((ext_vector_type(2)));
-};
-template <> struct rt_vec<4> {
-    typedef double type __attribute__((ext_vector_type(4)));
-};
-
-template <int R>
-__device__ __forceinline__ void rt_load(const double *__restrict__ p,
-                                        double (&v)[R])
-{
-    typedef typename rt_vec<R>::type V;
-    const V x = *reinterpret_cast<const V *>(p);
-    if constexpr (R == 1) {
-        v[0] = x;
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            v[r] = x[r];
-    }
-}
-
-template <int R, bool NT>
-__device__ __forceinline__ void rt_store(double *__restrict__ p,
-                                         const double (&v)[R])
-{
-    typedef typename rt_vec<R>::type V;
-    V x;
-    if constexpr (R == 1) {
-        x = v[0];
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            x[r] = v[r];
-    }
-    if constexpr (NT)
-        __builtin_nontemporal_store(x, reinterpret_cast<V *>(p));
-    else
-        *reinterpret_cast<V *>(p) = x;
-}
-
-/*
- * blockIdx -> chunk of rays.  Workgroup b is dispatched to XCD b % 8
- * (observed, used for speed only).  With XCD = true the chunks are dealt so
- * that each XCD streams one contiguous eighth of every result row instead of
- * every eighth 4 KiB chunk.
- */
-template <bool XCD>
-__device__ __forceinline__ int64_t rt_chunk(int64_t nblocks)
-{
-    const int64_t b = blockIdx.x;
-    if constexpr (!XCD)
-        return b;
-    const int64_t per = (nblocks + 7) / 8;
-    const int64_t c = (b & 7) * per + (b >> 3);
-    return c; /* may be >= nblocks for the ragged tail: caller checks */
-}
-
-/* read rows start-1 of Y,U for the R rays at offset j */
-template <int R>
-__device__ __forceinline__ void rt_load_state(const double *__restrict__ Y,
-                                              const double *__restrict__ U,
-                                              int64_t row, int64_t ld,
-                                              int64_t j, double (&y)[R][3],
-                                              double (&u)[R][3])
-{
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        double a[R], b[R];
-        rt_load<R>(Y + (row + c) * ld + j, a);
-        rt_load<R>(U + (row + c) * ld + j, b);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            y[r][c] = a[r];
-            u[r][c] = b[r];
-        }
-    }
-}
-
-/* the rows of one element for the R rays at offset j */
-template <int R, bool NT>
-__device__ __forceinline__ void rt_store_rows(
-    unsigned flags, int s, double *__restrict__ Y, double *__restrict__ U,
-    double *__restrict__ I, double *__restrict__ T, int64_t ld, int64_t j,
-    const double (&y)[R][3], const double (&u)[R][3],
-    const double (&iv)[R][3], const double (&t)[R])
-{
-    if (flags & RT_F_NOSTORE)
-        return;
-    const int64_t row = (int64_t)s * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        double a[R], b[R], d[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            a[r] = y[r][c];
-            b[r] = u[r][c];
-            d[r] = iv[r][c];
-        }
-        rt_store<R, NT>(Y + (row + c) * ld + j, a);
-        rt_store<R, NT>(U + (row + c) * ld + j, b);
-        if (flags & RT_F_STORE_I)
-            rt_store<R, NT>(I + (row + c) * ld + j, d);
-    }
-    rt_store<R, NT>(T + (int64_t)s * ld + j, t);
-}
-
-/* all elements start..stop-1 for the R rays of this lane; state in VGPRs */
-template <int R, bool NT>
-__device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
-                                         int start, int stop, int clip,
-                                         double *__restrict__ Y,
-                                         double *__restrict__ U,
-                                         double *__restrict__ I,
-                                         double *__restrict__ T, int64_t ld,
-                                         int64_t j, double (&y)[R][3],
-                                         double (&u)[R][3])
-{
-    double iv[R][3], t[R];
-    {
-        const rt_surface *S0 = surf + (start - 1);
-        rt_leave<R>(S0, S0->flags, y, u);
-    }
-    for (int s = start; s < stop; ++s) {
-        const rt_surface *S = surf + s;
-        const unsigned flags = S->flags;
-        rt_step<R>(S, flags, clip, y, u, iv, t);
-
-        /* all rows of the element leave in one burst: measured 3 % faster
-         * than sending y,t,i ahead of the refraction, and aligning the waves
-         * of a workgroup with a barrier first does not help
-         * (profiles/r01_probes/ab_store_order.log) */
-        rt_store_rows<R, NT>(flags, s, Y, U, I, T, ld, j, y, u, iv, t);
-
-        rt_leave<R>(S, flags, y, u);
-    }
-}
-
-template <int R, bool NT, bool XCD>
-__global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
-                                int stop, int clip, double *__restrict__ Y,
-                                double *__restrict__ U, double *__restrict__ I,
-                                double *__restrict__ T, int64_t ld,
-                                int64_t nblocks, int64_t group_rays,
-                                int nsurf)
-{
-    const int64_t chunk = rt_chunk<XCD>(nblocks);
-    const int64_t j = (chunk * blockDim.x + threadIdx.x) * R;
-    if (j >= ld)
-        return;
-    if (group_rays) {
-        /* ray groups with their own surface table (one wavelength each):
-         * group boundaries are multiples of 64 R rays, so the group -- and
-         * with it every table read -- stays wave-uniform (SGPRs) */
-        const int64_t j0 = j - (int64_t)(threadIdx.x & 63) * R;
-        const int g = __builtin_amdgcn_readfirstlane((int)(j0 / group_rays));
-        surf += (int64_t)g * nsurf;
-    }
-    double y[R][3], u[R][3];
-    rt_load_state<R>(Y, U, (int64_t)(start - 1) * 3, ld, j, y, u);
-    rt_march<R, NT>(surf, start, stop, clip, Y, U, I, T, ld, j, y, u);
-}
-
-/* rays_given: AoS (n,3) staging -> SoA row 0 of Y,U,I and T[0] = 0 */
-__global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
-                                   const double *__restrict__ u_aos,
-                                   int64_t n, double *__restrict__ Y,
-                                   double *__restrict__ U,
-                                   double *__restrict__ I,
-                                   double *__restrict__ T, int64_t ld,
-                                   int store_i, int64_t period)
-{
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ld)
-        return;
-    const bool in = j < n;
-    const int64_t k = j % period; /* the same rays for every group */
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double a = in ? y_aos[k * 3 + c] : 0.;
-        const double b = in ? u_aos[k * 3 + c] : 0.;
-        Y[c * ld + j] = a;
-        U[c * ld + j] = b;
-        if (store_i)
-            I[c * ld + j] = b;
-    }
-    T[j] = 0.;
-}
-
-/* rays_given for SoA (3,n) device/staged input */
-__global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
-                                   const double *__restrict__ u_soa,
-                                   int64_t n, double *__restrict__ Y,
-                                   double *__restrict__ U,
-                                   double *__restrict__ I,
-                                   double *__restrict__ T, int64_t ld,
-                                   int store_i, int64_t period)
-{
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ld)
-        return;
-    const bool in = j < n;
-    const int64_t k = j % period;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double a = in ? y_soa[c * period + k] : 0.;
-        const double b = in ? u_soa[c * period + k] : 0.;
-        Y[c * ld + j] = a;
-        U[c * ld + j] = b;
-        if (store_i)
-            I[c * ld + j] = b;
-    }
-    T[j] = 0.;
-}
-
-
-/*
- * Bandwidth probes (measurement only): the store pattern of the trace kernel
- * without its arithmetic, a linear fill and a 16-byte copy.  They calibrate
- * the memory-system ceiling the trace kernel is judged against.
- */
-__global__ void rt_probe_pattern_kernel(int start, int stop,
-                                        double *__restrict__ Y,
-                                        double *__restrict__ U,
-                                        double *__restrict__ I,
-                                        double *__restrict__ T, int64_t ld)
-{
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    if (j >= ld)
-        return;
-    v2 y[3], u[3];
-    const int64_t row0 = (int64_t)(start - 1) * 3;
-    for (int c = 0; c < 3; ++c) {
-        y[c] = *reinterpret_cast<const v2 *>(Y + (row0 + c) * ld + j);
-        u[c] = *reinterpret_cast<const v2 *>(U + (row0 + c) * ld + j);
-    }
-    for (int s = start; s < stop; ++s) {
-        const int64_t row = (int64_t)s * 3;
-        for (int c = 0; c < 3; ++c) {
-            y[c] += u[c];
-            *reinterpret_cast<v2 *>(Y + (row + c) * ld + j) = y[c];
-            *reinterpret_cast<v2 *>(U + (row + c) * ld + j) = u[c];
-            *reinterpret_cast<v2 *>(I + (row + c) * ld + j) = u[c];
-        }
-        *reinterpret_cast<v2 *>(T + (int64_t)s * ld + j) = y[2];
-    }
-}
-
-__global__ void rt_probe_fill_kernel(double *__restrict__ dst, int64_t n2)
-{
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    v2 v = {1., 2.};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-         i += stride)
-        reinterpret_cast<v2 *>(dst)[i] = v;
-}
-
-template <bool NT>
-__global__ void rt_probe_fill_once_kernel(double *__restrict__ dst, int64_t n2)
-{
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n2)
-        return;
-    v2 v = {1., 2.};
-    if constexpr (NT)
-        __builtin_nontemporal_store(v, reinterpret_cast<v2 *>(dst) + i);
-    else
-        reinterpret_cast<v2 *>(dst)[i] = v;
-}
-
-__global__ void rt_probe_copy_kernel(const double *__restrict__ src,
-                                     double *__restrict__ dst, int64_t n2)
-{
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-         i += stride)
-        reinterpret_cast<v2 *>(dst)[i] = reinterpret_cast<const v2 *>(src)[i];
-}
-
-
-
-/* rays of field f x pupil point p, see rt_generate_rays in rt_mi355.h */
-__global__ void rt_generate_kernel(const rt_field *__restrict__ fields,
-                                   const double *__restrict__ pupil,
-                                   int64_t npupil, int64_t n, rt_surface S0,
-                                   double *__restrict__ Y,
-                                   double *__restrict__ U,
-                                   double *__restrict__ I,
-                                   double *__restrict__ T, int64_t ld,
-                                   int store_i)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= ld)
-        return;
-    double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
-    if (r < n) {
-        const int64_t p = r % npupil;
-        rt_generate_ray(fields + r / npupil, pupil[2 * p], pupil[2 * p + 1],
-                        &S0, y, u);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        Y[c * ld + r] = y[0][c];
-        U[c * ld + r] = u[0][c];
-        if (store_i)
-            I[c * ld + r] = u[0][c];
-    }
-    T[r] = 0.;
-}
-
-/* ------------------------------------------------------------------ */
-/* device-side consumers: rms, refocus sums, opd rays                 */
-/* ------------------------------------------------------------------ */
-
-#define RT_RED_BLOCKS 1024
-#define RT_RED_THREADS 256
-
-/* deterministic two-level sum of K accumulators: wave shuffle -> LDS ->
- * one partial per workgroup; the host adds the RT_RED_BLOCKS partials in
- * index order (no atomics, run-to-run identical) */
-template <int K>
-__device__ __forceinline__ void rt_block_reduce(double (&acc)[K],
-                                                double *__restrict__ partials)
-{
-    __shared__ double sm[RT_RED_THREADS / 64][K];
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-        for (int off = 32; off > 0; off >>= 1)
-            acc[k] += __shfl_down(acc[k], off);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0)
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            sm[wave][k] = acc[k];
-    __syncthreads();
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double v = sm[0][k];
-            for (int w = 1; w < RT_RED_THREADS / 64; ++w)
-                v += sm[w][k];
-            partials[(int64_t)blockIdx.x * K + k] = v;
-        }
-}
-
-/* sum of x and y of one row (rms: y.mean(0)) */
-__global__ void rt_sum_xy_kernel(const double *__restrict__ Yrow, int64_t n,
-                                 int64_t ld, double *__restrict__ partials)
-{
-    double acc[2] = {0., 0.};
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
-        acc[0] += Yrow[j];
-        acc[1] += Yrow[ld + j];
-    }
-    rt_block_reduce<2>(acc, partials);
-}
-
-/* sum_k w_k ((x-x0)^2 + (y-y0)^2) */
-__global__ void rt_rms_kernel(const double *__restrict__ Yrow,
-                              const double *__restrict__ w, double wconst,
-                              double x0, double y0, int64_t n, int64_t ld,
-                              double *__restrict__ partials)
-{
-    double acc[1] = {0.};
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
-        const double dx = Yrow[j] - x0, dy = Yrow[ld + j] - y0;
-        const double r = dx * dx + dy * dy;
-        acc[0] += r * (w ? w[j] : wconst);
-    }
-    rt_block_reduce<1>(acc, partials);
-}
-
-/* refocus pass A: over rays with finite u = i_xy/i_z: count, sum y, sum u */
-__global__ void rt_refocus_sums_kernel(const double *__restrict__ Yrow,
-                                       const double *__restrict__ Irow,
-                                       int64_t n, int64_t ld,
-                                       double *__restrict__ partials)
-{
-    double acc[5] = {0., 0., 0., 0., 0.};
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
-        const double iz = Irow[2 * ld + j];
-        const double ux = Irow[j] / iz, uy = Irow[ld + j] / iz;
-        if (isfinite(ux) && isfinite(uy)) {
-            acc[0] += 1.;
-            acc[1] += Yrow[j];
-            acc[2] += Yrow[ld + j];
-            acc[3] += ux;
-            acc[4] += uy;
-        }
-    }
-    rt_block_reduce<5>(acc, partials);
-}
-
-/* refocus pass B: <w yc, uc> and <w uc, uc> with centred y, u */
-__global__ void rt_refocus_dots_kernel(const double *__restrict__ Yrow,
-                                       const double *__restrict__ Irow,
-                                       const double *__restrict__ w,
-                                       double wconst, double my0, double my1,
-                                       double mu0, double mu1, int64_t n,
-                                       int64_t ld,
-                                       double *__restrict__ partials)
-{
-    double acc[2] = {0., 0.};
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
-        const double iz = Irow[2 * ld + j];
-        const double ux = Irow[j] / iz, uy = Irow[ld + j] / iz;
-        if (isfinite(ux) && isfinite(uy)) {
-            const double wk = w ? w[j] : wconst;
-            const double y0 = Yrow[j] - my0, y1 = Yrow[ld + j] - my1;
-            const double u0 = ux - mu0, u1 = uy - mu1;
-            acc[0] += (wk * y0) * u0 + (wk * y1) * u1;
-            acc[1] += (wk * u0) * u0 + (wk * u1) * u1;
-        }
-    }
-    rt_block_reduce<2>(acc, partials);
-}
-
-/* max over rays of x^2 + y^2 of one row; NaN if any ray is NaN (np.max) */
-__global__ void rt_r2max_kernel(const double *__restrict__ Yrow, int64_t n,
-                                int64_t ld, double *__restrict__ partials)
-{
-    __shared__ double sm[RT_RED_THREADS / 64][2];
-    double mx = 0., bad = 0.;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
-        const double x = Yrow[j], y = Yrow[ld + j];
-        const double r2 = x * x + y * y;
-        if (r2 != r2)
-            bad = 1.;
-        else
-            mx = r2 > mx ? r2 : mx;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_down(mx, off), b = __shfl_down(bad, off);
-        mx = o > mx ? o : mx;
-        bad = b > bad ? b : bad;
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        sm[wave][0] = mx;
-        sm[wave][1] = bad;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < RT_RED_THREADS / 64; ++w) {
-            mx = sm[w][0] > mx ? sm[w][0] : mx;
-            bad = sm[w][1] > bad ? sm[w][1] : bad;
-        }
-        partials[(int64_t)blockIdx.x * 2] = mx;
-        partials[(int64_t)blockIdx.x * 2 + 1] = bad;
-    }
-}
-
-/* reference-ray columns the opd kernel needs, all wave-uniform */
-struct rt_opd_ref {
-    double t[RT_MAX_SURFACES]; /* T[row][ref] */
-    double y0[3], u0[3];       /* Y[0][ref], U[0][ref] */
-    double ya[3], ua[3];       /* Y[after][ref], U[after][ref] */
-    double yi[3];              /* Y[image][ref] */
-};
-
-/* transform + reference-sphere intercept of one ray (opd, :118-131) */
-__device__ __forceinline__ void rt_opd_point(const rt_opd_args &a,
-                                             const double (&yi_ref)[3],
-                                             double (&y)[3], double (&u)[3],
-                                             double &ti, double (&py)[3])
-{
-    if (a.rot_after) { /* ea.from_normal */
-        rt_rot_from(a.r_after, y);
-        rt_rot_from(a.r_after, u);
-    }
-    y[0] = y[0] + a.shift[0];
-    y[1] = y[1] + a.shift[1];
-    y[2] = y[2] + a.shift[2];
-    if (a.rot_image) { /* ei.to_normal */
-        rt_rot_to(a.r_image, y);
-        rt_rot_to(a.r_image, u);
-    }
-    y[0] -= yi_ref[0];
-    y[1] -= yi_ref[1];
-    y[2] -= yi_ref[2];
-    y[2] += a.radius;
-    /* Spheroid(curvature=1/radius).intercept(y, u), elements.py:477-501 */
-    const double c = 1. / a.radius;
-    if (c == 0.) {
-        ti = -y[2] / u[2];
-    } else {
-        const double uy = (u[0] * y[0] + u[1] * y[1]) + u[2] * y[2];
-        const double yy = (y[0] * y[0] + y[1] * y[1]) + y[2] * y[2];
-        const double d = c * uy - u[2];
-        const double e = c * 1.;
-        const double f = c * yy - 2. * y[2];
-        const double g = sqrt(d * d - e * f);
-        ti = -(d + g) / e;
-    }
-    py[0] = y[0] + ti * u[0];
-    py[1] = y[1] + ti * u[1];
-    py[2] = y[2] + ti * u[2];
-    py[2] -= a.radius;
-}
-
-__global__ void rt_opd_kernel(rt_opd_args a, const rt_opd_ref *__restrict__ ref,
-                              const double *__restrict__ Y,
-                              const double *__restrict__ U,
-                              const double *__restrict__ T, int64_t n,
-                              int64_t ld, double *__restrict__ out)
-{
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n)
-        return;
-    /* t = (t[:after+1] - t[:after+1, ref]).sum(0): row by row */
-    double t = 0.;
-    for (int s = 0; s < a.nrows; ++s) {
-        const double d = T[(int64_t)s * ld + j] - ref->t[s];
-        t = s ? t + d : d;
-    }
-    if (!a.finite) { /* input reference sphere is a tilted plane (:104-109) */
-        const double tj =
-            (ref->u0[0] * (ref->y0[0] - Y[j]) +
-             ref->u0[1] * (ref->y0[1] - Y[ld + j])) +
-            ref->u0[2] * (ref->y0[2] - Y[2 * ld + j]);
-        t -= tj * a.n0;
-    }
-    double y[3], u[3], py[3], ti;
-    const int64_t ra = (int64_t)a.after * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        y[c] = Y[(ra + c) * ld + j];
-        u[c] = U[(ra + c) * ld + j];
-    }
-    rt_opd_point(a, ref->yi, y, u, ti, py);
-    /* the same for the reference ray (uniform; every lane recomputes it) */
-    double yr[3], ur[3], pr[3], tr;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        yr[c] = ref->ya[c];
-        ur[c] = ref->ua[c];
-    }
-    rt_opd_point(a, ref->yi, yr, ur, tr, pr);
-    t += (ti - tr) * a.n_after;
-    t = -t / a.lscale;
-    out[j] = py[0] - pr[0];
-    out[n + j] = py[1] - pr[1];
-    out[2 * n + j] = t;
-}
+#include "rt_kernels.h"
 
 /* ------------------------------------------------------------------ */
 /* context                                                            */
