@@ -581,3 +581,13 @@ def test_many_contexts_lifecycle():
     big = gpu_trace(ra.system_from_yaml(P.DOUBLE_GAUSS), *_c3_rays(2_000_000),
                     None, True)
     assert big.y.shape == (13, 2_000_000, 3)
+
+
+def test_negative_index_medium():
+    from test_oracle_golden import NEGATIVE_INDEX
+    system = ra.system_from_yaml(NEGATIVE_INDEX)
+    y, u = disc_bundle(20000, 10., 3., 1)
+    g = gpu_trace(system, y, u, None, True)
+    want, _ = oracle_trace(system, y, u, g.l, True)
+    compare(g, want, 1, 4, RTOL_SPHERICAL, "negative index")
+    assert np.isfinite(np.asarray(g.y[-1])).any()

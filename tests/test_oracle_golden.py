@@ -117,3 +117,33 @@ def test_oracle_matches_live_reference(key):
         for field in mine.dtype.names:
             np.testing.assert_allclose(mine[field], table[field], rtol=0,
                                        atol=1e-15)
+
+
+NEGATIVE_INDEX = """
+wavelengths: [587.56e-9]
+elements:
+- {material: 1.0}
+- {roc: 40, distance: 10, material: -1.5, radius: 12}
+- {roc: -60, conic: -0.5, distance: 6, material: 1.2, radius: 12}
+- {distance: 30, radius: 50}
+"""
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+def test_negative_index_medium_matches_reference():
+    """mu < 0 but != -1: refraction with sign(mu) = -1
+    (rayopt/elements.py:365-367), not a mirror."""
+    ro = refshim.load()
+    s = ro.system_from_yaml(NEGATIVE_INDEX)
+    y, u = ra.bundles.disc_bundle(500, 10., 3., 1)
+    g = ro.GeometricTrace(s)
+    g.rays_given(y, u)
+    with np.errstate(all="ignore"):
+        g.propagate(clip=True)
+    table, ns = pack_system(ra.system_from_yaml(NEGATIVE_INDEX), g.l, g.n[0])
+    assert table["mu"][1] < 0 and table["smu"][1] == -1 and \
+        not table["flags"][1] & 0x40
+    got = tn.propagate(table, y, u, clip=True)
+    for a, b in zip(got, (g.y[1:], g.u[1:], g.i[1:], g.t[1:])):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.isfinite(g.y[-1]).any()
