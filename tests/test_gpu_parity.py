@@ -591,3 +591,30 @@ def test_negative_index_medium():
     want, _ = oracle_trace(system, y, u, g.l, True)
     compare(g, want, 1, 4, RTOL_SPHERICAL, "negative index")
     assert np.isfinite(np.asarray(g.y[-1])).any()
+
+
+def test_nan_and_inf_inputs_propagate_like_numpy():
+    """NaN / inf / zero-direction launch data: in-band failure exactly where
+    numpy produces it (the reference has no input validation)."""
+    system = ra.system_from_yaml(P.TORTURE)
+    y, u = disc_bundle(640, 8., 2., 9)
+    y[::7, 0] = np.nan
+    u[3::11, 1] = np.nan
+    y[5::13, 2] = np.inf
+    u[2::17] = 0.
+    u[4::19, 2] = -u[4::19, 2]
+    y[6::23] = 1e300
+    for clip in (True, False):
+        g = gpu_trace(system, y, u, None, clip)
+        with np.errstate(all="ignore"):
+            want, _ = oracle_trace(system, y, u, g.l, clip)
+        compare(g, want, 1, 9, RTOL_SPHERICAL, "nan inputs")
+    a = ra.system_from_yaml(P.ASPHERE_PHONE)
+    y, u = disc_bundle(640, 0.6, 10., 9)
+    y[::7, 1] = np.nan
+    u[2::17] = 0.
+    y[5::13, 2] = -np.inf
+    g = gpu_trace(a, y, u, None, True)
+    with np.errstate(all="ignore"):
+        want, _ = oracle_trace(a, y, u, g.l, True)
+    compare(g, want, 1, 9, RTOL_ASPHERE, "nan inputs asphere")
