@@ -618,3 +618,39 @@ def test_nan_and_inf_inputs_propagate_like_numpy():
     with np.errstate(all="ignore"):
         want, _ = oracle_trace(a, y, u, g.l, True)
     compare(g, want, 1, 9, RTOL_ASPHERE, "nan inputs asphere")
+
+
+def test_full_size_every_ray_against_c_oracle():
+    """BASELINE C3 at full size, EVERY ray and row: the device result equals
+    the plain-C oracle (oracle/trace_c.c, itself bit-identical to the
+    reference's goldens) bit for bit -- 1.2*10^8 ray-surface ops, 10 values
+    each."""
+    from oracle import build_c
+    n = 10**7
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = _c3_rays(n)
+    g = gpu_trace(system, y, u, None, True)
+    table, ns = pack_system(system, g.l, g.n[0])
+    Y, U, I, T = build_c.propagate(table, y, u, clip=True)
+    for j in range(1, len(system)):
+        for rows, ref in ((g.y, Y), (g.u, U), (g.i, I)):
+            assert np.array_equal(rows[j], ref[j - 1], equal_nan=True), j
+        assert np.array_equal(g.t[j], T[j - 1], equal_nan=True), j
+    assert np.array_equal(g.n[1:], ns[1:])
+
+
+def test_full_size_asphere_every_ray_against_c_oracle():
+    from oracle import build_c
+    n = 4*10**6
+    system = ra.system_from_yaml(P.ASPHERE_PHONE)
+    y, u = disc_bundle(n, 0.62, 20., 5)
+    y[:, 1] -= 0.5*np.tan(np.radians(20.))
+    g = gpu_trace(system, y, u, None, True)
+    table, ns = pack_system(system, g.l, g.n[0])
+    want = build_c.propagate(table, y, u, clip=True)
+    for rows, ref in zip((g.y, g.u, g.i, g.t), want):
+        assert_parity(np.asarray(rows[1:]), ref, 1e-13, "asphere full")
+    exact = sum(int((np.asarray(r[1:]) == w).sum())
+                for r, w in zip((g.y, g.u, g.i, g.t), want))
+    total = sum(int(np.isfinite(w).sum()) for w in want)
+    assert exact >= 0.999*total      # in practice: all of them

@@ -1,0 +1,51 @@
+"""The plain-C oracle (oracle/trace_c.c): pinned to the reference's golden
+vectors and to the numpy oracle on random systems."""
+import copy
+
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd.pack import pack_system, resolve_range
+from oracle import build_c, trace_numpy as tn
+
+from conftest import golden_names, load_golden, assert_parity
+from random_systems import random_prescription, random_rays
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_c_oracle_matches_reference_golden(name):
+    g = load_golden(name)
+    system = ra.system_from_yaml(g["yaml"])
+    a, b = resolve_range(len(system), g["start"], g["stop"])
+    table, ns = pack_system(system, g["l"],
+                            system.refractive_index(g["l"], 0), a, b)
+    got = build_c.propagate(table, g["y0"], g["u0"], a, b, g["clip"])
+    exact = not any(k in g["yaml"] for k in ("aspherics", "angles",
+                                             "direction"))
+    for label, x, want in zip("yuit", got, (g["y"], g["u"], g["i"], g["t"])):
+        want = want[a:b]
+        if exact:
+            assert np.array_equal(x, want, equal_nan=True), (name, label)
+        else:
+            assert_parity(x, want, 1e-12, "%s.%s" % (name, label))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_c_oracle_matches_numpy_oracle_on_random_systems(seed):
+    p = random_prescription(seed)
+    system = ra.system_from_dict(copy.deepcopy(p))
+    y, u = random_rays(seed, 300, p)
+    table, ns = pack_system(system, 587.56e-9,
+                            system.refractive_index(587.56e-9, 0))
+    asph = any("aspherics" in e for e in p["elements"])
+    tilted = any("angles" in e or "direction" in e for e in p["elements"])
+    for clip in (True, False):
+        a = build_c.propagate(table, y, u, clip=clip)
+        with np.errstate(all="ignore"):
+            b = tn.propagate(table, y, u, clip=clip)
+        for x, w in zip(a, b):
+            if asph or tilted:   # BLAS dot / np.dot orders in the numpy one
+                assert_parity(x, w, 1e-11, "seed %d" % seed)
+            else:
+                assert np.array_equal(x, w, equal_nan=True), seed
