@@ -16,7 +16,8 @@ def build(force=False):
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(
             os.path.getmtime(SRC), os.path.getmtime(HDR)):
         subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off",
-                               "-fPIC", "-shared", "-o", LIB, SRC, "-lm"])
+                               "-fopenmp", "-fPIC", "-shared", "-o", LIB, SRC,
+                               "-lm"])
     return LIB
 
 
