@@ -40,6 +40,8 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   cpu_baseline  the numpy port of the reference path (oracle/trace_numpy.py,
                 same whole-array numpy operations as rayopt) timed on this
                 host, one core, on a bounded sample of the same workload
+  cpu_baseline_c the independent plain-C port (oracle/trace_c.c) with OpenMP
+                on every host core: the compiled multi-threaded CPU figure
 """
 import argparse
 import json
@@ -79,6 +81,35 @@ def _shard_worker(k):
     lo, hi = bounds[k]
     Y, U, I, T = tn.propagate(table, y[lo:hi], u[lo:hi], clip=clip)
     return float(np.nansum(Y[-1]))      # touch the result
+
+
+def cpu_c_oracle(table, y, u, clip, S, g, L, sample=2_000_000):
+    """The independent plain-C oracle (oracle/trace_c.c, OpenMP over rays) on
+    every host core: what a compiled multi-threaded CPU implementation of the
+    same path reaches on this box.  Doubles as a second parity check."""
+    from oracle import build_c
+    build_c.build()
+    m = min(sample, y.shape[0])
+    ys, us = np.ascontiguousarray(y[:m]), np.ascontiguousarray(u[:m])
+    build_c.propagate(table, ys[:100000], us[:100000], clip=clip)      # warm
+    best, out = None, None
+    for _ in range(4):      # the first pass touches the output pages
+        t0 = time.perf_counter()
+        out = build_c.propagate(table, ys, us, clip=clip, out=out)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    Y = out[0]
+    got = np.asarray(g.y[L - 1])[:m]
+    same = np.array_equal(got, Y[-1], equal_nan=True)
+    return {
+        "value": m*S/best,
+        "unit": "ray-surface-ops/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": "first %d rays, best of 4 propagate() of the C port with "
+                  "OpenMP into the same output arrays (%.3f s)" % (m, best),
+        "image_row_bit_identical_to_gpu": bool(same),
+    }
 
 
 def cpu_port_on_processes(system, y, u, clip, procs):
@@ -489,6 +520,10 @@ def main():
                       "propagate() of the numpy port (%.1f s); host has %d "
                       "cores" % (m, dt, os.cpu_count()),
         }
+        try:
+            out["cpu_baseline_c"] = cpu_c_oracle(table, y, u, clip, S, g, L)
+        except Exception as err:      # a reported extra, never fatal
+            out["cpu_baseline_c"] = {"error": repr(err)[:200]}
     if cpu_procs is not None:
         out["cpu_baseline_procs"] = cpu_procs
     emit(json.dumps(out))

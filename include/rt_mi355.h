@@ -267,6 +267,23 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift);
 /* max over rays of hypot(x, y) on row `surf` (NaN if any ray is NaN):
  * GeometricTrace.resize (geometric_trace.py:231-234) */
 int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax);
+/*
+ * Spot statistics of every bundle of a batch in one call: the batch is
+ * `ngroups` contiguous groups of `group_rays` rays (field x wavelength bundles
+ * in the order rt_generate_rays / rt_upload_system_groups lay them out).  For
+ * each group, over the rays whose intercept on row `surf` is finite:
+ *   out[g][0] = number of such rays      out[g][1..2] = centroid (plain mean)
+ *   out[g][3] = sum w d^2 / sum w        out[g][4] = max d^2
+ *   out[g][5] = sum w                    (d = distance from the centroid)
+ * i.e. sqrt(out[g][3]) is GeometricTrace.rms() (geometric_trace.py:171-183) of
+ * that bundle traced on its own with its weights normalised (what a caller of
+ * the reference obtains with one rays_point() + rms() per field and
+ * wavelength) when no ray of it is lost; with lost rays the reference's value
+ * is NaN (test out[g][0] < group_rays), this one covers the survivors.
+ * Weights: rt_set_weights, NULL = uniform.  out: ngroups x 6 doubles (host).
+ */
+int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
+                  double *out);
 
 typedef struct rt_opd_args {
     int32_t nrows;      /* t rows 0..nrows-1 are summed (t[:after + 1]) */

@@ -21,8 +21,9 @@ def build(force=False):
     return LIB
 
 
-def propagate(table, y, u, start=1, stop=None, clip=False):
-    """Same signature and outputs as oracle.trace_numpy.propagate."""
+def propagate(table, y, u, start=1, stop=None, clip=False, out=None):
+    """Same signature and outputs as oracle.trace_numpy.propagate; ``out``:
+    (Y, U, I, T) of an earlier call to write into (pages already touched)."""
     dll = ctypes.CDLL(build())
     table = np.ascontiguousarray(table)
     idx = range(len(table))[start:stop]
@@ -30,10 +31,15 @@ def propagate(table, y, u, start=1, stop=None, clip=False):
     y = np.ascontiguousarray(y, dtype=float)
     u = np.ascontiguousarray(u, dtype=float)
     n = y.shape[0]
-    Y = np.empty((b - a, n, 3))
-    U = np.empty_like(Y)
-    I = np.empty_like(Y)
-    T = np.empty((b - a, n))
+    if out is None:
+        Y = np.empty((b - a, n, 3))
+        U = np.empty_like(Y)
+        I = np.empty_like(Y)
+        T = np.empty((b - a, n))
+    else:
+        Y, U, I, T = out
+        assert Y.shape == U.shape == I.shape == (b - a, n, 3)
+        assert T.shape == (b - a, n)
     ptr = lambda arr: ctypes.c_void_p(arr.ctypes.data)   # noqa: E731
     rc = dll.oracle_propagate(ptr(table), a, b, int(bool(clip)), ptr(y),
                               ptr(u), ctypes.c_int64(n), ptr(Y), ptr(U),

@@ -22,6 +22,32 @@ def rms(y_row, w=None, ref=None):
     return np.sqrt((r*w).sum())
 
 
+def spot_stats(y_row, group_rays, w=None):
+    """Per-bundle spot statistics for a batch of contiguous bundles of
+    ``group_rays`` rays -- ``rms`` above applied to every bundle on its own
+    with its weights normalised, restricted to the rays that arrived
+    (finite intercept); checks ``rt_spot_stats``.  Rows: count, centroid x,
+    centroid y, sum(w d^2)/sum(w), max d^2, sum(w)."""
+    n = y_row.shape[0]
+    groups = n//group_rays
+    assert groups*group_rays == n
+    out = np.empty((groups, 6))
+    for g in range(groups):
+        sl = slice(g*group_rays, (g + 1)*group_rays)
+        y = y_row[sl, :2]
+        wg = np.ones(group_rays) if w is None else np.asarray(w)[sl]
+        good = np.all(np.isfinite(y), axis=1)
+        y, wg = y[good], wg[good]
+        if not len(y):
+            out[g] = 0., np.nan, np.nan, np.nan, np.nan, 0.
+            continue
+        y0 = y.mean(0)
+        r = np.square(y - y0).sum(1)
+        out[g] = len(y), y0[0], y0[1], (r*wg).sum()/wg.sum(), r.max(), \
+            wg.sum()
+    return out
+
+
 def refocus_shift(y_row, i_row, w=None):
     """The shift ``t`` GeometricTrace.refocus adds to ``system[at].distance``
     (rayopt/geometric_trace.py:82-97)."""

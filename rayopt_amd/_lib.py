@@ -97,6 +97,8 @@ SIGNATURES = {
                               _c_double_p]),
     "rt_refocus_shift": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p]),
     "rt_row_rmax": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p]),
+    "rt_spot_stats": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,
+                                     ctypes.c_int, ctypes.c_void_p]),
     "rt_opd_rays": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p]),
     "rt_device_ptr": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_void_p)]),

@@ -86,6 +86,8 @@ struct rt_ctx {
     double *d_w;  /* ray weights, NULL = uniform 1/n */
     size_t w_cap;
     double *d_partials; /* RT_RED_BLOCKS x 8 doubles */
+    double *d_group;    /* rt_spot_stats: stats | partials */
+    size_t group_cap;   /* doubles */
     rt_opd_ref *d_opd_ref;
 
     /* kernel variant */
@@ -279,6 +281,8 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_w);
     if (ctx->d_partials)
         (void)hipFree(ctx->d_partials);
+    if (ctx->d_group)
+        (void)hipFree(ctx->d_group);
     if (ctx->d_opd_ref)
         (void)hipFree(ctx->d_opd_ref);
     if (ctx->d_surf)
@@ -1033,6 +1037,54 @@ int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax)
         bad = host[2 * b + 1] > bad ? host[2 * b + 1] : bad;
     }
     *rmax = bad ? __builtin_nan("") : sqrt(mx);
+    return RT_OK;
+}
+
+int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
+                  double *out)
+{
+    int rc = rt_consumer_ready(ctx, surf, "rt_spot_stats");
+    if (rc != RT_OK)
+        return rc;
+    if (!out || group_rays < 1 || ngroups < 1 || ngroups > 65535 ||
+        group_rays * (int64_t)ngroups != ctx->n)
+        return rt_fail(ctx, RT_ERR_ARG,
+                       "rt_spot_stats: %d groups of %lld rays do not tile the "
+                       "%lld rays of the batch", ngroups, (long long)group_rays,
+                       (long long)ctx->n);
+    /* enough workgroups per group to fill the chip, no more than it has rays
+     * for */
+    int64_t pb = 2048 / ngroups;
+    const int64_t fit = (group_rays + RT_RED_THREADS - 1) / RT_RED_THREADS;
+    pb = pb > fit ? fit : pb;
+    pb = pb < 1 ? 1 : (pb > 256 ? 256 : pb);
+    const size_t need = (size_t)ngroups * (RT_GRP_STATS + (size_t)pb * 4);
+    if (need > ctx->group_cap) {
+        if (ctx->d_group)
+            (void)hipFree(ctx->d_group);
+        ctx->d_group = nullptr;
+        ctx->group_cap = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_group, need * sizeof(double)));
+        ctx->group_cap = need;
+    }
+    double *stats = ctx->d_group;
+    double *partials = stats + (size_t)ngroups * RT_GRP_STATS;
+    const double *Yrow = rt_row(ctx, RT_Y, surf);
+    const dim3 grid((unsigned)pb, (unsigned)ngroups), block(RT_RED_THREADS);
+    const dim3 fgrid((unsigned)((ngroups + 63) / 64)), fblock(64);
+    hipLaunchKernelGGL(rt_group_sums_kernel, grid, block, 0, ctx->stream, Yrow,
+                       ctx->d_w, group_rays, ctx->ld, partials);
+    hipLaunchKernelGGL(rt_group_centroid_kernel, fgrid, fblock, 0, ctx->stream,
+                       partials, (int)pb, ngroups, stats);
+    hipLaunchKernelGGL(rt_group_spread_kernel, grid, block, 0, ctx->stream,
+                       Yrow, ctx->d_w, group_rays, ctx->ld, stats, partials);
+    hipLaunchKernelGGL(rt_group_finish_kernel, fgrid, fblock, 0, ctx->stream,
+                       partials, (int)pb, ngroups, stats);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(out, stats,
+                               sizeof(double) * RT_GRP_STATS * ngroups,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 

@@ -478,6 +478,118 @@ __global__ void rt_r2max_kernel(const double *__restrict__ Yrow, int64_t n,
     }
 }
 
+/*
+ * Per-group spot statistics: the batch is `gridDim.y` contiguous groups of
+ * group_rays rays (field x wavelength bundles as rt_generate_rays lays them
+ * out); what GeometricTrace.rms() gives when called once per bundle
+ * (geometric_trace.py:171-183), for every bundle in two passes over the row.
+ * Rays whose intercept is not finite are left out and counted.
+ * stats[g] = {count, mean x, mean y, sum w d^2 / sum w, max d^2, sum w}.
+ */
+#define RT_GRP_STATS 6
+
+/* pass A: count, sum x, sum y, sum w over the finite rays of group g */
+__global__ void rt_group_sums_kernel(const double *__restrict__ Yrow,
+                                     const double *__restrict__ w,
+                                     int64_t group_rays, int64_t ld,
+                                     double *__restrict__ partials)
+{
+    const int64_t base = (int64_t)blockIdx.y * group_rays;
+    double acc[4] = {0., 0., 0., 0.};
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+         j < group_rays; j += (int64_t)gridDim.x * blockDim.x) {
+        const double x = Yrow[base + j], y = Yrow[ld + base + j];
+        if (isfinite(x) && isfinite(y)) {
+            acc[0] += 1.;
+            acc[1] += x;
+            acc[2] += y;
+            acc[3] += w ? w[base + j] : 1.;
+        }
+    }
+    rt_block_reduce<4>(acc, partials + (int64_t)blockIdx.y * gridDim.x * 4);
+}
+
+/* one thread per group adds its pb partials in index order */
+__global__ void rt_group_centroid_kernel(const double *__restrict__ partials,
+                                         int pb, int ngroups,
+                                         double *__restrict__ stats)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups)
+        return;
+    double a[4] = {0., 0., 0., 0.};
+    for (int b = 0; b < pb; ++b)
+        for (int k = 0; k < 4; ++k)
+            a[k] += partials[((int64_t)g * pb + b) * 4 + k];
+    double *s = stats + (int64_t)g * RT_GRP_STATS;
+    s[0] = a[0];
+    s[1] = a[1] / a[0];
+    s[2] = a[2] / a[0];
+    s[5] = a[3];
+}
+
+/* pass B: sum w d^2 and max d^2 about the centroid of group g */
+__global__ void rt_group_spread_kernel(const double *__restrict__ Yrow,
+                                       const double *__restrict__ w,
+                                       int64_t group_rays, int64_t ld,
+                                       const double *__restrict__ stats,
+                                       double *__restrict__ partials)
+{
+    __shared__ double sm[RT_RED_THREADS / 64][2];
+    const int64_t base = (int64_t)blockIdx.y * group_rays;
+    const double x0 = stats[(int64_t)blockIdx.y * RT_GRP_STATS + 1];
+    const double y0 = stats[(int64_t)blockIdx.y * RT_GRP_STATS + 2];
+    double sum = 0., mx = 0.;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+         j < group_rays; j += (int64_t)gridDim.x * blockDim.x) {
+        const double x = Yrow[base + j], y = Yrow[ld + base + j];
+        if (isfinite(x) && isfinite(y)) {
+            const double dx = x - x0, dy = y - y0;
+            const double r = dx * dx + dy * dy;
+            sum += r * (w ? w[base + j] : 1.);
+            mx = r > mx ? r : mx;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_down(sum, off);
+        const double o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sm[wave][0] = sum;
+        sm[wave][1] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int v = 1; v < RT_RED_THREADS / 64; ++v) {
+            sum += sm[v][0];
+            mx = sm[v][1] > mx ? sm[v][1] : mx;
+        }
+        double *p = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        p[0] = sum;
+        p[1] = mx;
+    }
+}
+
+__global__ void rt_group_finish_kernel(const double *__restrict__ partials,
+                                       int pb, int ngroups,
+                                       double *__restrict__ stats)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups)
+        return;
+    double sum = 0., mx = 0.;
+    for (int b = 0; b < pb; ++b) {
+        const double *p = partials + ((int64_t)g * pb + b) * 2;
+        sum += p[0];
+        mx = p[1] > mx ? p[1] : mx;
+    }
+    double *s = stats + (int64_t)g * RT_GRP_STATS;
+    s[3] = sum / s[5];
+    s[4] = s[0] > 0. ? mx : __builtin_nan("");
+}
+
 /* reference-ray columns the opd kernel needs, all wave-uniform */
 struct rt_opd_ref {
     double t[RT_MAX_SURFACES]; /* T[row][ref] */

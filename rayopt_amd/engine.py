@@ -225,6 +225,15 @@ class Engine:
                                          ctypes.byref(out)), "rt_row_rmax")
         return out.value
 
+    def spot_stats(self, surf, group_rays, ngroups):
+        """(ngroups, 6): count, centroid x y, weighted mean d^2, max d^2,
+        sum w of every bundle of the batch (rt_spot_stats)."""
+        out = np.empty((int(ngroups), 6))
+        self._check(self.lib.rt_spot_stats(self.ctx, int(surf),
+                                           int(group_rays), int(ngroups),
+                                           out.ctypes.data), "rt_spot_stats")
+        return out
+
     def refocus_shift(self, surf):
         out = ctypes.c_double()
         self._check(self.lib.rt_refocus_shift(self.ctx, int(surf),

@@ -81,6 +81,10 @@ class OracleEngine:
     def rms(self, surf, ref=-1):
         return cn.rms(self.rows[RT_Y][surf], self.w, None if ref < 0 else ref)
 
+    def spot_stats(self, surf, group_rays, ngroups):
+        assert group_rays*ngroups == self.nrays
+        return cn.spot_stats(self.rows[RT_Y][surf], group_rays, self.w)
+
     def refocus_shift(self, surf):
         w = self.w if self.w is not None else \
             np.ones(self.nrays)/self.nrays
