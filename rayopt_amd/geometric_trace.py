@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import RT_Y, RT_U, RT_I, RT_T
-from .engine import Engine
+from .engine import Engine, get_engine
 from .pack import pack_system, resolve_range
 
 
@@ -172,10 +172,25 @@ class GeometricTrace(Trace):
         self.w = None
         self.ref = None
         self.l = 1.
+        self._reset_bundles()
         self.y = DeviceRows(self, RT_Y)
         self.u = DeviceRows(self, RT_U)
         self.i = DeviceRows(self, RT_I)
         self.t = DeviceRows(self, RT_T)
+
+    def _aux_engine(self):
+        """Engine for the small aiming batches: the process-wide context of
+        this device rather than a new one per aimer (for a test double: a
+        second instance of it)."""
+        if isinstance(self.engine, Engine):
+            return get_engine(self._device)
+        return type(self.engine)()
+
+    def _reset_bundles(self):
+        """Forget the bundle layout of an earlier rays_points()."""
+        self.rays_per_field = None
+        self.rays_alive_per_field = None
+        self.rays_per_group = None
 
     def _upload_table(self, start, stop, n_init):
         """Pack + hand over the surface table(s): one per wavelength when
@@ -202,6 +217,7 @@ class GeometricTrace(Trace):
         if not hasattr(self, "y") or self.nrays != n \
                 or self.length != len(self.system):
             self.allocate(n)
+        self._reset_bundles()
         if l is None:
             l = self.system.wavelengths[0]
         if np.ndim(l) == 1:
@@ -283,6 +299,7 @@ class GeometricTrace(Trace):
         if not hasattr(self, "y") or self.nrays != nrays \
                 or self.length != len(self.system):
             self.allocate(nrays)
+        self._reset_bundles()
         self.l = self.system.wavelengths[0] if l is None else l
         self.w = w
         self.ref = ref
@@ -299,20 +316,49 @@ class GeometricTrace(Trace):
         ``system.aim(yo[f], yp, z[f], a[f], filter=False)`` + ``rays_given``
         would (rayopt/system.py:504, rayopt/conjugates.py:137-166,236-255)
         -- ray ``f*P + p`` -- without the 48 B/ray host transfer.  ``z, a``:
-        pupil distance and aperture per field (e.g. from ``system.pupil``)."""
+        pupil distance and aperture per field (e.g. from ``system.pupil``).
+
+        ``l`` may be a sequence of W wavelengths (extension): the batch then
+        holds W groups of F bundles, ray ``(w*F + f)*P + p``, traced in one
+        launch with one surface table per wavelength; ``z``, ``a`` are given
+        per wavelength, (W,) / (W,F) and (W,F,2,2); ``n`` becomes (W, L).
+        ``F*P`` must be a multiple of 64 (see :meth:`rays_points`, which
+        pads the pupil pattern)."""
         from .launch import field_frames
         yp = np.atleast_2d(np.asarray(yp, dtype=float))
-        fields = field_frames(self.system, yo, z, a)
+        if l is None:
+            l = self.system.wavelengths[0]
+        if np.ndim(l) == 0:
+            fields = field_frames(self.system, yo, z, a)
+            groups = 0
+        else:
+            l = np.asarray(l, dtype=float)
+            groups = len(l)
+            fields = np.concatenate([
+                field_frames(self.system, yo, z[g], a[g])
+                for g in range(groups)])
+            per = len(fields)//groups*yp.shape[0]
+            if per % 64:
+                raise ValueError(
+                    "several wavelengths in one batch need a multiple of 64 "
+                    "rays per wavelength, got %d" % per)
         nrays = len(fields)*yp.shape[0]
         if not hasattr(self, "y") or self.nrays != nrays \
                 or self.length != len(self.system):
             self.allocate(nrays)
-        self.l = self.system.wavelengths[0] if l is None else l
+        self._reset_bundles()
+        self.l = l
         self._uniform_w = True
         self.w = np.broadcast_to(np.ones(1)/nrays, (nrays,))
         self.ref = ref
-        self.n[0] = self.system.refractive_index(self.l, 0)
-        self._upload_table(1, None, self.n[0])
+        if groups:
+            self.n = np.empty((groups, self.length))
+            self.n[:, 0] = [self.system.refractive_index(li, 0) for li in l]
+            self._upload_table(1, None, self.n[:, 0])
+        else:
+            self.n = np.empty(self.length)
+            self.n[0] = self.system.refractive_index(l, 0)
+            self._upload_table(1, None, self.n[0])
         self.engine.generate_rays(fields, yp)
         self.engine.set_weights(None)
         for rows in (self.y, self.u, self.i, self.t):
@@ -320,31 +366,93 @@ class GeometricTrace(Trace):
 
     def rays_points(self, fields, wavelength=None, nrays=11,
                     distribution="meridional", clip=False, aim=True,
-                    rim=False):
+                    rim=False, keep=None):
         """Bundles for many field points in one go -- the batched counterpart
         of ``rays_point`` (rayopt/geometric_trace.py:204-209): pupil pattern
         (``pupil_distribution``), aiming of every field on the GPU
         (:class:`rayopt_amd.aiming.FieldAimer`; ``aim=False`` uses the
         paraxial entrance pupil), ray construction on the GPU, trace.  Ray
         ``f*P + p`` belongs to field ``f``; ``self.w`` carries the quadrature
-        weights of the pattern, normalised per field."""
+        weights of the pattern, normalised per field.
+
+        ``wavelength`` may be a sequence of W wavelengths: every field is
+        aimed and traced at every wavelength in the same launch, ray
+        ``(w*F + f)*P + p``.  The pupil pattern is then padded with dead
+        (NaN) rays of weight 0 to the next multiple of 64 so that every
+        wavefront reads a single surface table; ``rays_per_field`` is the
+        padded bundle size, ``rays_alive_per_field`` the pattern's.
+        ``keep`` is handed to :meth:`propagate`."""
         from .aiming import FieldAimer, entrance_pupil
         from .pupil import pupil_distribution
         fields = np.atleast_2d(np.asarray(fields, dtype=float))
         ref, yp, weight = pupil_distribution(distribution, nrays)
         l = self.system.wavelengths[0] if wavelength is None else wavelength
-        if aim:
-            z, a = FieldAimer(self.system, l).pupil(fields, rim=rim)
+        alive = len(yp)
+        if np.ndim(l) == 0:
+            if aim:
+                z, a = FieldAimer(self.system, l, self._aux_engine()).pupil(
+                    fields, rim=rim)
+            else:
+                z, a = entrance_pupil(self.system, l)
+            copies = len(fields)
         else:
-            z, a = entrance_pupil(self.system, l)
+            l = np.asarray(l, dtype=float)
+            za = [FieldAimer(self.system, li, self._aux_engine()).pupil(
+                      fields, rim=rim) if aim
+                  else entrance_pupil(self.system, li) for li in l]
+            z = [np.broadcast_to(zi, (len(fields),)) for zi, _ in za]
+            a = [ai for _, ai in za]
+            pad = -alive % 64
+            if pad:
+                yp = np.concatenate([yp, np.full((pad, 2), np.nan)])
+                if weight is None:
+                    weight = np.ones(alive)/alive
+                weight = np.concatenate([weight, np.zeros(pad)])
+            copies = len(fields)*len(l)
         self.rays_fields(fields, yp, z, a, l, ref=ref)
         if weight is not None:
-            self.w = np.tile(weight, len(fields))
+            self.w = np.tile(weight, copies)
             self._uniform_w = False
             self.engine.set_weights(self.w)
         self.fields = fields
         self.rays_per_field = len(yp)
-        self.propagate(clip=clip)
+        self.rays_alive_per_field = alive
+        self.propagate(clip=clip, keep=keep)
+
+    def spot_stats(self, i=-1, group_rays=None):
+        """Spot statistics of every bundle of the batch at surface ``i`` in
+        one device reduction (``rt_spot_stats``): array (..., 6) with
+        ``count, centroid x, centroid y, sum(w d^2)/sum(w), max d^2, sum(w)``
+        over the rays of the bundle that arrived; leading shape (F,) after
+        :meth:`rays_points`, (W, F) with several wavelengths."""
+        if group_rays is None:
+            group_rays = self.rays_per_field or self.rays_per_group or \
+                self.nrays
+        groups, rest = divmod(self.nrays, int(group_rays))
+        if rest:
+            raise ValueError("bundles of %d rays do not tile %d rays"
+                             % (group_rays, self.nrays))
+        out = self.engine.spot_stats(range(self.length)[i], group_rays, groups)
+        if np.ndim(self.l) == 1 and groups % len(self.l) == 0:
+            out = out.reshape(len(self.l), -1, 6)
+        return out
+
+    def rms_fields(self, i=-1, lost="nan"):
+        """RMS spot radius of every bundle about its own centroid: what
+        ``rays_point(field) ; rms()`` gives per field (and wavelength) in the
+        reference (rayopt/geometric_trace.py:171-183,204-209), for the whole
+        batch at once.  ``lost``: "nan" = a bundle that lost a ray gives NaN
+        as the reference does; "omit" = statistics of the rays that
+        arrived."""
+        s = self.spot_stats(i)
+        r = np.sqrt(s[..., 3])
+        if lost == "nan":
+            alive = self.rays_alive_per_field or \
+                self.nrays//max(1, s[..., 0].size)
+            r = np.where(s[..., 0] < alive, np.nan, r)
+        elif lost != "omit":
+            raise ValueError("lost must be 'nan' or 'omit'")
+        return r
 
     def rays_point(self, yo, wavelength=None, nrays=11,
                    distribution="meridional", filter=None, stop=None,
@@ -361,7 +469,8 @@ class GeometricTrace(Trace):
             filter = not clip
         ref, yp, weight = pupil_distribution(distribution, nrays)
         l = self.system.wavelengths[0] if wavelength is None else wavelength
-        z, a = FieldAimer(self.system, l).pupil([yo], rim=(stop == -1))
+        z, a = FieldAimer(self.system, l, self._aux_engine()).pupil(
+            [yo], rim=(stop == -1))
         if filter:
             am = np.fabs(a[0]).max()
             c = np.sum(a[0], axis=0)/2

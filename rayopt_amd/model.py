@@ -513,6 +513,27 @@ class System(list):
         design tools outside the accelerated path."""
         return self
 
+    def _walk(self, path):
+        node = self
+        for key in path:
+            node = getattr(node, key) if isinstance(key, str) else node[key]
+        return node
+
+    def get_path(self, path):
+        """Follow ``path`` from the system: strings are attributes, anything
+        else an index -- ``(2, "curvature")`` is ``self[2].curvature``
+        (rayopt/system.py:112-119)."""
+        return self._walk(path)
+
+    def set_path(self, path, value):
+        """Assign to what :meth:`get_path` reads (rayopt/system.py:121-132)."""
+        *head, last = path
+        node = self._walk(head)
+        if isinstance(last, str):
+            setattr(node, last, value)
+        else:
+            node[last] = value
+
     @property
     def aperture(self):
         return self[self.stop]

@@ -157,3 +157,75 @@ def test_rays_point_matches_reference_quadrature():
     r.rays_point((0, 1.), nrays=13, distribution="radau", filter=False)
     assert g.rms() == pytest.approx(r.rms(), rel=2e-2)
     assert g.nrays == r.nrays
+
+
+DISPERSIVE_COOKE = ra.prescriptions.COOKE % dict(
+    air=1.0, sk16="1.62041/60.32", f2="1.62004/36.37")
+
+
+def _polychromatic_checks(make_trace):
+    """rays_points(wavelength=[...]): every field at every wavelength in one
+    launch equals the single-wavelength batches ray for ray, and
+    rms_fields() equals rms() of each bundle traced on its own."""
+    system = ra.system_from_yaml(DISPERSIVE_COOKE)
+    fields = np.c_[np.zeros(3), [0, .7, 1.]]
+    ls = system.wavelengths
+    g = make_trace(system)
+    g.rays_points(fields, wavelength=ls, nrays=12, distribution="hexapolar")
+    P, A = g.rays_per_field, g.rays_alive_per_field
+    assert P % 64 == 0 and A < P and g.nrays == len(ls)*3*P
+    assert g.n.shape == (len(ls), len(system))
+    batch = np.asarray(g.y[-1]).reshape(len(ls), 3, P, 3)
+    assert np.isnan(batch[:, :, A:]).all()          # the padding is dead
+    rms = g.rms_fields()
+    stats = g.spot_stats()
+    assert rms.shape == (len(ls), 3) and stats.shape == (len(ls), 3, 6)
+    assert (stats[..., 0] == A).all()
+    for w, l in enumerate(ls):
+        h = make_trace(system)
+        h.rays_points(fields, wavelength=l, nrays=12,
+                      distribution="hexapolar")
+        assert h.rays_per_field == A
+        assert np.array_equal(batch[w][:, :A],
+                              np.asarray(h.y[-1]).reshape(3, A, 3))
+        np.testing.assert_allclose(h.rms_fields(), rms[w], rtol=1e-12)
+        for f in range(3):      # one bundle on its own, reference-style
+            k = make_trace(system)
+            k.rays_points(fields[f:f + 1], wavelength=l, nrays=12,
+                          distribution="hexapolar")
+            assert k.rms() == pytest.approx(rms[w, f], rel=1e-9)
+    # blue focuses differently from red: the wavelengths really differ
+    assert abs(rms[1, 2] - rms[2, 2]) > 1e-4
+    # a later plain rays_given forgets the bundle layout
+    g.rays_given(np.zeros((8, 3)), np.tile([0, 0, 1.], (8, 1)))
+    assert g.rays_per_field is None and np.ndim(g.n) == 1
+
+
+def test_polychromatic_rays_points_host_logic():
+    from fake_engine import OracleEngine
+    _polychromatic_checks(lambda s: ra.GeometricTrace(s, engine=OracleEngine()))
+
+
+@pytest.mark.gpu
+def test_polychromatic_rays_points_gpu():
+    _polychromatic_checks(lambda s: ra.GeometricTrace(s))
+
+
+@pytest.mark.gpu
+def test_rms_fields_lost_ray_policy():
+    """Clipped batch: bundles that lost rays give NaN like the reference's
+    rms(); lost='omit' gives the statistics of the survivors."""
+    system = ra.system_from_yaml(ra.prescriptions.cooke())
+    fields = np.c_[np.zeros(4), np.linspace(0, 1, 4)]
+    g = ra.GeometricTrace(system)
+    g.rays_points(fields, nrays=400, distribution="square", clip=True,
+                  aim=False)
+    P = g.rays_per_field
+    spots = np.asarray(g.y[-1])[:, :2].reshape(4, P, 2)
+    lost = np.isnan(spots[..., 0]).sum(1)
+    assert lost[-1] > 0                       # the corner field vignettes
+    strict, omit = g.rms_fields(), g.rms_fields(lost="omit")
+    assert np.array_equal(np.isnan(strict), lost > 0)
+    want = np.sqrt(np.nanmean(np.square(
+        spots - np.nanmean(spots, 1, keepdims=True)).sum(2), 1))
+    np.testing.assert_allclose(omit, want, rtol=1e-11)

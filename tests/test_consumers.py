@@ -159,3 +159,65 @@ def test_resize_and_print_trace():
     tr.propagate(clip=True)
     tr.resize()
     assert np.isnan(system[8].radius)
+
+
+# -- per-bundle spot statistics (rt_spot_stats) -------------------------------
+
+def test_oracle_spot_stats_is_reference_rms_per_bundle():
+    """The grouped oracle equals the reference formula (``rms`` above, pinned
+    to the reference by the goldens) applied to every bundle on its own."""
+    rng = np.random.default_rng(3)
+    P, G = 37, 5
+    y = rng.normal(size=(P*G, 3))*[1., 2., 0.] + [3., -1., 0.]
+    w = rng.random(P*G)
+    for g in range(G):          # the reference normalises w per trace
+        w[g*P:(g + 1)*P] /= w[g*P:(g + 1)*P].sum()
+    s = cn.spot_stats(y, P, w)
+    for g in range(G):
+        sl = slice(g*P, (g + 1)*P)
+        assert s[g, 0] == P and s[g, 5] == pytest.approx(1., rel=1e-14)
+        assert np.sqrt(s[g, 3]) == pytest.approx(cn.rms(y[sl], w[sl]),
+                                                 rel=1e-13)
+        assert np.sqrt(s[g, 4]) == pytest.approx(
+            np.hypot(*(y[sl, :2] - y[sl, :2].mean(0)).T).max(), rel=1e-14)
+    # lost rays are left out and counted; an empty bundle gives NaN
+    y[P + 3, 0] = np.nan
+    y[2*P:3*P, 1] = np.nan
+    s = cn.spot_stats(y, P, None)
+    assert s[1, 0] == P - 1 and s[2, 0] == 0 and np.isnan(s[2, 1:5]).all()
+    keep = np.r_[P:P + 3, P + 4:2*P]
+    assert np.sqrt(s[1, 3]) == pytest.approx(
+        cn.rms(y[keep]), rel=1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,per", [(1, 100_000), (5, 200_000),
+                                        (1000, 7), (64, 4096), (4001, 129)])
+def test_device_spot_stats_vs_oracle(groups, per):
+    """rt_spot_stats against the numpy oracle on the row the device itself
+    produced: vignetted rays, weights, bundle sizes that are not multiples of
+    anything, more bundles than workgroups per bundle."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    n = groups*per
+    y, u = ra.bundles.disc_bundle(n, 17.5, 12., 7,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    rng = np.random.default_rng(groups)
+    w = rng.random(n)
+    tr = ra.GeometricTrace(system)
+    for weights in (None, w/w.sum()):
+        tr.rays_given(y, u, None, weights, 0)
+        tr.propagate(clip=True, keep=[-1])
+        got = tr.spot_stats(group_rays=per)
+        want = cn.spot_stats(np.asarray(tr.y[-1]), per, weights)
+        assert got.shape == (groups, 6)
+        assert np.array_equal(got[:, 0], want[:, 0])         # counts exact
+        assert 0 < (want[:, 0] < per).sum()                  # some vignetted
+        for c in range(1, 6):
+            assert_parity(got[None, :, c], want[None, :, c], 1e-11,
+                          "stats column %d" % c)
+    # run-to-run identical (no atomics)
+    assert np.array_equal(tr.spot_stats(group_rays=per), got, equal_nan=True)
+    with pytest.raises(ra.EngineError):
+        tr.engine.spot_stats(len(system) - 1, per + 1, groups)
+    with pytest.raises(ra.EngineError):
+        tr.engine.spot_stats(3, per, groups)      # row not stored (keep)
