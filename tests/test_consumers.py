@@ -212,8 +212,11 @@ def test_device_spot_stats_vs_oracle(groups, per):
         assert got.shape == (groups, 6)
         assert np.array_equal(got[:, 0], want[:, 0])         # counts exact
         assert 0 < (want[:, 0] < per).sum()                  # some vignetted
-        for c in range(1, 6):
-            assert_parity(got[None, :, c], want[None, :, c], 1e-11,
+        # the spread about the centroid inherits the centroid's summation
+        # rounding magnified by |centroid| / spot size (~1e3 here)
+        for c, rtol in ((1, 1e-12), (2, 1e-12), (3, 1e-9), (4, 1e-9),
+                        (5, 1e-12)):
+            assert_parity(got[None, :, c], want[None, :, c], rtol,
                           "stats column %d" % c)
     # run-to-run identical (no atomics)
     assert np.array_equal(tr.spot_stats(group_rays=per), got, equal_nan=True)
