@@ -13,7 +13,7 @@ from .formats import (system_from_yaml, system_from_json, system_from_dict,
 from .geometric_trace import GeometricTrace, Trace, DeviceRows
 from .engine import Engine, get_engine
 from ._lib import EngineError
-from . import prescriptions, bundles, pupil, merit
+from . import prescriptions, bundles, pupil, merit, catalog
 
 __all__ = [
     "System", "Element", "Interface", "Spheroid", "Pose", "Material",
@@ -21,5 +21,5 @@ __all__ = [
     "system_from_yaml", "system_from_json", "system_from_dict",
     "system_to_yaml", "system_to_json", "GeometricTrace", "Trace",
     "DeviceRows", "Engine", "get_engine", "EngineError", "prescriptions",
-    "bundles", "pupil", "merit",
+    "bundles", "pupil", "merit", "catalog",
 ]

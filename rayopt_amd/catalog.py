@@ -1,0 +1,163 @@
+"""Glass catalogues from Zemax ``.agf`` and OSLO ``.glc`` files (SURVEY.md
+section 8 f4).
+
+The reference keeps its glasses in an SQLite library filled by parsers
+(rayopt/library.py, rayopt/zemax.py:186-268); the data files are the
+vendors'.  Here a catalogue is read straight from the ``.agf`` text the user
+points to and glass *names* (``N-BK7``, ``schott/N-BK7``) then resolve in
+``Material.make`` -- hence in YAML prescriptions and in the ``.zmx`` /
+``.len`` importers -- to :class:`rayopt_amd.model.DispersionGlass` with the
+same dispersion formulas and coefficient order as the reference's
+``agf_to_material``.  Host-side setup only: what reaches the GPU is
+``n(lambda)`` per surface in the packed table.
+
+``NM name formula glasscode nd vd exclude status``; ``CD`` the dispersion
+coefficients; ``GC`` comment; ``ED`` expansion/density; ``LD`` the valid
+wavelength range in micrometres.
+"""
+import codecs
+import os
+
+import numpy as np
+
+from .model import DispersionGlass, DISPERSION
+
+# .agf formula number -> dispersion formula (rayopt/zemax.py:231-235).  The
+# reference lists "sellmeier2", "extended1" and "sellmeier5" but has no
+# formula under those names (it warns and cannot evaluate them); they are
+# served here by the published Zemax forms: Extended = Schott with more
+# inverse powers, Sellmeier 5 = five squared Sellmeier terms.
+AGF_FORMULAS = (
+    "schott", "sellmeier_squared", "herzberger", "sellmeier2", "conrady",
+    "sellmeier_squared", "handbook_of_optics1", "handbook_of_optics2",
+    "sellmeier_squared_offset", "schott", "sellmeier_squared", "extended2",
+    "hikari")
+
+# Sellmeier 2: n^2 - 1 = A + B1 w^2/(w^2 - l1^2) + B2/(w^2 - l2^2)
+DISPERSION.setdefault(
+    "sellmeier2", lambda w, c: np.sqrt(
+        1. + c[0] + c[1]*w**2/(w**2 - c[2]**2) + c[3]/(w**2 - c[4]**2)))
+
+
+def _number(text):
+    try:
+        return float(text)
+    except ValueError:
+        return float("nan")
+
+
+def _open_text(path):
+    with open(path, "rb") as f:
+        head = f.read(4)
+    enc = "utf-16" if head.startswith((codecs.BOM_UTF16_LE,
+                                       codecs.BOM_UTF16_BE)) else "latin1"
+    with open(path, encoding=enc) as f:
+        return f.read()
+
+
+def parse_agf(text):
+    """``{name: DispersionGlass}`` from the text of an ``.agf`` catalogue."""
+    glasses, glass = {}, None
+    for line in text.splitlines():
+        line = line.strip()
+        if not line or line.startswith("!"):
+            continue
+        cmd, _, rest = line.partition(" ")
+        args = rest.split()
+        if cmd == "NM":
+            formula = int(_number(args[1]))
+            if not 1 <= formula <= len(AGF_FORMULAS):
+                raise ValueError("glass %s: unknown .agf dispersion formula "
+                                 "%d" % (args[0], formula))
+            glass = DispersionGlass(AGF_FORMULAS[formula - 1], [],
+                                    name=args[0])
+            glass.glasscode = _number(args[2]) if len(args) > 2 else None
+            glass.nd = _number(args[3]) if len(args) > 3 else None
+            glass.vd = _number(args[4]) if len(args) > 4 else None
+            glass.status = int(_number(args[6])) if len(args) > 6 else None
+            glasses[glass.name] = glass
+        elif glass is None or cmd == "CC":
+            continue
+        elif cmd == "CD":
+            glass.coefficients = np.array([_number(a) for a in args])
+        elif cmd == "GC":
+            glass.comment = rest.strip()
+        elif cmd == "ED" and len(args) >= 3:
+            glass.alpham3070, glass.alpha20300, glass.density = (
+                _number(a) for a in args[:3])
+        elif cmd == "LD" and len(args) >= 2:
+            glass.lambda_min, glass.lambda_max = (_number(a)
+                                                  for a in args[:2])
+    return glasses
+
+
+# OSLO .glc dispersion type -> formula (rayopt/oslo.py:201-205)
+GLC_FORMULAS = {1: "schott", 2: "sellmeier_squared_transposed", 3: "conrady",
+                6: "hikari"}
+
+
+def parse_glc(text):
+    """``{name: DispersionGlass}`` from the text of an OSLO ``.glc``
+    catalogue: a header line ``version count name``, then one glass per line
+    -- ``name nd vd density``, eight fields not used here, the dispersion
+    type, the coefficient count and the coefficients
+    (rayopt/oslo.py:169-205)."""
+    glasses = {}
+    lines = text.splitlines()
+    for line in lines[1:]:
+        fields = line.split()
+        if len(fields) < 14:
+            continue
+        name = fields[0]
+        kind, count = int(_number(fields[12])), int(_number(fields[13]))
+        if kind not in GLC_FORMULAS:
+            continue                      # no published formula: skip
+        glass = DispersionGlass(
+            GLC_FORMULAS[kind],
+            [_number(f) for f in fields[14:14 + count]], name=name)
+        glass.nd, glass.vd, glass.density = (_number(f)
+                                             for f in fields[1:4])
+        glasses[name] = glass
+    return glasses
+
+
+class GlassCatalogs:
+    """The catalogues loaded in this process, by name (file stem, lower
+    case).  ``find("N-BK7")`` searches all of them in loading order,
+    ``find("schott/N-BK7")`` one."""
+    def __init__(self):
+        self.catalogs = {}
+
+    def load(self, path, name=None):
+        stem, ext = os.path.splitext(os.path.basename(path))
+        name = (name or stem).lower()
+        parse = parse_glc if ext.lower() == ".glc" else parse_agf
+        self.catalogs[name] = parse(_open_text(path))
+        return self.catalogs[name]
+
+    def add(self, name, glasses):
+        self.catalogs[name.lower()] = dict(glasses)
+
+    def clear(self):
+        self.catalogs.clear()
+
+    def find(self, spec):
+        parts = str(spec).split("/")
+        if len(parts) == 2:
+            books = [self.catalogs.get(parts[0].lower(), {})]
+        elif len(parts) == 1:
+            books = list(self.catalogs.values())
+        else:
+            return None
+        key = parts[-1]
+        for book in books:
+            if key in book:
+                return book[key]
+            for name, glass in book.items():      # Zemax names: any case
+                if name.upper() == key.upper():
+                    return glass
+        return None
+
+
+catalogs = GlassCatalogs()
+load_agf = load_glc = load = catalogs.load

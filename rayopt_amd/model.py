@@ -54,7 +54,9 @@ class Material:
         """Same dispatch as rayopt's Material.make for the forms that need no
         catalogue database: ``None``, a Material, a float (constant index), an
         ``(nd, vd)`` tuple or ``"nd/vd"`` string (Abbe model), and the basic
-        names ``vacuum``, ``air``, ``mirror`` (optionally ``basic/<name>``).
+        names ``vacuum``, ``air``, ``mirror`` (optionally ``basic/<name>``);
+        other names (``N-BK7``, ``schott/N-BK7``) resolve in the ``.agf``
+        catalogues loaded with :func:`rayopt_amd.catalog.load_agf`.
         """
         if spec is None or isinstance(spec, Material):
             return spec
@@ -80,7 +82,12 @@ class Material:
         key = parts[-1].lower()
         if (len(parts) == 1 or parts[-2].lower() == "basic") and key in BASIC:
             return BASIC[key]
-        raise KeyError("material %r needs a glass catalogue; give a numeric "
+        from .catalog import catalogs            # glasses by name
+        glass = catalogs.find(text)
+        if glass is not None:
+            return glass
+        raise KeyError("material %r: not in a loaded glass catalogue "
+                       "(rayopt_amd.catalog.load_agf); or give a numeric "
                        "index or an 'nd/vd' pair" % (spec,))
 
 
