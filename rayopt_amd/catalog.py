@@ -20,7 +20,7 @@ import os
 
 import numpy as np
 
-from .model import DispersionGlass, DISPERSION
+from .model import DispersionGlass
 
 # .agf formula number -> dispersion formula (rayopt/zemax.py:231-235).  The
 # reference lists "sellmeier2", "extended1" and "sellmeier5" but has no
@@ -32,12 +32,6 @@ AGF_FORMULAS = (
     "sellmeier_squared", "handbook_of_optics1", "handbook_of_optics2",
     "sellmeier_squared_offset", "schott", "sellmeier_squared", "extended2",
     "hikari")
-
-# Sellmeier 2: n^2 - 1 = A + B1 w^2/(w^2 - l1^2) + B2/(w^2 - l2^2)
-DISPERSION.setdefault(
-    "sellmeier2", lambda w, c: np.sqrt(
-        1. + c[0] + c[1]*w**2/(w**2 - c[2]**2) + c[3]/(w**2 - c[4]**2)))
-
 
 def _number(text):
     try:

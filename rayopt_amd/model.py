@@ -156,6 +156,10 @@ DISPERSION = {
         1. + (_pairs(c)[0]*w**2/(w**2 - _pairs(c)[1])).sum()),
     "sellmeier_squared_transposed": lambda w, c: np.sqrt(
         1. + (c.reshape(2, -1)[0]*w**2/(w**2 - c.reshape(2, -1)[1])).sum()),
+    # Zemax "Sellmeier 2" (.agf formula 4; no counterpart in the reference):
+    # n^2 - 1 = A + B1 w^2/(w^2 - l1^2) + B2/(w^2 - l2^2)
+    "sellmeier2": lambda w, c: np.sqrt(
+        1. + c[0] + c[1]*w**2/(w**2 - c[2]**2) + c[3]/(w**2 - c[4]**2)),
     "conrady": lambda w, c: c[0] + c[1]/w + c[2]/w**3.5,
     "herzberger": lambda w, c: (
         c[0] + c[1]/(w**2 - .028) + c[2]/(w**2 - .028)**2 + c[3]*w**2 +
