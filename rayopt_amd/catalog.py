@@ -1,5 +1,5 @@
-"""Glass catalogues from Zemax ``.agf`` and OSLO ``.glc`` files (SURVEY.md
-section 8 f4).
+"""Glass catalogues from Zemax ``.agf``, OSLO ``.glc`` and CODE V ``.xml``
+files and refractiveindex.info pages.
 
 The reference keeps its glasses in an SQLite library filled by parsers
 (rayopt/library.py, rayopt/zemax.py:186-268); the data files are the
@@ -115,6 +115,65 @@ def parse_glc(text):
     return glasses
 
 
+# refractiveindex.info page: DATA[].type "formula N" (rayopt/rii.py:80-90)
+RII_FORMULAS = {1: "sellmeier_offset", 2: "sellmeier_squared_offset",
+                3: "polynomial", 4: "refractiveindex_info", 5: "cauchy",
+                6: "gas_offset", 7: "herzberger", 8: "retro", 9: "exotic"}
+
+
+def parse_rii(text, name="rii"):
+    """One refractiveindex.info database page (YAML with a ``DATA`` list
+    holding a ``formula N`` entry: ``range``, ``coefficients``) as a
+    :class:`DispersionGlass` (rayopt/rii.py:95-111)."""
+    import yaml
+    page = yaml.safe_load(text)
+    glass = None
+    for entry in page["DATA"]:
+        kind = str(entry["type"])
+        if kind.startswith("formula"):
+            glass = DispersionGlass(
+                RII_FORMULAS[int(kind.split()[1])],
+                [_number(c) for c in str(entry["coefficients"]).split()],
+                name=name)
+            lo, hi = str(entry.get("range", "nan nan")).split()[:2]
+            glass.lambda_min, glass.lambda_max = _number(lo), _number(hi)
+    if glass is None:
+        raise ValueError("refractiveindex.info page %r holds no dispersion "
+                         "formula (tabulated data only)" % name)
+    glass.comment = page.get("COMMENTS")
+    glass.references = page.get("REFERENCES")
+    return glass
+
+
+# CODE V glass catalogue XML: EquationType -> formula (rayopt/codev.py:52-67)
+CODEV_FORMULAS = {
+    "Standard Sellmeier": "sellmeier",
+    "Glass Manufacturer Sellmeier": "sellmeier_squared_offset",
+    "Laurent": "schott", "Glass Manufacturer Laurent": "schott",
+    "Herzberger": "herzberger", "Cauchy": "conrady"}
+
+
+def parse_codev_xml(text):
+    """``{name: DispersionGlass}`` from a CODE V glass catalogue in XML
+    (``<Glasses><Glass>`` with ``GlassName`` carrying the catalogue ``ID`` as
+    prefix, ``EquationType``, ``DispersionCoefficients/Coefficient``;
+    rayopt/codev.py:32-67)."""
+    import xml.etree.ElementTree as et
+    root = et.fromstring(text)
+    prefix = root.findtext("./ID") or ""
+    glasses = {}
+    for node in root.iterfind("./Glasses/Glass"):
+        full = node.findtext("./GlassName")
+        name = full[len(prefix):] if full.startswith(prefix) else full
+        glass = DispersionGlass(
+            CODEV_FORMULAS[node.findtext("./EquationType")],
+            [float(c.text) for c in node.iterfind(
+                "./DispersionCoefficients/Coefficient")], name=name)
+        glass.comment = node.findtext("./NumericName")
+        glasses[name] = glass
+    return glasses
+
+
 class GlassCatalogs:
     """The catalogues loaded in this process, by name (file stem, lower
     case).  ``find("N-BK7")`` searches all of them in loading order,
@@ -125,7 +184,8 @@ class GlassCatalogs:
     def load(self, path, name=None):
         stem, ext = os.path.splitext(os.path.basename(path))
         name = (name or stem).lower()
-        parse = parse_glc if ext.lower() == ".glc" else parse_agf
+        parse = {".glc": parse_glc, ".xml": parse_codev_xml}.get(
+            ext.lower(), parse_agf)
         self.catalogs[name] = parse(_open_text(path))
         return self.catalogs[name]
 

@@ -184,3 +184,74 @@ def test_glc_catalogue(tmp_path):
         for l in LINES:
             assert mine.refractive_index(l) == pytest.approx(
                 float(theirs.refractive_index(l)), rel=1e-15)
+
+
+RII_PAGE = """
+REFERENCES: "a reference"
+COMMENTS: "fused silica, 20 C"
+DATA:
+  - type: formula 1
+    range: 0.21 6.7
+    coefficients: 0 0.6961663 0.0684043 0.4079426 0.1162414 0.8974794 9.896161
+  - type: tabulated k
+    data: |
+        0.21 1e-9
+"""
+
+CODEV_XML = """<Catalog><Name>Test</Name><ID>T_</ID><Glasses>
+<Glass><GlassName>T_SILICA</GlassName><NumericName>458678</NumericName>
+<Availability>1</Availability><EquationType>Standard Sellmeier</EquationType>
+<DispersionCoefficients><Coefficient>0.6961663</Coefficient>
+<Coefficient>0.0684043</Coefficient><Coefficient>0.4079426</Coefficient>
+<Coefficient>0.1162414</Coefficient><Coefficient>0.8974794</Coefficient>
+<Coefficient>9.896161</Coefficient></DispersionCoefficients></Glass>
+<Glass><GlassName>T_LAUR</GlassName><NumericName>517642</NumericName>
+<Availability>1</Availability><EquationType>Laurent</EquationType>
+<DispersionCoefficients><Coefficient>2.2718929</Coefficient>
+<Coefficient>-0.010108077</Coefficient><Coefficient>0.010592509</Coefficient>
+<Coefficient>0.00020816965</Coefficient><Coefficient>-7.6472538e-06</Coefficient>
+<Coefficient>4.9240991e-07</Coefficient></DispersionCoefficients></Glass>
+</Glasses></Catalog>"""
+
+
+def test_rii_page_and_codev_catalogue(tmp_path):
+    silica = catalog.parse_rii(RII_PAGE, "SiO2|Malitson")
+    assert silica.typ == "sellmeier_offset"
+    assert (silica.lambda_min, silica.lambda_max) == (0.21, 6.7)
+    assert silica.refractive_index(LINES[0]) == pytest.approx(1.45846,
+                                                              abs=2e-5)
+    with pytest.raises(ValueError):
+        catalog.parse_rii("DATA:\n  - type: tabulated nk\n    data: '1 1 0'\n")
+    book = catalog.parse_codev_xml(CODEV_XML)
+    assert sorted(book) == ["LAUR", "SILICA"] and book["LAUR"].typ == "schott"
+    assert book["SILICA"].refractive_index(LINES[0]) == \
+        silica.refractive_index(LINES[0])
+    path = tmp_path / "cv.xml"
+    path.write_text(CODEV_XML)
+    try:
+        catalog.load(str(path))
+        assert ra.Material.make("cv/LAUR").refractive_index(LINES[0]) == \
+            pytest.approx(1.5168, abs=2e-5)
+    finally:
+        catalog.catalogs.clear()
+    if not refshim.available():
+        return
+    refshim.load()
+    import importlib
+    import xml.etree.ElementTree as et
+    import yaml
+    ref_rii = importlib.import_module("rayopt.rii")
+    page = yaml.safe_load(RII_PAGE)
+    page.update(BOOK="SiO2", PAGE="Malitson")
+    theirs = ref_rii.rii_to_material(yaml.dump(page))
+    assert theirs.typ == silica.typ
+    assert np.array_equal(theirs.coefficients, silica.coefficients)
+    ref_codev = importlib.import_module("rayopt.codev")
+    for node in et.fromstring(CODEV_XML).iterfind("./Glasses/Glass"):
+        theirs = ref_codev.codevxml_to_material(et.tostring(node))
+        mine = book[theirs.name]
+        assert theirs.typ == mine.typ
+        assert np.array_equal(theirs.coefficients, mine.coefficients)
+        for l in LINES:
+            assert mine.refractive_index(l) == pytest.approx(
+                float(theirs.refractive_index(l)), rel=1e-15)
