@@ -9,10 +9,39 @@ installed rayopt unchanged, so aiming, pupils and conjugates keep running
 rayopt's own host code.  ``rayopt.GeometricTrace`` and the name imported by
 ``rayopt.analysis`` are rebound, so ``Analysis`` traces on the GPU too.
 """
+import numpy as np
+
 from .geometric_trace import GeometricTrace
 
 BORROWED = ("rays", "rays_point", "rays_line", "rays_clipping",
             "rays_paraxial", "resize", "plot", "print_trace")
+
+
+class LegacyArray(np.ndarray):
+    """ndarray with the methods numpy 2 dropped that rayopt's Analysis still
+    calls on trace results (``ptp``, rayopt/analysis.py:314)."""
+    def ptp(self, *args, **kwargs):
+        return np.ptp(np.asarray(self), *args, **kwargs)
+
+
+def modernize(rayopt=None):
+    """Let an unmodified rayopt run on current numpy / matplotlib: restore
+    the aliases and the no-op axis method it still uses (``np.int``,
+    ``np.complex_``, ``np.float_``; ``Axis.set_smart_bounds``, removed in
+    matplotlib 3.4; rayopt/special_sums.py:149, gaussian_trace.py:39,
+    analysis.py:160-161).  Idempotent; touches nothing that exists."""
+    for name, value in (("int", int), ("float_", np.float64),
+                        ("complex_", np.complex128)):
+        try:
+            getattr(np, name)
+        except AttributeError:
+            setattr(np, name, value)
+    try:
+        from matplotlib.axis import Axis
+    except ImportError:
+        return
+    if not hasattr(Axis, "set_smart_bounds"):
+        Axis.set_smart_bounds = lambda self, value: None
 
 
 def accelerate(rayopt, install=True, engine_factory=None):
@@ -24,6 +53,13 @@ def accelerate(rayopt, install=True, engine_factory=None):
     for name in BORROWED:
         if hasattr(ref_cls, name):
             namespace[name] = ref_cls.__dict__.get(name, getattr(ref_cls, name))
+    base_opd = GeometricTrace.opd
+
+    def opd(self, *args, **kwargs):
+        return tuple(np.asarray(a).view(LegacyArray)
+                     for a in base_opd(self, *args, **kwargs))
+    opd.__doc__ = base_opd.__doc__
+    namespace["opd"] = opd
     if engine_factory is not None:
         def engine(self):
             if self._engine is None:

@@ -85,6 +85,30 @@ class OracleEngine:
         assert group_rays*ngroups == self.nrays
         return cn.spot_stats(self.rows[RT_Y][surf], group_rays, self.w)
 
+    def opd_rays(self, args):
+        L = self.nsurf
+        after, image = int(args["after"]), int(args["image"])
+        origins = np.zeros((L, 3))
+        origins[after] = args["shift"]          # only the difference is used
+        frames = [None]*L
+        if args["rot_after"]:
+            frames[after] = np.array(args["r_after"]).reshape(3, 3)
+        if args["rot_image"]:
+            frames[image] = np.array(args["r_image"]).reshape(3, 3)
+        n = np.zeros(L)
+        n[0], n[after] = args["n0"], args["n_after"]
+        return cn.opd_rays(self.rows[RT_Y], self.rows[RT_U], self.rows[RT_T],
+                           n, int(args["ref"]), origins, frames,
+                           bool(args["finite"]), float(args["radius"]),
+                           float(args["lscale"]), after - L, image - L)
+
+    def row_rmax(self, surf):
+        return np.hypot(*self.rows[RT_Y][surf][:, :2].T).max()
+
+    def download_ray(self, which, ray):
+        a = self.rows[which][:, ray]
+        return np.array(a)
+
     def refocus_shift(self, surf):
         w = self.w if self.w is not None else \
             np.ones(self.nrays)/self.nrays

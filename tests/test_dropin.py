@@ -120,3 +120,60 @@ def test_multi_wavelength_groups_glue(ro):
     assert g.n[0, 1] != g.n[2, 1]
     with pytest.raises(ValueError, match="multiple of 64"):
         g.rays_given(y[:100], u[:100], ls)
+
+
+def _run_analysis(ro, engine_factory):
+    """rayopt's own top-level consumer (rayopt/analysis.py:78-146: refocus,
+    ray fans, spots at five defocus positions, OPD + PSF + encircled energy
+    per field, longitudinal aberrations) on the accelerated trace."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    dropin.modernize(ro)
+    dropin.accelerate(ro, engine_factory=engine_factory)
+    s = ro.system_from_yaml(
+        ra.prescriptions.cooke().replace("radius: 20.", "radius: 0.364"))
+    s.update()
+    before = s[-1].distance
+    with np.errstate(all="ignore"):
+        a = ro.Analysis(s, print=False)
+    try:
+        assert len(a.figures) == 5 and len(a.text) == 2
+        assert "triplet" in a.text[0]
+        # refocus_full moved the image plane by the least-squares shift
+        assert 0 < abs(s[-1].distance - before) < 1.
+    finally:
+        for fig in a.figures:
+            plt.close(fig)
+    return s[-1].distance - before
+
+
+def test_reference_analysis_runs_on_the_accelerated_trace(ro):
+    """Unmodified Analysis end to end through the swapped-in class (engine
+    double on CPU); the refocus it performs equals the reference's own."""
+    shift = _run_analysis(ro, OracleEngine)
+    dropin.restore(ro)
+    s = ro.system_from_yaml(
+        ra.prescriptions.cooke().replace("radius: 20.", "radius: 0.364"))
+    s.update()
+    before = s[-1].distance
+    t = ro.GeometricTrace(s)
+    t.rays_point((0, 0.), nrays=13, distribution="radau", clip=False,
+                 filter=False)
+    t.refocus()
+    assert shift == pytest.approx(s[-1].distance - before, rel=1e-9)
+
+
+@pytest.mark.gpu
+def test_reference_analysis_runs_on_the_gpu(ro):
+    _run_analysis(ro, None)
+
+
+def test_modernize_is_idempotent_and_minimal():
+    from matplotlib.axis import Axis
+    dropin.modernize()
+    dropin.modernize()
+    assert np.int is int and np.complex_ is np.complex128
+    assert hasattr(Axis, "set_smart_bounds")
+    a = np.arange(6.).view(dropin.LegacyArray)
+    assert a.ptp() == 5. and a[a > 2].ptp() == 2.
