@@ -454,20 +454,17 @@ class GeometricTrace(Trace):
             raise ValueError("lost must be 'nan' or 'omit'")
         return r
 
-    def rays_point(self, yo, wavelength=None, nrays=11,
-                   distribution="meridional", filter=None, stop=None,
-                   clip=False):
-        """One field point, as the reference's ``rays_point``
-        (rayopt/geometric_trace.py:204-209): pupil pattern, aiming
-        (``stop=-1``: to the rim of the limiting aperture), optional
-        filtering of the pattern to the aimed pupil ellipse
-        (``Pupil.map(filter=True)``, rayopt/pupils.py:97-107; default
-        ``not clip``), trace."""
+    def rays(self, yo, yp, wavelength=None, stop=None, filter=None,
+             clip=False, weight=None, ref=0):
+        """One field point ``yo`` through the pupil coordinates ``yp`` (P,2):
+        aiming (``stop=-1``: to the rim of the limiting aperture), optional
+        filtering of ``yp`` to the aimed pupil ellipse (``Pupil.map(
+        filter=True)``, rayopt/pupils.py:97-107; default ``not clip``), ray
+        construction on the GPU, trace (rayopt/geometric_trace.py:195-202)."""
         from .aiming import FieldAimer
-        from .pupil import pupil_distribution
         if filter is None:
             filter = not clip
-        ref, yp, weight = pupil_distribution(distribution, nrays)
+        yp = np.atleast_2d(np.asarray(yp, dtype=float))
         l = self.system.wavelengths[0] if wavelength is None else wavelength
         z, a = FieldAimer(self.system, l, self._aux_engine()).pupil(
             [yo], rim=(stop == -1))
@@ -478,7 +475,7 @@ class GeometricTrace(Trace):
             inside = (np.square(yp*am - c)/np.square(d)).sum(1) <= 1
             yp = yp[inside]
             if weight is not None:
-                weight = weight[inside]
+                weight = np.asarray(weight)[inside]
             ref = int(np.count_nonzero(inside[:ref]))
         self.rays_fields([yo], yp, z, a, l, ref=ref)
         if weight is not None:
@@ -486,6 +483,61 @@ class GeometricTrace(Trace):
             self._uniform_w = False
             self.engine.set_weights(weight)
         self.propagate(clip=clip)
+
+    def rays_point(self, yo, wavelength=None, nrays=11,
+                   distribution="meridional", filter=None, stop=None,
+                   clip=False):
+        """One field point with a pupil sampling pattern, as the reference's
+        ``rays_point`` (rayopt/geometric_trace.py:204-209)."""
+        from .pupil import pupil_distribution
+        ref, yp, weight = pupil_distribution(distribution, nrays)
+        self.rays(yo, yp, wavelength, filter=filter, stop=stop, clip=clip,
+                  weight=weight, ref=ref)
+
+    def rays_clipping(self, yo, wavelength=None, axis=1):
+        """Chief ray and the two rays grazing the limiting apertures along
+        ``axis`` (rayopt/geometric_trace.py:211-215)."""
+        from .aiming import FieldAimer
+        l = self.system.wavelengths[0] if wavelength is None else wavelength
+        z, a = FieldAimer(self.system, l, self._aux_engine()).pupil(
+            [yo], rim=True)
+        yp = np.zeros((3, 2))
+        yp[1:, axis] = a[0][:, axis]/np.fabs(a[0]).max()
+        self.rays_fields([yo], yp, z, a, l)
+        self.propagate()
+
+    def rays_line(self, yo, wavelength=None, nrays=21, eps=1e-2):
+        """``nrays`` field points from the axis to ``yo``, three rays each:
+        chief, and the neighbours at pupil coordinate ``eps`` along the
+        meridional and the sagittal direction; ray ``k*nrays + f`` is ray
+        kind ``k`` (0 chief, 1 meridional, 2 sagittal) of field ``f``
+        (rayopt/geometric_trace.py:217-229).  The chief rays of all fields
+        are aimed together on the GPU."""
+        from .aiming import FieldAimer
+        l = self.system.wavelengths[0] if wavelength is None else wavelength
+        fields = np.linspace(0, 1, nrays)[:, None]*np.atleast_2d(yo)
+        e = np.zeros((3, 2))
+        e[(1, 2), (1, 0)] = eps
+        aimer = FieldAimer(self.system, l, self._aux_engine())
+        z0, a = aimer.pupil([(0., 0.)])
+        z = aimer.chief(fields, z0[0], np.fabs(a[0]).max())
+        # built field-major on the device, re-ordered kind-major (a few
+        # dozen rays: the reference's layout is part of the contract)
+        self.rays_fields(fields, e, z, a[0], l)
+        y0 = np.asarray(self.y[0]).reshape(nrays, 3, 3)
+        u0 = np.asarray(self.u[0]).reshape(nrays, 3, 3)
+        self.rays_given(y0.transpose(1, 0, 2).reshape(-1, 3),
+                        u0.transpose(1, 0, 2).reshape(-1, 3), l)
+        self.propagate()
+
+    def plot(self, ax, axis=1, **kwargs):
+        """Ray paths in the global frame, ``axis`` against z
+        (rayopt/geometric_trace.py:236-240)."""
+        kwargs.setdefault("color", "green")
+        rows = np.asarray(self.y)
+        y = np.array([el.from_normal(yi) + oi for el, yi, oi
+                      in zip(self.system, rows, self.origins)])
+        ax.plot(y[:, :, 2], y[:, :, axis], **kwargs)
 
     # -- the hot path ---------------------------------------------------------
     def propagate(self, start=1, stop=None, clip=False, keep=None):

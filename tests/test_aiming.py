@@ -229,3 +229,99 @@ def test_rms_fields_lost_ray_policy():
     want = np.sqrt(np.nanmean(np.square(
         spots - np.nanmean(spots, 1, keepdims=True)).sum(2), 1))
     np.testing.assert_allclose(omit, want, rtol=1e-11)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+def test_native_ray_generators_match_reference():
+    """rays / rays_clipping / rays_line built natively (batched aiming +
+    device ray construction, engine double on CPU) against the reference's
+    own generators on the Cooke fixture: same ray order and layout, values to
+    the reference's aiming tolerance."""
+    from fake_engine import OracleEngine
+    ro = refshim.load()
+    text = COOKE.replace("radius: 20.", "radius: 0.364")
+    ref_sys = ro.system_from_yaml(text)
+    ref_sys.update()
+    ro.ParaxialTrace(ref_sys).update_conjugates()
+    mine_sys = ra.system_from_yaml(text)
+
+    def pair():
+        return (ra.GeometricTrace(mine_sys, engine=OracleEngine()),
+                ro.GeometricTrace(ref_sys))
+
+    def close(g, r, tol):
+        assert g.nrays == r.nrays and g.y.shape == r.y.shape
+        for a, b in ((g.y, r.y), (g.u, r.u)):
+            a, b = np.asarray(a), np.asarray(b)
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            assert np.nanmax(np.abs(a - b)) < tol
+
+    g, r = pair()
+    g.rays_clipping((0, 1.))
+    r.rays_clipping((0, 1.))
+    close(g, r, 2e-2)
+    # the two outer rays graze a limiting aperture, the chief ray the stop
+    # centre -- to the native solver's tolerance, tighter than the reference
+    ys = np.asarray(g.y)[1:-1, :, :2]
+    rad = np.array([e.radius for e in mine_sys[1:-1]])
+    fill = (np.hypot(ys[..., 0], ys[..., 1])/rad[:, None]).max(0)
+    assert fill[1] == pytest.approx(1., abs=1e-6)
+    assert fill[2] == pytest.approx(1., abs=1e-6)
+    assert np.abs(np.asarray(g.y[mine_sys.stop])[0, :2]).max() < 1e-6
+
+    g, r = pair()
+    g.rays_line((0, 1.), nrays=7)
+    r.rays_line((0, 1.), nrays=7)
+    close(g, r, 2e-2)
+    assert g.nrays == 21
+    stop = np.asarray(g.y[mine_sys.stop])
+    assert np.abs(stop[:7, :2]).max() < 1e-6        # rays 0..6: chief rays
+
+    g, r = pair()
+    yp = np.array([(0, 0), (0, .5), (.5, 0), (-.7, .7), (0, -1.)])
+    w = np.array([.2, .2, .2, .2, .2])
+    for kw in (dict(filter=False), dict(filter=True), dict(clip=True)):
+        g.rays((0, .7), yp, None, weight=w, ref=1, **kw)
+        r.rays((0, .7), yp, None, weight=w, ref=1, **kw)
+        close(g, r, 2e-2)
+        # (with filter=True the reference keeps the unfiltered weights and
+        # reference index; here they follow the surviving rays)
+        assert g.w.shape == (g.nrays,)
+        if not kw.get("filter"):
+            assert g.ref == r.ref and np.allclose(g.w, r.w)
+
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    fig, (ax1, ax2) = plt.subplots(1, 2)
+    g.plot(ax1)
+    r.plot(ax2)
+    for la, lb in zip(ax1.lines, ax2.lines):
+        assert np.allclose(la.get_xydata(), lb.get_xydata(), atol=2e-2,
+                           equal_nan=True)
+    plt.close(fig)
+
+
+@pytest.mark.gpu
+def test_native_ray_generators_gpu():
+    """rays_clipping / rays_line / rays on the device: defining conditions
+    (grazing rays, chief rays through the stop centre) and layouts."""
+    system = ra.system_from_yaml(COOKE.replace("radius: 20.",
+                                               "radius: 0.364"))
+    g = ra.GeometricTrace(system)
+    g.rays_clipping((0, 1.))
+    assert g.nrays == 3
+    ys = np.asarray(g.y)[1:-1, :, :2]
+    rad = np.array([e.radius for e in system[1:-1]])
+    fill = (np.hypot(ys[..., 0], ys[..., 1])/rad[:, None]).max(0)
+    assert fill[1] == pytest.approx(1., abs=1e-6)
+    assert fill[2] == pytest.approx(1., abs=1e-6)
+    g.rays_line((0, 1.), nrays=9)
+    assert g.nrays == 27 and np.isfinite(np.asarray(g.y[-1])).all()
+    stop = np.asarray(g.y[system.stop])
+    assert np.abs(stop[:9, :2]).max() < 1e-6
+    # image height grows monotonically along the line of fields
+    h = np.asarray(g.y[-1])[:9, 1]
+    assert (np.diff(np.abs(h)) > 0).all()
+    g.rays((0, .7), [(0, 0), (0, .5), (.5, 0)], weight=[.5, .25, .25], ref=0)
+    assert g.nrays == 3 and np.isfinite(g.rms())
