@@ -223,7 +223,9 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * Kernel variant selection for A/B measurements (defaults are the tuned
  * ones): key "rays_per_thread" (1,2,4), "nontemporal" (0,1), "xcd_remap"
  * (0,1), "block" (64..1024), "alias_i" (1 = do not write I[j] where it is
- * identical to U[j-1], the default; 0 = materialise every row of I).
+ * identical to U[j-1], the default; 0 = materialise every row of I),
+ * "lds_pad" (bytes of unused dynamic LDS per workgroup: caps the resident
+ * workgroups per CU for occupancy experiments; default 0).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
 /*

@@ -92,6 +92,7 @@ struct rt_ctx {
 
     /* kernel variant */
     int opt_r, opt_nt, opt_xcd, opt_block, opt_alias;
+    int opt_lds; /* bytes of unused dynamic LDS per workgroup (occupancy) */
     /* per row of I: 0 = materialised, 1 = identical to U[j-1], 2 = to U[j] */
     unsigned char i_alias[RT_MAX_SURFACES];
 
@@ -165,7 +166,8 @@ static void rt_launch(rt_ctx *c, int start, int stop, int clip)
     const int64_t nblocks = (c->ld + per_block - 1) / per_block;
     const int64_t grid = XCD ? (nblocks + 7) / 8 * 8 : nblocks;
     hipLaunchKernelGGL((rt_trace_kernel<R, NT, XCD>), dim3((unsigned)grid),
-                       dim3(block), 0, c->stream, c->d_surf, start, stop, clip,
+                       dim3(block), (size_t)c->opt_lds, c->stream, c->d_surf,
+                       start, stop, clip,
                        rt_arr(c, RT_Y), rt_arr(c, RT_U), rt_arr(c, RT_I),
                        rt_arr(c, RT_T), c->ld, nblocks,
                        c->ngroups > 1 ? c->n / c->ngroups : (int64_t)0,
@@ -781,6 +783,12 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
     } else if (!strcmp(key, "alias_i")) {
         ctx->opt_alias = value ? 1 : 0;
         ctx->table_dirty = 1;
+    } else if (!strcmp(key, "lds_pad")) {
+        /* measurement only: dynamic LDS the kernel never touches, to cap
+         * the workgroups resident per CU (160 KB / lds_pad) */
+        if (value < 0 || value > 65536)
+            return rt_fail(ctx, RT_ERR_ARG, "lds_pad must be in [0, 65536]");
+        ctx->opt_lds = value;
     } else if (!strcmp(key, "block")) {
         if (value < 64 || value > 1024 || value % 64)
             return rt_fail(ctx, RT_ERR_ARG, "block must be k*64 in [64,1024]");

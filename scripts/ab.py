@@ -13,6 +13,7 @@ from rayopt_amd import prescriptions as P
 from bench import workload_rays
 
 DEFAULTS = dict(rays_per_thread=1, nontemporal=0, xcd_remap=0, block=256,
+                lds_pad=0,
                 alias_i=1)
 
 
