@@ -533,11 +533,13 @@ class GeometricTrace(Trace):
     def plot(self, ax, axis=1, **kwargs):
         """Ray paths in the global frame, ``axis`` against z
         (rayopt/geometric_trace.py:236-240)."""
-        kwargs.setdefault("color", "green")
-        rows = np.asarray(self.y)
-        y = np.array([el.from_normal(yi) + oi for el, yi, oi
-                      in zip(self.system, rows, self.origins)])
-        ax.plot(y[:, :, 2], y[:, :, axis], **kwargs)
+        style = dict(color="green")
+        style.update(kwargs)
+        rows = np.asarray(self.y)                       # (L, N, 3), host
+        path = np.empty_like(rows)
+        for j, element in enumerate(self.system):
+            path[j] = element.from_normal(rows[j]) + self.origins[j]
+        ax.plot(path[..., 2], path[..., axis], **style)
 
     # -- the hot path ---------------------------------------------------------
     def propagate(self, start=1, stop=None, clip=False, keep=None):
