@@ -232,8 +232,9 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value);
  * Memory-system calibration on the context's own result arrays (row 0 is
  * preserved): mode 0 = the trace kernel's 80 B store pattern without
  * arithmetic, 1 = grid-stride 16-byte fill, 2 = 16-byte copy, 3 = fill with one
- * 16-byte store per lane, 4 = same, non-temporal.  Returns kernel time and the
- * bytes moved.  Overwrites rows >= 1.
+ * 16-byte store per lane, 4 = same, non-temporal; 5 / 6 = mode 0 with the
+ * 48 B/ray input read from an L2-resident window / not at all.  Returns
+ * kernel time and the bytes moved.  Overwrites rows >= 1.
  */
 int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes);
 

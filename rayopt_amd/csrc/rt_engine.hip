@@ -854,6 +854,24 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
                            ctx->stream, rt_arr(ctx, RT_Y) + (size_t)3 * ld,
                            rt_arr(ctx, RT_I) + (size_t)3 * ld, n2);
         *bytes = (double)n2 * 32.;
+    } else if (mode == 5 || mode == 6) {
+        /* store pattern with the input read from an L2-resident window (5)
+         * or without any read (6) */
+        const int block = 256;
+        const unsigned grid = (unsigned)((ld / 2 + block - 1) / block);
+        if (mode == 5)
+            hipLaunchKernelGGL(rt_probe_pattern_in_kernel<1>, dim3(grid),
+                               dim3(block), 0, ctx->stream, 1, L,
+                               rt_arr(ctx, RT_Y), rt_arr(ctx, RT_Y),
+                               rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
+                               rt_arr(ctx, RT_T), ld);
+        else
+            hipLaunchKernelGGL(rt_probe_pattern_in_kernel<2>, dim3(grid),
+                               dim3(block), 0, ctx->stream, 1, L,
+                               rt_arr(ctx, RT_Y), rt_arr(ctx, RT_Y),
+                               rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
+                               rt_arr(ctx, RT_T), ld);
+        *bytes = (double)ld * 80. * (L - 1);
     } else {
         return rt_fail(ctx, RT_ERR_ARG, "rt_probe: mode %d", mode);
     }

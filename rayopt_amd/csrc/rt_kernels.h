@@ -266,6 +266,45 @@ __global__ void rt_probe_pattern_kernel(int start, int stop,
     }
 }
 
+/* the same store pattern with the 48 B/ray input read served from a 3 MB
+ * window that stays in L2 (IN = 1) or not read at all (IN = 2): what the
+ * read costs the saturated write stream */
+template <int IN>
+__global__ void rt_probe_pattern_in_kernel(int start, int stop,
+                                           const double *__restrict__ in,
+                                           double *__restrict__ Y,
+                                           double *__restrict__ U,
+                                           double *__restrict__ I,
+                                           double *__restrict__ T, int64_t ld)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (j >= ld)
+        return;
+    v2 y[3], u[3];
+    for (int c = 0; c < 3; ++c) {
+        if constexpr (IN == 1) {
+            const int64_t k = j & 0xffff;
+            y[c] = *reinterpret_cast<const v2 *>(in + (int64_t)c * 65536 + k);
+            u[c] = *reinterpret_cast<const v2 *>(in + (int64_t)(3 + c) * 65536 +
+                                                 k);
+        } else {
+            y[c] = v2{(double)threadIdx.x, 1.};
+            u[c] = v2{(double)blockIdx.x, 2.};
+        }
+    }
+    for (int s = start; s < stop; ++s) {
+        const int64_t row = (int64_t)s * 3;
+        for (int c = 0; c < 3; ++c) {
+            y[c] += u[c];
+            *reinterpret_cast<v2 *>(Y + (row + c) * ld + j) = y[c];
+            *reinterpret_cast<v2 *>(U + (row + c) * ld + j) = u[c];
+            *reinterpret_cast<v2 *>(I + (row + c) * ld + j) = u[c];
+        }
+        *reinterpret_cast<v2 *>(T + (int64_t)s * ld + j) = y[2];
+    }
+}
+
 __global__ void rt_probe_fill_kernel(double *__restrict__ dst, int64_t n2)
 {
     typedef double v2 __attribute__((ext_vector_type(2)));

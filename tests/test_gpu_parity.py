@@ -654,3 +654,108 @@ def test_full_size_asphere_every_ray_against_c_oracle():
                 for r, w in zip((g.y, g.u, g.i, g.t), want))
     total = sum(int(np.isfinite(w).sum()) for w in want)
     assert exact >= 0.999*total      # in practice: all of them
+
+
+# -- repeated traces of one seed, new seeds, partial re-propagation ------------
+
+def _rows(g, which=("y", "u", "t")):
+    return [np.array(np.asarray(getattr(g, k))) for k in which]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [10_000, 1_000_037])
+def test_repeated_traces_are_identical_and_follow_new_seeds(n):
+    """Re-tracing the same seed is bit-identical every time (and equal to the
+    oracle) under every kernel variant; new rays or a row uploaded through
+    the C ABI take effect."""
+    from oracle import build_c
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    y, u = ra.bundles.disc_bundle(n, 17., 10., 3,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    table, _ = pack_system(system, g.l, g.n[0])
+    want = build_c.propagate(table, y, u, clip=True)
+    first = None
+    for rep in range(4):
+        g.propagate(clip=True)
+        got = _rows(g, ("y", "u", "i", "t"))
+        for a, b in zip(got, want):
+            assert np.array_equal(a[1:], b, equal_nan=True), rep
+        first = first or got
+    for variant in (dict(rays_per_thread=2), dict(rays_per_thread=4),
+                    dict(block=64), dict(block=1024, xcd_remap=1),
+                    dict(lds_pad=40960)):
+        for k, v in variant.items():
+            g.engine.set_option(k, v)
+        for rep in range(3):
+            g.propagate(clip=True)
+            assert np.array_equal(np.asarray(g.y[-1]), first[0][-1],
+                                  equal_nan=True), (variant, rep)
+        for k, v in dict(rays_per_thread=1, block=256, xcd_remap=0,
+                         lds_pad=0).items():
+            g.engine.set_option(k, v)
+    # new rays of the same count
+    y2, u2 = ra.bundles.disc_bundle(n, 12., -6., 9,
+                                    ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    g.rays_given(y2, u2)
+    want2 = build_c.propagate(table, y2, u2, clip=True)
+    for rep in range(3):
+        g.propagate(clip=True)
+        assert np.array_equal(np.asarray(g.y)[1:], want2[0], equal_nan=True)
+    # a row uploaded behind the engine's back (C ABI) is seen too
+    g.engine.upload_row(0, 0, np.ascontiguousarray(y.T))     # RT_Y, row 0
+    g.engine.upload_row(1, 0, np.ascontiguousarray(u.T))     # RT_U, row 0
+    g.engine.trace(1, 0, True)
+    assert np.array_equal(np.asarray(g.engine.download(0, 12, 13))[0].T,
+                          want[0][-1], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_repeated_partial_propagation():
+    """propagate(start=k) seeds from row k-1, repeatedly; a full trace that
+    rewrites that row is picked up."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    y, u = ra.bundles.disc_bundle(300_000, 17., 10., 5,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    full = _rows(g)
+    for rep in range(3):                 # seed row 5, three times
+        g.propagate(start=6, clip=True)
+        for a, b in zip(_rows(g), full):
+            assert np.array_equal(a, b, equal_nan=True)
+    system[3].curvature *= 1.01          # rows 3.. change, row 5 with them
+    g.propagate(clip=True)
+    changed = _rows(g)
+    assert not np.array_equal(changed[0][5], full[0][5], equal_nan=True)
+    for rep in range(3):
+        g.propagate(start=6, clip=True)
+        for a, b in zip(_rows(g), changed):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_repeated_traces_with_wavelength_groups():
+    system = ra.system_from_yaml(ra.prescriptions.COOKE % dict(
+        air=1.0, sk16="1.62041/60.32", f2="1.62004/36.37"))
+    y, u = ra.bundles.disc_bundle(64*500, 5., 4., 2)
+    ls = system.wavelengths
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u, l=ls)
+    ref = None
+    for rep in range(4):
+        g.propagate(clip=True)
+        rows = _rows(g)
+        if ref is None:
+            ref = rows
+        for a, b in zip(rows, ref):
+            assert np.array_equal(a, b, equal_nan=True)
+    for w, l in enumerate(ls):
+        h = ra.GeometricTrace(system)
+        h.rays_given(y, u, l=l)
+        h.propagate(clip=True)
+        assert np.array_equal(np.asarray(h.y[-1]),
+                              ref[0][-1][w*len(y):(w + 1)*len(y)],
+                              equal_nan=True)
