@@ -17,6 +17,16 @@ from ._lib import (SURFACE_DTYPE, RT_MAX_ASPH, RT_MAX_SURFACES, F_ROTATED,
                    F_CURVED, F_CONIC, F_ASPH, F_ALT, F_REFRACT, F_MIRROR)
 
 
+_SCALARS = ("c", "k", "kw", "kc2", "radius2", "mu", "muf", "smu", "mu2m1",
+            "n0", "nasph", "flags")
+_IDENTITY = np.eye(3).reshape(9)
+
+
+def _sign(x):
+    """np.sign for a Python float (NaN stays NaN)."""
+    return float((x > 0) - (x < 0)) if x == x else x
+
+
 def resolve_range(length, start=1, stop=None):
     """Absolute [start, stop) of ``system[start:stop]`` (system.py:460)."""
     idx = range(length)[start:stop]
@@ -37,62 +47,75 @@ def pack_system(system, wavelength, n_init, start=1, stop=None):
         raise ValueError("system has %d elements, the engine limit is %d"
                          % (length, RT_MAX_SURFACES))
     start, stop = resolve_range(length, start, stop)
-    table = np.zeros(length, dtype=SURFACE_DTYPE)
     n = np.full(length, np.nan)
     n0 = float(n_init)
     if start >= 1:
         n[start - 1] = n0
+    # one Python pass collecting columns, then one assignment per field: the
+    # table is rebuilt on every propagate(), so this runs once per merit
+    # evaluation / aiming iteration and must stay in the tens of microseconds
+    offsets, rots, aspheres = [], [], []
+    cols = {name: [] for name in _SCALARS}
     for j, el in enumerate(system):
-        row = table[j]
         flags = 0
         # --- frame: TransformMixin (elements.py:120-154) ---
-        row["offset"] = np.asarray(el.offset, dtype=float)
+        offsets.append(el.offset)
         if getattr(el, "rotated", False):
             flags |= F_ROTATED
-            row["rot"] = np.asarray(el.rot_normal, dtype=float).reshape(9)
+            rots.append(np.asarray(el.rot_normal, dtype=float).reshape(9))
         else:
-            row["rot"] = np.eye(3).reshape(9)
+            rots.append(_IDENTITY)
         # --- shape: Spheroid (elements.py:411-501) ---
         c = getattr(el, "curvature", 0.)
         k = getattr(el, "conic", 0.)
         asph = getattr(el, "aspherics", None)
-        row["c"] = c
-        row["k"] = k
-        row["kw"] = 1 + k                      # elements.py:489
-        row["kc2"] = (1 + k)*c**2              # elements.py:451,468
         if c:                                  # `if self.curvature:` :450
             flags |= F_CURVED
         if k:                                  # `if not k:` :484
             flags |= F_CONIC
+        nasph = 0
         if asph is not None:                   # elements.py:478
-            if len(asph) > RT_MAX_ASPH:
+            nasph = len(asph)
+            if nasph > RT_MAX_ASPH:
                 raise ValueError("element %d: %d aspheric terms, limit %d"
-                                 % (j, len(asph), RT_MAX_ASPH))
+                                 % (j, nasph, RT_MAX_ASPH))
             flags |= F_ASPH
-            row["nasph"] = len(asph)
-            for i, ai in enumerate(asph):
-                row["asph"][i] = ai            # elements.py:452-454
-                row["dasph"][i] = 2*(i + 1)*ai  # elements.py:471-472
+            aspheres.append((j, asph))
         if getattr(el, "alternate_intersection", False):
             flags |= F_ALT                     # elements.py:497
-        row["radius2"] = el.radius**2          # elements.py:207
         # --- index / Snell: Interface.get_n_mu (elements.py:283-289) ---
         mu = 1.
-        row["n0"] = n0 if start <= j < stop else 1.
-        if start <= j < stop:
+        inside = start <= j < stop
+        before = n0 if inside else 1.
+        if inside:
             if hasattr(el, "get_n_mu"):
                 nj, mu = el.get_n_mu(n0, wavelength)
             else:                              # plain Element.propagate :230
                 nj, mu = n0, 1.
             n[j] = nj
             n0 = nj
-        row["mu"] = mu
-        row["muf"] = abs(mu)                   # elements.py:358
-        row["smu"] = np.sign(mu)               # elements.py:366
-        row["mu2m1"] = mu**2 - 1               # elements.py:365
         if mu and mu != 1:                     # elements.py:313, :356
             flags |= F_REFRACT
             if mu == -1:                       # elements.py:363
                 flags |= F_MIRROR
-        row["flags"] = flags
+        for name, value in zip(_SCALARS, (
+                c, k,
+                1 + k,                         # kw, elements.py:489
+                (1 + k)*c**2,                  # kc2, elements.py:451,468
+                el.radius**2,                  # elements.py:207
+                mu,
+                abs(mu),                       # muf, elements.py:358
+                _sign(mu),                     # smu, elements.py:366
+                mu**2 - 1,                     # mu2m1, elements.py:365
+                before, nasph, flags)):
+            cols[name].append(value)
+    table = np.zeros(length, dtype=SURFACE_DTYPE)
+    table["offset"] = np.asarray(offsets, dtype=float)
+    table["rot"] = rots
+    for name in _SCALARS:
+        table[name] = cols[name]
+    for j, asph in aspheres:
+        a = np.asarray(asph, dtype=float)
+        table["asph"][j, :len(a)] = a                              # :452-454
+        table["dasph"][j, :len(a)] = 2*(np.arange(len(a)) + 1)*a   # :471-472
     return table, n
