@@ -24,7 +24,7 @@ _IDENTITY = np.eye(3).reshape(9)
 
 def _sign(x):
     """np.sign for a Python float (NaN stays NaN)."""
-    return float((x > 0) - (x < 0)) if x == x else x
+    return float(int(x > 0) - int(x < 0)) if x == x else x
 
 
 def resolve_range(length, start=1, stop=None):
