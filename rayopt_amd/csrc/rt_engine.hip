@@ -85,7 +85,7 @@ struct rt_ctx {
     int pin_busy[2]; /* a DMA recorded in pin_done[k] may still use h_pin[k] */
     double *d_w;  /* ray weights, NULL = uniform 1/n */
     size_t w_cap;
-    double *d_partials; /* RT_RED_BLOCKS x 8 doubles */
+    double *d_partials; /* RT_RED_BLOCKS x 8 doubles + 16 reduced values */
     double *d_group;    /* rt_spot_stats: stats | partials */
     size_t group_cap;   /* doubles */
     rt_opd_ref *d_opd_ref;
@@ -969,23 +969,6 @@ int rt_set_weights(rt_ctx *ctx, const double *w)
 }
 
 /* fetch and add the per-workgroup partials in index order */
-static int rt_collect(rt_ctx *ctx, int k, double *out)
-{
-    double host[RT_RED_BLOCKS * 8];
-    RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipMemcpyAsync(host, ctx->d_partials,
-                               sizeof(double) * RT_RED_BLOCKS * k,
-                               hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int c = 0; c < k; ++c) {
-        double v = 0.;
-        for (int b = 0; b < RT_RED_BLOCKS; ++b)
-            v += host[b * k + c];
-        out[c] = v;
-    }
-    return RT_OK;
-}
-
 static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
 {
     if (!ctx)
@@ -997,8 +980,21 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_partials)
         RT_HIP(ctx, hipMalloc((void **)&ctx->d_partials,
-                              sizeof(double) * RT_RED_BLOCKS * 8));
+                              sizeof(double) * (RT_RED_BLOCKS * 8 + 16)));
     return RT_OK;
+}
+
+/* workgroups of a reduction over n rays: no more than there is work for */
+static inline unsigned rt_red_blocks(int64_t n)
+{
+    const int64_t b = (n + RT_RED_THREADS - 1) / RT_RED_THREADS;
+    return (unsigned)(b < 1 ? 1 : (b > RT_RED_BLOCKS ? RT_RED_BLOCKS : b));
+}
+
+/* device-side second level of a reduction: k sums -> ctx->d_partials tail */
+static inline double *rt_reduced(rt_ctx *ctx, int slot)
+{
+    return ctx->d_partials + (size_t)RT_RED_BLOCKS * 8 + slot;
 }
 
 int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
@@ -1009,34 +1005,28 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
     if (!rms || ref >= ctx->n)
         return rt_fail(ctx, RT_ERR_ARG, "rt_rms: bad argument");
     const double *Yrow = rt_row(ctx, RT_Y, surf);
-    double x0, y0;
+    const unsigned blocks = rt_red_blocks(ctx->n);
+    /* both passes and their second levels are queued back to back; the host
+     * waits once, for one double */
     if (ref < 0) {
-        double sums[2];
-        hipLaunchKernelGGL(rt_sum_xy_kernel, dim3(RT_RED_BLOCKS),
+        hipLaunchKernelGGL(rt_sum_xy_kernel, dim3(blocks),
                            dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, ctx->n,
                            ctx->ld, ctx->d_partials);
-        rc = rt_collect(ctx, 2, sums);
-        if (rc != RT_OK)
-            return rc;
-        x0 = sums[0] / (double)ctx->n;
-        y0 = sums[1] / (double)ctx->n;
-    } else {
-        double xy[2];
-        RT_HIP(ctx, hipMemcpy2DAsync(xy, sizeof(double), Yrow + ref,
-                                     ctx->ld * sizeof(double), sizeof(double),
-                                     2, hipMemcpyDeviceToHost, ctx->stream));
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        x0 = xy[0];
-        y0 = xy[1];
+        hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0,
+                           ctx->stream, ctx->d_partials, (int)blocks, 2,
+                           rt_reduced(ctx, 0));
     }
-    double sum;
-    hipLaunchKernelGGL(rt_rms_kernel, dim3(RT_RED_BLOCKS),
-                       dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, ctx->d_w,
-                       1. / (double)ctx->n, x0, y0, ctx->n, ctx->ld,
+    hipLaunchKernelGGL(rt_rms_kernel, dim3(blocks), dim3(RT_RED_THREADS), 0,
+                       ctx->stream, Yrow, ctx->d_w, 1. / (double)ctx->n,
+                       rt_reduced(ctx, 0), ref, ctx->n, ctx->ld,
                        ctx->d_partials);
-    rc = rt_collect(ctx, 1, &sum);
-    if (rc != RT_OK)
-        return rc;
+    hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       ctx->d_partials, (int)blocks, 1, rt_reduced(ctx, 2));
+    RT_HIP(ctx, hipGetLastError());
+    double sum;
+    RT_HIP(ctx, hipMemcpyAsync(&sum, rt_reduced(ctx, 2), sizeof sum,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *rms = sqrt(sum);
     return RT_OK;
 }
@@ -1123,22 +1113,23 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
         return rt_fail(ctx, RT_ERR_ARG, "rt_refocus_shift: NULL");
     const double *Yrow = rt_row(ctx, RT_Y, surf);
     const double *Irow = rt_row(ctx, RT_I, surf);
-    double a[5], d[2];
-    hipLaunchKernelGGL(rt_refocus_sums_kernel, dim3(RT_RED_BLOCKS),
+    double d[2];
+    const unsigned blocks = rt_red_blocks(ctx->n);
+    hipLaunchKernelGGL(rt_refocus_sums_kernel, dim3(blocks),
                        dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow, ctx->n,
                        ctx->ld, ctx->d_partials);
-    rc = rt_collect(ctx, 5, a);
-    if (rc != RT_OK)
-        return rc;
-    const double cnt = a[0];
-    hipLaunchKernelGGL(rt_refocus_dots_kernel, dim3(RT_RED_BLOCKS),
+    hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       ctx->d_partials, (int)blocks, 5, rt_reduced(ctx, 0));
+    hipLaunchKernelGGL(rt_refocus_dots_kernel, dim3(blocks),
                        dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow,
-                       ctx->d_w, 1. / (double)ctx->n, a[1] / cnt, a[2] / cnt,
-                       a[3] / cnt,
-                       a[4] / cnt, ctx->n, ctx->ld, ctx->d_partials);
-    rc = rt_collect(ctx, 2, d);
-    if (rc != RT_OK)
-        return rc;
+                       ctx->d_w, 1. / (double)ctx->n, rt_reduced(ctx, 0),
+                       ctx->n, ctx->ld, ctx->d_partials);
+    hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       ctx->d_partials, (int)blocks, 2, rt_reduced(ctx, 5));
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(d, rt_reduced(ctx, 5), sizeof d,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *shift = -d[0] / d[1];
     return RT_OK;
 }

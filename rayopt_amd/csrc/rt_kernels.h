@@ -405,6 +405,24 @@ __device__ __forceinline__ void rt_block_reduce(double (&acc)[K],
         }
 }
 
+/* second level on the device: one wavefront adds the per-workgroup partials
+ * (lane l takes b = l, l + 64, ... in order, then a fixed shuffle tree), so
+ * a two-pass consumer needs no host round trip between its passes */
+__global__ void rt_finalize_kernel(const double *__restrict__ partials,
+                                   int nblocks, int K,
+                                   double *__restrict__ out)
+{
+    for (int k = 0; k < K; ++k) {
+        double v = 0.;
+        for (int b = threadIdx.x; b < nblocks; b += 64)
+            v += partials[(int64_t)b * K + k];
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_down(v, off);
+        if (threadIdx.x == 0)
+            out[k] = v;
+    }
+}
+
 /* sum of x and y of one row (rms: y.mean(0)) */
 __global__ void rt_sum_xy_kernel(const double *__restrict__ Yrow, int64_t n,
                                  int64_t ld, double *__restrict__ partials)
@@ -421,9 +439,13 @@ __global__ void rt_sum_xy_kernel(const double *__restrict__ Yrow, int64_t n,
 /* sum_k w_k ((x-x0)^2 + (y-y0)^2) */
 __global__ void rt_rms_kernel(const double *__restrict__ Yrow,
                               const double *__restrict__ w, double wconst,
-                              double x0, double y0, int64_t n, int64_t ld,
+                              const double *__restrict__ sums, int64_t ref,
+                              int64_t n, int64_t ld,
                               double *__restrict__ partials)
 {
+    /* centre: ray `ref`, or the plain mean from the sums of pass A */
+    const double x0 = ref >= 0 ? Yrow[ref] : sums[0] / (double)n;
+    const double y0 = ref >= 0 ? Yrow[ld + ref] : sums[1] / (double)n;
     double acc[1] = {0.};
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
          j += (int64_t)gridDim.x * blockDim.x) {
@@ -460,11 +482,14 @@ __global__ void rt_refocus_sums_kernel(const double *__restrict__ Yrow,
 __global__ void rt_refocus_dots_kernel(const double *__restrict__ Yrow,
                                        const double *__restrict__ Irow,
                                        const double *__restrict__ w,
-                                       double wconst, double my0, double my1,
-                                       double mu0, double mu1, int64_t n,
-                                       int64_t ld,
+                                       double wconst,
+                                       const double *__restrict__ sums,
+                                       int64_t n, int64_t ld,
                                        double *__restrict__ partials)
 {
+    /* means over the finite rays from the sums of pass A */
+    const double my0 = sums[1] / sums[0], my1 = sums[2] / sums[0];
+    const double mu0 = sums[3] / sums[0], mu1 = sums[4] / sums[0];
     double acc[2] = {0., 0.};
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
          j += (int64_t)gridDim.x * blockDim.x) {
