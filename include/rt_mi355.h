@@ -190,6 +190,52 @@ int rt_sizeof_field(void);
 int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
                      const double *pupil_xy, int64_t npupil);
 
+/*
+ * Batched aiming on the device -- System.pupil / _aim_pupil / aim_chief /
+ * aim_marginal (rayopt/system.py:507-593) for F field points at once.  The
+ * reference runs ~130 serial one-ray traces per field on the host; here one
+ * lane owns one field and runs the whole root finding in registers: the
+ * launch frame (Conjugate.aim, conjugates.py:137-166,236-255), the one-ray
+ * trace up to the stop (or through every aperture, rim = 1) and the solver
+ * updates never leave the kernel.  Secant for the pupil distance that puts
+ * the chief ray on the stop centre, bracket + Illinois regula falsi for the
+ * four marginal rays.  Uses the surface table last handed to
+ * rt_upload_system (group 0).
+ *
+ * rt_aim_seed: what the frame of one field is built from -- the parts that
+ * do not depend on the pupil distance (the host evaluates the projection of
+ * an object at infinity, InfiniteConjugate.map :208-234, once per field).
+ */
+typedef struct rt_aim_seed {
+    int32_t finite;      /* object at finite distance */
+    int32_t telecentric; /* finite only: chief rays parallel to the axis */
+    double yo[2];        /* fractional field coordinates */
+    double dir[3];       /* infinite: unit direction of the field */
+    double point[3];     /* finite: object point, sag of element 0 included */
+} rt_aim_seed;
+
+typedef struct rt_aim_args {
+    int32_t stop;    /* index of the aperture stop */
+    int32_t rim;     /* 1: marginal rays graze the first limiting aperture
+                        of elements 1..nsurf-2 instead of the stop */
+    int32_t maxiter; /* per root find */
+    int32_t pad_;
+    double tol;      /* convergence: secant step / |margin| */
+    double z0;       /* starting pupil distance from the vertex of element 0 */
+    double a0;       /* starting pupil aperture (radius, or angle basis) */
+} rt_aim_args;
+int rt_sizeof_aim_seed(void);
+int rt_sizeof_aim_args(void);
+/*
+ * z[F]: aimed pupil distance per field; a[F][2][2]: aimed apertures
+ * [[-sag, -mer], [+sag, +mer]]; status[F]: 0 ok, 1 chief ray did not
+ * converge, 2 no marginal bracket, 3 marginal ray did not converge (the
+ * values of a failed field are NaN).  Host arrays; synchronous.
+ */
+int rt_aim_pupil(rt_ctx *ctx, const rt_aim_seed *seeds, int nfields,
+                 const rt_aim_args *args, double *z, double *a,
+                 int32_t *status);
+
 /* overwrite one surface row of one array from a host SoA buffer */
 int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa);
 

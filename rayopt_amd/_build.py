@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_mi355.so")
 SOURCES = [os.path.join(CSRC, "rt_engine.hip")]
 HEADERS = [os.path.join(CSRC, "rt_math.h"), os.path.join(CSRC, "rt_kernels.h"),
+           os.path.join(CSRC, "rt_aim.h"),
            os.path.join(HERE, "..", "include", "rt_mi355.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
          "-fPIC", "-shared"]

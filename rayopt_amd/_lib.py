@@ -42,6 +42,16 @@ FIELD_DTYPE = np.dtype([
     ("m", "f8", (3,)),
 ], align=True)
 
+AIM_SEED_DTYPE = np.dtype([
+    ("finite", "i4"), ("telecentric", "i4"), ("yo", "f8", (2,)),
+    ("dir", "f8", (3,)), ("point", "f8", (3,)),
+], align=True)
+
+AIM_ARGS_DTYPE = np.dtype([
+    ("stop", "i4"), ("rim", "i4"), ("maxiter", "i4"), ("pad_", "i4"),
+    ("tol", "f8"), ("z0", "f8"), ("a0", "f8"),
+], align=True)
+
 LIB_PATH = os.environ.get("RT_MI355_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "librt_mi355.so")
 
@@ -97,6 +107,11 @@ SIGNATURES = {
                               _c_double_p]),
     "rt_refocus_shift": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p]),
     "rt_row_rmax": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p]),
+    "rt_sizeof_aim_seed": (ctypes.c_int, []),
+    "rt_sizeof_aim_args": (ctypes.c_int, []),
+    "rt_aim_pupil": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p]),
     "rt_spot_stats": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_void_p]),
     "rt_opd_rays": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p]),
@@ -145,5 +160,8 @@ def load():
         raise EngineError("struct rt_field layout mismatch")
     if lib.rt_sizeof_opd_args() != OPD_ARGS_DTYPE.itemsize:
         raise EngineError("struct rt_opd_args layout mismatch")
+    if lib.rt_sizeof_aim_seed() != AIM_SEED_DTYPE.itemsize or \
+            lib.rt_sizeof_aim_args() != AIM_ARGS_DTYPE.itemsize:
+        raise EngineError("struct rt_aim_seed / rt_aim_args layout mismatch")
     _lib = lib
     return lib

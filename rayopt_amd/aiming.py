@@ -4,9 +4,14 @@ The reference aims one field point at a time: ``System.pupil`` ->
 ``_aim_pupil`` -> ``aim_chief`` (secant on the chief ray's stop intercept) and
 four ``aim_marginal`` solves (Brent on the marginal rays' aperture margin),
 each evaluation a trace of ONE ray (rayopt/system.py:507-593; ~130 serial
-N=1 traces per field).  Here every solver iteration is ONE trace of all F
-field points at once (rays built on the device by ``rays_fields``), so the
-cost is ~5 solves x ~30 launches independent of F.  The roots are the same
+N=1 traces per field).  Here all F field points are aimed by ONE kernel: a
+lane owns a field and runs the five root finds -- launch frame, one-ray
+trace, solver update -- in registers (``rt_aim_pupil``,
+rayopt_amd/csrc/rt_aim.h); a few hundred microseconds whatever F is.  The
+same solvers also exist as host loops in which every iteration is one device
+trace of all fields (``on_device=False``; ~150 launches): the cross-check of
+the kernel, and the form an engine without ``aim_pupil`` gets.  The roots are
+the same
 (the chief ray through the centre of the stop; marginal rays grazing the stop
 edge, or the first limiting aperture for ``rim=True``); the reference stops
 at ``tol=1e-3``, this solver iterates to ``tol`` (default 1e-9), so the two
@@ -50,12 +55,14 @@ def entrance_pupil(system, l=None):
 class FieldAimer:
     """Aims F field points at once.  ``engine`` is injectable (tests)."""
 
-    def __init__(self, system, l=None, engine=None, tol=1e-9, maxiter=60):
+    def __init__(self, system, l=None, engine=None, tol=1e-9, maxiter=60,
+                 on_device=True):
         self.system = system
         self.l = system.wavelengths[0] if l is None else l
         self.trace = GeometricTrace(system, engine=engine)
         self.tol = tol
         self.maxiter = maxiter
+        self.on_device = on_device
 
     # one trace of F rays: field f through pupil point yp with (z_f, a_f)
     def _stop_xy(self, yo, yp, z, a, last):
@@ -151,6 +158,32 @@ class FieldAimer:
             raise ValueError("marginal-ray aiming did not converge")
         return x*p
 
+    _FAILURES = {1: "chief-ray aiming did not converge",
+                 2: "no viable marginal-ray interval",
+                 3: "marginal-ray aiming did not converge"}
+
+    def _pupil_on_device(self, yo, z0, a0, rim):
+        """All fields, all five root finds, one kernel (rt_aim_pupil)."""
+        from ._lib import AIM_ARGS_DTYPE
+        from .launch import aim_seeds
+        from .pack import pack_system
+        system = self.system
+        table, _ = pack_system(system, self.l,
+                               system.refractive_index(self.l, 0))
+        engine = self.trace.engine
+        engine.upload_system(table)
+        args = np.zeros((), dtype=AIM_ARGS_DTYPE)
+        args["stop"], args["rim"] = system.stop, bool(rim)
+        args["maxiter"], args["tol"] = self.maxiter, self.tol
+        args["z0"], args["a0"] = z0, a0
+        z, a, status = engine.aim_pupil(aim_seeds(system, yo), args)
+        if status.any():
+            bad = int(np.flatnonzero(status)[0])
+            raise ValueError("%s (field %d: %r)" % (
+                self._FAILURES.get(int(status[bad]), "aiming failed"), bad,
+                tuple(yo[bad])))
+        return z, a
+
     def pupil(self, yo, z0=None, a0=None, rim=False):
         """(z (F,), a (F,2,2)) for every field: chief aiming, then the four
         marginal rays -sag, -mer, +sag, +mer (_aim_pupil,
@@ -166,6 +199,9 @@ class FieldAimer:
             # a specified object pupil radius is the starting aperture, as in
             # the reference (Pupil.update only tracks it if update_radius)
             a0 = (given or ap) if a0 is None else a0
+        if self.on_device and np.ndim(z0) == 0 and np.ndim(a0) == 0 \
+                and hasattr(self.trace.engine, "aim_pupil"):
+            return self._pupil_on_device(yo, float(z0), float(a0), rim)
         z = self.chief(yo, z0, np.fabs(a0))
         a = np.empty((nf, 2, 2))
         for axis in (1, 0):

@@ -609,6 +609,56 @@ int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
     return RT_OK;
 }
 
+int rt_sizeof_aim_seed(void) { return (int)sizeof(rt_aim_seed); }
+int rt_sizeof_aim_args(void) { return (int)sizeof(rt_aim_args); }
+
+int rt_aim_pupil(rt_ctx *ctx, const rt_aim_seed *seeds, int nfields,
+                 const rt_aim_args *args, double *z, double *a,
+                 int32_t *status)
+{
+    if (!ctx || !seeds || !args || !z || !a || !status || nfields < 1)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_aim_pupil: bad argument");
+    if (ctx->nsurf < 3)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_aim_pupil: rt_upload_system must come first");
+    if (args->stop < 1 || args->stop > ctx->nsurf - 2 || args->maxiter < 1)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_aim_pupil: stop %d of %d elements",
+                       args->stop, ctx->nsurf);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    /* scratch: table | seeds | z | a | status, each 256-byte aligned */
+    const size_t tb = (sizeof(rt_surface) * ctx->nsurf + 255) / 256 * 256;
+    const size_t sb = (sizeof(rt_aim_seed) * nfields + 255) / 256 * 256;
+    const size_t zb = (sizeof(double) * nfields + 255) / 256 * 256;
+    const size_t ab = (sizeof(double) * 4 * nfields + 255) / 256 * 256;
+    const size_t cb = (sizeof(int32_t) * nfields + 255) / 256 * 256;
+    int rc = rt_need_scratch(ctx, tb + sb + zb + ab + cb);
+    if (rc != RT_OK)
+        return rc;
+    char *base = (char *)ctx->d_scratch;
+    rt_surface *d_tab = (rt_surface *)base;
+    rt_aim_seed *d_seeds = (rt_aim_seed *)(base + tb);
+    double *d_z = (double *)(base + tb + sb);
+    double *d_a = (double *)(base + tb + sb + zb);
+    int32_t *d_status = (int32_t *)(base + tb + sb + zb + ab);
+    RT_HIP(ctx, hipMemcpyAsync(d_tab, ctx->h_surf,
+                               sizeof(rt_surface) * ctx->nsurf,
+                               hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(d_seeds, seeds, sizeof(rt_aim_seed) * nfields,
+                               hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(rt_aim_kernel, dim3((unsigned)((nfields + 63) / 64)),
+                       dim3(64), 0, ctx->stream, d_tab, ctx->nsurf, d_seeds,
+                       nfields, *args, d_z, d_a, d_status);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(z, d_z, sizeof(double) * nfields,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(a, d_a, sizeof(double) * 4 * nfields,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(status, d_status, sizeof(int32_t) * nfields,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
 {
     if (!ctx || !src_soa || which < RT_Y || which > RT_T)

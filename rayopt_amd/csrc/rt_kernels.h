@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 #include "rt_math.h"
+#include "rt_aim.h"
 
 /* ------------------------------------------------------------------ */
 /* kernels                                                            */
@@ -368,6 +369,26 @@ __global__ void rt_generate_kernel(const rt_field *__restrict__ fields,
             I[c * ld + r] = u[0][c];
     }
     T[r] = 0.;
+}
+
+/* batched aiming: one lane per field runs System.pupil start to finish
+ * (rt_aim.h); the table, seeds and results live in the scratch buffer */
+__global__ void rt_aim_kernel(const rt_surface *__restrict__ tab, int nsurf,
+                              const rt_aim_seed *__restrict__ seeds, int nf,
+                              rt_aim_args args, double *__restrict__ z,
+                              double *__restrict__ a,
+                              int32_t *__restrict__ status)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf)
+        return;
+    const rt_aim_seed sd = seeds[f];
+    double zf, af[2][2];
+    status[f] = rt_aim_field(tab, nsurf, &sd, &args, &zf, af);
+    z[f] = zf;
+    for (int i = 0; i < 2; ++i)
+        for (int k = 0; k < 2; ++k)
+            a[(f * 2 + i) * 2 + k] = af[i][k];
 }
 
 /* ------------------------------------------------------------------ */

@@ -124,6 +124,19 @@ class Engine:
             pupil.shape[0]), "rt_generate_rays")
         return len(fields)*pupil.shape[0]
 
+    def aim_pupil(self, seeds, args):
+        """System.pupil for every field on the device (rt_aim_pupil):
+        returns z (F,), a (F,2,2), status (F,) int32."""
+        seeds = np.ascontiguousarray(seeds, dtype=_lib.AIM_SEED_DTYPE)
+        args = np.ascontiguousarray(args, dtype=_lib.AIM_ARGS_DTYPE)
+        nf = len(seeds)
+        z, a = np.empty(nf), np.empty((nf, 2, 2))
+        status = np.empty(nf, dtype=np.int32)
+        self._check(self.lib.rt_aim_pupil(
+            self.ctx, seeds.ctypes.data, nf, args.ctypes.data, z.ctypes.data,
+            a.ctypes.data, status.ctypes.data), "rt_aim_pupil")
+        return z, a, status
+
     def upload_row(self, which, surf, src_soa):
         src = np.ascontiguousarray(src_soa, dtype=np.float64)
         self._check(self.lib.rt_upload_row(self.ctx, which, surf,

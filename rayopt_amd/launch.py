@@ -11,7 +11,7 @@ grid (``rt_generate_rays``).  ``system.object`` may be this package's
 """
 import numpy as np
 
-from ._lib import FIELD_DTYPE
+from ._lib import FIELD_DTYPE, AIM_SEED_DTYPE
 
 
 def _unit(v):
@@ -127,4 +127,29 @@ def field_frames(system, yo, z, a):
             row["u"] = u
             row["base"] = y
         row["s"], row["m"] = s, m
+    return out
+
+
+def aim_seeds(system, yo):
+    """``AIM_SEED_DTYPE`` array for ``rt_aim_pupil``: per field the parts of
+    the launch frame that do not depend on the pupil distance (direction of
+    a field at infinity in the object's projection; object point of a finite
+    field), from which the device rebuilds :func:`field_frames` for every
+    trial distance."""
+    obj = system.object
+    projection = getattr(obj, "projection", None) or \
+        getattr(obj, "extra", {}).get("projection", "rectilinear")
+    yo = np.atleast_2d(np.asarray(yo, dtype=float))
+    out = np.zeros(len(yo), dtype=AIM_SEED_DTYPE)
+    out["yo"] = yo
+    for f in range(len(yo)):
+        if not obj.finite:
+            out[f]["dir"] = _direction(yo[f], obj.angle, projection)
+        else:
+            y = np.zeros(3)
+            y[:2] = -yo[f]*obj.radius
+            y[2] = _sag0(system[0], y)
+            out[f]["finite"] = 1
+            out[f]["telecentric"] = _telecentric(obj)
+            out[f]["point"] = y
     return out

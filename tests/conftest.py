@@ -96,6 +96,7 @@ def build_hostemu():
     src = os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")
     lib = os.path.join(ROOT, "tests", "hostemu", "libhostemu.so")
     hdrs = [os.path.join(ROOT, "rayopt_amd", "csrc", "rt_math.h"),
+            os.path.join(ROOT, "rayopt_amd", "csrc", "rt_aim.h"),
             os.path.join(ROOT, "include", "rt_mi355.h")]
     if (not os.path.exists(lib) or
             os.path.getmtime(lib) < max(os.path.getmtime(f)

@@ -116,6 +116,25 @@ class OracleEngine:
                                 w)
 
 
+def _aim_pupil(self, seeds, args):
+    """Test double of rt_aim_pupil: the same host+device aiming code
+    (rayopt_amd/csrc/rt_aim.h) compiled for the host."""
+    import ctypes
+    from conftest import build_hostemu
+    from rayopt_amd import _lib
+    lib = ctypes.CDLL(build_hostemu())
+    seeds = np.ascontiguousarray(seeds, dtype=_lib.AIM_SEED_DTYPE)
+    args = np.ascontiguousarray(args, dtype=_lib.AIM_ARGS_DTYPE)
+    table = np.ascontiguousarray(self.table)
+    nf = len(seeds)
+    z, a = np.empty(nf), np.empty((nf, 2, 2))
+    status = np.empty(nf, dtype=np.int32)
+    ptr = lambda arr: ctypes.c_void_p(arr.ctypes.data)   # noqa: E731
+    lib.emu_aim_pupil(ptr(table), len(table), ptr(seeds), nf, ptr(args),
+                      ptr(z), ptr(a), ptr(status))
+    return z, a, status
+
+
 def _generate_rays(self, fields, pupil_xy):
     """Test double of rt_generate_rays: the generation arithmetic compiled
     for the host (tests/hostemu)."""
@@ -138,3 +157,4 @@ def _generate_rays(self, fields, pupil_xy):
 
 
 OracleEngine.generate_rays = _generate_rays
+OracleEngine.aim_pupil = _aim_pupil

@@ -6,6 +6,7 @@
  */
 #include <stdint.h>
 #include "../../rayopt_amd/csrc/rt_math.h"
+#include "../../rayopt_amd/csrc/rt_aim.h"
 
 template <int R>
 static void run(const rt_surface *surf, int start, int stop, int clip,
@@ -70,5 +71,27 @@ extern "C" int emu_generate(const rt_field *fields, int nfields,
                 U[r * 3 + c] = u[0][c];
             }
         }
+    return 0;
+}
+
+extern "C" int emu_field_frame(const rt_aim_seed *seed, double z, double a,
+                               rt_field *out)
+{
+    rt_field_frame(seed, z, a, out);
+    return 0;
+}
+
+extern "C" int emu_aim_pupil(const rt_surface *tab, int nsurf,
+                             const rt_aim_seed *seeds, int nfields,
+                             const rt_aim_args *args, double *z, double *a,
+                             int32_t *status)
+{
+    for (int f = 0; f < nfields; ++f) {
+        double af[2][2];
+        status[f] = rt_aim_field(tab, nsurf, seeds + f, args, z + f, af);
+        for (int i = 0; i < 2; ++i)
+            for (int k = 0; k < 2; ++k)
+                a[(f * 2 + i) * 2 + k] = af[i][k];
+    }
     return 0;
 }

@@ -325,3 +325,124 @@ def test_native_ray_generators_gpu():
     assert (np.diff(np.abs(h)) > 0).all()
     g.rays((0, .7), [(0, 0), (0, .5), (.5, 0)], weight=[.5, .25, .25], ref=0)
     assert g.nrays == 3 and np.isfinite(g.rms())
+
+
+# -- the aiming kernel (rt_aim.h): frames, solvers, against the host loops -----
+
+AIM_SYSTEMS = {
+    "cooke": COOKE,
+    "cooke_small_image": COOKE.replace("radius: 20.", "radius: 0.364"),
+    "double_gauss": ra.prescriptions.DOUBLE_GAUSS,
+    "asphere_phone": ra.prescriptions.ASPHERE_PHONE,
+}
+
+
+def _finite_variant(text, telecentric=False):
+    s = ra.system_from_yaml(text)
+    spec = {"type": "finite", "radius": 8.}
+    if telecentric:       # chief rays parallel to the axis: a small object
+        spec = {"type": "finite", "radius": 2.,
+                "pupil": {"telecentric": True}}
+    s.object = ra.Conjugate(spec, True)
+    s[1].distance = 60.
+    return s
+
+
+def test_device_frames_equal_host_frames():
+    """rt_field_frame (what the aiming kernel builds per trial distance)
+    against launch.field_frames (what rays_fields hands the generator): every
+    member bit for bit, infinite / finite / telecentric / curved object."""
+    import ctypes
+    from conftest import build_hostemu
+    from rayopt_amd import _lib
+    from rayopt_amd.launch import field_frames, aim_seeds
+    lib = ctypes.CDLL(build_hostemu())
+    lib.emu_field_frame.argtypes = [ctypes.c_void_p, ctypes.c_double,
+                                    ctypes.c_double, ctypes.c_void_p]
+    curved = _finite_variant(COOKE)
+    curved[0].curvature = 1/300.
+    systems = [ra.system_from_yaml(COOKE), _finite_variant(COOKE),
+               _finite_variant(COOKE, telecentric=True), curved]
+    fields = np.array([(0, 0), (0, 1.), (.3, -.4), (-1., 0), (0, -.7)])
+    for system in systems:
+        seeds = aim_seeds(system, fields)
+        for z in (37.5, -12.25, 1e3):
+            for a in (6.25, 0.01):
+                want = field_frames(system, fields, z, a)
+                for f in range(len(fields)):
+                    got = np.zeros((), dtype=_lib.FIELD_DTYPE)
+                    lib.emu_field_frame(seeds[f:f + 1].ctypes.data, z, a,
+                                        got.ctypes.data)
+                    for name in _lib.FIELD_DTYPE.names:
+                        assert np.array_equal(got[name], want[f][name]), \
+                            (name, z, a, f)
+
+
+@pytest.mark.parametrize("name", sorted(AIM_SYSTEMS))
+@pytest.mark.parametrize("rim", [False, True])
+def test_aiming_kernel_code_vs_host_loops(name, rim):
+    """The aiming kernel's code compiled for the host (engine double) against
+    the host-loop solvers, whose every iteration is a batched trace: same
+    roots (to the solver tolerance), defining conditions hold."""
+    from fake_engine import OracleEngine
+    system = ra.system_from_yaml(AIM_SYSTEMS[name])
+    fields = np.r_[np.c_[np.zeros(5), np.linspace(0, 1, 5)],
+                   [[.3, .4], [-.5, .2], [.6, -.6]]]
+    fast = FieldAimer(system, engine=OracleEngine())
+    slow = FieldAimer(system, engine=OracleEngine(), on_device=False)
+    z, a = fast.pupil(fields, rim=rim)
+    zs, as_ = slow.pupil(fields, rim=rim)
+    np.testing.assert_allclose(z, zs, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(a, as_, rtol=1e-6)
+    assert (a[:, 0] < 0).all() and (a[:, 1] > 0).all()
+    if not rim:
+        check_conditions(system, slow, fields, z, a)
+
+
+def test_aiming_kernel_code_finite_objects_and_failures():
+    from fake_engine import OracleEngine
+    for system in (_finite_variant(COOKE),
+                   _finite_variant(COOKE, telecentric=True)):
+        fields = np.c_[np.zeros(4), np.linspace(0, 1, 4)]
+        z0, a0 = entrance_pupil(system)
+        fast = FieldAimer(system, engine=OracleEngine())
+        slow = FieldAimer(system, engine=OracleEngine(), on_device=False)
+        z, a = fast.pupil(fields, z0, a0)
+        zs, as_ = slow.pupil(fields, z0, a0)
+        np.testing.assert_allclose(z, zs, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(a, as_, rtol=1e-6)
+    # a solver that cannot converge reports which field failed
+    system = ra.system_from_yaml(COOKE)
+    with pytest.raises(ValueError, match="did not converge .field 0"):
+        FieldAimer(system, engine=OracleEngine(), maxiter=2).pupil(
+            [(0, 0), (0, 1.)])
+
+
+@pytest.mark.gpu
+def test_aiming_kernel_gpu():
+    """rt_aim_pupil on the device against the host-loop solvers driving
+    batched device traces, for every prescription; 2000 fields in one launch."""
+    import time
+    for name, text in AIM_SYSTEMS.items():
+        system = ra.system_from_yaml(text)
+        fields = np.r_[np.c_[np.zeros(5), np.linspace(0, 1, 5)],
+                       [[.3, .4], [-.5, .2], [.6, -.6]]]
+        for rim in (False, True):
+            z, a = FieldAimer(system).pupil(fields, rim=rim)
+            zs, as_ = FieldAimer(system, on_device=False).pupil(fields,
+                                                                rim=rim)
+            np.testing.assert_allclose(z, zs, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(a, as_, rtol=1e-6)
+    system = ra.system_from_yaml(COOKE)
+    rng = np.random.default_rng(1)
+    many = rng.uniform(-1, 1, (4000, 2))
+    many = many[np.square(many).sum(1) <= 1][:2000]
+    aimer = FieldAimer(system)
+    aimer.pupil(many[:10])
+    t0 = time.perf_counter()
+    z, a = aimer.pupil(many)
+    dt = time.perf_counter() - t0
+    check_conditions(system, aimer, many, z, a)
+    assert dt < 0.2, "2000 fields took %.1f ms" % (dt*1e3)
+    with pytest.raises(ValueError, match="did not converge"):
+        FieldAimer(system, maxiter=2).pupil([(0, 0), (0, 1.)])
