@@ -203,6 +203,7 @@ class GeometricTrace(Trace):
             table = np.stack([t for t, _ in packed])
             ns = np.stack([n for _, n in packed])
         self.engine.upload_system(table)
+        self._packed = (resolve_range(self.length, start, stop), ns)
         return table, ns
 
     # -- seeding ------------------------------------------------------------
@@ -417,7 +418,7 @@ class GeometricTrace(Trace):
         self.fields = fields
         self.rays_per_field = len(yp)
         self.rays_alive_per_field = alive
-        self.propagate(clip=clip, keep=keep)
+        self.propagate(clip=clip, keep=keep, _fresh=True)
 
     def spot_stats(self, i=-1, group_rays=None):
         """Spot statistics of every bundle of the batch at surface ``i`` in
@@ -482,7 +483,7 @@ class GeometricTrace(Trace):
             self.w = weight
             self._uniform_w = False
             self.engine.set_weights(weight)
-        self.propagate(clip=clip)
+        self.propagate(clip=clip, _fresh=True)
 
     def rays_point(self, yo, wavelength=None, nrays=11,
                    distribution="meridional", filter=None, stop=None,
@@ -504,7 +505,7 @@ class GeometricTrace(Trace):
         yp = np.zeros((3, 2))
         yp[1:, axis] = a[0][:, axis]/np.fabs(a[0]).max()
         self.rays_fields([yo], yp, z, a, l)
-        self.propagate()
+        self.propagate(_fresh=True)
 
     def rays_line(self, yo, wavelength=None, nrays=21, eps=1e-2):
         """``nrays`` field points from the axis to ``yo``, three rays each:
@@ -542,7 +543,8 @@ class GeometricTrace(Trace):
         ax.plot(path[..., 2], path[..., axis], **style)
 
     # -- the hot path ---------------------------------------------------------
-    def propagate(self, start=1, stop=None, clip=False, keep=None):
+    def propagate(self, start=1, stop=None, clip=False, keep=None,
+                  _fresh=False):
         """Trace elements ``start .. stop-1`` for all rays on the GPU
         (rayopt/geometric_trace.py:72-80 + rayopt/system.py:459-464).
 
@@ -559,8 +561,15 @@ class GeometricTrace(Trace):
         if a < 1:
             raise ValueError("start must be >= 1")
         grouped = np.ndim(self.l) == 1
-        _, ns = self._upload_table(
-            a, b, self.n[:, a - 1] if grouped else self.n[a - 1])
+        packed, self._packed = getattr(self, "_packed", None), None
+        if _fresh and packed is not None and packed[0] == (a, b):
+            # called by a compound method right after its own seeding: the
+            # table that was packed for it is the one on the device
+            ns = packed[1]
+        else:
+            _, ns = self._upload_table(
+                a, b, self.n[:, a - 1] if grouped else self.n[a - 1])
+            self._packed = None
         if keep is None:
             self.engine.set_keep_rows(None)
         else:

@@ -103,30 +103,31 @@ def field_frames(system, yo, z, a):
         a = a[..., None, None]*np.array(((-1., -1.), (1., 1.)))
     a = np.broadcast_to(a, (nf, 2, 2))
     out = np.zeros(nf, dtype=FIELD_DTYPE)
-    for f in range(nf):
-        zf = float(z[f])
-        row = out[f]
-        row["z"] = zf
-        if not obj.finite:
-            u = _direction(yo[f], obj.angle, projection)
-            s, m = _frame(u, zf)
-            row["finite"] = 0
-            row["am"] = np.fabs(a[f]).max()
-            row["u"] = u
-            row["base"] = np.array((0., 0., zf)) - zf*u
-        else:
-            y = np.zeros(3)
-            y[:2] = -yo[f]*obj.radius
-            y[2] = _sag0(system[0], y)
-            uz = np.array((0., 0., zf))
-            u = uz if _telecentric(obj) else uz - y
-            s, m = _frame(u, zf)
-            row["finite"] = 1
-            row["flip"] = zf < 0
-            row["am"] = np.fabs(np.arctan2(a[f], zf)).max()
-            row["u"] = u
-            row["base"] = y
-        row["s"], row["m"] = s, m
+    out["z"] = z
+    axis = np.zeros((nf, 3))
+    axis[:, 2] = z
+    if not obj.finite:
+        u = np.array([_direction(yo[f], obj.angle, projection)
+                      for f in range(nf)])
+        out["am"] = np.fabs(a).max((1, 2))
+        out["base"] = axis - z[:, None]*u
+    else:
+        y = np.zeros((nf, 3))
+        y[:, :2] = -yo*obj.radius
+        y[:, 2] = [_sag0(system[0], yf) for yf in y]
+        u = axis if _telecentric(obj) else axis - y
+        out["finite"] = 1
+        out["flip"] = z < 0
+        out["am"] = np.fabs(np.arctan2(a, z[:, None, None])).max((1, 2))
+        out["base"] = y
+    # sagittal / meridional unit vectors about the axis (0, 0, z), all
+    # fields at once (_frame)
+    s = np.cross(u, axis)
+    s[np.all(s == 0, axis=1)] = (1., 0., 0.)
+    m = np.cross(u, s)
+    out["u"] = u
+    out["s"] = s/np.sqrt(np.square(s).sum(-1))[:, None]
+    out["m"] = m/np.sqrt(np.square(m).sum(-1))[:, None]
     return out
 
 
