@@ -199,8 +199,9 @@ int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
  * trace up to the stop (or through every aperture, rim = 1) and the solver
  * updates never leave the kernel.  Secant for the pupil distance that puts
  * the chief ray on the stop centre, bracket + Illinois regula falsi for the
- * four marginal rays.  Uses the surface table last handed to
- * rt_upload_system (group 0).
+ * four marginal rays.  Uses the surface table(s) last handed to
+ * rt_upload_system[_groups]; a field names its table (wavelength) in
+ * rt_aim_seed.group, so every field at every wavelength is one launch.
  *
  * rt_aim_seed: what the frame of one field is built from -- the parts that
  * do not depend on the pupil distance (the host evaluates the projection of
@@ -209,9 +210,14 @@ int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
 typedef struct rt_aim_seed {
     int32_t finite;      /* object at finite distance */
     int32_t telecentric; /* finite only: chief rays parallel to the axis */
+    int32_t group;       /* surface table (wavelength) this field is aimed at */
+    int32_t pad_;
     double yo[2];        /* fractional field coordinates */
     double dir[3];       /* infinite: unit direction of the field */
     double point[3];     /* finite: object point, sag of element 0 included */
+    double z0;           /* starting pupil distance from the vertex of
+                            element 0 */
+    double a0;           /* starting pupil aperture (radius, or angle basis) */
 } rt_aim_seed;
 
 typedef struct rt_aim_args {
@@ -221,8 +227,6 @@ typedef struct rt_aim_args {
     int32_t maxiter; /* per root find */
     int32_t pad_;
     double tol;      /* convergence: secant step / |margin| */
-    double z0;       /* starting pupil distance from the vertex of element 0 */
-    double a0;       /* starting pupil aperture (radius, or angle basis) */
 } rt_aim_args;
 int rt_sizeof_aim_seed(void);
 int rt_sizeof_aim_args(void);

@@ -43,13 +43,14 @@ FIELD_DTYPE = np.dtype([
 ], align=True)
 
 AIM_SEED_DTYPE = np.dtype([
-    ("finite", "i4"), ("telecentric", "i4"), ("yo", "f8", (2,)),
-    ("dir", "f8", (3,)), ("point", "f8", (3,)),
+    ("finite", "i4"), ("telecentric", "i4"), ("group", "i4"), ("pad_", "i4"),
+    ("yo", "f8", (2,)), ("dir", "f8", (3,)), ("point", "f8", (3,)),
+    ("z0", "f8"), ("a0", "f8"),
 ], align=True)
 
 AIM_ARGS_DTYPE = np.dtype([
     ("stop", "i4"), ("rim", "i4"), ("maxiter", "i4"), ("pad_", "i4"),
-    ("tol", "f8"), ("z0", "f8"), ("a0", "f8"),
+    ("tol", "f8"),
 ], align=True)
 
 LIB_PATH = os.environ.get("RT_MI355_LIB") or os.path.join(

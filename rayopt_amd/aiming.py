@@ -162,27 +162,62 @@ class FieldAimer:
                  2: "no viable marginal-ray interval",
                  3: "marginal-ray aiming did not converge"}
 
-    def _pupil_on_device(self, yo, z0, a0, rim):
-        """All fields, all five root finds, one kernel (rt_aim_pupil)."""
+    def _start(self, l, z0=None, a0=None):
+        """Starting pupil at wavelength ``l``: paraxial image of the stop; a
+        specified object pupil radius is the starting aperture, as in the
+        reference (Pupil.update only tracks it if update_radius)."""
+        if z0 is None or a0 is None:
+            zp, ap = entrance_pupil(self.system, l)
+            spec = getattr(self.system.object, "pupil", None)
+            given = spec.get("radius") if isinstance(spec, dict) else \
+                getattr(spec, "radius", None)
+            z0 = zp if z0 is None else z0
+            a0 = (given or ap) if a0 is None else a0
+        return z0, a0
+
+    def _pupil_on_device(self, yo, wavelengths, starts, rim):
+        """All fields at all wavelengths, all five root finds, one kernel
+        (rt_aim_pupil): z (W,F), a (W,F,2,2)."""
         from ._lib import AIM_ARGS_DTYPE
         from .launch import aim_seeds
         from .pack import pack_system
         system = self.system
-        table, _ = pack_system(system, self.l,
-                               system.refractive_index(self.l, 0))
+        tables = np.stack([
+            pack_system(system, l, system.refractive_index(l, 0))[0]
+            for l in wavelengths])
         engine = self.trace.engine
-        engine.upload_system(table)
+        engine.upload_system(tables)
         args = np.zeros((), dtype=AIM_ARGS_DTYPE)
         args["stop"], args["rim"] = system.stop, bool(rim)
         args["maxiter"], args["tol"] = self.maxiter, self.tol
-        args["z0"], args["a0"] = z0, a0
-        z, a, status = engine.aim_pupil(aim_seeds(system, yo), args)
+        seeds = np.concatenate([
+            aim_seeds(system, yo, z0, a0, group)
+            for group, (z0, a0) in enumerate(starts)])
+        z, a, status = engine.aim_pupil(seeds, args)
         if status.any():
             bad = int(np.flatnonzero(status)[0])
             raise ValueError("%s (field %d: %r)" % (
-                self._FAILURES.get(int(status[bad]), "aiming failed"), bad,
-                tuple(yo[bad])))
-        return z, a
+                self._FAILURES.get(int(status[bad]), "aiming failed"),
+                bad % len(yo), tuple(yo[bad % len(yo)])))
+        groups = len(wavelengths)
+        return z.reshape(groups, -1), a.reshape(groups, -1, 2, 2)
+
+    def pupils(self, yo, wavelengths, rim=False):
+        """:meth:`pupil` for every field at every wavelength -- z (W,F),
+        a (W,F,2,2) -- in one launch where the engine aims on the device."""
+        yo = np.atleast_2d(np.asarray(yo, dtype=float))
+        starts = [self._start(l) for l in wavelengths]
+        if self.on_device and hasattr(self.trace.engine, "aim_pupil"):
+            return self._pupil_on_device(yo, wavelengths, starts, rim)
+        keep = self.l
+        try:
+            out = []
+            for l, (z0, a0) in zip(wavelengths, starts):
+                self.l = l
+                out.append(self.pupil(yo, z0, a0, rim))
+        finally:
+            self.l = keep
+        return np.array([z for z, _ in out]), np.array([a for _, a in out])
 
     def pupil(self, yo, z0=None, a0=None, rim=False):
         """(z (F,), a (F,2,2)) for every field: chief aiming, then the four
@@ -190,18 +225,12 @@ class FieldAimer:
         rayopt/system.py:557-583; a = [[-sag,-mer],[+sag,+mer]])."""
         yo = np.atleast_2d(np.asarray(yo, dtype=float))
         nf = len(yo)
-        if z0 is None or a0 is None:
-            zp, ap = entrance_pupil(self.system, self.l)
-            spec = getattr(self.system.object, "pupil", None)
-            given = spec.get("radius") if isinstance(spec, dict) else \
-                getattr(spec, "radius", None)
-            z0 = zp if z0 is None else z0
-            # a specified object pupil radius is the starting aperture, as in
-            # the reference (Pupil.update only tracks it if update_radius)
-            a0 = (given or ap) if a0 is None else a0
+        z0, a0 = self._start(self.l, z0, a0)
         if self.on_device and np.ndim(z0) == 0 and np.ndim(a0) == 0 \
                 and hasattr(self.trace.engine, "aim_pupil"):
-            return self._pupil_on_device(yo, float(z0), float(a0), rim)
+            z, a = self._pupil_on_device(yo, [self.l],
+                                         [(float(z0), float(a0))], rim)
+            return z[0], a[0]
         z = self.chief(yo, z0, np.fabs(a0))
         a = np.empty((nf, 2, 2))
         for axis in (1, 0):

@@ -115,7 +115,8 @@ RT_HD int rt_aim_chief(const rt_surface *__restrict__ tab,
                        const rt_aim_seed *sd, const rt_aim_args *g, double p,
                        double *z)
 {
-    *z = g->z0;
+    const double z0 = sd->z0;
+    *z = z0;
     /* np.isclose(yo, 0): on axis there is nothing to aim */
     if (fabs(sd->yo[0]) <= 1e-8 && fabs(sd->yo[1]) <= 1e-8)
         return 0;
@@ -123,10 +124,10 @@ RT_HD int rt_aim_chief(const rt_surface *__restrict__ tab,
     rt_field F;
     double hit[2], fl, fw;
     double a0 = 0., a1 = 1e-4, f0, f1;
-    rt_field_frame(sd, g->z0 + a0 * p, p, &F);
+    rt_field_frame(sd, z0 + a0 * p, p, &F);
     rt_aim_trace(tab, g->stop, &F, 0., 0., hit, fl, fw);
     f0 = (sd->yo[0] * hit[0] + sd->yo[1] * hit[1]) / rad;
-    rt_field_frame(sd, g->z0 + a1 * p, p, &F);
+    rt_field_frame(sd, z0 + a1 * p, p, &F);
     rt_aim_trace(tab, g->stop, &F, 0., 0., hit, fl, fw);
     f1 = (sd->yo[0] * hit[0] + sd->yo[1] * hit[1]) / rad;
     for (int it = 0; it < g->maxiter; ++it) {
@@ -135,10 +136,10 @@ RT_HD int rt_aim_chief(const rt_surface *__restrict__ tab,
         f0 = f1;
         a1 = a1 - step;
         if (fabs(step) <= g->tol) {
-            *z = g->z0 + a1 * p;
+            *z = z0 + a1 * p;
             return 0;
         }
-        rt_field_frame(sd, g->z0 + a1 * p, p, &F);
+        rt_field_frame(sd, z0 + a1 * p, p, &F);
         rt_aim_trace(tab, g->stop, &F, 0., 0., hit, fl, fw);
         f1 = (sd->yo[0] * hit[0] + sd->yo[1] * hit[1]) / rad;
     }
@@ -154,7 +155,7 @@ RT_HD int rt_aim_marginal(const rt_surface *__restrict__ tab, int nsurf,
                           double z, double px, double py, double *x_out)
 {
     const int last = g->rim ? nsurf - 2 : g->stop;
-    const double p = g->a0;
+    const double p = sd->a0;
     rt_field F;
     double hit[2], fl, fw;
 #define RT_MARGIN(scale, out)                                                 \
@@ -218,7 +219,7 @@ RT_HD int rt_aim_field(const rt_surface *__restrict__ tab, int nsurf,
 {
     for (int i = 0; i < 2; ++i)
         a[i][0] = a[i][1] = NAN;
-    int rc = rt_aim_chief(tab, sd, g, fabs(g->a0), z);
+    int rc = rt_aim_chief(tab, sd, g, fabs(sd->a0), z);
     if (rc)
         return rc;
     for (int axis = 1; axis >= 0; --axis)

@@ -624,9 +624,15 @@ int rt_aim_pupil(rt_ctx *ctx, const rt_aim_seed *seeds, int nfields,
     if (args->stop < 1 || args->stop > ctx->nsurf - 2 || args->maxiter < 1)
         return rt_fail(ctx, RT_ERR_ARG, "rt_aim_pupil: stop %d of %d elements",
                        args->stop, ctx->nsurf);
+    for (int f = 0; f < nfields; ++f)
+        if (seeds[f].group < 0 || seeds[f].group >= ctx->ngroups)
+            return rt_fail(ctx, RT_ERR_ARG,
+                           "rt_aim_pupil: field %d names table %d of %d", f,
+                           seeds[f].group, ctx->ngroups);
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    /* scratch: table | seeds | z | a | status, each 256-byte aligned */
-    const size_t tb = (sizeof(rt_surface) * ctx->nsurf + 255) / 256 * 256;
+    /* scratch: tables | seeds | z | a | status, each 256-byte aligned */
+    const size_t ntab = (size_t)ctx->nsurf * ctx->ngroups;
+    const size_t tb = (sizeof(rt_surface) * ntab + 255) / 256 * 256;
     const size_t sb = (sizeof(rt_aim_seed) * nfields + 255) / 256 * 256;
     const size_t zb = (sizeof(double) * nfields + 255) / 256 * 256;
     const size_t ab = (sizeof(double) * 4 * nfields + 255) / 256 * 256;
@@ -640,8 +646,7 @@ int rt_aim_pupil(rt_ctx *ctx, const rt_aim_seed *seeds, int nfields,
     double *d_z = (double *)(base + tb + sb);
     double *d_a = (double *)(base + tb + sb + zb);
     int32_t *d_status = (int32_t *)(base + tb + sb + zb + ab);
-    RT_HIP(ctx, hipMemcpyAsync(d_tab, ctx->h_surf,
-                               sizeof(rt_surface) * ctx->nsurf,
+    RT_HIP(ctx, hipMemcpyAsync(d_tab, ctx->h_surf, sizeof(rt_surface) * ntab,
                                hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipMemcpyAsync(d_seeds, seeds, sizeof(rt_aim_seed) * nfields,
                                hipMemcpyHostToDevice, ctx->stream));

@@ -384,7 +384,8 @@ __global__ void rt_aim_kernel(const rt_surface *__restrict__ tab, int nsurf,
         return;
     const rt_aim_seed sd = seeds[f];
     double zf, af[2][2];
-    status[f] = rt_aim_field(tab, nsurf, &sd, &args, &zf, af);
+    status[f] = rt_aim_field(tab + (int64_t)sd.group * nsurf, nsurf, &sd,
+                             &args, &zf, af);
     z[f] = zf;
     for (int i = 0; i < 2; ++i)
         for (int k = 0; k < 2; ++k)

@@ -398,11 +398,14 @@ class GeometricTrace(Trace):
             copies = len(fields)
         else:
             l = np.asarray(l, dtype=float)
-            za = [FieldAimer(self.system, li, self._aux_engine()).pupil(
-                      fields, rim=rim) if aim
-                  else entrance_pupil(self.system, li) for li in l]
-            z = [np.broadcast_to(zi, (len(fields),)) for zi, _ in za]
-            a = [ai for _, ai in za]
+            if aim:
+                z, a = FieldAimer(self.system, l[0],
+                                  self._aux_engine()).pupils(fields, l,
+                                                             rim=rim)
+            else:
+                za = [entrance_pupil(self.system, li) for li in l]
+                z = [np.broadcast_to(zi, (len(fields),)) for zi, _ in za]
+                a = [ai for _, ai in za]
             pad = -alive % 64
             if pad:
                 yp = np.concatenate([yp, np.full((pad, 2), np.nan)])

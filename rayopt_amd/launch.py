@@ -131,18 +131,20 @@ def field_frames(system, yo, z, a):
     return out
 
 
-def aim_seeds(system, yo):
+def aim_seeds(system, yo, z0, a0, group=0):
     """``AIM_SEED_DTYPE`` array for ``rt_aim_pupil``: per field the parts of
     the launch frame that do not depend on the pupil distance (direction of
     a field at infinity in the object's projection; object point of a finite
     field), from which the device rebuilds :func:`field_frames` for every
-    trial distance."""
+    trial distance; the starting pupil ``z0, a0`` and the surface table
+    (wavelength) ``group`` the fields are aimed at."""
     obj = system.object
     projection = getattr(obj, "projection", None) or \
         getattr(obj, "extra", {}).get("projection", "rectilinear")
     yo = np.atleast_2d(np.asarray(yo, dtype=float))
     out = np.zeros(len(yo), dtype=AIM_SEED_DTYPE)
     out["yo"] = yo
+    out["z0"], out["a0"], out["group"] = z0, a0, group
     for f in range(len(yo)):
         if not obj.finite:
             out[f]["dir"] = _direction(yo[f], obj.angle, projection)

@@ -125,12 +125,12 @@ def _aim_pupil(self, seeds, args):
     lib = ctypes.CDLL(build_hostemu())
     seeds = np.ascontiguousarray(seeds, dtype=_lib.AIM_SEED_DTYPE)
     args = np.ascontiguousarray(args, dtype=_lib.AIM_ARGS_DTYPE)
-    table = np.ascontiguousarray(self.table)
+    table = np.ascontiguousarray(self.tables)
     nf = len(seeds)
     z, a = np.empty(nf), np.empty((nf, 2, 2))
     status = np.empty(nf, dtype=np.int32)
     ptr = lambda arr: ctypes.c_void_p(arr.ctypes.data)   # noqa: E731
-    lib.emu_aim_pupil(ptr(table), len(table), ptr(seeds), nf, ptr(args),
+    lib.emu_aim_pupil(ptr(table), self.nsurf, ptr(seeds), nf, ptr(args),
                       ptr(z), ptr(a), ptr(status))
     return z, a, status
 

@@ -88,7 +88,8 @@ extern "C" int emu_aim_pupil(const rt_surface *tab, int nsurf,
 {
     for (int f = 0; f < nfields; ++f) {
         double af[2][2];
-        status[f] = rt_aim_field(tab, nsurf, seeds + f, args, z + f, af);
+        status[f] = rt_aim_field(tab + (int64_t)seeds[f].group * nsurf, nsurf,
+                                 seeds + f, args, z + f, af);
         for (int i = 0; i < 2; ++i)
             for (int k = 0; k < 2; ++k)
                 a[(f * 2 + i) * 2 + k] = af[i][k];

@@ -365,7 +365,7 @@ def test_device_frames_equal_host_frames():
                _finite_variant(COOKE, telecentric=True), curved]
     fields = np.array([(0, 0), (0, 1.), (.3, -.4), (-1., 0), (0, -.7)])
     for system in systems:
-        seeds = aim_seeds(system, fields)
+        seeds = aim_seeds(system, fields, 0., 1.)
         for z in (37.5, -12.25, 1e3):
             for a in (6.25, 0.01):
                 want = field_frames(system, fields, z, a)
@@ -446,3 +446,33 @@ def test_aiming_kernel_gpu():
     assert dt < 0.2, "2000 fields took %.1f ms" % (dt*1e3)
     with pytest.raises(ValueError, match="did not converge"):
         FieldAimer(system, maxiter=2).pupil([(0, 0), (0, 1.)])
+
+
+def _pupils_checks(engine_factory):
+    """Every field at every wavelength in one launch equals one aimer per
+    wavelength, value for value; the host-loop form agrees."""
+    system = ra.system_from_yaml(DISPERSIVE_COOKE)
+    ls = system.wavelengths
+    fields = np.c_[np.zeros(4), np.linspace(0, 1, 4)]
+    z, a = FieldAimer(system, engine=engine_factory()).pupils(fields, ls)
+    assert z.shape == (3, 4) and a.shape == (3, 4, 2, 2)
+    for w, l in enumerate(ls):
+        zl, al = FieldAimer(system, l, engine=engine_factory()).pupil(fields)
+        assert np.array_equal(zl, z[w]) and np.array_equal(al, a[w])
+    assert np.abs(z[1] - z[2]).max() > 1e-6          # dispersion is seen
+    zs, as_ = FieldAimer(system, engine=engine_factory(),
+                         on_device=False).pupils(fields, ls, rim=True)
+    zr, ar = FieldAimer(system, engine=engine_factory()).pupils(fields, ls,
+                                                                rim=True)
+    np.testing.assert_allclose(zr, zs, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ar, as_, rtol=1e-6)
+
+
+def test_pupils_all_wavelengths_host_logic():
+    from fake_engine import OracleEngine
+    _pupils_checks(OracleEngine)
+
+
+@pytest.mark.gpu
+def test_pupils_all_wavelengths_gpu():
+    _pupils_checks(lambda: None)
