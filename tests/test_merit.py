@@ -188,3 +188,18 @@ def test_spot_operand_optimisation_gpu():
     want = np.sqrt(np.square(spots - spots.mean(2, keepdims=True))
                    .sum(3).mean(2)).ravel()
     np.testing.assert_allclose(after, want, rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_polychromatic_example_runs():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "examples", "optimize_polychromatic.py")
+    spec = importlib.util.spec_from_file_location("optimize_polychromatic",
+                                                  path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    before, after, res = mod.main(nrays=300, verbose=False)
+    assert np.square(after).sum() < np.square(before).sum()
+    assert np.isfinite(after).all()
