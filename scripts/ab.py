@@ -18,7 +18,7 @@ DEFAULTS = dict(rays_per_thread=1, nontemporal=0, xcd_remap=0, block=256,
 
 
 def main():
-    n = 10_000_000
+    n = int(os.environ.get("RT_AB_RAYS", 10_000_000))
     variants = [dict(v) for v in json.loads(sys.argv[1])] if len(sys.argv) > 1 \
         else [{}]
     if os.environ.get("RT_AB_CONFIG") == "asphere":
