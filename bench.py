@@ -427,12 +427,17 @@ def main():
     total_rays = n*world
     ms_per_step = elapsed*1e3/args.steps
     value = total_rays*S*args.steps/elapsed
-    from rayopt_amd._lib import F_ROTATED
+    from rayopt_amd._lib import F_ROTATED, F_REFRACT
     rot = (table["flags"] & F_ROTATED) != 0
+    bends = (table["flags"] & F_REFRACT) != 0
     alias_on = not any(kv == "alias_i=0" for kv in args.option)
     stored_i = sum(1 for j in range(1, L)
                    if not alias_on or rot[j] or rot[j - 1])
-    alg_bytes = n*(56*S + 24*stored_i + 48)  # per launch (one GPU's shard)
+    # an unclipped trace does not write u[j] where the element does not bend
+    # the ray (u[j] is i[j] bit for bit: stop, image)
+    skipped_u = sum(1 for j in range(1, L)
+                    if alias_on and not clip and not bends[j])
+    alg_bytes = n*(56*S + 24*stored_i - 24*skipped_u + 48)  # one GPU's shard
     kernel_ms = (ev_ms/args.steps if not (dist_mode and args.gather_every_step)
                  else last_kernel_ms)
     achieved = alg_bytes/(kernel_ms*1e-3)/1e9
@@ -484,7 +489,7 @@ def main():
             "kernel": "rt_trace_kernel",
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "bytes_per_ray_surface_op": (56*S + 24*stored_i)/S,
+            "bytes_per_ray_surface_op": (56*S + 24*stored_i - 24*skipped_u)/S,
             "frac_of_achievable_6290": achieved/HBM_ACHIEVABLE_GBS,
         },
     }

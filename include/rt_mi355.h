@@ -54,6 +54,12 @@ extern "C" {
 #define RT_F_STORE_I 0x80u
 /* set by the library: this row is not stored (rt_set_keep_rows) */
 #define RT_F_NOSTORE 0x100u
+/* set by the library: row U[j] is not written because it is I[j] bit for
+ * bit -- the element does not bend the ray (no material change, mu == 1:
+ * stop, image, dummy surface; elements.py:311-313) and the trace does not
+ * clip (Element.clip is what would poison u, :206-209) -- and is served
+ * from I[j] (which may in turn be U[j-1]) */
+#define RT_F_SKIP_U 0x200u
 
 /* which array (rt_download / rt_upload_row / rt_device_ptr) */
 #define RT_Y 0 /* intercepts, element-normal frame, relative to vertex */

@@ -96,6 +96,9 @@ struct rt_ctx {
     int opt_lds; /* bytes of unused dynamic LDS per workgroup (occupancy) */
     /* per row of I: 0 = materialised, 1 = identical to U[j-1], 2 = to U[j] */
     unsigned char i_alias[RT_MAX_SURFACES];
+    /* per row of U: 1 = identical to I[j] (RT_F_SKIP_U), not materialised */
+    unsigned char u_alias[RT_MAX_SURFACES];
+    int table_clip; /* clip the device table was finalised for */
 
     /* multi GPU */
     ncclComm_t comm;
@@ -152,11 +155,28 @@ static inline int rt_ncomp(int which) { return which == RT_T ? 1 : 3; }
 /* device address of one surface row, resolving the I -> U aliasing */
 static inline double *rt_row(const rt_ctx *c, int which, int surf)
 {
-    if (which == RT_I && c->i_alias[surf]) {
-        const int src = c->i_alias[surf] == 1 ? surf - 1 : surf;
-        return rt_arr(c, RT_U) + (size_t)src * 3 * c->ld;
-    }
+    if (which == RT_I && c->i_alias[surf])
+        return rt_row(c, RT_U, c->i_alias[surf] == 1 ? surf - 1 : surf);
+    if (which == RT_U && c->u_alias[surf])
+        return rt_row(c, RT_I, surf); /* surf >= 1, and I[surf] never points
+                                         back at U[surf] there */
     return rt_arr(c, which) + (size_t)surf * rt_ncomp(which) * c->ld;
+}
+
+/* give row `surf` of U or I its own copy of the data it is served from (a
+ * kernel is about to read it at its natural address, or the row it is served
+ * from is about to be overwritten) */
+static int rt_detach(rt_ctx *c, int which, int surf)
+{
+    unsigned char *alias = which == RT_U ? c->u_alias : c->i_alias;
+    if ((which != RT_U && which != RT_I) || !alias[surf])
+        return RT_OK;
+    const double *src = rt_row(c, which, surf);
+    alias[surf] = 0;
+    double *dst = rt_row(c, which, surf);
+    RT_HIP(c, hipMemcpyAsync(dst, src, (size_t)3 * c->ld * sizeof(double),
+                             hipMemcpyDeviceToDevice, c->stream));
+    return RT_OK;
 }
 
 template <int R, bool NT, bool XCD>
@@ -375,6 +395,7 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     ctx->buf_nsurf = ctx->nsurf;
     ctx->traced = 0;
     memset(ctx->i_alias, 0, sizeof ctx->i_alias);
+    memset(ctx->u_alias, 0, sizeof ctx->u_alias);
     memset(ctx->valid, 0, sizeof ctx->valid);
     return RT_OK;
 }
@@ -419,6 +440,7 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
                            !ctx->opt_alias, period);
     RT_HIP(ctx, hipGetLastError());
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
+    ctx->u_alias[0] = 0;
     ctx->valid[0] = 1;
     return RT_OK;
 }
@@ -645,6 +667,7 @@ int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
     ctx->traced = 1;
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0;
+    ctx->u_alias[0] = 0;
     ctx->valid[0] = 1;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
@@ -713,8 +736,22 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
         return rt_fail(ctx, RT_ERR_STATE, "rt_upload_row: no such row %d",
                        surf);
     const int nc = rt_ncomp(which);
+    /* rows served from the one being replaced keep what they show now */
+    if (which == RT_U && surf + 1 < ctx->buf_nsurf && ctx->valid[surf + 1] &&
+        ctx->i_alias[surf + 1] == 1) {
+        int rc = rt_detach(ctx, RT_I, surf + 1);
+        if (rc != RT_OK)
+            return rc;
+    }
+    if (which == RT_I && ctx->u_alias[surf]) {
+        int rc = rt_detach(ctx, RT_U, surf);
+        if (rc != RT_OK)
+            return rc;
+    }
     if (which == RT_I)
         ctx->i_alias[surf] = 0; /* now holds its own data */
+    if (which == RT_U)
+        ctx->u_alias[surf] = 0;
     ctx->valid[surf] = 1;
     double *dst = rt_row(ctx, which, surf);
     RT_HIP(ctx, hipMemcpy2DAsync(dst, ctx->ld * sizeof(double), src_soa,
@@ -753,6 +790,19 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
                        "multiple of %d rays", (long long)ctx->n, ctx->ngroups,
                        64 * ctx->opt_r);
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->table_clip != (clip != 0))
+        ctx->table_dirty = 1; /* what is stored depends on clip (SKIP_U) */
+    /* the kernel reads the seed rows at their natural address, and rows
+     * beyond `stop` that are served from a row about to be rewritten keep
+     * what they show now */
+    {
+        int rc = rt_detach(ctx, RT_U, start - 1);
+        if (rc == RT_OK && stop < ctx->buf_nsurf && ctx->valid[stop] &&
+            ctx->i_alias[stop] == 1)
+            rc = rt_detach(ctx, RT_I, stop);
+        if (rc != RT_OK)
+            return rc;
+    }
     if (ctx->table_dirty) {
         /* a kernel in flight may still read the device table, and the pinned
          * staging copy must not change under a pending DMA */
@@ -762,7 +812,15 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
         for (int jj = 0; jj < ntab; ++jj) {
             const int j = jj % ctx->nsurf; /* element index in its group */
             unsigned f = ctx->h_stage[jj].flags &
-                         ~(RT_F_STORE_I | RT_F_NOSTORE);
+                         ~(RT_F_STORE_I | RT_F_NOSTORE | RT_F_SKIP_U);
+            /* u[j] == i[j] bit for bit where no table bends the ray at j and
+             * nothing clips it */
+            bool bends = false;
+            for (int g = 0; g < ctx->ngroups; ++g)
+                bends = bends || (ctx->h_surf[(size_t)g * ctx->nsurf + j].flags &
+                                  RT_F_REFRACT);
+            if (ctx->opt_alias && !clip && !bends && j > 0)
+                f |= RT_F_SKIP_U;
             if (!ctx->keep[j])
                 f |= RT_F_NOSTORE;
             /* i[j] == u[j-1] bit for bit unless j or j-1 is tilted; it can
@@ -781,6 +839,7 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
                                    hipMemcpyHostToDevice, ctx->stream));
         ctx->table_dirty = 0;
         ctx->table_start = start;
+        ctx->table_clip = clip != 0;
     } else if (ctx->table_start != start) {
         ctx->table_dirty = 1; /* alias decisions depend on start */
         return rt_trace(ctx, start, stop, clip);
@@ -807,6 +866,7 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
         const unsigned f = ctx->h_stage[sidx].flags;
         ctx->valid[sidx] = !(f & RT_F_NOSTORE);
         ctx->i_alias[sidx] = (f & (RT_F_STORE_I | RT_F_NOSTORE)) ? 0 : 1;
+        ctx->u_alias[sidx] = (f & RT_F_SKIP_U) && !(f & RT_F_NOSTORE);
     }
     ctx->traced = 1;
     return RT_OK;
@@ -996,10 +1056,10 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
                            "rt_set_keep_rows, or not traced yet)", j);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     int rc = RT_OK;
-    if (which != RT_I) {
+    if (which == RT_Y || which == RT_T) {
         rc = rt_rows_to_host(ctx, dst, rt_row(ctx, which, surf_lo),
                              (size_t)(surf_hi - surf_lo) * nc);
-    } else { /* rows of I may live in U (aliasing): one by one */
+    } else { /* rows of I may live in U and rows of U in I: one by one */
         for (int j = surf_lo; j < surf_hi && rc == RT_OK; ++j)
             rc = rt_rows_to_host(ctx,
                                  dst + (size_t)(j - surf_lo) * nc * ctx->n,
@@ -1273,6 +1333,9 @@ int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t bytes = (size_t)ctx->n * 3 * sizeof(double);
     rc = rt_need_scratch(ctx, bytes);
+    if (rc != RT_OK)
+        return rc;
+    rc = rt_detach(ctx, RT_U, args->after); /* read at its natural address */
     if (rc != RT_OK)
         return rc;
     const unsigned grid = (unsigned)((ctx->n + 255) / 256);

@@ -118,7 +118,8 @@ __device__ __forceinline__ void rt_store_rows(
             d[r] = iv[r][c];
         }
         rt_store<R, NT>(Y + (row + c) * ld + j, a);
-        rt_store<R, NT>(U + (row + c) * ld + j, b);
+        if (!(flags & RT_F_SKIP_U))
+            rt_store<R, NT>(U + (row + c) * ld + j, b);
         if (flags & RT_F_STORE_I)
             rt_store<R, NT>(I + (row + c) * ld + j, d);
     }

@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rayopt_amd as ra
 from rayopt_amd import prescriptions as P
-from rayopt_amd._lib import F_ROTATED
+from rayopt_amd._lib import F_ROTATED, F_REFRACT
 from rayopt_amd.bundles import disc_bundle, multi_field_bundle
 from rayopt_amd.pack import pack_system
 
@@ -25,8 +25,11 @@ def run(name, system, y, u, l, clip, reps=60):
     n, S = y.shape[0], len(system) - 1
     table, _ = pack_system(system, g.l, g.n[0])
     rot = (table["flags"] & F_ROTATED) != 0
+    bends = (table["flags"] & F_REFRACT) != 0
     stored_i = sum(1 for j in range(1, S + 1) if rot[j] or rot[j - 1])
-    nbytes = n*(56*S + 24*stored_i + 48)
+    skipped_u = 0 if clip else sum(1 for j in range(1, S + 1)
+                                   if not bends[j])
+    nbytes = n*(56*S + 24*stored_i - 24*skipped_u + 48)
     dead = float(np.isnan(np.asarray(g.u[-1])[:, 0]).mean())
     print(json.dumps(dict(config=name, rays=n, surfaces=S, clip=clip,
                           kernel_ms=ms, ops_per_s=n*S/ms*1e3,

@@ -759,3 +759,88 @@ def test_repeated_traces_with_wavelength_groups():
         assert np.array_equal(np.asarray(h.y[-1]),
                               ref[0][-1][w*len(y):(w + 1)*len(y)],
                               equal_nan=True)
+
+
+# -- u[j] served from i[j] for unclipped traces (RT_F_SKIP_U) ----------------
+
+@pytest.mark.gpu
+def test_u_rows_of_unbending_elements_are_served_not_stored():
+    """Unclipped trace: u at the stop and the image is i bit for bit and is
+    not written; every consumer still sees the reference's values -- full
+    download, toggling clip, keep=[-1], partial re-propagation on either
+    side of such a row, rows beyond `stop` keeping their old content."""
+    from oracle import build_c
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    L = len(system)
+    stop = system.stop
+    y, u = ra.bundles.disc_bundle(200_003, 17., 10., 3,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    table, _ = pack_system(system, g.l, g.n[0])
+
+    def check(clip, rows=slice(1, None)):
+        want = build_c.propagate(table, y, u, clip=clip)
+        for name, b in zip("yuit", want):
+            a = np.asarray(getattr(g, name))[1:]
+            assert np.array_equal(a[rows.start - 1:], b[rows.start - 1:],
+                                  equal_nan=True), (name, clip)
+        return want
+
+    for clip in (False, True, False, False, True):
+        g.propagate(clip=clip)
+        check(clip)
+    # device pointers of the served rows resolve to stored data
+    g.propagate(clip=False)
+    eng = g.engine
+    assert eng.device_ptr(1, stop) == eng.device_ptr(2, stop)   # U -> I
+    assert eng.device_ptr(1, stop) == eng.device_ptr(1, stop - 1)
+    for alias in (0, 1):
+        eng.set_option("alias_i", alias)
+        g.propagate(clip=False)
+        old = check(False)
+    # image row only
+    g.propagate(clip=False, keep=[-1])
+    assert np.array_equal(np.asarray(g.u[-1]), old[1][-1], equal_nan=True)
+    assert np.array_equal(np.asarray(g.i[-1]), old[2][-1], equal_nan=True)
+    # seed from a served row: re-trace the rear half from the stop
+    g.propagate(clip=False)
+    g.propagate(start=stop + 1, clip=False)
+    check(False)
+    # rewrite the front half of a CHANGED system up to (not including) the
+    # stop: rows from the stop on keep the old trace, as in the reference
+    system[2].curvature *= 1.02
+    g.propagate(stop=stop, clip=False)
+    table2, _ = pack_system(system, g.l, g.n[0])
+    new = build_c.propagate(table2, y, u, clip=False)
+    for k, name in enumerate("yui"):
+        a = np.asarray(getattr(g, name))[1:]
+        assert np.array_equal(a[:stop - 1], new[k][:stop - 1], equal_nan=True)
+        assert np.array_equal(a[stop - 1:], old[k][stop - 1:],
+                              equal_nan=True), name
+        assert not np.array_equal(new[k][stop - 2], old[k][stop - 2],
+                                  equal_nan=True)
+    assert L - 1 > stop
+
+
+@pytest.mark.gpu
+def test_opd_reference_row_served_from_i():
+    """opd(after=stop): the kernel reads U[after] at its natural address, so
+    a served row is given its own copy first; same numbers as with every row
+    materialised."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    y, u = ra.bundles.disc_bundle(50_000, 10., 0., 3,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    out = []
+    for alias in (1, 0):
+        g = ra.GeometricTrace(system)
+        g.engine.set_option("alias_i", alias)
+        g.rays_given(y, u)
+        g.propagate(clip=False)
+        out.append(g.opd(radius=80., after=system.stop, resample=0))
+        # the row is still right after having been given its own storage
+        want = np.asarray(g.i[system.stop])
+        assert np.array_equal(np.asarray(g.u[system.stop]), want,
+                              equal_nan=True)
+    for a, b in zip(*out):
+        assert np.array_equal(a, b, equal_nan=True)
