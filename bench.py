@@ -36,6 +36,8 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   full_i        (--extras) the same timed loop with every row of `i`
                 materialised (rt_set_option alias_i=0): the 80 B/op figure of
                 SURVEY 8(d)
+  unclipped     (--extras) the same timed loop with clip=False, the
+                reference's default
   image_row_only (--extras) propagate(keep=[-1]): the FP64 side of the kernel
   cpu_baseline  the numpy port of the reference path (oracle/trace_numpy.py,
                 same whole-array numpy operations as rayopt) timed on this
@@ -336,8 +338,10 @@ def main():
         else:
             eng.gather_final(RT_Y, L - 1, counts, 0, d_dst)
 
+    mode = {"clip": clip}
+
     def step():
-        eng.trace(1, 0, clip)
+        eng.trace(1, 0, mode["clip"])
         if dist_mode and args.gather_every_step:
             gather()
 
@@ -381,6 +385,14 @@ def main():
         e_img, ev_img, _ = timed_loop()
         image_only = (e_img, ev_img/args.steps)
         eng.set_keep_rows(None)
+    unclipped = None
+    if args.extras and not dist_mode and not args.option and clip:
+        # the reference's default: propagate(clip=False); the u rows of the
+        # elements that do not bend the ray are not written either
+        mode["clip"] = False
+        e_nc, ev_nc, _ = timed_loop()
+        unclipped = (e_nc, ev_nc/args.steps)
+        mode["clip"] = clip
     full_i = None
     if args.extras and not dist_mode and not any(kv.startswith("alias_i")
                                                  for kv in args.option):
@@ -504,6 +516,21 @@ def main():
             "achieved": b_full/(k_full*1e-3)/1e9,
             "frac": b_full/(k_full*1e-3)/1e9/HBM_PEAK_GBS,
             "note": "every row of i materialised (alias_i=0): 80 B per op",
+        }
+
+    if unclipped is not None:
+        e_nc, k_nc = unclipped
+        b_nc = n*(56*S + 24*stored_i + 48 - 24*sum(
+            1 for j in range(1, L) if alias_on and not bends[j]))
+        out["unclipped"] = {
+            "value": total_rays*S*args.steps/e_nc,
+            "kernel_ms": k_nc,
+            "algorithmic_bytes_per_launch": b_nc,
+            "achieved": b_nc/(k_nc*1e-3)/1e9,
+            "frac": b_nc/(k_nc*1e-3)/1e9/HBM_PEAK_GBS,
+            "note": "propagate(clip=False), the reference's default: u rows "
+                    "of stop and image are i rows bit for bit and are not "
+                    "written",
         }
 
     if image_only is not None:
