@@ -63,6 +63,7 @@ class FieldAimer:
         self.tol = tol
         self.maxiter = maxiter
         self.on_device = on_device
+        self.packed = None      # (tables, n) of the last device aiming
 
     # one trace of F rays: field f through pupil point yp with (z_f, a_f)
     def _stop_xy(self, yo, yp, z, a, last):
@@ -182,9 +183,10 @@ class FieldAimer:
         from .launch import aim_seeds
         from .pack import pack_system
         system = self.system
-        tables = np.stack([
-            pack_system(system, l, system.refractive_index(l, 0))[0]
-            for l in wavelengths])
+        packs = [pack_system(system, l, system.refractive_index(l, 0))
+                 for l in wavelengths]
+        tables = np.stack([t for t, _ in packs])
+        self.packed = (tables, np.stack([n for _, n in packs]))
         engine = self.trace.engine
         engine.upload_system(tables)
         args = np.zeros((), dtype=AIM_ARGS_DTYPE)

@@ -192,10 +192,16 @@ class GeometricTrace(Trace):
         self.rays_alive_per_field = None
         self.rays_per_group = None
 
-    def _upload_table(self, start, stop, n_init):
+    def _upload_table(self, start, stop, n_init, packed=None):
         """Pack + hand over the surface table(s): one per wavelength when
-        ``self.l`` is a sequence (ray groups), returns (tables, n)."""
-        if np.ndim(self.l) == 0:
+        ``self.l`` is a sequence (ray groups), returns (tables, n).
+        ``packed``: tables a caller packed a moment ago for the same
+        wavelength(s) and the full range (the aimer's), reused as they are."""
+        if packed is not None:
+            table, ns = packed
+            if np.ndim(self.l) == 0 and table.ndim == 2:
+                table, ns = table[0], ns[0]
+        elif np.ndim(self.l) == 0:
             table, ns = pack_system(self.system, self.l, n_init, start, stop)
         else:
             packed = [pack_system(self.system, l, n0, start, stop)
@@ -310,7 +316,7 @@ class GeometricTrace(Trace):
         for rows in (self.y, self.u, self.i, self.t):
             rows.invalidate(0, self.length)
 
-    def rays_fields(self, yo, yp, z, a, l=None, ref=0):
+    def rays_fields(self, yo, yp, z, a, l=None, ref=0, _packed=None):
         """Launch ``len(yo) x len(yp)`` rays built on the GPU: for every
         field point ``yo[f]`` (fractional object coordinates) the bundle
         through the pupil coordinates ``yp`` (P,2), as
@@ -355,11 +361,11 @@ class GeometricTrace(Trace):
         if groups:
             self.n = np.empty((groups, self.length))
             self.n[:, 0] = [self.system.refractive_index(li, 0) for li in l]
-            self._upload_table(1, None, self.n[:, 0])
+            self._upload_table(1, None, self.n[:, 0], _packed)
         else:
             self.n = np.empty(self.length)
             self.n[0] = self.system.refractive_index(l, 0)
-            self._upload_table(1, None, self.n[0])
+            self._upload_table(1, None, self.n[0], _packed)
         self.engine.generate_rays(fields, yp)
         self.engine.set_weights(None)
         for rows in (self.y, self.u, self.i, self.t):
@@ -389,19 +395,21 @@ class GeometricTrace(Trace):
         ref, yp, weight = pupil_distribution(distribution, nrays)
         l = self.system.wavelengths[0] if wavelength is None else wavelength
         alive = len(yp)
+        packed = None
         if np.ndim(l) == 0:
             if aim:
-                z, a = FieldAimer(self.system, l, self._aux_engine()).pupil(
-                    fields, rim=rim)
+                aimer = FieldAimer(self.system, l, self._aux_engine())
+                z, a = aimer.pupil(fields, rim=rim)
+                packed = aimer.packed
             else:
                 z, a = entrance_pupil(self.system, l)
             copies = len(fields)
         else:
             l = np.asarray(l, dtype=float)
             if aim:
-                z, a = FieldAimer(self.system, l[0],
-                                  self._aux_engine()).pupils(fields, l,
-                                                             rim=rim)
+                aimer = FieldAimer(self.system, l[0], self._aux_engine())
+                z, a = aimer.pupils(fields, l, rim=rim)
+                packed = aimer.packed
             else:
                 za = [entrance_pupil(self.system, li) for li in l]
                 z = [np.broadcast_to(zi, (len(fields),)) for zi, _ in za]
@@ -413,7 +421,7 @@ class GeometricTrace(Trace):
                     weight = np.ones(alive)/alive
                 weight = np.concatenate([weight, np.zeros(pad)])
             copies = len(fields)*len(l)
-        self.rays_fields(fields, yp, z, a, l, ref=ref)
+        self.rays_fields(fields, yp, z, a, l, ref=ref, _packed=packed)
         if weight is not None:
             self.w = np.tile(weight, copies)
             self._uniform_w = False
