@@ -25,6 +25,7 @@ space.
 import numpy as np
 
 from .geometric_trace import GeometricTrace
+from .launch import _telecentric
 
 
 def entrance_pupil(system, l=None):
@@ -80,6 +81,9 @@ class FieldAimer:
         rad = self.system[stop].radius
         z0 = np.broadcast_to(np.asarray(z0, dtype=float), (len(yo),))
         todo = ~np.all(np.isclose(yo, 0), axis=1)   # on-axis: nothing to aim
+        obj = self.system.object
+        if obj.finite and _telecentric(obj):        # system.py:509-510
+            todo[:] = False
         if not todo.any():
             return z0.copy()
 

@@ -117,8 +117,11 @@ RT_HD int rt_aim_chief(const rt_surface *__restrict__ tab,
 {
     const double z0 = sd->z0;
     *z = z0;
-    /* np.isclose(yo, 0): on axis there is nothing to aim */
-    if (fabs(sd->yo[0]) <= 1e-8 && fabs(sd->yo[1]) <= 1e-8)
+    /* np.isclose(yo, 0): on axis there is nothing to aim; nor for a
+     * telecentric object, whose chief rays do not depend on the pupil
+     * distance (aim_chief, system.py:509-510) */
+    if ((fabs(sd->yo[0]) <= 1e-8 && fabs(sd->yo[1]) <= 1e-8) ||
+        (sd->finite && sd->telecentric))
         return 0;
     const double rad = sqrt(tab[g->stop].radius2);
     rt_field F;

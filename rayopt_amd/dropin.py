@@ -7,7 +7,9 @@ while the ray-generation helpers that only *call* ``rays_given``/``propagate``
 print_trace`` (rayopt/geometric_trace.py:185-259) -- are taken from the
 installed rayopt unchanged, so aiming, pupils and conjugates keep running
 rayopt's own host code.  ``rayopt.GeometricTrace`` and the name imported by
-``rayopt.analysis`` are rebound, so ``Analysis`` traces on the GPU too.
+``rayopt.analysis`` are rebound, so ``Analysis`` traces on the GPU too; with
+``aim=True`` (default) ``System.pupil`` -- ~130 serial one-ray traces per
+field in the reference -- is answered by the aiming kernel.
 """
 import numpy as np
 
@@ -44,7 +46,41 @@ def modernize(rayopt=None):
         Axis.set_smart_bounds = lambda self, value: None
 
 
-def accelerate(rayopt, install=True, engine_factory=None):
+def _device_pupil(reference_pupil, engine_factory):
+    """``System.pupil`` (rayopt/system.py:585-593) with the root finding of
+    ``_aim_pupil`` done by the aiming kernel: same starting values (the
+    object pupil the paraxial trace left in ``system.object.pupil``), same
+    return value ``(z, a[2][2])``; the reference's own code handles what the
+    kernel does not model (``pupil.aim`` off, an explicit ``stop`` index)."""
+    from .aiming import FieldAimer
+    from .engine import get_engine
+
+    def pupil(self, yo, l=None, stop=None, **kwargs):
+        pup = self.object.pupil
+        if stop not in (None, -1) or not pup.aim or kwargs:
+            return reference_pupil(self, yo, l=l, stop=stop, **kwargs)
+        cache = self.__dict__.setdefault("_mi355_pupils", {})
+        key = (l, stop, float(yo[0]), float(yo[1]), float(pup.distance),
+               float(pup.radius), len(self))
+        if key not in cache:
+            engine = engine_factory() if engine_factory else get_engine()
+            aimer = FieldAimer(self, self.wavelengths[0] if l is None else l,
+                               engine=engine)
+            z, a = aimer.pupil([yo], float(pup.distance), float(pup.radius),
+                               rim=(stop == -1))
+            cache[key] = (float(z[0]), a[0])
+        z, a = cache[key]
+        return z, a.copy()
+    pupil._mi355 = True
+    pupil._reference = reference_pupil
+    return pupil
+
+
+def accelerate(rayopt, install=True, engine_factory=None, aim=True):
+    if install and aim and not getattr(rayopt.system.System.pupil, "_mi355",
+                                       False):
+        rayopt.system.System.pupil = _device_pupil(
+            rayopt.system.System.pupil, engine_factory)
     ref_cls = rayopt.geometric_trace.GeometricTrace
     if getattr(ref_cls, "_mi355", False):
         return ref_cls
@@ -77,6 +113,9 @@ def accelerate(rayopt, install=True, engine_factory=None):
 
 
 def restore(rayopt):
+    pupil = rayopt.system.System.pupil
+    if getattr(pupil, "_mi355", False):
+        rayopt.system.System.pupil = pupil._reference
     cls = rayopt.geometric_trace.GeometricTrace
     ref = getattr(cls, "_reference_class", None)
     if ref is not None:

@@ -122,7 +122,7 @@ def test_multi_wavelength_groups_glue(ro):
         g.rays_given(y[:100], u[:100], ls)
 
 
-def _run_analysis(ro, engine_factory):
+def _run_analysis(ro, engine_factory, aim=True):
     """rayopt's own top-level consumer (rayopt/analysis.py:78-146: refocus,
     ray fans, spots at five defocus positions, OPD + PSF + encircled energy
     per field, longitudinal aberrations) on the accelerated trace."""
@@ -130,7 +130,7 @@ def _run_analysis(ro, engine_factory):
     matplotlib.use("Agg")
     import matplotlib.pyplot as plt
     dropin.modernize(ro)
-    dropin.accelerate(ro, engine_factory=engine_factory)
+    dropin.accelerate(ro, engine_factory=engine_factory, aim=aim)
     s = ro.system_from_yaml(
         ra.prescriptions.cooke().replace("radius: 20.", "radius: 0.364"))
     s.update()
@@ -148,11 +148,15 @@ def _run_analysis(ro, engine_factory):
     return s[-1].distance - before
 
 
-def test_reference_analysis_runs_on_the_accelerated_trace(ro):
+@pytest.mark.parametrize("aim", [False, True])
+def test_reference_analysis_runs_on_the_accelerated_trace(ro, aim):
     """Unmodified Analysis end to end through the swapped-in class (engine
-    double on CPU); the refocus it performs equals the reference's own."""
-    shift = _run_analysis(ro, OracleEngine)
+    double on CPU); the refocus it performs equals the reference's own --
+    exactly with rayopt's own aiming, to its aiming tolerance (1e-3) when
+    System.pupil is answered by the aiming kernel."""
+    shift = _run_analysis(ro, OracleEngine, aim)
     dropin.restore(ro)
+    assert not getattr(ro.system.System.pupil, "_mi355", False)
     s = ro.system_from_yaml(
         ra.prescriptions.cooke().replace("radius: 20.", "radius: 0.364"))
     s.update()
@@ -161,7 +165,43 @@ def test_reference_analysis_runs_on_the_accelerated_trace(ro):
     t.rays_point((0, 0.), nrays=13, distribution="radau", clip=False,
                  filter=False)
     t.refocus()
-    assert shift == pytest.approx(s[-1].distance - before, rel=1e-9)
+    assert shift == pytest.approx(s[-1].distance - before,
+                                  rel=1e-3 if aim else 1e-9)
+
+
+def test_device_pupil_behind_the_reference_interface(ro):
+    """accelerate(aim=True): rayopt's System.pupil keeps its signature and
+    return value, agrees with the reference's own solver to its tolerance,
+    satisfies the aiming conditions far more tightly, and falls back to the
+    reference's code for what the kernel does not model."""
+    text = ra.prescriptions.cooke()
+    s = ro.system_from_yaml(text)
+    s.update()
+    ro.ParaxialTrace(s).update_conjugates()
+    want = [s.pupil(yo) for yo in ((0, 0.), (0, .7), (.3, -.4))]
+    rim = s.pupil((0, 1.), stop=-1)
+    dropin.accelerate(ro, engine_factory=OracleEngine)
+    s2 = ro.system_from_yaml(text)
+    s2.update()
+    ro.ParaxialTrace(s2).update_conjugates()
+    for yo, (z, a) in zip(((0, 0.), (0, .7), (.3, -.4)), want):
+        z2, a2 = s2.pupil(yo)
+        assert a2.shape == (2, 2)
+        assert z2 == pytest.approx(z, rel=5e-3, abs=5e-3*6.25)
+        np.testing.assert_allclose(a2, a, rtol=5e-3)
+        assert s2.pupil(yo)[1] is not a2                 # cached, copied
+    z2, a2 = s2.pupil((0, 1.), stop=-1)
+    np.testing.assert_allclose(a2, rim[1], rtol=5e-3)
+    # the chief ray of the aimed pupil goes through the stop centre
+    g = ro.GeometricTrace(s2)
+    g.rays((0, 1.), np.zeros((1, 2)), None, filter=False)
+    assert np.abs(np.asarray(g.y[s2.stop])[0, :2]).max() < 1e-7
+    # aiming switched off in the prescription: rayopt's own path answers
+    s2.object.pupil.aim = False
+    z3, a3 = s2.pupil((0, .5))
+    assert z3 == s2.object.pupil.distance
+    dropin.restore(ro)
+    assert not getattr(ro.system.System.pupil, "_mi355", False)
 
 
 @pytest.mark.gpu
