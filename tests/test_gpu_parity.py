@@ -844,3 +844,33 @@ def test_opd_reference_row_served_from_i():
                               equal_nan=True)
     for a, b in zip(*out):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_uploaded_rows_do_not_leak_into_rows_served_from_them():
+    """y, u, i are independent arrays in the reference: replacing a row of U
+    (or I) through the C ABI must not change the row of I (or U) that was
+    being served from it."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    stop = system.stop
+    y, u = ra.bundles.disc_bundle(4096, 15., 5., 2,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    g.propagate(clip=False)
+    eng = g.engine
+    U, I = 1, 2
+    old_u = np.array(eng.download(U, 0, len(system)))
+    old_i = np.array(eng.download(I, 0, len(system)))
+    assert np.array_equal(old_i[4], old_u[3])            # served from U[3]
+    assert np.array_equal(old_u[stop], old_i[stop])      # served from I[stop]
+    junk = np.full((3, 4096), 7.25)
+    eng.upload_row(U, 3, junk)
+    assert np.array_equal(eng.download(U, 3, 4)[0], junk)
+    assert np.array_equal(eng.download(I, 4, 5)[0], old_i[4])
+    eng.upload_row(I, stop, junk)
+    assert np.array_equal(eng.download(I, stop, stop + 1)[0], junk)
+    assert np.array_equal(eng.download(U, stop, stop + 1)[0], old_u[stop])
+    # and the next row, served from U[stop], still shows the old direction
+    assert np.array_equal(eng.download(I, stop + 1, stop + 2)[0],
+                          old_i[stop + 1])
