@@ -173,6 +173,11 @@ class GeometricTrace(Trace):
         self.ref = None
         self.l = 1.
         self._reset_bundles()
+        if nrays == 0:      # nothing to trace: plain empty host arrays
+            self.y, self.u, self.i = (np.empty((self.length, 0, 3))
+                                      for _ in range(3))
+            self.t = np.empty((self.length, 0))
+            return
         self.y = DeviceRows(self, RT_Y)
         self.u = DeviceRows(self, RT_U)
         self.i = DeviceRows(self, RT_I)
@@ -217,10 +222,17 @@ class GeometricTrace(Trace):
         """Seed surface 0 (rayopt/geometric_trace.py:49-70)."""
         y, u = np.atleast_2d(y, u)
         y, u = np.broadcast_arrays(y, u)
-        if y.ndim != 2 or y.shape[1] not in (2, 3) or y.shape[0] < 1:
+        if y.ndim != 2 or y.shape[1] not in (2, 3):
             raise ValueError("rays_given: y and u must broadcast to (N,2) or "
                              "(N,3), got %r" % (y.shape,))
         n, m = y.shape
+        if n == 0:          # an empty batch is legal in the reference
+            self.allocate(0)
+            self.l = self.system.wavelengths[0] if l is None else l
+            self.w = np.empty(0) if w is None else np.asarray(w)
+            self.ref = ref
+            self.n[0] = self.system.refractive_index(self.l, 0)
+            return
         if not hasattr(self, "y") or self.nrays != n \
                 or self.length != len(self.system):
             self.allocate(n)
@@ -571,6 +583,10 @@ class GeometricTrace(Trace):
         a, b = resolve_range(self.length, start, stop)
         if a < 1:
             raise ValueError("start must be >= 1")
+        if self.nrays == 0:     # only the indices are there to be filled in
+            self.n[a:b] = pack_system(self.system, self.l, self.n[a - 1],
+                                      a, b)[1][a:b]
+            return
         grouped = np.ndim(self.l) == 1
         packed, self._packed = getattr(self, "_packed", None), None
         if _fresh and packed is not None and packed[0] == (a, b):
@@ -605,6 +621,8 @@ class GeometricTrace(Trace):
         """RMS spot radius at surface ``i`` about the centroid (or ray
         ``ref``), weighted with ``w`` (rayopt/geometric_trace.py:171-183);
         reduced on the GPU, two scalars cross PCIe."""
+        if self.nrays == 0:
+            return 0.       # sqrt of an empty sum, as in the reference
         return self.engine.rms(range(self.length)[i],
                                -1 if ref is None else range(self.nrays)[ref])
 

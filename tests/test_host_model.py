@@ -151,3 +151,25 @@ def test_dispersion_formulas_match_reference():
         1.03961212, 0.00600069867, 0.231792344, 0.0200179144, 1.01046945,
         103.560653], "name": "N-BK7"})
     assert bk7.refractive_index(587.5618e-9) == pytest.approx(1.5168, abs=2e-5)
+
+
+def test_empty_batch_like_the_reference():
+    """Zero rays: legal in the reference (arrays of shape (L,0,3), the index
+    column filled in, rms 0); nothing to run on the device."""
+    s = ra.system_from_yaml(ra.prescriptions.SINGLET)
+    g = ra.GeometricTrace(s)
+    g.rays_given(np.zeros((0, 3)), np.zeros((0, 3)))
+    g.propagate(clip=True)
+    assert g.y.shape == g.u.shape == g.i.shape == (4, 0, 3)
+    assert g.t.shape == (4, 0) and g.nrays == 0
+    assert np.array_equal(g.n, [1., 1.5168, 1., 1.])
+    assert g.rms() == 0.
+    assert g.y[-1, :, :2].shape == (0, 2)
+    if refshim.available():
+        ro = refshim.load()
+        r = ro.system_from_yaml(ra.prescriptions.SINGLET)
+        r.update()
+        t = ro.GeometricTrace(r)
+        t.rays_given(np.zeros((0, 3)), np.zeros((0, 3)))
+        t.propagate(clip=True)
+        assert t.y.shape == g.y.shape and np.array_equal(t.n, g.n)
