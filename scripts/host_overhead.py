@@ -7,7 +7,6 @@ import pstats
 import sys
 import time
 
-import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rayopt_amd as ra

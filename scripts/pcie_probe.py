@@ -1,6 +1,5 @@
 """End-to-end host<->device rates of the boundary (not part of `value`)."""
 import os, sys, time
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rayopt_amd as ra
 from bench import workload_rays

@@ -2,7 +2,6 @@
 vectors of the reference -- at the tolerances the GPU parity tests use.  This
 is how the HIP code's numerics are checked in a container without a GPU; the
 `-m gpu` tests repeat the same comparison through the C ABI on the device."""
-import numpy as np
 import pytest
 
 import rayopt_amd as ra
