@@ -133,8 +133,10 @@ const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: global */
  */
 int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf);
 /*
- * Extension: ngroups surface tables (surf[g*nsurf + j], typically the same
- * geometry evaluated at ngroups wavelengths; <= 16).  The ray batch is then
+ * Extension: ngroups surface tables (surf[g*nsurf + j]: the same geometry
+ * evaluated at ngroups wavelengths, or ngroups variants of a system -- a
+ * tolerancing run, the points of a finite-difference gradient; <= 65535).
+ * The ray batch is then
  * read as ngroups equal, contiguous groups and group g is traced through
  * table g in the same launch; the group size must be a multiple of 64 rays
  * so every wavefront stays inside one group and the table reads remain

@@ -38,7 +38,8 @@
 /* ------------------------------------------------------------------ */
 
 #define RT_NEVENTS 8
-#define RT_MAX_GROUPS 16
+#define RT_MAX_GROUPS 65535 /* surface tables per launch (wavelengths, or
+                               variants of a system: tolerancing runs) */
 
 struct rt_rccl_api {
     void *lib;
@@ -65,6 +66,7 @@ struct rt_ctx {
     rt_surface *d_surf;
     int nsurf;
     rt_surface *h_surf;                 /* [ngroups][nsurf] as given */
+    size_t tab_cap;                     /* entries h_surf/h_stage/d_surf hold */
     int ngroups;                        /* surface tables (wavelengths) */
     rt_surface *h_stage;                /* pinned: flags finalised */
     int table_dirty;
@@ -261,18 +263,15 @@ int rt_create(int device, rt_ctx **out)
             hipEventCreateWithFlags(&c->gathered[i], hipEventDisableTiming));
     }
     c->ngroups = 1;
-    c->h_surf = (rt_surface *)calloc((size_t)RT_MAX_GROUPS * RT_MAX_SURFACES,
-                                     sizeof(rt_surface));
+    c->tab_cap = (size_t)4 * RT_MAX_SURFACES; /* grows in rt_upload_system */
+    c->h_surf = (rt_surface *)calloc(c->tab_cap, sizeof(rt_surface));
     if (!c->h_surf) {
         free(c);
         return rt_fail(NULL, RT_ERR_NOMEM, "rt_create: host allocation");
     }
-    RT_HIP_C(hipMalloc((void **)&c->d_surf, sizeof(rt_surface) *
-                                                RT_MAX_GROUPS *
-                                                RT_MAX_SURFACES));
-    RT_HIP_C(hipHostMalloc((void **)&c->h_stage, sizeof(rt_surface) *
-                                                     RT_MAX_GROUPS *
-                                                     RT_MAX_SURFACES));
+    RT_HIP_C(hipMalloc((void **)&c->d_surf, sizeof(rt_surface) * c->tab_cap));
+    RT_HIP_C(hipHostMalloc((void **)&c->h_stage,
+                           sizeof(rt_surface) * c->tab_cap));
     memset(c->keep, 1, sizeof c->keep);
 #undef RT_HIP_C
     *out = c;
@@ -349,7 +348,29 @@ int rt_upload_system_groups(rt_ctx *ctx, const rt_surface *surf, int nsurf,
                            "terms, limit %d",
                            j % nsurf, surf[j].nasph, RT_MAX_ASPH);
     }
-    memcpy(ctx->h_surf, surf, sizeof(rt_surface) * nsurf * ngroups);
+    const size_t ntab = (size_t)nsurf * ngroups;
+    if (ntab > ctx->tab_cap) {
+        /* the device table may be in use by a kernel in flight, the pinned
+         * one by a pending DMA */
+        RT_HIP(ctx, hipSetDevice(ctx->device));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rt_surface *h = (rt_surface *)calloc(ntab, sizeof(rt_surface));
+        if (!h)
+            return rt_fail(ctx, RT_ERR_NOMEM, "rt_upload_system: %zu tables",
+                           (size_t)ngroups);
+        free(ctx->h_surf);
+        ctx->h_surf = h;
+        (void)hipFree(ctx->d_surf);
+        (void)hipHostFree(ctx->h_stage);
+        ctx->d_surf = NULL;
+        ctx->h_stage = NULL;
+        ctx->tab_cap = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_surf, sizeof(rt_surface) * ntab));
+        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_stage,
+                                  sizeof(rt_surface) * ntab));
+        ctx->tab_cap = ntab;
+    }
+    memcpy(ctx->h_surf, surf, sizeof(rt_surface) * ntab);
     ctx->table_dirty = 1; /* finalised and sent by the next rt_trace */
     ctx->nsurf = nsurf;
     ctx->ngroups = ngroups;
@@ -809,17 +830,17 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const int ntab = ctx->nsurf * ctx->ngroups;
         memcpy(ctx->h_stage, ctx->h_surf, sizeof(rt_surface) * ntab);
+        /* u[j] == i[j] bit for bit where no table bends the ray at j and
+         * nothing clips it */
+        unsigned char bends[RT_MAX_SURFACES] = {0};
+        for (int jj = 0; jj < ntab; ++jj)
+            if (ctx->h_surf[jj].flags & RT_F_REFRACT)
+                bends[jj % ctx->nsurf] = 1;
         for (int jj = 0; jj < ntab; ++jj) {
             const int j = jj % ctx->nsurf; /* element index in its group */
             unsigned f = ctx->h_stage[jj].flags &
                          ~(RT_F_STORE_I | RT_F_NOSTORE | RT_F_SKIP_U);
-            /* u[j] == i[j] bit for bit where no table bends the ray at j and
-             * nothing clips it */
-            bool bends = false;
-            for (int g = 0; g < ctx->ngroups; ++g)
-                bends = bends || (ctx->h_surf[(size_t)g * ctx->nsurf + j].flags &
-                                  RT_F_REFRACT);
-            if (ctx->opt_alias && !clip && !bends && j > 0)
+            if (ctx->opt_alias && !clip && !bends[j] && j > 0)
                 f |= RT_F_SKIP_U;
             if (!ctx->keep[j])
                 f |= RT_F_NOSTORE;

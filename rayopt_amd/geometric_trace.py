@@ -192,17 +192,26 @@ class GeometricTrace(Trace):
         return type(self.engine)()
 
     def _reset_bundles(self):
-        """Forget the bundle layout of an earlier rays_points()."""
+        """Forget the bundle layout of an earlier rays_points() and the
+        system variants of an earlier rays_variants()."""
         self.rays_per_field = None
         self.rays_alive_per_field = None
         self.rays_per_group = None
+        self._variants = None
 
     def _upload_table(self, start, stop, n_init, packed=None):
         """Pack + hand over the surface table(s): one per wavelength when
         ``self.l`` is a sequence (ray groups), returns (tables, n).
         ``packed``: tables a caller packed a moment ago for the same
         wavelength(s) and the full range (the aimer's), reused as they are."""
-        if packed is not None:
+        variants = getattr(self, "_variants", None)
+        if variants is not None:
+            # the batch holds one group of rays per system variant
+            packed = [pack_system(v, self.l, n0, start, stop)
+                      for v, n0 in zip(variants, n_init)]
+            table = np.stack([t for t, _ in packed])
+            ns = np.stack([n for _, n in packed])
+        elif packed is not None:
             table, ns = packed
             if np.ndim(self.l) == 0 and table.ndim == 2:
                 table, ns = table[0], ns[0]
@@ -308,6 +317,56 @@ class GeometricTrace(Trace):
         self._upload_table(1, None, self.n[:, 0])
         self.engine.set_rays_repeat(y0, u0, groups)
         self.engine.set_weights(None if self._uniform_w else w)
+        for rows in (self.y, self.u, self.i, self.t):
+            rows.invalidate(0, self.length)
+
+    def rays_variants(self, y, u, variants, l=None, w=None, ref=0):
+        """The same P rays through V variants of the system in ONE trace
+        (extension): a tolerancing run (V perturbed copies), the points of a
+        finite-difference gradient, a design family.  ``variants``: sequence
+        of V systems with the same number of elements as ``self.system``
+        (e.g. deep copies with perturbed curvatures, thicknesses, tilts,
+        glasses); they are packed again on every ``propagate()``, like
+        ``self.system`` is.  The batch holds V groups, ray ``v*P' + p`` is ray
+        ``p`` in variant ``v``; ``P'`` = P padded with dead (NaN, weight 0)
+        rays to a multiple of 64 (``rays_per_group``; ``rays_alive_per_group``
+        = P).  ``n`` becomes (V, L); ``spot_stats()`` / ``rms_fields()`` give
+        one row per variant."""
+        y, u = np.atleast_2d(y, u)
+        y, u = np.broadcast_arrays(y, u)
+        p, m = y.shape
+        variants = list(variants)
+        nv = len(variants)
+        if nv < 1 or any(len(v) != len(self.system) for v in variants):
+            raise ValueError("rays_variants: every variant needs %d elements"
+                             % len(self.system))
+        pp = p + (-p % 64)
+        n = pp*nv
+        if not hasattr(self, "y") or self.nrays != n \
+                or self.length != len(self.system):
+            self.allocate(n)
+        self._reset_bundles()
+        y0 = np.full((pp, 3), np.nan)
+        y0[:p] = 0.
+        y0[:p, :m] = y
+        u0 = np.full((pp, 3), np.nan)
+        u0[:p, :m] = u
+        if m < 3:
+            u0[:p, 2] = np.sqrt(1 - np.square(u0[:p, :2]).sum(-1))
+        self.l = self.system.wavelengths[0] if l is None else l
+        wp = np.zeros(pp)
+        wp[:p] = 1./p if w is None else w
+        self.w = np.tile(wp, nv)
+        self._uniform_w = False
+        self.ref = ref
+        self._variants = variants
+        self.rays_per_group = pp
+        self.rays_alive_per_field = p     # what rms_fields(lost=...) counts
+        self.n = np.empty((nv, self.length))
+        self.n[:, 0] = [v.refractive_index(self.l, 0) for v in variants]
+        self._upload_table(1, None, self.n[:, 0])
+        self.engine.set_rays_repeat(y0, u0, nv)
+        self.engine.set_weights(self.w)
         for rows in (self.y, self.u, self.i, self.t):
             rows.invalidate(0, self.length)
 
@@ -587,7 +646,7 @@ class GeometricTrace(Trace):
             self.n[a:b] = pack_system(self.system, self.l, self.n[a - 1],
                                       a, b)[1][a:b]
             return
-        grouped = np.ndim(self.l) == 1
+        grouped = np.ndim(self.l) == 1 or self._variants is not None
         packed, self._packed = getattr(self, "_packed", None), None
         if _fresh and packed is not None and packed[0] == (a, b):
             # called by a compound method right after its own seeding: the

@@ -874,3 +874,42 @@ def test_uploaded_rows_do_not_leak_into_rows_served_from_them():
     # and the next row, served from U[stop], still shows the old direction
     assert np.array_equal(eng.download(I, stop + 1, stop + 2)[0],
                           old_i[stop + 1])
+
+
+@pytest.mark.gpu
+def test_system_variants_in_one_trace_gpu():
+    from test_host_model import _variants_checks
+    _variants_checks(lambda s: ra.GeometricTrace(s))
+
+
+@pytest.mark.gpu
+def test_two_thousand_variants_one_launch():
+    """A tolerancing run: 2000 perturbed triplets x 192 rays in one launch
+    (one surface table per variant); spot statistics per variant against
+    the oracle on a sample of them."""
+    import copy
+    from oracle import build_c
+    from oracle import consumers_numpy as cn
+    base = ra.system_from_yaml(ra.prescriptions.cooke())
+    rng = np.random.default_rng(3)
+    variants = []
+    for v in range(2000):
+        s = copy.deepcopy(base)
+        for el in s[1:-1]:
+            el.curvature *= 1 + 2e-3*rng.standard_normal()
+        variants.append(s)
+    y, u = ra.bundles.disc_bundle(192, 4., 8., 1)
+    g = ra.GeometricTrace(base)
+    g.rays_variants(y, u, variants)
+    g.propagate(clip=True, keep=[-1])
+    stats = g.spot_stats()
+    assert stats.shape == (2000, 6) and g.kernel_ms() < 5.
+    rows = np.asarray(g.y[-1]).reshape(2000, 192, 3)
+    for v in (0, 1, 777, 1999):
+        table, _ = pack_system(variants[v], g.l, g.n[v, 0])
+        want = build_c.propagate(table, y, u, clip=True)[0][-1]
+        assert np.array_equal(rows[v], want, equal_nan=True)
+        ref = cn.spot_stats(want, 192)[0]
+        assert stats[v, 0] == ref[0]
+        np.testing.assert_allclose(stats[v, 1:5], ref[1:5], rtol=1e-9)
+    assert np.std(np.sqrt(stats[:, 3])) > 0

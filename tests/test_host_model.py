@@ -173,3 +173,57 @@ def test_empty_batch_like_the_reference():
         t.rays_given(np.zeros((0, 3)), np.zeros((0, 3)))
         t.propagate(clip=True)
         assert t.y.shape == g.y.shape and np.array_equal(t.n, g.n)
+
+
+def _variants_checks(make_trace):
+    """rays_variants: V perturbed systems in one trace == V separate traces,
+    ray for ray; one statistics row per variant; re-propagation re-packs the
+    variants (they are mutable like the system itself)."""
+    import copy
+    base = ra.system_from_yaml(ra.prescriptions.cooke())
+    rng = np.random.default_rng(8)
+    variants = []
+    for v in range(7):
+        s = copy.deepcopy(base)
+        for el in s[1:-1]:
+            el.curvature *= 1 + 1e-3*rng.standard_normal()
+            el.distance += 1e-2*rng.standard_normal()
+        s[3].angles = (1e-3*rng.standard_normal(), 0., 0.)      # a tilt
+        variants.append(s)
+    y, u = ra.bundles.disc_bundle(100, 4., 5., 2)        # pads to 128
+    g = make_trace(base)
+    g.rays_variants(y, u, variants)
+    for clip in (False, True):
+        g.propagate(clip=clip)
+        P = g.rays_per_group
+        assert P == 128 and g.nrays == 7*P and g.n.shape == (7, len(base))
+        rms = g.rms_fields(lost="omit")
+        assert rms.shape == (7,)
+        for v, s in enumerate(variants):
+            h = make_trace(s)
+            h.rays_given(y, u)
+            h.propagate(clip=clip)
+            for name in "yuit":
+                a = np.asarray(getattr(g, name))[:, v*P:v*P + 100]
+                assert np.array_equal(a, np.asarray(getattr(h, name)),
+                                      equal_nan=True), (name, v, clip)
+            assert np.array_equal(g.n[v], h.n)
+            spot = np.asarray(h.y[-1])[:, :2]
+            spot = spot[np.isfinite(spot[:, 0])]
+            want = np.sqrt(np.square(spot - spot.mean(0)).sum(1).mean())
+            assert rms[v] == pytest.approx(want, rel=1e-9)
+        dead = np.asarray(g.y[-1]).reshape(7, P, 3)[:, 100:]
+        assert np.isnan(dead).all()
+    assert len(set(np.round(rms, 9))) == 7               # they do differ
+    variants[2][-1].distance += 0.5                      # edit, re-trace
+    before = g.rms_fields(lost="omit")[2]
+    g.propagate(clip=True)
+    assert g.rms_fields(lost="omit")[2] != before
+    g.rays_given(y, u)                                   # back to one system
+    g.propagate()
+    assert np.ndim(g.n) == 1 and g.nrays == 100
+
+
+def test_system_variants_in_one_trace_host_logic():
+    from fake_engine import OracleEngine
+    _variants_checks(lambda s: ra.GeometricTrace(s, engine=OracleEngine()))
