@@ -830,12 +830,18 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const int ntab = ctx->nsurf * ctx->ngroups;
         memcpy(ctx->h_stage, ctx->h_surf, sizeof(rt_surface) * ntab);
-        /* u[j] == i[j] bit for bit where no table bends the ray at j and
-         * nothing clips it */
+        /* whether a row is served from another one is decided per ROW, for
+         * all tables at once: u[j] == i[j] bit for bit where no table bends
+         * the ray at j and nothing clips it; i[j] == u[j-1] where no table
+         * tilts element j or j-1 */
         unsigned char bends[RT_MAX_SURFACES] = {0};
-        for (int jj = 0; jj < ntab; ++jj)
+        unsigned char tilted[RT_MAX_SURFACES] = {0};
+        for (int jj = 0; jj < ntab; ++jj) {
             if (ctx->h_surf[jj].flags & RT_F_REFRACT)
                 bends[jj % ctx->nsurf] = 1;
+            if (ctx->h_surf[jj].flags & RT_F_ROTATED)
+                tilted[jj % ctx->nsurf] = 1;
+        }
         for (int jj = 0; jj < ntab; ++jj) {
             const int j = jj % ctx->nsurf; /* element index in its group */
             unsigned f = ctx->h_stage[jj].flags &
@@ -844,11 +850,8 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
                 f |= RT_F_SKIP_U;
             if (!ctx->keep[j])
                 f |= RT_F_NOSTORE;
-            /* i[j] == u[j-1] bit for bit unless j or j-1 is tilted; it can
-             * only be served from U[j-1] if that row exists */
-            const bool rot = (f & RT_F_ROTATED) ||
-                             (j > 0 && (ctx->h_stage[jj - 1].flags &
-                                        RT_F_ROTATED));
+            /* i[j] can only be served from U[j-1] if that row exists */
+            const bool rot = tilted[j] || (j > 0 && tilted[j - 1]);
             const bool prev_kept =
                 j > 0 && (j - 1 < start ? ctx->valid[j - 1] : ctx->keep[j - 1]);
             if (!ctx->opt_alias || rot || j == 0 || !prev_kept)

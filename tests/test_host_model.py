@@ -190,6 +190,12 @@ def _variants_checks(make_trace):
             el.distance += 1e-2*rng.standard_normal()
         s[3].angles = (1e-3*rng.standard_normal(), 0., 0.)      # a tilt
         variants.append(s)
+    # a negative distance turns an element around (elements.py:126-128):
+    # variants that differ in which elements are rotated share one batch
+    variants[1][base.stop].distance = -0.01
+    variants[4][base.stop].distance = 0.02
+    assert variants[1][base.stop].rotated and \
+        not variants[4][base.stop].rotated
     y, u = ra.bundles.disc_bundle(100, 4., 5., 2)        # pads to 128
     g = make_trace(base)
     g.rays_variants(y, u, variants)
