@@ -192,8 +192,9 @@ def _variants_checks(make_trace):
         variants.append(s)
     # a negative distance turns an element around (elements.py:126-128):
     # variants that differ in which elements are rotated share one batch
-    variants[1][base.stop].distance = -0.01
-    variants[4][base.stop].distance = 0.02
+    for v, d in ((1, -0.01), (4, 0.02)):
+        variants[v][base.stop].direction = (0, 0, 1.)
+        variants[v][base.stop].distance = d
     assert variants[1][base.stop].rotated and \
         not variants[4][base.stop].rotated
     y, u = ra.bundles.disc_bundle(100, 4., 5., 2)        # pads to 128
