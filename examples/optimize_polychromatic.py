@@ -20,7 +20,7 @@ import rayopt_amd as ra
 from rayopt_amd import merit
 
 
-def main(nrays=2000, verbose=True):
+def main(nrays=2000, verbose=True, batched=False):
     system = ra.system_from_yaml(ra.prescriptions.COOKE % dict(
         air=1.0, sk16="1.62041/60.32", f2="1.62004/36.37"))
     system[-1].distance += 0.4                       # start out of focus
@@ -34,7 +34,10 @@ def main(nrays=2000, verbose=True):
     ]
     before = spot.get().reshape(3, 3)
     t0 = time.perf_counter()
-    res = merit.optimize(variables, [spot], options=dict(maxiter=40))
+    # batched: the finite-difference gradient (len(variables) + 1 systems)
+    # is traced as variants of the system in one launch
+    res = merit.optimize(variables, [spot], options=dict(maxiter=40),
+                         **(dict(jac="batched") if batched else {}))
     dt = time.perf_counter() - t0
     res.accept()
     after = spot.get().reshape(3, 3)
@@ -42,12 +45,14 @@ def main(nrays=2000, verbose=True):
         np.set_printoptions(precision=4, suppress=True)
         print("rms spot [wavelength, field] before:\n%s\nafter:\n%s" % (
             before, after))
-        print("%d merit evaluations of %d rays in %.3f s (%.2f ms each); "
-              "x = %s" % (res.nevaluations, spot.trace.nrays, dt,
-                          dt/res.nevaluations*1e3, res.x*[v.scale for v in
-                                                          variables]))
+        print("%s: %d operand evaluations (%d rays per system) in %.3f s; "
+              "x = %s" % ("batched gradients" if batched else "scipy "
+                          "finite differences", res.nevaluations,
+                          spot.trace.nrays, dt,
+                          res.x*[v.scale for v in variables]))
     return before, after, res
 
 
 if __name__ == "__main__":
     main()
+    main(batched=True)

@@ -53,6 +53,21 @@ def entrance_pupil(system, l=None):
     return b/a, system[stop].radius/a
 
 
+def start_pupil(system, l, z0=None, a0=None):
+    """Starting pupil (distance, aperture) at wavelength ``l``: the paraxial
+    image of the stop; a specified object pupil radius is the starting
+    aperture, as in the reference (Pupil.update only tracks it if
+    update_radius)."""
+    if z0 is None or a0 is None:
+        zp, ap = entrance_pupil(system, l)
+        spec = getattr(system.object, "pupil", None)
+        given = spec.get("radius") if isinstance(spec, dict) else \
+            getattr(spec, "radius", None)
+        z0 = zp if z0 is None else z0
+        a0 = (given or ap) if a0 is None else a0
+    return z0, a0
+
+
 class FieldAimer:
     """Aims F field points at once.  ``engine`` is injectable (tests)."""
 
@@ -168,17 +183,7 @@ class FieldAimer:
                  3: "marginal-ray aiming did not converge"}
 
     def _start(self, l, z0=None, a0=None):
-        """Starting pupil at wavelength ``l``: paraxial image of the stop; a
-        specified object pupil radius is the starting aperture, as in the
-        reference (Pupil.update only tracks it if update_radius)."""
-        if z0 is None or a0 is None:
-            zp, ap = entrance_pupil(self.system, l)
-            spec = getattr(self.system.object, "pupil", None)
-            given = spec.get("radius") if isinstance(spec, dict) else \
-                getattr(spec, "radius", None)
-            z0 = zp if z0 is None else z0
-            a0 = (given or ap) if a0 is None else a0
-        return z0, a0
+        return start_pupil(self.system, l, z0, a0)
 
     def _pupil_on_device(self, yo, wavelengths, starts, rim):
         """All fields at all wavelengths, all five root finds, one kernel

@@ -136,6 +136,85 @@ class SpotOperand(Operand):
         r = t.rms_fields(lost=self.lost).ravel()
         return np.where(np.isfinite(r), r, self.penalty)
 
+    def get_variants(self, systems):
+        """The operand for V variants of the system (same number of
+        elements) in ONE aiming launch, ONE trace and ONE reduction:
+        ``(V, wavelengths*fields)``, row v equal to what :meth:`get` gives on
+        ``systems[v]``.  This is what makes a finite-difference gradient cost
+        one evaluation instead of one per variable (``optimize(...,
+        jac="batched")``).  Group ``v*W + w`` of the batch is variant v at
+        wavelength w: its own surface table, its own aimed pupil per field."""
+        from ._lib import AIM_ARGS_DTYPE
+        from .aiming import start_pupil, entrance_pupil
+        from .launch import aim_seeds, field_frames
+        from .pack import pack_system
+        from .pupil import pupil_distribution
+        l = self.wavelengths
+        if l is None:
+            l = self.system.wavelengths
+        l = np.atleast_1d(np.asarray(l, dtype=float))
+        fields, nf, nw, nv = self.fields, len(self.fields), len(l), \
+            len(systems)
+        engine = self._variants_engine()
+        ref, yp, weight = pupil_distribution(self.distribution, self.nrays)
+        alive = len(yp)
+        pad = -alive % 64
+        yp = np.concatenate([yp, np.full((pad, 2), np.nan)])
+        if weight is None:
+            weight = np.ones(alive)/alive
+        weight = np.concatenate([weight, np.zeros(pad)])
+        groups = [(s, li) for s in systems for li in l]
+        tables = np.stack([
+            pack_system(s, li, s.refractive_index(li, 0))[0]
+            for s, li in groups])
+        engine.upload_system(tables)
+        starts = [start_pupil(s, li) if self.aim else entrance_pupil(s, li)
+                  for s, li in groups]
+        if self.aim:
+            args = np.zeros((), dtype=AIM_ARGS_DTYPE)
+            args["stop"], args["rim"] = self.system.stop, False
+            args["maxiter"], args["tol"] = 60, 1e-9
+            seeds = np.concatenate([
+                aim_seeds(s, fields, z0, a0, g)
+                for g, ((s, li), (z0, a0)) in enumerate(zip(groups, starts))])
+            z, a, status = engine.aim_pupil(seeds, args)
+            z, a = z.reshape(len(groups), nf), a.reshape(len(groups), nf, 2, 2)
+            failed = status.reshape(len(groups), nf).any(1)
+        else:
+            z = [np.broadcast_to(z0, (nf,)) for z0, _ in starts]
+            a = [a0 for _, a0 in starts]
+            failed = np.zeros(len(groups), dtype=bool)
+        z = np.where(np.isfinite(z), z, 0.) if self.aim else z
+        frames = np.concatenate([
+            field_frames(s, fields, z[g], np.nan_to_num(a[g]) if self.aim
+                         else a[g])
+            for g, (s, li) in enumerate(groups)])
+        engine.generate_rays(frames, yp)
+        engine.set_weights(np.tile(weight, len(frames)))
+        mask = np.zeros(len(self.system), dtype=np.uint8)
+        mask[0] = mask[-1] = 1
+        engine.set_keep_rows(mask)
+        engine.trace(1, 0, self.clip)
+        self.kernel_ms.append(engine.kernel_ms())
+        stats = engine.spot_stats(len(self.system) - 1, len(yp), len(frames))
+        r = np.sqrt(stats[:, 3])
+        if self.lost == "nan":
+            r = np.where(stats[:, 0] < alive, np.nan, r)
+        r = r.reshape(len(groups), nf)
+        r[failed] = np.nan                   # a variant that cannot be aimed
+        r = np.where(np.isfinite(r), r, self.penalty)
+        return r.reshape(nv, nw*nf)
+
+    def _variants_engine(self):
+        """A second context for variant batches, so the operand's own trace
+        keeps its rays and results."""
+        if getattr(self, "_vengine", None) is None:
+            base = self.trace.engine
+            from .engine import Engine
+            self._vengine = Engine(self.trace._device) \
+                if isinstance(base, Engine) else type(base)()
+        return self._vengine
+
 
 class _Problem:
     """Variables + operands -> the callables scipy needs.  The operand
@@ -184,6 +263,53 @@ class _Problem:
     def merit(self, x):
         return np.square(self._stack(self.objective, x)).sum()
 
+    # -- finite differences over system variants, one launch -----------------
+    def batchable(self):
+        """True if the forward-difference gradient of the merit can be taken
+        from ONE batched evaluation: every variable is a path into the same
+        system, every weighted operand can evaluate system variants."""
+        system = self.operands[0].system
+        return (not self.equality and not self.inequality and
+                all(isinstance(v, PathVariable) and v.system is system
+                    for v in self.variables) and
+                all(hasattr(self.operands[k], "get_variants") and
+                    self.operands[k].system is system
+                    for k, _ in self.objective))
+
+    def gradient(self, x, eps=1e-5):
+        """Forward differences ``(f(x + eps e_k) - f(x))/eps`` (backward
+        where the step would leave the box), all ``len(x) + 1`` points
+        evaluated as variants of the system in one launch per operand."""
+        import copy
+        x = np.asarray(x, dtype=float)
+        system = self.operands[0].system
+        nvar = len(self.variables)
+        if getattr(self, "_copies", None) is None or \
+                len(self._copies) != nvar + 1:
+            self._copies = [copy.deepcopy(system) for _ in range(nvar + 1)]
+        steps = np.where(x + eps > self.bounds[:, 1], -eps, eps)
+        points = np.tile(x, (nvar + 1, 1))
+        points[np.arange(1, nvar + 1), np.arange(nvar)] += steps
+        for clone, point in zip(self._copies, points):
+            for var, value in zip(self.variables, point*self.scale):
+                clone.set_path(var.path, value)
+        values = {k: self.operands[k].get_variants(self._copies)
+                  for k in {k for k, _ in self.objective}}
+        self.evaluations += 1
+        merits = np.array([
+            np.square(np.concatenate([f(values[k][p])
+                                      for k, f in self.objective])).sum()
+            for p in range(nvar + 1)])
+        self._batched = (tuple(x), merits[0])
+        return (merits[1:] - merits[0])/steps
+
+    def merit_batched(self, x):
+        """The merit at ``x``, from the gradient batch if it was there."""
+        hit = getattr(self, "_batched", None)
+        if hit is not None and hit[0] == tuple(np.asarray(x, dtype=float)):
+            return hit[1]
+        return self.merit(x)
+
     def constraints(self):
         out = []
         if self.equality:
@@ -206,7 +332,11 @@ def optimize(variables, operands, callback=None, tol=1e-4, options={},
     iteration, unscaled), ``trace_v`` (operand vectors) and ``trace_f``
     (``(operand index, weighted terms per iteration)``).  Extra keywords go
     to ``scipy.optimize.minimize``.  ``nevaluations`` counts the distinct
-    points the operands were evaluated at."""
+    points the operands were evaluated at.  ``jac="batched"`` (extension):
+    forward-difference gradients whose ``len(variables) + 1`` points are
+    traced as variants of the system in one launch
+    (:meth:`SpotOperand.get_variants`); a gradient then costs about one merit
+    evaluation instead of one per variable."""
     problem = _Problem(variables, operands)
     path_x, path_v, path_f = [], [], []
 
@@ -221,7 +351,17 @@ def optimize(variables, operands, callback=None, tol=1e-4, options={},
 
     settings = dict(maxiter=100, eps=1e-5)
     settings.update(options)
-    result = minimize(problem.merit, problem.start, bounds=problem.bounds,
+    fun = problem.merit
+    if isinstance(kwargs.get("jac"), str) and kwargs["jac"] == "batched":
+        # extension: the whole finite-difference gradient from one launch
+        if not problem.batchable():
+            raise ValueError("jac='batched' needs PathVariables of one "
+                             "system, operands with get_variants() and no "
+                             "constraints")
+        step = settings.pop("eps")
+        kwargs["jac"] = lambda x: problem.gradient(x, step)
+        fun = problem.merit_batched
+    result = minimize(fun, problem.start, bounds=problem.bounds,
                       constraints=problem.constraints(),
                       callback=each_iteration, tol=tol, options=settings,
                       **kwargs)

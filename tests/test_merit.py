@@ -203,3 +203,69 @@ def test_polychromatic_example_runs():
     before, after, res = mod.main(nrays=300, verbose=False)
     assert np.square(after).sum() < np.square(before).sum()
     assert np.isfinite(after).all()
+
+
+def _batched_problem(system, trace):
+    op = merit.SpotOperand(system, np.c_[np.zeros(3), [0., .7, 1.]],
+                           nrays=10, distribution="hexapolar", clip=False,
+                           weight=1., trace=trace)
+    variables = [
+        merit.PathVariable(system, (-1, "distance"), bounds=(40., 46.)),
+        merit.PathVariable(system, (6, "curvature"), bounds=(0.002, 0.012)),
+        merit.PathVariable(system, (7, "curvature"), bounds=(-0.08, -0.04)),
+    ]
+    return variables, op
+
+
+def _batched_gradient_checks(make_trace):
+    """get_variants == get() per variant; the one-launch gradient equals
+    forward differences from separate evaluations; optimize(jac='batched')
+    reaches the optimum of the default (scipy finite differences) run with a
+    fraction of the operand evaluations."""
+    import copy
+    system = ra.system_from_yaml(DISPERSIVE_COOKE)
+    system[-1].distance += 0.3
+    variables, op = _batched_problem(system, make_trace(system))
+    variants = []
+    for k in range(3):
+        s = copy.deepcopy(system)
+        s[7].curvature *= 1 + 1e-3*k
+        variants.append(s)
+    many = op.get_variants(variants)
+    assert many.shape == (3, 9)
+    for k, s in enumerate(variants):
+        one = merit.SpotOperand(s, op.fields, nrays=10, clip=False,
+                                distribution="hexapolar", weight=1.,
+                                trace=make_trace(s)).get()
+        np.testing.assert_allclose(many[k], one, rtol=1e-12)
+    problem = merit._Problem(variables, [op])
+    assert problem.batchable()
+    x = problem.start.copy()
+    g = problem.gradient(x, 1e-5)
+    f0 = problem.merit(x)
+    assert problem.merit_batched(x) == pytest.approx(f0, rel=1e-12)
+    for k in range(3):
+        xk = x.copy()
+        xk[k] += 1e-5
+        assert g[k] == pytest.approx((problem.merit(xk) - f0)/1e-5,
+                                     rel=1e-6, abs=1e-9)
+    problem.apply(problem.current)
+    slow = merit.optimize(variables, [op], options=dict(maxiter=30))
+    slow.reject()
+    fast = merit.optimize(variables, [op], options=dict(maxiter=30),
+                          jac="batched")
+    assert fast.fun == pytest.approx(slow.fun, rel=1e-3)
+    assert fast.nevaluations < 0.6*slow.nevaluations
+    # constraints or foreign operands: refused, not silently ignored
+    with pytest.raises(ValueError):
+        merit.optimize(variables, [op, merit.FuncOp(
+            system, lambda s: s[7].curvature, max=0.)], jac="batched")
+
+
+def test_batched_gradient_host_logic():
+    _batched_gradient_checks(oracle_trace)
+
+
+@pytest.mark.gpu
+def test_batched_gradient_gpu():
+    _batched_gradient_checks(lambda s: ra.GeometricTrace(s))
