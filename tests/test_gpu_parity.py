@@ -913,3 +913,9 @@ def test_two_thousand_variants_one_launch():
         assert stats[v, 0] == ref[0]
         np.testing.assert_allclose(stats[v, 1:5], ref[1:5], rtol=1e-9)
     assert np.std(np.sqrt(stats[:, 3])) > 0
+
+
+@pytest.mark.gpu
+def test_grouped_partial_propagation_gpu():
+    from test_host_model import _grouped_partial_checks
+    _grouped_partial_checks(lambda s: ra.GeometricTrace(s))

@@ -234,3 +234,40 @@ def _variants_checks(make_trace):
 def test_system_variants_in_one_trace_host_logic():
     from fake_engine import OracleEngine
     _variants_checks(lambda s: ra.GeometricTrace(s, engine=OracleEngine()))
+
+
+def _grouped_partial_checks(make_trace):
+    """Partial re-propagation of a multi-wavelength batch: rows before
+    `start` stay, rows from `start` on are re-traced per group with that
+    group's index in front of the first re-traced element."""
+    system = ra.system_from_yaml(ra.prescriptions.COOKE % dict(
+        air=1.0, sk16="1.62041/60.32", f2="1.62004/36.37"))
+    ls = system.wavelengths
+    y, u = ra.bundles.disc_bundle(128, 4., 6., 4)
+    g = make_trace(system)
+    g.rays_given(y, u, l=ls)
+    g.propagate(clip=True)
+    full = [np.array(np.asarray(getattr(g, k))) for k in "yuit"]
+    n_full = g.n.copy()
+    g.propagate(start=4, clip=True)
+    for k, name in enumerate("yuit"):
+        assert np.array_equal(np.asarray(getattr(g, name)), full[k],
+                              equal_nan=True), name
+    assert np.array_equal(g.n, n_full)
+    system[5].curvature = 0.004          # change behind the seed row
+    g.propagate(start=4, clip=True)
+    for w, l in enumerate(ls):
+        h = make_trace(system)
+        h.rays_given(y, u, l=l)
+        h.propagate(clip=True)
+        sl = slice(w*128, (w + 1)*128)
+        a, b = np.asarray(g.y)[:, sl], np.asarray(h.y)
+        assert np.array_equal(a[4:], b[4:], equal_nan=True)
+        assert np.array_equal(a[:4], full[0][:4, sl], equal_nan=True)
+        assert np.array_equal(g.n[w], h.n)
+
+
+def test_grouped_partial_propagation_host_logic():
+    from fake_engine import OracleEngine
+    _grouped_partial_checks(
+        lambda s: ra.GeometricTrace(s, engine=OracleEngine()))
