@@ -183,6 +183,10 @@ int rt_set_rays_device(rt_ctx *ctx, const double *d_y, const double *d_u,
  *   finite:   base = object point, u = (0,0,z) [- base],
  *             dir = u + z tan(am px) s + z tan(am py) m, normalised (flipped
  *             if z < 0)
+ * Row 0 is not written by this call: the first rt_trace from element 1
+ * builds the rays in registers, writes row 0 and marches on in the same
+ * launch (no 48 B/ray read); any other access to the batch first runs the
+ * stand-alone generation kernel (same arithmetic, same values).
  */
 typedef struct rt_field {
     int32_t finite;
@@ -282,6 +286,9 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * ones): key "rays_per_thread" (1,2,4), "nontemporal" (0,1), "xcd_remap"
  * (0,1), "block" (64..1024), "alias_i" (1 = do not write I[j] where it is
  * identical to U[j-1], the default; 0 = materialise every row of I),
+ * "fuse_generate" (1 = the first trace after rt_generate_rays builds the
+ * rays in registers and writes row 0 itself, the default; 0 = a separate
+ * generation kernel writes row 0 and the trace reads it),
  * "lds_pad" (bytes of unused dynamic LDS per workgroup: caps the resident
  * workgroups per CU for occupancy experiments; default 0).
  */

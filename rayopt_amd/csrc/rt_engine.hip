@@ -96,6 +96,15 @@ struct rt_ctx {
     /* kernel variant */
     int opt_r, opt_nt, opt_xcd, opt_block, opt_alias;
     int opt_lds; /* bytes of unused dynamic LDS per workgroup (occupancy) */
+    int opt_fuse; /* build generated rays inside the first trace */
+
+    /* rt_generate_rays: field frames | pupil points, and whether row 0 is
+     * still to be built from them */
+    void *d_gen;
+    size_t gen_bytes, gen_fpad;
+    int gen_pending, gen_nf;
+    int64_t gen_np, gen_n;
+    rt_surface gen_s0;
     /* per row of I: 0 = materialised, 1 = identical to U[j-1], 2 = to U[j] */
     unsigned char i_alias[RT_MAX_SURFACES];
     /* per row of U: 1 = identical to I[j] (RT_F_SKIP_U), not materialised */
@@ -181,6 +190,24 @@ static int rt_detach(rt_ctx *c, int which, int surf)
     return RT_OK;
 }
 
+/* row 0 of a generated batch, if no trace has built it yet */
+static int rt_gen_flush(rt_ctx *c)
+{
+    if (!c || !c->gen_pending)
+        return RT_OK;
+    c->gen_pending = 0;
+    RT_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(rt_generate_kernel,
+                       dim3((unsigned)((c->ld + 255) / 256)), dim3(256), 0,
+                       c->stream, (const rt_field *)c->d_gen,
+                       (const double *)((char *)c->d_gen + c->gen_fpad),
+                       c->gen_np, c->gen_n, c->gen_s0, rt_arr(c, RT_Y),
+                       rt_arr(c, RT_U), rt_arr(c, RT_I), rt_arr(c, RT_T), c->ld,
+                       !c->opt_alias);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
 template <int R, bool NT, bool XCD>
 static void rt_launch(rt_ctx *c, int start, int stop, int clip)
 {
@@ -241,6 +268,7 @@ int rt_create(int device, rt_ctx **out)
     c->opt_xcd = 0;
     c->opt_block = 256;
     c->opt_alias = 1;
+    c->opt_fuse = 1;
 #define RT_HIP_C(call)                                                        \
     do {                                                                      \
         hipError_t e_ = (call);                                               \
@@ -305,6 +333,8 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_partials);
     if (ctx->d_group)
         (void)hipFree(ctx->d_group);
+    if (ctx->d_gen)
+        (void)hipFree(ctx->d_gen);
     if (ctx->d_opd_ref)
         (void)hipFree(ctx->d_opd_ref);
     if (ctx->d_surf)
@@ -463,6 +493,7 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
     ctx->u_alias[0] = 0;
     ctx->valid[0] = 1;
+    ctx->gen_pending = 0; /* these rays replace a generated batch */
     return RT_OK;
 }
 
@@ -668,28 +699,40 @@ int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
     const size_t fbytes = sizeof(rt_field) * (size_t)nfields;
     const size_t fpad = (fbytes + 255) / 256 * 256;
     const size_t pbytes = sizeof(double) * 2 * (size_t)npupil;
-    rc = rt_need_scratch(ctx, fpad + pbytes);
-    if (rc != RT_OK)
-        return rc;
-    rt_field *d_fields = (rt_field *)ctx->d_scratch;
-    double *d_pupil = (double *)((char *)ctx->d_scratch + fpad);
-    RT_HIP(ctx, hipMemcpyAsync(d_fields, fields, fbytes, hipMemcpyHostToDevice,
-                               ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(d_pupil, pupil_xy, pbytes,
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (fpad + pbytes > ctx->gen_bytes) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_gen)
+            (void)hipFree(ctx->d_gen);
+        ctx->d_gen = NULL;
+        ctx->gen_bytes = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->d_gen, fpad + pbytes));
+        ctx->gen_bytes = fpad + pbytes;
+    }
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_gen, fields, fbytes,
                                hipMemcpyHostToDevice, ctx->stream));
-    const unsigned grid = (unsigned)((ctx->ld + 255) / 256);
-    rt_surface s0 = ctx->h_surf[0];
-    RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
-    hipLaunchKernelGGL(rt_generate_kernel, dim3(grid), dim3(256), 0,
-                       ctx->stream, d_fields, d_pupil, npupil, n, s0,
-                       rt_arr(ctx, RT_Y), rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
-                       rt_arr(ctx, RT_T), ctx->ld, !ctx->opt_alias);
-    RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync((char *)ctx->d_gen + fpad, pupil_xy, pbytes,
+                               hipMemcpyHostToDevice, ctx->stream));
+    ctx->gen_fpad = fpad;
+    ctx->gen_nf = nfields;
+    ctx->gen_np = npupil;
+    ctx->gen_n = n;
+    ctx->gen_s0 = ctx->h_surf[0];
+    /* row 0 is built by the first trace (rt_trace_gen_kernel), or by
+     * rt_gen_flush as soon as anything else asks for it */
+    ctx->gen_pending = 1;
     ctx->traced = 1;
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0;
     ctx->u_alias[0] = 0;
     ctx->valid[0] = 1;
+    RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
+    if (!ctx->opt_fuse) {
+        rc = rt_gen_flush(ctx);
+        if (rc != RT_OK)
+            return rc;
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream)); /* ~0 when deferred */
+    /* caller's host arrays may be released as soon as we return */
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -757,6 +800,11 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
         return rt_fail(ctx, RT_ERR_STATE, "rt_upload_row: no such row %d",
                        surf);
     const int nc = rt_ncomp(which);
+    {
+        int rc = rt_gen_flush(ctx);
+        if (rc != RT_OK)
+            return rc;
+    }
     /* rows served from the one being replaced keep what they show now */
     if (which == RT_U && surf + 1 < ctx->buf_nsurf && ctx->valid[surf + 1] &&
         ctx->i_alias[surf + 1] == 1) {
@@ -868,8 +916,33 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
         ctx->table_dirty = 1; /* alias decisions depend on start */
         return rt_trace(ctx, start, stop, clip);
     }
+    /* a generated batch that no one has looked at yet is built inside this
+     * launch (default kernel variant, from the first element on) */
+    const bool fused = ctx->gen_pending && start == 1 && start < stop &&
+                       ctx->opt_r == 1 && !ctx->opt_nt && !ctx->opt_xcd;
+    if (!fused) {
+        int rc = rt_gen_flush(ctx);
+        if (rc != RT_OK)
+            return rc;
+    }
     RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
-    if (start < stop) {
+    if (fused) {
+        const int block = ctx->opt_block;
+        ctx->gen_pending = 0;
+        hipLaunchKernelGGL(rt_trace_gen_kernel,
+                           dim3((unsigned)((ctx->ld + block - 1) / block)),
+                           dim3(block), (size_t)ctx->opt_lds, ctx->stream,
+                           ctx->d_surf, stop, clip, rt_arr(ctx, RT_Y),
+                           rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
+                           rt_arr(ctx, RT_T), ctx->ld,
+                           ctx->ngroups > 1 ? ctx->n / ctx->ngroups
+                                            : (int64_t)0,
+                           ctx->nsurf, (const rt_field *)ctx->d_gen,
+                           (const double *)((char *)ctx->d_gen + ctx->gen_fpad),
+                           ctx->gen_np, ctx->gen_n, ctx->gen_s0,
+                           !ctx->opt_alias);
+        RT_HIP(ctx, hipGetLastError());
+    } else if (start < stop) {
         const int key = ctx->opt_r * 4 + ctx->opt_nt * 2 + ctx->opt_xcd;
         switch (key) {
 #define RT_CASE(R, NT, X)                                                     \
@@ -963,6 +1036,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
     } else if (!strcmp(key, "alias_i")) {
         ctx->opt_alias = value ? 1 : 0;
         ctx->table_dirty = 1;
+    } else if (!strcmp(key, "fuse_generate")) {
+        ctx->opt_fuse = value ? 1 : 0;
     } else if (!strcmp(key, "lds_pad")) {
         /* measurement only: dynamic LDS the kernel never touches, to cap
          * the workgroups resident per CU (160 KB / lds_pad) */
@@ -1079,7 +1154,9 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
                            "rt_download: row %d holds no data (not kept by "
                            "rt_set_keep_rows, or not traced yet)", j);
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = RT_OK;
+    int rc = rt_gen_flush(ctx);
+    if (rc != RT_OK)
+        return rc;
     if (which == RT_Y || which == RT_T) {
         rc = rt_rows_to_host(ctx, dst, rt_row(ctx, which, surf_lo),
                              (size_t)(surf_hi - surf_lo) * nc);
@@ -1104,6 +1181,11 @@ int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
         return rt_fail(ctx, RT_ERR_STATE, "rt_download_ray: ray %lld of %lld",
                        (long long)ray, (long long)ctx->n);
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        int rc = rt_gen_flush(ctx);
+        if (rc != RT_OK)
+            return rc;
+    }
     const int nc = rt_ncomp(which);
     for (int j = 0; j < ctx->buf_nsurf; ++j) {
         if (!ctx->valid[j]) { /* row not stored: NaN, like a dead ray */
@@ -1161,7 +1243,7 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
     if (!ctx->d_partials)
         RT_HIP(ctx, hipMalloc((void **)&ctx->d_partials,
                               sizeof(double) * (RT_RED_BLOCKS * 8 + 16)));
-    return RT_OK;
+    return rt_gen_flush(ctx);
 }
 
 /* workgroups of a reduction over n rays: no more than there is work for */
@@ -1383,6 +1465,9 @@ int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
     if (!ctx->valid[surf])
         return rt_fail(ctx, RT_ERR_STATE, "rt_device_ptr: row %d holds no data",
                        surf);
+    int rc = rt_gen_flush(ctx);
+    if (rc != RT_OK)
+        return rc;
     *out = rt_row(ctx, which, surf);
     return RT_OK;
 }
@@ -1517,6 +1602,11 @@ int rt_gather_final(rt_ctx *ctx, int which, int surf, const int64_t *counts,
     if (ctx->rank == root && !d_dst)
         return rt_fail(ctx, RT_ERR_ARG, "rt_gather_final: root needs d_dst");
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        int rc = rt_gen_flush(ctx);
+        if (rc != RT_OK)
+            return rc;
+    }
 
     const int nc = rt_ncomp(which);
     const int p = ctx->parity;

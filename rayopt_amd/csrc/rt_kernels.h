@@ -182,6 +182,50 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
     rt_march<R, NT>(surf, start, stop, clip, Y, U, I, T, ld, j, y, u);
 }
 
+/*
+ * The first trace after rt_generate_rays: the launch rays are built in
+ * registers (field f = j / npupil through pupil point j % npupil), row 0 is
+ * written from there and the march goes on -- the generated batch never
+ * makes the round trip through HBM that a separate generation kernel plus
+ * the 48 B/ray input read would cost (the read is the expensive kind:
+ * profiles/r01_probes/ab_store_order.log (9)).
+ */
+__global__ void rt_trace_gen_kernel(const rt_surface *__restrict__ surf,
+                                    int stop, int clip, double *__restrict__ Y,
+                                    double *__restrict__ U,
+                                    double *__restrict__ I,
+                                    double *__restrict__ T, int64_t ld,
+                                    int64_t group_rays, int nsurf,
+                                    const rt_field *__restrict__ fields,
+                                    const double *__restrict__ pupil,
+                                    int64_t npupil, int64_t n, rt_surface S0,
+                                    int store_i0)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld)
+        return;
+    if (group_rays) {
+        const int64_t j0 = j - (int64_t)(threadIdx.x & 63);
+        const int g = __builtin_amdgcn_readfirstlane((int)(j0 / group_rays));
+        surf += (int64_t)g * nsurf;
+    }
+    double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
+    if (j < n) {
+        const int64_t p = j % npupil;
+        rt_generate_ray(fields + j / npupil, pupil[2 * p], pupil[2 * p + 1],
+                        &S0, y, u);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Y[c * ld + j] = y[0][c];
+        U[c * ld + j] = u[0][c];
+        if (store_i0)
+            I[c * ld + j] = u[0][c];
+    }
+    T[j] = 0.;
+    rt_march<1, false>(surf, 1, stop, clip, Y, U, I, T, ld, j, y, u);
+}
+
 /* rays_given: AoS (n,3) staging -> SoA row 0 of Y,U,I and T[0] = 0 */
 __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
                                    const double *__restrict__ u_aos,

@@ -124,3 +124,55 @@ def test_device_generation_vs_oracle(key):
     # (NaN rays); NaN in, NaN out on both sides
     assert (np.isnan(got_rms) and np.isnan(want_rms)) or \
         got_rms == pytest.approx(want_rms, rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_generation_fused_into_the_first_trace():
+    """rt_generate_rays defers row 0 to the first trace, which builds the
+    rays in registers: identical to the stand-alone generation + trace, for
+    every way the batch can be touched first (trace, download of row 0,
+    reduction, partial trace, non-default kernel variant, wavelength groups)."""
+    from rayopt_amd.prescriptions import COOKE
+    system = ra.system_from_yaml(COOKE % dict(
+        air=1.0, sk16="1.62041/60.32", f2="1.62004/36.37"))
+    fields = np.c_[np.zeros(5), np.linspace(0, 1, 5)]
+    ref, yp, w = ra.pupil.pupil_distribution("hexapolar", 3000)
+    from rayopt_amd.aiming import FieldAimer
+    z, a = FieldAimer(system).pupil(fields)
+
+    def run(first, fuse, **opts):
+        g = ra.GeometricTrace(system)
+        g.engine.set_option("fuse_generate", fuse)
+        for k, v in opts.items():
+            g.engine.set_option(k, v)
+        g.rays_fields(fields, yp, z, a)
+        out = {}
+        if first == "row0":
+            out["y0"] = np.array(np.asarray(g.y[0]))
+        elif first == "rms0":
+            out["r0"] = g.rms(i=0)
+        elif first == "partial":
+            g.propagate(stop=4, clip=True)
+        g.propagate(clip=True)
+        for name in "yuit":
+            out[name] = np.array(np.asarray(getattr(g, name)))
+        out["ms"] = g.kernel_ms()
+        return out
+
+    want = run("trace", 0)
+    for first in ("trace", "row0", "rms0", "partial"):
+        for opts in ({}, {"rays_per_thread": 2}, {"alias_i": 0}):
+            got = run(first, 1, **opts)
+            for name in "yuit":
+                assert np.array_equal(got[name], want[name], equal_nan=True), \
+                    (first, opts, name)
+    assert np.isfinite(want["y"][0]).all() and (want["t"][0] == 0).all()
+    # several wavelengths in one generated batch
+    g1, g0 = ra.GeometricTrace(system), ra.GeometricTrace(system)
+    g0.engine.set_option("fuse_generate", 0)
+    for g in (g1, g0):
+        g.rays_points(fields, wavelength=system.wavelengths, nrays=300,
+                      distribution="hexapolar", clip=True)
+    for name in "yuit":
+        assert np.array_equal(np.asarray(getattr(g1, name)),
+                              np.asarray(getattr(g0, name)), equal_nan=True)
