@@ -18,7 +18,11 @@ def main():
     yp = np.c_[r*np.cos(phi), r*np.sin(phi)]
     from rayopt_amd.aiming import entrance_pupil
     z, a = entrance_pupil(system)
-    for fuse in (0, 1, 0, 1):
+    g = ra.GeometricTrace(system)          # clocks settle before anything
+    g.rays_fields(fields, yp, z, a)        # is compared (~50 launches)
+    for rep in range(150):
+        g.propagate(clip=True)
+    for fuse in (0, 1, 0, 1, 0, 1):
         g = ra.GeometricTrace(system)
         g.engine.set_option("fuse_generate", fuse)
         tot, gen = [], []
