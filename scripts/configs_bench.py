@@ -76,7 +76,7 @@ def main():
     print(json.dumps(dict(config="C5 batch on one GPU: 1e8 rays, device-"
                           "generated", rays=n, surfaces=S, clip=True,
                           kernel_ms=ms, ops_per_s=n*S/ms*1e3,
-                          GBs=n*(56*S + 48)/ms/1e6, generate_ms=gen_ms,
+                          GBs=n*(56*S + 56)/ms/1e6, generate_ms=gen_ms,
                           result_GB=n*13*80/1e9)), flush=True)
 
 
