@@ -37,7 +37,13 @@ for seed in range(lo, hi):
                                                       clip=clip))):
                 try:
                     for a, b in zip(got, want):
-                        if asph or (tilt and name == "C"):
+                        if tilt and name == "C":
+                            # 3x3 products: numpy calls BLAS, C adds in
+                            # index order; the last-bit difference is
+                            # amplified by ill-conditioned geometry (seen:
+                            # 2.4e-11) -- the contract is 1e-10
+                            assert_parity(a, b, 1e-10, name)
+                        elif asph:
                             assert_parity(a, b, 1e-11, name)
                         else:
                             assert np.array_equal(a, b, equal_nan=True)
