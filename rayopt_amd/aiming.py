@@ -31,7 +31,7 @@ from .launch import _telecentric
 def entrance_pupil(system, l=None):
     """(distance from the vertex of element 0, radius) of the paraxial image
     of the stop in object space: y-nu trace of two rays through elements
-    1..stop (untilted, no mirror in front of the stop)."""
+    1..stop (untilted elements)."""
     if l is None:
         l = system.wavelengths[0]
     stop = system.stop
@@ -39,13 +39,16 @@ def entrance_pupil(system, l=None):
     rays = np.array([[1., 0.], [0., 1.]])        # (y, n u) for two rays
     n_prev = n0
     for el in system[1:stop + 1]:
-        if getattr(getattr(el, "material", None), "mirror", False):
-            raise NotImplementedError("mirror in front of the stop")
         rays[:, 0] += el.distance*rays[:, 1]/n_prev
         c = getattr(el, "curvature", 0.)
         asph = getattr(el, "aspherics", None)
         if asph:
             c = c + 2*asph[0]
+        if getattr(getattr(el, "material", None), "mirror", False):
+            # reflection as the reference's paraxial matrix has it
+            # (rayopt/elements.py:517-520): u' = u + 2 c y, index unchanged
+            rays[:, 1] += 2*c*rays[:, 0]
+            continue
         n_next, _ = el.get_n_mu(n_prev, l)
         rays[:, 1] -= rays[:, 0]*c*(n_next - n_prev)
         n_prev = n_next

@@ -476,3 +476,43 @@ def test_pupils_all_wavelengths_host_logic():
 @pytest.mark.gpu
 def test_pupils_all_wavelengths_gpu():
     _pupils_checks(lambda: None)
+
+
+MIRROR_FIRST = """
+description: mirror in front of the stop
+wavelengths: [587.56e-9]
+object: {angle_deg: 0.5, pupil: {radius: 20, aim: True}}
+image: {type: finite}
+stop: 2
+elements:
+- {material: 1.0}
+- {roc: -400, distance: 50, material: mirror, radius: 30}
+- {distance: -80, material: 1.0, radius: 12}
+- {distance: -119, radius: 10}
+"""
+
+
+def test_entrance_pupil_and_aiming_behind_a_mirror():
+    """The paraxial starting pupil follows the reference through a mirror in
+    front of the stop (u' = u + 2 c y), and the aiming kernel then puts the
+    chief and marginal rays where they belong."""
+    from fake_engine import OracleEngine
+    system = ra.system_from_yaml(MIRROR_FIRST)
+    z, r = entrance_pupil(system)
+    assert z == pytest.approx(550/3, rel=1e-12) and r == pytest.approx(20.)
+    if refshim.available():
+        ro = refshim.load()
+        ref = ro.system_from_yaml(MIRROR_FIRST)
+        ref.object.pupil.update_radius = True
+        ref.update()
+        ro.ParaxialTrace(ref).update_conjugates()
+        assert z == pytest.approx(ref.object.pupil.distance, rel=1e-12)
+        assert r == pytest.approx(ref.object.pupil.radius, rel=1e-12)
+    fields = np.c_[np.zeros(3), [0., .6, 1.]]
+    fast = FieldAimer(system, engine=OracleEngine())
+    slow = FieldAimer(system, engine=OracleEngine(), on_device=False)
+    zz, aa = fast.pupil(fields)
+    zs, as_ = slow.pupil(fields)
+    np.testing.assert_allclose(zz, zs, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(aa, as_, rtol=1e-6)
+    check_conditions(system, slow, fields, zz, aa)
