@@ -613,6 +613,32 @@ class GeometricTrace(Trace):
                         u0.transpose(1, 0, 2).reshape(-1, 3), l)
         self.propagate()
 
+    def rays_paraxial(self, wavelength=None, axis=1):
+        """The paraxial marginal and chief ray traced as real rays
+        (rayopt/geometric_trace.py:185-193 with ParaxialTrace.rays,
+        rayopt/paraxial_trace.py:66-79): launched from the object with the
+        first-order pupil (``entrance_pupil``; a specified object pupil
+        radius is kept) -- ray 0 marginal, ray 1 chief."""
+        from .aiming import start_pupil
+        l = self.system.wavelengths[0] if wavelength is None else wavelength
+        z, r = start_pupil(self.system, l)
+        n0 = self.system.refractive_index(l, 0)
+        obj = self.system.object
+        if obj.finite:
+            heights = (0., -obj.radius)
+            slopes = (n0*r/z, n0*obj.radius/z)
+        else:
+            c = np.tan(obj.angle)
+            heights = (r, -c*z)
+            slopes = (0., n0*c)
+        y = np.zeros((2, 2))
+        y[:, axis] = heights
+        u = np.zeros((2, 2))
+        tan = np.array(slopes)
+        u[:, axis] = tan/np.sqrt(1 + np.square(tan))      # sinarctan
+        self.rays_given(y, u, l)
+        self.propagate()
+
     def plot(self, ax, axis=1, **kwargs):
         """Ray paths in the global frame, ``axis`` against z
         (rayopt/geometric_trace.py:236-240)."""

@@ -516,3 +516,26 @@ def test_entrance_pupil_and_aiming_behind_a_mirror():
     np.testing.assert_allclose(zz, zs, rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(aa, as_, rtol=1e-6)
     check_conditions(system, slow, fields, zz, aa)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+@pytest.mark.parametrize("finite", [False, True])
+def test_rays_paraxial_matches_reference(finite):
+    from fake_engine import OracleEngine
+    ro = refshim.load()
+    text = COOKE
+    ref = ro.system_from_yaml(text)
+    mine = ra.system_from_yaml(text)
+    if finite:
+        ref.object = ro.conjugates.FiniteConjugate(radius=8.)
+        ref[1].distance = 60.
+        ref.object.pupil.update_radius = True
+        mine = _finite_variant(text)
+    ref.update()
+    ro.ParaxialTrace(ref).update_conjugates()
+    r = ro.GeometricTrace(ref)
+    r.rays_paraxial()
+    g = ra.GeometricTrace(mine, engine=OracleEngine())
+    g.rays_paraxial()
+    for a, b in ((g.y, r.y), (g.u, r.u), (g.t, r.t)):
+        np.testing.assert_allclose(np.asarray(a), b, rtol=1e-9, atol=1e-11)
