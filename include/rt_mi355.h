@@ -60,6 +60,11 @@ extern "C" {
  * clip (Element.clip is what would poison u, :206-209) -- and is served
  * from I[j] (which may in turn be U[j-1]) */
 #define RT_F_SKIP_U 0x200u
+/* set by the library (rt_set_option "fast_asphere"): this aspheric element
+ * runs its Newton intercept and refraction on FMA / rcp / rsq arithmetic
+ * (csrc/rt_math.h) -- same iteration, results inside the 1e-8 contract for
+ * iterated aspheres instead of bit-identical to the reference */
+#define RT_F_FAST 0x400u
 
 /* which array (rt_download / rt_upload_row / rt_device_ptr) */
 #define RT_Y 0 /* intercepts, element-normal frame, relative to vertex */
@@ -290,7 +295,17 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * rays in registers and writes row 0 itself, the default; 0 = a separate
  * generation kernel writes row 0 and the trace reads it),
  * "lds_pad" (bytes of unused dynamic LDS per workgroup: caps the resident
- * workgroups per CU for occupancy experiments; default 0).
+ * workgroups per CU for occupancy experiments; default 0),
+ * "fast_asphere" (0 = default: even aspheres reproduce the reference's Newton
+ * solve operation for operation; 1 = the same iteration on fused
+ * multiply-adds and rcp/rsq + refinement, one reciprocal per iterate:
+ * results within the 1e-8 contract for iterated aspheres, ~1e-13 in
+ * practice, identical NaN masks up to rays that sit on a decision boundary
+ * to 1e-15),
+ * "tile_rays" (measurement only: 0 = the documented SoA layout; TR = a power
+ * of two: results are written tile-major [tile of TR rays][L][10][TR] so a
+ * workgroup's whole output is one contiguous region; nothing can be read
+ * back in that layout -- it exists to measure the store pattern).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
 /*
@@ -298,7 +313,9 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value);
  * preserved): mode 0 = the trace kernel's 80 B store pattern without
  * arithmetic, 1 = grid-stride 16-byte fill, 2 = 16-byte copy, 3 = fill with one
  * 16-byte store per lane, 4 = same, non-temporal; 5 / 6 = mode 0 with the
- * 48 B/ray input read from an L2-resident window / not at all.  Returns
+ * 48 B/ray input read from an L2-resident window / not at all; 7 / 8 = the
+ * default kernel's own pattern (56 B per op, 8-byte stores) with / without
+ * the input read.  Modes 0 and 5-8 honour "tile_rays" and "block".  Returns
  * kernel time and the bytes moved.  Overwrites rows >= 1.
  */
 int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes);

@@ -14,6 +14,7 @@ RT_MAX_SURFACES = 256
 
 F_ROTATED, F_CURVED, F_CONIC, F_ASPH, F_ALT, F_REFRACT, F_MIRROR = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40)
+F_FAST = 0x400          # set by the library: rt_set_option("fast_asphere")
 RT_Y, RT_U, RT_I, RT_T = 0, 1, 2, 3
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 

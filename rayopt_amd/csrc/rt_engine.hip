@@ -63,12 +63,17 @@ struct rt_ctx {
     hipEvent_t ev[RT_NEVENTS];
     int traced;
 
-    rt_surface *d_surf;
+    rt_surface *d_surf;  /* = d_tab[tab_cur]: the table kernels read */
+    rt_surface *d_tab[2]; /* double buffered: a changed table is sent while a
+                             kernel in flight still reads the previous one */
+    hipEvent_t tab_used[2]; /* last DMA into / kernel reading buffer k */
+    int tab_cur;
     int nsurf;
     rt_surface *h_surf;                 /* [ngroups][nsurf] as given */
     size_t tab_cap;                     /* entries h_surf/h_stage/d_surf hold */
     int ngroups;                        /* surface tables (wavelengths) */
-    rt_surface *h_stage;                /* pinned: flags finalised */
+    rt_surface *h_stage;                /* = h_pinned[tab_cur] */
+    rt_surface *h_pinned[2];            /* pinned: flags finalised */
     int table_dirty;
     int table_start;
     unsigned char keep[RT_MAX_SURFACES];  /* rows propagate() stores */
@@ -97,6 +102,8 @@ struct rt_ctx {
     int opt_r, opt_nt, opt_xcd, opt_block, opt_alias;
     int opt_lds; /* bytes of unused dynamic LDS per workgroup (occupancy) */
     int opt_fuse; /* build generated rays inside the first trace */
+    int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
+    int opt_tile; /* measurement only: tile-major result layout, rays/tile */
 
     /* rt_generate_rays: field frames | pupil points, and whether row 0 is
      * still to be built from them */
@@ -163,6 +170,44 @@ static inline double *rt_arr(const rt_ctx *c, int which)
 
 static inline int rt_ncomp(int which) { return which == RT_T ? 1 : 3; }
 
+/* addressing of the result arrays as the kernels see it (rt_kernels.h) */
+static inline rt_lay rt_layout(const rt_ctx *c)
+{
+    rt_lay a;
+    if (!c->opt_tile) {
+        a.Y = rt_arr(c, RT_Y);
+        a.U = rt_arr(c, RT_U);
+        a.I = rt_arr(c, RT_I);
+        a.T = rt_arr(c, RT_T);
+        a.cs = c->ld;
+        a.ss = 3 * c->ld;
+        a.ssT = c->ld;
+        a.tshift = 8;
+        a.ts = 256;
+    } else { /* [tile][L][10][TR] */
+        const int64_t tr = c->opt_tile;
+        a.Y = c->d_buf;
+        a.U = c->d_buf + 3 * tr;
+        a.I = c->d_buf + 6 * tr;
+        a.T = c->d_buf + 9 * tr;
+        a.cs = tr;
+        a.ss = a.ssT = 10 * tr;
+        a.ts = (int64_t)c->buf_nsurf * 10 * tr;
+        a.tshift = __builtin_ctzll((unsigned long long)tr);
+    }
+    return a;
+}
+
+/* everything that reads rows back assumes the documented SoA layout */
+static int rt_soa_only(rt_ctx *c, const char *who)
+{
+    if (c && c->opt_tile)
+        return rt_fail(c, RT_ERR_STATE,
+                       "%s: the tile_rays layout is a measurement option; "
+                       "results can only be read back in the SoA layout", who);
+    return RT_OK;
+}
+
 /* device address of one surface row, resolving the I -> U aliasing */
 static inline double *rt_row(const rt_ctx *c, int which, int surf)
 {
@@ -201,8 +246,7 @@ static int rt_gen_flush(rt_ctx *c)
                        dim3((unsigned)((c->ld + 255) / 256)), dim3(256), 0,
                        c->stream, (const rt_field *)c->d_gen,
                        (const double *)((char *)c->d_gen + c->gen_fpad),
-                       c->gen_np, c->gen_n, c->gen_s0, rt_arr(c, RT_Y),
-                       rt_arr(c, RT_U), rt_arr(c, RT_I), rt_arr(c, RT_T), c->ld,
+                       c->gen_np, c->gen_n, c->gen_s0, rt_layout(c), c->ld,
                        !c->opt_alias);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
@@ -217,9 +261,7 @@ static void rt_launch(rt_ctx *c, int start, int stop, int clip)
     const int64_t grid = XCD ? (nblocks + 7) / 8 * 8 : nblocks;
     hipLaunchKernelGGL((rt_trace_kernel<R, NT, XCD>), dim3((unsigned)grid),
                        dim3(block), (size_t)c->opt_lds, c->stream, c->d_surf,
-                       start, stop, clip,
-                       rt_arr(c, RT_Y), rt_arr(c, RT_U), rt_arr(c, RT_I),
-                       rt_arr(c, RT_T), c->ld, nblocks,
+                       start, stop, clip, rt_layout(c), c->ld, nblocks,
                        c->ngroups > 1 ? c->n / c->ngroups : (int64_t)0,
                        c->nsurf);
 }
@@ -297,9 +339,16 @@ int rt_create(int device, rt_ctx **out)
         free(c);
         return rt_fail(NULL, RT_ERR_NOMEM, "rt_create: host allocation");
     }
-    RT_HIP_C(hipMalloc((void **)&c->d_surf, sizeof(rt_surface) * c->tab_cap));
-    RT_HIP_C(hipHostMalloc((void **)&c->h_stage,
+    for (int k = 0; k < 2; ++k) {
+        RT_HIP_C(hipMalloc((void **)&c->d_tab[k],
                            sizeof(rt_surface) * c->tab_cap));
+        RT_HIP_C(hipHostMalloc((void **)&c->h_pinned[k],
+                               sizeof(rt_surface) * c->tab_cap));
+        RT_HIP_C(hipEventCreateWithFlags(&c->tab_used[k],
+                                         hipEventDisableTiming));
+    }
+    c->d_surf = c->d_tab[0];
+    c->h_stage = c->h_pinned[0];
     memset(c->keep, 1, sizeof c->keep);
 #undef RT_HIP_C
     *out = c;
@@ -337,10 +386,13 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_gen);
     if (ctx->d_opd_ref)
         (void)hipFree(ctx->d_opd_ref);
-    if (ctx->d_surf)
-        (void)hipFree(ctx->d_surf);
-    if (ctx->h_stage)
-        (void)hipHostFree(ctx->h_stage);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->d_tab[k])
+            (void)hipFree(ctx->d_tab[k]);
+        if (ctx->h_pinned[k])
+            (void)hipHostFree(ctx->h_pinned[k]);
+        (void)hipEventDestroy(ctx->tab_used[k]);
+    }
     free(ctx->h_surf);
     for (int i = 0; i < 2; ++i) {
         if (ctx->d_stage[i])
@@ -390,15 +442,29 @@ int rt_upload_system_groups(rt_ctx *ctx, const rt_surface *surf, int nsurf,
                            (size_t)ngroups);
         free(ctx->h_surf);
         ctx->h_surf = h;
-        (void)hipFree(ctx->d_surf);
-        (void)hipHostFree(ctx->h_stage);
-        ctx->d_surf = NULL;
-        ctx->h_stage = NULL;
         ctx->tab_cap = 0;
-        RT_HIP(ctx, hipMalloc((void **)&ctx->d_surf, sizeof(rt_surface) * ntab));
-        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_stage,
+        for (int k = 0; k < 2; ++k) {
+            (void)hipFree(ctx->d_tab[k]);
+            (void)hipHostFree(ctx->h_pinned[k]);
+            ctx->d_tab[k] = NULL;
+            ctx->h_pinned[k] = NULL;
+        }
+        for (int k = 0; k < 2; ++k) {
+            RT_HIP(ctx, hipMalloc((void **)&ctx->d_tab[k],
                                   sizeof(rt_surface) * ntab));
+            RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_pinned[k],
+                                      sizeof(rt_surface) * ntab));
+        }
+        ctx->d_surf = ctx->d_tab[ctx->tab_cur];
+        ctx->h_stage = ctx->h_pinned[ctx->tab_cur];
         ctx->tab_cap = ntab;
+        ctx->table_dirty = 1;
+    } else if (nsurf == ctx->nsurf && ngroups == ctx->ngroups &&
+               !memcmp(ctx->h_surf, surf, sizeof(rt_surface) * ntab)) {
+        /* the table the device already holds (a propagate() that re-packs an
+         * unchanged System, rayopt/geometric_trace.py:98-99 allows edits
+         * between calls): nothing to finalise, nothing to send */
+        return RT_OK;
     }
     memcpy(ctx->h_surf, surf, sizeof(rt_surface) * ntab);
     ctx->table_dirty = 1; /* finalised and sent by the next rt_trace */
@@ -419,7 +485,8 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     if (ctx->nsurf < 2)
         return rt_fail(ctx, RT_ERR_STATE,
                        "rt_reserve: rt_upload_system must come first");
-    const int64_t ld = (nrays + 63) / 64 * 64;
+    const int64_t quantum = ctx->opt_tile ? ctx->opt_tile : 64;
+    const int64_t ld = (nrays + quantum - 1) / quantum * quantum;
     if (ld == ctx->ld && ctx->buf_nsurf == ctx->nsurf && ctx->d_buf) {
         ctx->n = nrays;
         return RT_OK;
@@ -479,15 +546,13 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
 {
     const int block = 256;
     const unsigned grid = (unsigned)((ctx->ld + block - 1) / block);
-    double *Y = rt_arr(ctx, RT_Y), *U = rt_arr(ctx, RT_U),
-           *I = rt_arr(ctx, RT_I), *T = rt_arr(ctx, RT_T);
     if (layout == RT_LAYOUT_AOS)
         hipLaunchKernelGGL(rt_seed_aos_kernel, dim3(grid), dim3(block), 0,
-                           ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld,
+                           ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
                            !ctx->opt_alias, period);
     else
         hipLaunchKernelGGL(rt_seed_soa_kernel, dim3(grid), dim3(block), 0,
-                           ctx->stream, d_y, d_u, n, Y, U, I, T, ctx->ld,
+                           ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
                            !ctx->opt_alias, period);
     RT_HIP(ctx, hipGetLastError());
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
@@ -799,6 +864,8 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
     if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
         return rt_fail(ctx, RT_ERR_STATE, "rt_upload_row: no such row %d",
                        surf);
+    if (rt_soa_only(ctx, "rt_upload_row") != RT_OK)
+        return RT_ERR_STATE;
     const int nc = rt_ncomp(which);
     {
         int rc = rt_gen_flush(ctx);
@@ -873,9 +940,17 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
             return rc;
     }
     if (ctx->table_dirty) {
-        /* a kernel in flight may still read the device table, and the pinned
-         * staging copy must not change under a pending DMA */
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        /* the table goes into the buffer that is NOT in use: a kernel in
+         * flight keeps reading the previous one, so back-to-back propagate()
+         * calls on a changing System pipeline instead of draining the stream.
+         * The other buffer was retired two uploads ago; tab_used[] marks the
+         * last work that touched it */
+        const int k = ctx->tab_cur ^ 1;
+        RT_HIP(ctx, hipEventRecord(ctx->tab_used[ctx->tab_cur], ctx->stream));
+        RT_HIP(ctx, hipEventSynchronize(ctx->tab_used[k]));
+        ctx->tab_cur = k;
+        ctx->d_surf = ctx->d_tab[k];
+        ctx->h_stage = ctx->h_pinned[k];
         const int ntab = ctx->nsurf * ctx->ngroups;
         memcpy(ctx->h_stage, ctx->h_surf, sizeof(rt_surface) * ntab);
         /* whether a row is served from another one is decided per ROW, for
@@ -904,6 +979,14 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
                 j > 0 && (j - 1 < start ? ctx->valid[j - 1] : ctx->keep[j - 1]);
             if (!ctx->opt_alias || rot || j == 0 || !prev_kept)
                 f |= RT_F_STORE_I;
+            f &= ~RT_F_FAST;
+            if (ctx->opt_fast && (f & RT_F_ASPH)) {
+                f |= RT_F_FAST;
+                /* the fast path evaluates a fixed number of terms */
+                rt_surface *S = ctx->h_stage + jj;
+                for (int q = S->nasph; q < RT_MAX_ASPH; ++q)
+                    S->asph[q] = S->dasph[q] = 0.;
+            }
             ctx->h_stage[jj].flags = f;
         }
         RT_HIP(ctx, hipMemcpyAsync(ctx->d_surf, ctx->h_stage,
@@ -932,9 +1015,7 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
         hipLaunchKernelGGL(rt_trace_gen_kernel,
                            dim3((unsigned)((ctx->ld + block - 1) / block)),
                            dim3(block), (size_t)ctx->opt_lds, ctx->stream,
-                           ctx->d_surf, stop, clip, rt_arr(ctx, RT_Y),
-                           rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
-                           rt_arr(ctx, RT_T), ctx->ld,
+                           ctx->d_surf, stop, clip, rt_layout(ctx), ctx->ld,
                            ctx->ngroups > 1 ? ctx->n / ctx->ngroups
                                             : (int64_t)0,
                            ctx->nsurf, (const rt_field *)ctx->d_gen,
@@ -973,11 +1054,15 @@ int rt_set_keep_rows(rt_ctx *ctx, const unsigned char *keep, int n)
 {
     if (!ctx || (keep && (n < 1 || n > RT_MAX_SURFACES)))
         return rt_fail(ctx, RT_ERR_ARG, "rt_set_keep_rows: bad argument");
-    memset(ctx->keep, 1, sizeof ctx->keep);
+    unsigned char want[RT_MAX_SURFACES];
+    memset(want, 1, sizeof want);
     if (keep)
         for (int j = 0; j < n; ++j)
-            ctx->keep[j] = keep[j] ? 1 : 0;
-    ctx->table_dirty = 1;
+            want[j] = keep[j] ? 1 : 0;
+    if (memcmp(want, ctx->keep, sizeof want)) {
+        memcpy(ctx->keep, want, sizeof want);
+        ctx->table_dirty = 1;
+    }
     return RT_OK;
 }
 
@@ -1038,6 +1123,24 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         ctx->table_dirty = 1;
     } else if (!strcmp(key, "fuse_generate")) {
         ctx->opt_fuse = value ? 1 : 0;
+    } else if (!strcmp(key, "fast_asphere")) {
+        if ((value != 0) != ctx->opt_fast)
+            ctx->table_dirty = 1;
+        ctx->opt_fast = value ? 1 : 0;
+    } else if (!strcmp(key, "tile_rays")) {
+        /* measurement only: tile-major layout (rt_kernels.h, rt_lay); takes
+         * effect with the next rt_reserve / rt_set_rays */
+        if (value && (value < 64 || value > 65536 || (value & (value - 1))))
+            return rt_fail(ctx, RT_ERR_ARG,
+                           "tile_rays must be 0 or a power of two in "
+                           "[64, 65536]");
+        if (value != ctx->opt_tile) {
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->opt_tile = value;
+            ctx->ld = 0; /* the next rt_reserve lays the arrays out anew */
+            ctx->n = 0;
+            memset(ctx->valid, 0, sizeof ctx->valid);
+        }
     } else if (!strcmp(key, "lds_pad")) {
         /* measurement only: dynamic LDS the kernel never touches, to cap
          * the workgroups resident per CU (160 KB / lds_pad) */
@@ -1064,16 +1167,37 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int L = ctx->buf_nsurf;
     const int64_t ld = ctx->ld;
+    if (ctx->opt_tile && (mode >= 1 && mode <= 4))
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_probe: the linear fills address the SoA layout");
     /* rows 1..L-1 of the four arrays; row 0 (the input rays) is preserved */
     RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
-    if (mode == 0) {
-        const int block = 256;
-        const unsigned grid = (unsigned)((ld / 2 + block - 1) / block);
-        hipLaunchKernelGGL(rt_probe_pattern_kernel, dim3(grid), dim3(block), 0,
-                           ctx->stream, 1, L, rt_arr(ctx, RT_Y),
-                           rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
-                           rt_arr(ctx, RT_T), ld);
-        *bytes = (double)ld * (80. * (L - 1) + 48.);
+    if (mode == 0 || (mode >= 5 && mode <= 8)) {
+        /* the trace kernel's store pattern without its arithmetic, in the
+         * layout in force (SoA or tile_rays):
+         *   0  80 B/op, 16-byte stores, 48 B/ray input read from HBM
+         *   5  same, input from an L2-resident window     6  no input read
+         *   7  56 B/op (i served from u), 8-byte stores like the default
+         *      kernel, input from HBM                     8  same, no read */
+        const int block = ctx->opt_block;
+        const int rp = mode >= 7 ? 1 : 2;
+        const unsigned grid =
+            (unsigned)((ld / rp + block - 1) / block);
+        const rt_lay lay = rt_layout(ctx);
+        const double *win = ctx->d_buf;
+#define RT_PROBE(IN, RP, SI)                                                  \
+    hipLaunchKernelGGL((rt_probe_pattern_kernel<IN, RP>), dim3(grid),         \
+                       dim3(block), 0, ctx->stream, 1, L, win, lay, ld, SI)
+        switch (mode) {
+        case 0: RT_PROBE(0, 2, 1); break;
+        case 5: RT_PROBE(1, 2, 1); break;
+        case 6: RT_PROBE(2, 2, 1); break;
+        case 7: RT_PROBE(0, 1, 0); break;
+        default: RT_PROBE(2, 1, 0); break;
+        }
+#undef RT_PROBE
+        *bytes = (double)ld * ((mode >= 7 ? 56. : 80.) * (L - 1) +
+                               ((mode == 0 || mode == 7) ? 48. : 0.));
     } else if (mode == 1) {
         double total = 0.;
         for (int w = RT_Y; w <= RT_T; ++w) {
@@ -1109,24 +1233,6 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
                            ctx->stream, rt_arr(ctx, RT_Y) + (size_t)3 * ld,
                            rt_arr(ctx, RT_I) + (size_t)3 * ld, n2);
         *bytes = (double)n2 * 32.;
-    } else if (mode == 5 || mode == 6) {
-        /* store pattern with the input read from an L2-resident window (5)
-         * or without any read (6) */
-        const int block = 256;
-        const unsigned grid = (unsigned)((ld / 2 + block - 1) / block);
-        if (mode == 5)
-            hipLaunchKernelGGL(rt_probe_pattern_in_kernel<1>, dim3(grid),
-                               dim3(block), 0, ctx->stream, 1, L,
-                               rt_arr(ctx, RT_Y), rt_arr(ctx, RT_Y),
-                               rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
-                               rt_arr(ctx, RT_T), ld);
-        else
-            hipLaunchKernelGGL(rt_probe_pattern_in_kernel<2>, dim3(grid),
-                               dim3(block), 0, ctx->stream, 1, L,
-                               rt_arr(ctx, RT_Y), rt_arr(ctx, RT_Y),
-                               rt_arr(ctx, RT_U), rt_arr(ctx, RT_I),
-                               rt_arr(ctx, RT_T), ld);
-        *bytes = (double)ld * 80. * (L - 1);
     } else {
         return rt_fail(ctx, RT_ERR_ARG, "rt_probe: mode %d", mode);
     }
@@ -1147,6 +1253,8 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
         surf_lo >= surf_hi)
         return rt_fail(ctx, RT_ERR_STATE, "rt_download: rows [%d,%d) of %d",
                        surf_lo, surf_hi, ctx->buf_nsurf);
+    if (rt_soa_only(ctx, "rt_download") != RT_OK)
+        return RT_ERR_STATE;
     const int nc = rt_ncomp(which);
     for (int j = surf_lo; j < surf_hi; ++j)
         if (!ctx->valid[j])
@@ -1180,6 +1288,8 @@ int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
     if (!ctx->d_buf || ray < 0 || ray >= ctx->n)
         return rt_fail(ctx, RT_ERR_STATE, "rt_download_ray: ray %lld of %lld",
                        (long long)ray, (long long)ctx->n);
+    if (rt_soa_only(ctx, "rt_download_ray") != RT_OK)
+        return RT_ERR_STATE;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     {
         int rc = rt_gen_flush(ctx);
@@ -1239,6 +1349,8 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
         !ctx->valid[surf])
         return rt_fail(ctx, RT_ERR_STATE, "%s: row %d holds no data", who,
                        surf);
+    if (rt_soa_only(ctx, who) != RT_OK)
+        return RT_ERR_STATE;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_partials)
         RT_HIP(ctx, hipMalloc((void **)&ctx->d_partials,
@@ -1465,6 +1577,8 @@ int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
     if (!ctx->valid[surf])
         return rt_fail(ctx, RT_ERR_STATE, "rt_device_ptr: row %d holds no data",
                        surf);
+    if (rt_soa_only(ctx, "rt_device_ptr") != RT_OK)
+        return RT_ERR_STATE;
     int rc = rt_gen_flush(ctx);
     if (rc != RT_OK)
         return rc;
@@ -1601,6 +1715,8 @@ int rt_gather_final(rt_ctx *ctx, int which, int surf, const int64_t *counts,
                        (long long)ctx->n);
     if (ctx->rank == root && !d_dst)
         return rt_fail(ctx, RT_ERR_ARG, "rt_gather_final: root needs d_dst");
+    if (rt_soa_only(ctx, "rt_gather_final") != RT_OK)
+        return RT_ERR_STATE;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     {
         int rc = rt_gen_flush(ctx);

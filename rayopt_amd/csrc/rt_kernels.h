@@ -76,65 +76,83 @@ __device__ __forceinline__ int64_t rt_chunk(int64_t nblocks)
     return c; /* may be >= nblocks for the ragged tail: caller checks */
 }
 
-/* read rows start-1 of Y,U for the R rays at offset j */
+/*
+ * Where the result arrays live.  Default ("SoA", include/rt_mi355.h):
+ *     Y,U,I [L][3][ld], T [L][ld]      cs = ld, ss = 3 ld, ssT = ld
+ * and a ray's column is its index j.  Measurement-only alternative
+ * (rt_set_option "tile_rays" = TR): the batch is cut into tiles of TR rays
+ * and a tile holds ALL its rows back to back, [tile][L][10][TR] with the ten
+ * components y0 y1 y2 u0 u1 u2 i0 i1 i2 t, so that a workgroup's whole
+ * output is one contiguous region:
+ *     cs = TR, ss = ssT = 10 TR, tile stride ts = L 10 TR.
+ * Element (array, s, c) of ray j is at
+ *     base[array] + s*ss + c*cs + (j >> tshift)*ts + (j & (TR - 1)).
+ * For SoA ts = TR = 1 << tshift, which makes the last two terms j again.
+ */
+struct rt_lay {
+    double *Y, *U, *I, *T;
+    int64_t cs, ss, ssT, ts;
+    int tshift;
+};
+
+__device__ __forceinline__ int64_t rt_col(const rt_lay &a, int64_t j)
+{
+    return (j >> a.tshift) * a.ts + (j & (((int64_t)1 << a.tshift) - 1));
+}
+
+/* read rows start-1 of Y,U for the R rays at column `col` */
 template <int R>
-__device__ __forceinline__ void rt_load_state(const double *__restrict__ Y,
-                                              const double *__restrict__ U,
-                                              int64_t row, int64_t ld,
-                                              int64_t j, double (&y)[R][3],
+__device__ __forceinline__ void rt_load_state(const rt_lay &a, int srow,
+                                              int64_t col, double (&y)[R][3],
                                               double (&u)[R][3])
 {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        double a[R], b[R];
-        rt_load<R>(Y + (row + c) * ld + j, a);
-        rt_load<R>(U + (row + c) * ld + j, b);
+        double p[R], q[R];
+        rt_load<R>(a.Y + srow * a.ss + c * a.cs + col, p);
+        rt_load<R>(a.U + srow * a.ss + c * a.cs + col, q);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            y[r][c] = a[r];
-            u[r][c] = b[r];
+            y[r][c] = p[r];
+            u[r][c] = q[r];
         }
     }
 }
 
-/* the rows of one element for the R rays at offset j */
+/* the rows of one element for the R rays at column `col` */
 template <int R, bool NT>
 __device__ __forceinline__ void rt_store_rows(
-    unsigned flags, int s, double *__restrict__ Y, double *__restrict__ U,
-    double *__restrict__ I, double *__restrict__ T, int64_t ld, int64_t j,
+    unsigned flags, int s, const rt_lay &a, int64_t col,
     const double (&y)[R][3], const double (&u)[R][3],
     const double (&iv)[R][3], const double (&t)[R])
 {
     if (flags & RT_F_NOSTORE)
         return;
-    const int64_t row = (int64_t)s * 3;
+    const int64_t row = s * a.ss + col;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        double a[R], b[R], d[R];
+        double p[R], q[R], d[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            a[r] = y[r][c];
-            b[r] = u[r][c];
+            p[r] = y[r][c];
+            q[r] = u[r][c];
             d[r] = iv[r][c];
         }
-        rt_store<R, NT>(Y + (row + c) * ld + j, a);
+        rt_store<R, NT>(a.Y + row + c * a.cs, p);
         if (!(flags & RT_F_SKIP_U))
-            rt_store<R, NT>(U + (row + c) * ld + j, b);
+            rt_store<R, NT>(a.U + row + c * a.cs, q);
         if (flags & RT_F_STORE_I)
-            rt_store<R, NT>(I + (row + c) * ld + j, d);
+            rt_store<R, NT>(a.I + row + c * a.cs, d);
     }
-    rt_store<R, NT>(T + (int64_t)s * ld + j, t);
+    rt_store<R, NT>(a.T + s * a.ssT + col, t);
 }
 
 /* all elements start..stop-1 for the R rays of this lane; state in VGPRs */
 template <int R, bool NT>
 __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
                                          int start, int stop, int clip,
-                                         double *__restrict__ Y,
-                                         double *__restrict__ U,
-                                         double *__restrict__ I,
-                                         double *__restrict__ T, int64_t ld,
-                                         int64_t j, double (&y)[R][3],
+                                         const rt_lay &a, int64_t col,
+                                         double (&y)[R][3],
                                          double (&u)[R][3])
 {
     double iv[R][3], t[R];
@@ -145,13 +163,31 @@ __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
     for (int s = start; s < stop; ++s) {
         const rt_surface *S = surf + s;
         const unsigned flags = S->flags;
-        rt_step<R>(S, flags, clip, y, u, iv, t);
+        /* a ray whose direction is NaN (clipped, missed, TIR, Newton failure:
+         * elements.py:206-209,:496,:367,:347) yields NaN in every array of
+         * every later element; a wavefront with no other ray left stores
+         * that without evaluating it */
+        bool alive = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            alive = alive || u[r][0] == u[r][0];
+        if (RT_WAVE_ANY(alive)) {
+            rt_step<R>(S, flags, clip, y, u, iv, t);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                t[r] = RT_NAN;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    y[r][c] = u[r][c] = iv[r][c] = RT_NAN;
+            }
+        }
 
         /* all rows of the element leave in one burst: measured 3 % faster
          * than sending y,t,i ahead of the refraction, and aligning the waves
          * of a workgroup with a barrier first does not help
          * (profiles/r01_probes/ab_store_order.log) */
-        rt_store_rows<R, NT>(flags, s, Y, U, I, T, ld, j, y, u, iv, t);
+        rt_store_rows<R, NT>(flags, s, a, col, y, u, iv, t);
 
         rt_leave<R>(S, flags, y, u);
     }
@@ -159,9 +195,7 @@ __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
 
 template <int R, bool NT, bool XCD>
 __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
-                                int stop, int clip, double *__restrict__ Y,
-                                double *__restrict__ U, double *__restrict__ I,
-                                double *__restrict__ T, int64_t ld,
+                                int stop, int clip, rt_lay a, int64_t ld,
                                 int64_t nblocks, int64_t group_rays,
                                 int nsurf)
 {
@@ -177,9 +211,10 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
         const int g = __builtin_amdgcn_readfirstlane((int)(j0 / group_rays));
         surf += (int64_t)g * nsurf;
     }
+    const int64_t col = rt_col(a, j);
     double y[R][3], u[R][3];
-    rt_load_state<R>(Y, U, (int64_t)(start - 1) * 3, ld, j, y, u);
-    rt_march<R, NT>(surf, start, stop, clip, Y, U, I, T, ld, j, y, u);
+    rt_load_state<R>(a, start - 1, col, y, u);
+    rt_march<R, NT>(surf, start, stop, clip, a, col, y, u);
 }
 
 /*
@@ -191,10 +226,7 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
  * profiles/r01_probes/ab_store_order.log (9)).
  */
 __global__ void rt_trace_gen_kernel(const rt_surface *__restrict__ surf,
-                                    int stop, int clip, double *__restrict__ Y,
-                                    double *__restrict__ U,
-                                    double *__restrict__ I,
-                                    double *__restrict__ T, int64_t ld,
+                                    int stop, int clip, rt_lay a, int64_t ld,
                                     int64_t group_rays, int nsurf,
                                     const rt_field *__restrict__ fields,
                                     const double *__restrict__ pupil,
@@ -215,24 +247,22 @@ __global__ void rt_trace_gen_kernel(const rt_surface *__restrict__ surf,
         rt_generate_ray(fields + j / npupil, pupil[2 * p], pupil[2 * p + 1],
                         &S0, y, u);
     }
+    const int64_t col = rt_col(a, j);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        Y[c * ld + j] = y[0][c];
-        U[c * ld + j] = u[0][c];
+        a.Y[c * a.cs + col] = y[0][c];
+        a.U[c * a.cs + col] = u[0][c];
         if (store_i0)
-            I[c * ld + j] = u[0][c];
+            a.I[c * a.cs + col] = u[0][c];
     }
-    T[j] = 0.;
-    rt_march<1, false>(surf, 1, stop, clip, Y, U, I, T, ld, j, y, u);
+    a.T[col] = 0.;
+    rt_march<1, false>(surf, 1, stop, clip, a, col, y, u);
 }
 
 /* rays_given: AoS (n,3) staging -> SoA row 0 of Y,U,I and T[0] = 0 */
 __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
                                    const double *__restrict__ u_aos,
-                                   int64_t n, double *__restrict__ Y,
-                                   double *__restrict__ U,
-                                   double *__restrict__ I,
-                                   double *__restrict__ T, int64_t ld,
+                                   int64_t n, rt_lay a, int64_t ld,
                                    int store_i, int64_t period)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -240,42 +270,41 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
         return;
     const bool in = j < n;
     const int64_t k = j % period; /* the same rays for every group */
+    const int64_t col = rt_col(a, j);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double a = in ? y_aos[k * 3 + c] : 0.;
-        const double b = in ? u_aos[k * 3 + c] : 0.;
-        Y[c * ld + j] = a;
-        U[c * ld + j] = b;
+        const double p = in ? y_aos[k * 3 + c] : 0.;
+        const double q = in ? u_aos[k * 3 + c] : 0.;
+        a.Y[c * a.cs + col] = p;
+        a.U[c * a.cs + col] = q;
         if (store_i)
-            I[c * ld + j] = b;
+            a.I[c * a.cs + col] = q;
     }
-    T[j] = 0.;
+    a.T[col] = 0.;
 }
 
 /* rays_given for SoA (3,n) device/staged input */
 __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
                                    const double *__restrict__ u_soa,
-                                   int64_t n, double *__restrict__ Y,
-                                   double *__restrict__ U,
-                                   double *__restrict__ I,
-                                   double *__restrict__ T, int64_t ld,
+                                   int64_t n, rt_lay a, int64_t ld,
                                    int store_i, int64_t period)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
         return;
     const bool in = j < n;
-    const int64_t k = j % period;
+    const int64_t k = j % period; /* the same rays for every group */
+    const int64_t col = rt_col(a, j);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double a = in ? y_soa[c * period + k] : 0.;
-        const double b = in ? u_soa[c * period + k] : 0.;
-        Y[c * ld + j] = a;
-        U[c * ld + j] = b;
+        const double p = in ? y_soa[c * period + k] : 0.;
+        const double q = in ? u_soa[c * period + k] : 0.;
+        a.Y[c * a.cs + col] = p;
+        a.U[c * a.cs + col] = q;
         if (store_i)
-            I[c * ld + j] = b;
+            a.I[c * a.cs + col] = q;
     }
-    T[j] = 0.;
+    a.T[col] = 0.;
 }
 
 
@@ -284,70 +313,44 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
  * without its arithmetic, a linear fill and a 16-byte copy.  They calibrate
  * the memory-system ceiling the trace kernel is judged against.
  */
+template <int IN, int RP>
 __global__ void rt_probe_pattern_kernel(int start, int stop,
-                                        double *__restrict__ Y,
-                                        double *__restrict__ U,
-                                        double *__restrict__ I,
-                                        double *__restrict__ T, int64_t ld)
+                                        const double *__restrict__ in,
+                                        rt_lay a, int64_t ld, int stored_i)
 {
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    typedef typename rt_vec<RP>::type V;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * RP;
     if (j >= ld)
         return;
-    v2 y[3], u[3];
-    const int64_t row0 = (int64_t)(start - 1) * 3;
+    const int64_t col = rt_col(a, j);
+    V y[3], u[3];
     for (int c = 0; c < 3; ++c) {
-        y[c] = *reinterpret_cast<const v2 *>(Y + (row0 + c) * ld + j);
-        u[c] = *reinterpret_cast<const v2 *>(U + (row0 + c) * ld + j);
-    }
-    for (int s = start; s < stop; ++s) {
-        const int64_t row = (int64_t)s * 3;
-        for (int c = 0; c < 3; ++c) {
-            y[c] += u[c];
-            *reinterpret_cast<v2 *>(Y + (row + c) * ld + j) = y[c];
-            *reinterpret_cast<v2 *>(U + (row + c) * ld + j) = u[c];
-            *reinterpret_cast<v2 *>(I + (row + c) * ld + j) = u[c];
-        }
-        *reinterpret_cast<v2 *>(T + (int64_t)s * ld + j) = y[2];
-    }
-}
-
-/* the same store pattern with the 48 B/ray input read served from a 3 MB
- * window that stays in L2 (IN = 1) or not read at all (IN = 2): what the
- * read costs the saturated write stream */
-template <int IN>
-__global__ void rt_probe_pattern_in_kernel(int start, int stop,
-                                           const double *__restrict__ in,
-                                           double *__restrict__ Y,
-                                           double *__restrict__ U,
-                                           double *__restrict__ I,
-                                           double *__restrict__ T, int64_t ld)
-{
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    if (j >= ld)
-        return;
-    v2 y[3], u[3];
-    for (int c = 0; c < 3; ++c) {
-        if constexpr (IN == 1) {
+        if constexpr (IN == 0) { /* the 48 B/ray input rows, from HBM */
+            y[c] = *reinterpret_cast<const V *>(
+                a.Y + (start - 1) * a.ss + c * a.cs + col);
+            u[c] = *reinterpret_cast<const V *>(
+                a.U + (start - 1) * a.ss + c * a.cs + col);
+        } else if constexpr (IN == 1) { /* from a 3 MB window that stays in
+                                           L2 */
             const int64_t k = j & 0xffff;
-            y[c] = *reinterpret_cast<const v2 *>(in + (int64_t)c * 65536 + k);
-            u[c] = *reinterpret_cast<const v2 *>(in + (int64_t)(3 + c) * 65536 +
-                                                 k);
-        } else {
-            y[c] = v2{(double)threadIdx.x, 1.};
-            u[c] = v2{(double)blockIdx.x, 2.};
+            y[c] = *reinterpret_cast<const V *>(in + (int64_t)c * 65536 + k);
+            u[c] = *reinterpret_cast<const V *>(in + (int64_t)(3 + c) * 65536 +
+                                                k);
+        } else { /* no read at all */
+            y[c] = (V)((double)threadIdx.x);
+            u[c] = (V)((double)blockIdx.x);
         }
     }
     for (int s = start; s < stop; ++s) {
-        const int64_t row = (int64_t)s * 3;
+        const int64_t row = s * a.ss + col;
         for (int c = 0; c < 3; ++c) {
             y[c] += u[c];
-            *reinterpret_cast<v2 *>(Y + (row + c) * ld + j) = y[c];
-            *reinterpret_cast<v2 *>(U + (row + c) * ld + j) = u[c];
-            *reinterpret_cast<v2 *>(I + (row + c) * ld + j) = u[c];
+            *reinterpret_cast<V *>(a.Y + row + c * a.cs) = y[c];
+            *reinterpret_cast<V *>(a.U + row + c * a.cs) = u[c];
+            if (stored_i)
+                *reinterpret_cast<V *>(a.I + row + c * a.cs) = u[c];
         }
-        *reinterpret_cast<v2 *>(T + (int64_t)s * ld + j) = y[2];
+        *reinterpret_cast<V *>(a.T + s * a.ssT + col) = y[2];
     }
 }
 
@@ -391,11 +394,7 @@ __global__ void rt_probe_copy_kernel(const double *__restrict__ src,
 __global__ void rt_generate_kernel(const rt_field *__restrict__ fields,
                                    const double *__restrict__ pupil,
                                    int64_t npupil, int64_t n, rt_surface S0,
-                                   double *__restrict__ Y,
-                                   double *__restrict__ U,
-                                   double *__restrict__ I,
-                                   double *__restrict__ T, int64_t ld,
-                                   int store_i)
+                                   rt_lay a, int64_t ld, int store_i)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= ld)
@@ -406,14 +405,15 @@ __global__ void rt_generate_kernel(const rt_field *__restrict__ fields,
         rt_generate_ray(fields + r / npupil, pupil[2 * p], pupil[2 * p + 1],
                         &S0, y, u);
     }
+    const int64_t col = rt_col(a, r);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        Y[c * ld + r] = y[0][c];
-        U[c * ld + r] = u[0][c];
+        a.Y[c * a.cs + col] = y[0][c];
+        a.U[c * a.cs + col] = u[0][c];
         if (store_i)
-            I[c * ld + r] = u[0][c];
+            a.I[c * a.cs + col] = u[0][c];
     }
-    T[r] = 0.;
+    a.T[col] = 0.;
 }
 
 /* batched aiming: one lane per field runs System.pupil start to finish
