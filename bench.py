@@ -3,19 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one fused pass of the hot path (all S = len(system)-1 elements)
-over one batch of synthetic rays that is already resident in HBM.  Workload
-at every N: BASELINE.json configs[2] -- the double-Gauss (L=13, S=12,
-spherical + stop), 10^7 rays per GPU in five field bundles, clip=True (weak
-scaling: each rank traces its own 10^7-ray shard, different seeds).  For N>1
-(one process per GPU, launched by torch.distributed.run) the trace itself
+A "step" is one call of the public ``GeometricTrace.propagate(clip=True)`` --
+re-packing the System, handing the table over and one fused pass of the hot
+path over all S = len(system)-1 elements -- on one batch of synthetic rays
+that is already resident in HBM.  Workload at every N: BASELINE.json
+configs[2] -- the double-Gauss (L=13, S=12, spherical + stop), 10^7 rays per
+GPU in five field bundles, clip=True (weak scaling: each rank traces its own
+10^7-ray shard, different seeds).
+
+N > 1 is one process per GPU.  ``python bench.py --gpus N`` starts the N
+workers itself; started by a per-GPU launcher (``python -m
+torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK /
+LOCAL_RANK / WORLD_SIZE in the environment) it uses the ranks it is given.
+Either way the host side is PyTorch-free: rendezvous, barrier and the
+max-over-ranks of the timing go over rayopt_amd.distributed.HostGroup (TCP on
+127.0.0.1), the device exchange is the engine's own RCCL gather.  The trace
 needs no communication; the one exchange of the job -- the RCCL gather of the
 last-surface intercepts y[L-1] of all ranks to rank 0 over xGMI -- runs once,
 after the last step, INSIDE the timed region (results otherwise stay sharded
-in HBM exactly as they stay in HBM at N=1).  `gather_ms` reports it alone;
+in HBM exactly as they stay in HBM at N=1).  ``gather_ms`` reports it alone;
 --gather-every-step makes every step a complete job (trace + gather,
 pipelined), which is bound by the root's xGMI ingest (24 B/ray over <= 7
-links), not by the engine.
+links), not by the engine.  For N > 1 the line also carries ``configs4``:
+BASELINE configs[4], 10^8 rays in total sharded over the N GPUs (1.25*10^7
+per GPU at N=8), rays built on the device, same timed-loop rules.
 
 Setup (untimed, before the W warm-up steps): rays are generated and uploaded
 and the kernel is launched for --settle seconds (default 0.3 s) so the device
@@ -33,17 +44,23 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                 tilted (rayopt/system.py:461,464), so by default the engine
                 serves those rows of `i` from `u` instead of writing them
                 again; the double-Gauss has no tilted element -> 56 B.
-  full_i        (--extras) the same timed loop with every row of `i`
-                materialised (rt_set_option alias_i=0): the 80 B/op figure of
-                SURVEY 8(d)
-  unclipped     (--extras) the same timed loop with clip=False, the
-                reference's default
-  image_row_only (--extras) propagate(keep=[-1]): the FP64 side of the kernel
+                ``traffic`` = HBM bytes per launch from PMC counters; it is
+                not re-measured in this run (counters need rocprofv3) but
+                taken from the committed profile named in ``traffic_source``.
+  propagate_api the public call against the bare engine call (Engine.trace
+                in the same timed loop) and the wall time of one propagate()
+                on a 10^4-ray batch, where the host path decides
+  full_i / unclipped / image_row_only   (--extras) other store modes
   cpu_baseline  the numpy port of the reference path (oracle/trace_numpy.py,
                 same whole-array numpy operations as rayopt) timed on this
-                host, one core, on a bounded sample of the same workload
-  cpu_baseline_c the independent plain-C port (oracle/trace_c.c) with OpenMP
-                on every host core: the compiled multi-threaded CPU figure
+                host, ONE core, on a bounded sample of the same workload;
+                kind "reference" = rayopt itself, when /root/reference is
+                present on the box
+  cpu_baseline_all_cores   the same port on every host core (one forked
+                process per core over contiguous ray shards)
+  cpu_baseline_c the independent plain-C port (oracle/trace_c.c) with OpenMP:
+                the compiled multi-threaded CPU figure, as a range over team
+                sizes (boxes of the pool differ by x1.8)
 """
 import argparse
 import json
@@ -59,6 +76,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.  # same guide: measured float4 copy
+FIELD_FRACTIONS = (0, .35, .5, .7, 1.)
+BUNDLE_RADIUS = 17.
 
 
 def log(*a):
@@ -68,10 +87,14 @@ def log(*a):
 def workload_rays(n, rank):
     from rayopt_amd import prescriptions as P
     from rayopt_amd.bundles import multi_field_bundle
-    fields = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in (0, .35, .5, .7, 1.)]
-    return multi_field_bundle(n, 17., fields, seed=1000*rank,
+    fields = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in FIELD_FRACTIONS]
+    return multi_field_bundle(n, BUNDLE_RADIUS, fields, seed=1000*rank,
                               z_pupil=P.DOUBLE_GAUSS_PUPIL_Z)
 
+
+# --------------------------------------------------------------------------
+# CPU baselines (N = 1, rank 0 only; test infrastructure used as a yardstick)
+# --------------------------------------------------------------------------
 
 _SHARD = {}
 
@@ -83,49 +106,6 @@ def _shard_worker(k):
     lo, hi = bounds[k]
     Y, U, I, T = tn.propagate(table, y[lo:hi], u[lo:hi], clip=clip)
     return float(np.nansum(Y[-1]))      # touch the result
-
-
-def cpu_c_oracle(table, y, u, clip, S, g, L, sample=2_000_000):
-    """The independent plain-C oracle (oracle/trace_c.c, OpenMP over rays) on
-    every host core: what a compiled multi-threaded CPU implementation of the
-    same path reaches on this box.  Doubles as a second parity check."""
-    from oracle import build_c
-    build_c.build()
-    m = min(sample, y.shape[0])
-    ys, us = np.ascontiguousarray(y[:m]), np.ascontiguousarray(u[:m])
-    build_c.propagate(table, ys[:100000], us[:100000], clip=clip)      # warm
-    import ctypes
-    try:
-        gomp = ctypes.CDLL("libgomp.so.1")
-    except OSError:
-        gomp = None
-    # more threads are not always faster (cgroup quota, memory system): take
-    # the best team size
-    teams = sorted({min(os.cpu_count(), t) for t in (16, 64, os.cpu_count())})
-    best, out, cores = None, None, os.cpu_count()
-    build_c.propagate(table, ys, us, clip=clip)      # touch the output pages
-    for team in (teams if gomp is not None else teams[-1:]):
-        if gomp is not None:
-            gomp.omp_set_num_threads(team)
-        for _ in range(3):
-            t0 = time.perf_counter()
-            out = build_c.propagate(table, ys, us, clip=clip, out=out)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best:
-                best, cores = dt, team
-    Y = out[0]
-    got = np.asarray(g.y[L - 1])[:m]
-    same = np.array_equal(got, Y[-1], equal_nan=True)
-    return {
-        "value": m*S/best,
-        "unit": "ray-surface-ops/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": "first %d rays, best propagate() of the C port with OpenMP "
-                  "over team sizes %s, same output arrays (%.3f s); host has "
-                  "%d cores" % (m, teams, best, os.cpu_count()),
-        "image_row_bit_identical_to_gpu": bool(same),
-    }
 
 
 def cpu_port_on_processes(system, y, u, clip, procs):
@@ -144,60 +124,91 @@ def cpu_port_on_processes(system, y, u, clip, procs):
         t0 = time.perf_counter()
         pool.map(_shard_worker, range(procs))
         dt = time.perf_counter() - t0
+    _SHARD.clear()
     S = len(system) - 1
     return {"value": len(y)*S/dt, "unit": "ray-surface-ops/s",
             "cores": procs, "kind": "port",
-            "sample": "the whole batch on %d processes, contiguous shards "
-                      "(%.2f s)" % (procs, dt)}
+            "sample": "the whole %d-ray batch on %d forked processes (one "
+                      "per host core), contiguous shards, one propagate() of "
+                      "the numpy port each (%.2f s)" % (len(y), procs, dt)}
 
 
-class _DeviceView:
-    """numpy-style view of raw device memory for torch.as_tensor."""
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {
-            "shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
-            "version": 2, "strides": None}
+def cpu_one_core(table, system, y, u, clip, S, g, L, sample, l):
+    """One propagate() of the numpy port -- or of rayopt itself where
+    /root/reference exists -- on one core; doubles as a parity check of the
+    bench run itself."""
+    from oracle import trace_numpy as tn
+    m = min(sample, y.shape[0])
+    ys, us = y[:m], u[:m]
+    tn.propagate(table, ys[:100000], us[:100000], clip=clip)   # warm
+    t0 = time.perf_counter()
+    Y, U, I, T = tn.propagate(table, ys, us, clip=clip)
+    dt = time.perf_counter() - t0
+    got = np.asarray(g.y[L - 1])[:m]
+    ref = Y[-1]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    fin = np.isfinite(ref)
+    assert (np.abs(got[fin] - ref[fin]) <=
+            1e-10*np.maximum(np.abs(ref[fin]), 1.)).all()
+    out = {
+        "value": m*S/dt, "unit": "ray-surface-ops/s", "cores": 1,
+        "kind": "port",
+        "sample": "first %d rays of the same workload, one propagate() of "
+                  "the numpy port (%.1f s); host has %d cores" % (
+                      m, dt, os.cpu_count()),
+    }
+    from oracle import ref_timing
+    ref = ref_timing.time_reference(ys, us, l, clip, want_image_row=Y[-1])
+    if ref is not None:         # rayopt itself, where the box has it
+        ref["port_value"] = m*S/dt
+        out = ref
+    return out
 
 
-class TorchGather:
-    """Gather of row y[L-1] to rank 0 with torch.distributed send/recv on
-    views of the engine's buffers; used only if the engine's own RCCL
-    communicator cannot be created."""
-    def __init__(self, torch, dist, eng, n, world, rank, d_dst, L):
-        from rayopt_amd._lib import RT_Y
-        self.torch, self.dist, self.eng = torch, dist, eng
-        self.n, self.world, self.rank = n, world, rank
-        self.row, self.d_dst = (RT_Y, L - 1), d_dst
-        self.src = self.dst = None
-
-    def _views(self):
-        torch, n = self.torch, self.n
-        src = torch.as_tensor(_DeviceView(self.eng.device_ptr(*self.row),
-                                          (3, self.eng.ld)), device="cuda")
-        self.src = src[:, :n]
-        if self.rank == 0:
-            self.dst = torch.as_tensor(
-                _DeviceView(self.d_dst, (3, n*self.world)), device="cuda")
-
-    def __call__(self):
-        torch, dist = self.torch, self.dist
-        self.eng.sync()                  # the trace that produced the row
-        if self.src is None:
-            self._views()
-        if self.rank == 0:
-            self.dst[:, :self.n].copy_(self.src)
-            ops = []
-            for r in range(1, self.world):
-                for c in range(3):
-                    ops.append(dist.P2POp(
-                        dist.irecv, self.dst[c, r*self.n:(r + 1)*self.n], r))
-        else:
-            stage = self.src.contiguous()
-            ops = [dist.P2POp(dist.isend, stage[c], 0) for c in range(3)]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        torch.cuda.synchronize()
+def cpu_c_oracle(table, y, u, clip, S, g, L, sample=2_000_000):
+    """The independent plain-C oracle (oracle/trace_c.c, OpenMP over rays):
+    what a compiled multi-threaded CPU implementation of the same path
+    reaches on this box, per team size.  Doubles as a second parity check."""
+    from oracle import build_c
+    build_c.build()
+    m = min(sample, y.shape[0])
+    ys, us = np.ascontiguousarray(y[:m]), np.ascontiguousarray(u[:m])
+    build_c.propagate(table, ys[:100000], us[:100000], clip=clip)      # warm
+    import ctypes
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+    teams = sorted({min(os.cpu_count(), t) for t in (16, 64, os.cpu_count())})
+    out = build_c.propagate(table, ys, us, clip=clip)   # touch output pages
+    by_team = {}
+    for team in (teams if gomp is not None else teams[-1:]):
+        if gomp is not None:
+            gomp.omp_set_num_threads(team)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = build_c.propagate(table, ys, us, clip=clip, out=out)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        by_team[team] = m*S/best
+    Y = out[0]
+    got = np.asarray(g.y[L - 1])[:m]
+    same = np.array_equal(got, Y[-1], equal_nan=True)
+    cores = max(by_team, key=by_team.get)
+    return {
+        "value": by_team[cores],
+        "range": [min(by_team.values()), max(by_team.values())],
+        "by_team_size": {str(k): v for k, v in by_team.items()},
+        "unit": "ray-surface-ops/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "first %d rays, best of 3 propagate() of the C port with "
+                  "OpenMP per team size, same output arrays; host has %d "
+                  "cores; boxes of the pool differ by up to x1.8 on this "
+                  "figure -- read it as a range" % (m, os.cpu_count()),
+        "image_row_bit_identical_to_gpu": bool(same),
+    }
 
 
 def traffic_from_profile():
@@ -212,10 +223,107 @@ def traffic_from_profile():
         return None
 
 
+# --------------------------------------------------------------------------
+# timed loops
+# --------------------------------------------------------------------------
+
+class Job:
+    """One rank's share of the benchmark: its trace, its engine and the host
+    group it synchronises with."""
+
+    def __init__(self, args, group, g, counts, d_dst):
+        self.args, self.group, self.g = args, group, g
+        self.eng = g.engine
+        self.dist = group is not None
+        self.counts, self.d_dst = counts, d_dst
+        self.L = len(g.system)
+
+    def gather(self):
+        from rayopt_amd._lib import RT_Y
+        self.eng.gather_final(RT_Y, self.L - 1, self.counts, 0, self.d_dst)
+
+    def fence(self):
+        self.eng.sync()
+        if self.dist:
+            self.eng.comm_sync()
+            self.group.barrier()
+
+    def timed(self, step, steps, warmup, final_gather):
+        """W untimed + exactly K timed calls of `step`, bracketed by device
+        sync + barrier on both sides.  Returns (wall s, HIP-event ms over the
+        K steps on the trace stream, ms of the last kernel)."""
+        eng = self.eng
+        for _ in range(warmup):
+            step()
+        self.fence()
+        t0 = time.perf_counter()
+        eng.event_record(0)
+        for _ in range(steps):
+            step()
+        eng.event_record(1)
+        if final_gather:
+            self.gather()       # the job's one exchange
+        self.fence()
+        return (time.perf_counter() - t0, eng.event_elapsed(0, 1),
+                eng.kernel_ms())
+
+
 def main():
     # the contract is ONE JSON line on stdout: native libraries (RCCL prints a
     # version banner) must not get at it, so fd 1 is pointed at stderr for the
     # whole run and the line is written to the saved descriptor at the end
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=10_000_000,
+                    help="rays per GPU")
+    ap.add_argument("--total-rays", type=int, default=0,
+                    help="rays of the whole job, sharded over the GPUs "
+                         "(overrides --rays; 100000000 at --gpus 8 is "
+                         "BASELINE configs[4])")
+    ap.add_argument("--no-clip", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
+                    help="rays of the workload timed on the host (0: skip "
+                         "every CPU leg); the default is the whole batch, "
+                         "~10 s on one core")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="processes of the all-cores leg of the numpy port "
+                         "(forked before the GPU is touched); -1 = one per "
+                         "host core, 0 = skip")
+    ap.add_argument("--settle", type=float, default=0.3,
+                    help="seconds of untimed launches during setup so the "
+                         "device reaches its sustained clocks (boxes of the "
+                         "pool take ~50 launches); 0 disables")
+    ap.add_argument("--extras", action="store_true",
+                    help="also time the full_i (80 B/op), unclipped and "
+                         "image-row-only modes (separate timed loops, "
+                         "reported as extra objects)")
+    ap.add_argument("--no-api-leg", action="store_true",
+                    help="skip the propagate_api comparison legs")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="N>1: gather y[L-1] to rank 0 in every step")
+    ap.add_argument("--no-configs4", action="store_true",
+                    help="N>1: skip the BASELINE configs[4] leg (10^8 rays "
+                         "in total)")
+    ap.add_argument("--option", action="append", default=[],
+                    help="kernel variant key=value (rt_set_option)")
+    args = ap.parse_args()
+
+    from rayopt_amd import distributed as D
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        # plain `python bench.py --gpus N`: one worker per GPU, this process
+        # only waits (rank 0's JSON line goes to the inherited stdout)
+        raise SystemExit(D.spawn_workers(args.gpus))
+    world, rank, local_rank = D.world_info()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    have = D.visible_devices()
+    if local_rank >= have:
+        raise SystemExit("--gpus %d: %d devices needed, %d visible"
+                         % (args.gpus, max(world, local_rank + 1), have))
+
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -224,74 +332,34 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (line + "\n").encode())
 
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=10_000_000,
-                    help="rays per GPU")
-    ap.add_argument("--no-clip", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
-                    help="rays of the workload timed on the host (0: skip); "
-                         "the default is the whole batch, ~10 s on one core")
-    ap.add_argument("--settle", type=float, default=0.3,
-                    help="seconds of untimed launches during setup so the "
-                         "device reaches its sustained clocks (boxes of the "
-                         "pool take ~50 launches); 0 disables")
-    ap.add_argument("--extras", action="store_true",
-                    help="also time the full_i (80 B/op) and image-row-only "
-                         "modes (separate timed loops, reported as extra "
-                         "objects); off by default so that every launch of "
-                         "the default command is the headline kernel")
-    ap.add_argument("--gather-every-step", action="store_true",
-                    help="N>1: gather y[L-1] to rank 0 in every step")
-    ap.add_argument("--cpu-procs", type=int, default=0,
-                    help="also time the numpy port on this many host "
-                         "processes over contiguous ray shards (forked "
-                         "before the GPU is touched); reported as "
-                         "cpu_baseline_procs")
-    ap.add_argument("--option", action="append", default=[],
-                    help="kernel variant key=value (rt_set_option)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(
-                "--gpus %d needs one process per GPU: launch with python -m "
-                "torch.distributed.run --nproc-per-node %d ..." % (
-                    args.gpus, args.gpus))
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-
-    # RT_BENCH_FORCE_DIST=1 exercises the whole multi-process path (torch
-    # rendezvous, RCCL communicator, pipelined gather) with a single rank
+    # RT_BENCH_FORCE_DIST=1 exercises the whole multi-process path (host
+    # group, RCCL communicator, pipelined gather) with a single rank
     dist_mode = world > 1 or bool(os.environ.get("RT_BENCH_FORCE_DIST"))
-    dist = None
-    torch = None
-    if dist_mode:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(
-            "cuda", local_rank))
+    group = D.HostGroup(world, rank) if dist_mode else None
 
     import rayopt_amd as ra
     from rayopt_amd import prescriptions as P
-    from rayopt_amd._lib import RT_Y
+    from rayopt_amd.pack import pack_system
 
     clip = not args.no_clip
     system = ra.system_from_yaml(P.DOUBLE_GAUSS)
     L = len(system)
     S = L - 1
-    n = args.rays
+    if args.total_rays:
+        counts = D.shard_counts(args.total_rays, world)
+    else:
+        counts = np.full(world, args.rays, dtype=np.int64)
+    n = int(counts[rank])
 
     t0 = time.perf_counter()
     y, u = workload_rays(n, rank)
-    cpu_procs = None
-    if args.cpu_procs > 1 and rank == 0 and not dist_mode:
-        cpu_procs = cpu_port_on_processes(system, y, u, clip, args.cpu_procs)
+    cpu_all = None
+    procs = os.cpu_count() if args.cpu_procs < 0 else args.cpu_procs
+    if procs > 1 and args.cpu_sample > 0 and rank == 0 and not dist_mode:
+        try:            # forks: before this process opens the GPU
+            cpu_all = cpu_port_on_processes(system, y, u, clip, procs)
+        except Exception as err:      # a reported extra, never fatal
+            cpu_all = {"error": repr(err)[:200]}
     g = ra.GeometricTrace(system, device=local_rank)
     eng = g.engine
     for kv in args.option:
@@ -301,121 +369,78 @@ def main():
     log("[rank %d] %d rays generated + uploaded in %.2f s" % (
         rank, n, time.perf_counter() - t0))
 
-    # RCCL gather of the final intercepts (only where there is an exchange)
-    counts = None
+    # RCCL communicator for the gather of the final intercepts (only where
+    # there is an exchange); no fallback: without it the job fails
     d_dst = 0
-    torch_gather = None
     if dist_mode:
-        from rayopt_amd.distributed import init_engine_comm, shard_counts
-        counts = shard_counts(n*world, world)   # weak scaling: n per rank
+        D.init_engine_comm(eng, group)
         if rank == 0:
             d_dst = eng.scratch(int(counts.sum())*3*8)
-        try:
-            if os.environ.get("RT_BENCH_FORCE_TORCH_GATHER"):
-                raise ra.EngineError("forced")
-            init_engine_comm(eng, dist)
-            ok = 1
-        except ra.EngineError as exc:
-            log("[rank %d] engine RCCL communicator unavailable (%s)" % (
-                rank, exc))
-            ok = 0
-        flag = torch.tensor([ok], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            # safety net for the exchange only: the same RCCL send/recv
-            # through torch.distributed on views of the engine's device
-            # memory (no host staging, no CPU path)
-            torch_gather = TorchGather(torch, dist, eng, n, world, rank,
-                                       d_dst, L)
-
-    from rayopt_amd.pack import pack_system
-    table, ns = pack_system(system, g.l, g.n[0])
-    eng.upload_system(table)
-
-    def gather():
-        if torch_gather is not None:
-            torch_gather()
-        else:
-            eng.gather_final(RT_Y, L - 1, counts, 0, d_dst)
+    job = Job(args, group, g, counts, d_dst)
 
     mode = {"clip": clip}
 
-    def step():
-        eng.trace(1, 0, mode["clip"])
+    def step():                 # the public call
+        g.propagate(clip=mode["clip"])
         if dist_mode and args.gather_every_step:
-            gather()
+            job.gather()
 
-    def fence():
-        eng.sync()
-        if dist_mode:
-            eng.comm_sync()
-            torch.cuda.synchronize()
-            dist.barrier()
+    def step_engine():          # the bare C-ABI call, table already there
+        eng.trace(1, 0, mode["clip"])
 
     if args.settle > 0:         # setup, not part of W or K
+        g.propagate(clip=clip)
         t_end = time.perf_counter() + args.settle
         while time.perf_counter() < t_end:
             for _ in range(10):
                 eng.trace(1, 0, clip)
             eng.sync()
 
-    def timed_loop():
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        eng.event_record(0)
-        for _ in range(args.steps):
-            step()
-        eng.event_record(1)
-        if dist_mode and not args.gather_every_step:
-            # the job's one exchange: final intercepts to rank 0
-            gather()
-        fence()
-        return (time.perf_counter() - t0, eng.event_elapsed(0, 1),
-                eng.kernel_ms())
+    final_gather = dist_mode and not args.gather_every_step
+    plain = not dist_mode and not args.option
 
-    image_only = None
-    if args.extras and not dist_mode and not args.option:
+    image_only = unclipped = full_i = engine_leg = None
+    if args.extras and plain:
         # extension: keep only the image row (merit-function use): the
         # kernel leaves the HBM roofline for the FP64 one
-        mask = np.zeros(L, dtype=np.uint8)
-        mask[0] = mask[L - 1] = 1
-        eng.set_keep_rows(mask)
-        e_img, ev_img, _ = timed_loop()
+        def step_image():
+            g.propagate(clip=clip, keep=[0, -1])
+        e_img, ev_img, _ = job.timed(step_image, args.steps, args.warmup,
+                                     False)
         image_only = (e_img, ev_img/args.steps)
-        eng.set_keep_rows(None)
-    unclipped = None
-    if args.extras and not dist_mode and not args.option and clip:
+    if args.extras and plain and clip:
         # the reference's default: propagate(clip=False); the u rows of the
         # elements that do not bend the ray are not written either
         mode["clip"] = False
-        e_nc, ev_nc, _ = timed_loop()
+        e_nc, ev_nc, _ = job.timed(step, args.steps, args.warmup, False)
         unclipped = (e_nc, ev_nc/args.steps)
         mode["clip"] = clip
-    full_i = None
-    if args.extras and not dist_mode and not any(kv.startswith("alias_i")
-                                                 for kv in args.option):
+    if args.extras and plain:
         # reference point: every row of `i` written (80 B per op)
         eng.set_option("alias_i", 0)
-        eng.upload_system(table)
-        e_full, ev_full, _ = timed_loop()
+        e_full, ev_full, _ = job.timed(step, args.steps, args.warmup, False)
         full_i = (e_full, ev_full/args.steps)
         eng.set_option("alias_i", 1)
-        eng.upload_system(table)
-    elapsed, ev_ms, last_kernel_ms = timed_loop()
+    if not args.no_api_leg and not dist_mode:
+        g.propagate(clip=clip)
+        e_eng, ev_eng, _ = job.timed(step_engine, args.steps, args.warmup,
+                                     False)
+        engine_leg = (e_eng, ev_eng/args.steps)
+
+    elapsed, ev_ms, last_kernel_ms = job.timed(step, args.steps, args.warmup,
+                                               final_gather)
     gather_ms = None
     if dist_mode:
         # the exchange alone (not part of `value`'s timed region)
-        fence()
+        job.fence()
         t0 = time.perf_counter()
-        gather()
-        fence()
-        gather_ms = (time.perf_counter() - t0)*1e3
-    if dist_mode:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        job.gather()
+        job.fence()
+        gather_ms = group.allreduce_max((time.perf_counter() - t0)*1e3)
+        elapsed = group.allreduce_max(elapsed)
+    kernel_ms = (ev_ms/args.steps if not (dist_mode and args.gather_every_step)
+                 else last_kernel_ms)
+    per_rank_kernel_ms = group.gather(kernel_ms) if dist_mode else [kernel_ms]
 
     # sanity on the result of the last step (not timed): a few per cent of
     # the rays vignette, everything else reaches the image
@@ -429,14 +454,33 @@ def main():
         assert np.array_equal(mine, ylast, equal_nan=True), \
             "gathered shard 0 differs from the local result"
         assert np.isfinite(gathered).mean() > 0.9
+        del gathered
+
+    api = None
+    if engine_leg is not None and rank == 0:
+        api = {"engine_trace_ms_per_step": engine_leg[0]*1e3/args.steps,
+               "propagate_ms_per_step": elapsed*1e3/args.steps,
+               "ratio": elapsed/engine_leg[0],
+               "note": "`value` times the public GeometricTrace.propagate() "
+                       "(re-pack + table hand-over + launch); "
+                       "engine_trace = the bare rt_trace call in the same "
+                       "timed loop"}
+        api.update(small_batch_latency(ra, system, local_rank))
+
+    configs4 = None
+    if dist_mode and world > 1 and not args.no_configs4 and \
+            not args.total_rays:
+        del ylast, ulast, y, u
+        configs4 = run_configs4(ra, system, g, job, group, world, rank, args,
+                                clip)
 
     if rank != 0:
-        if dist_mode:
-            dist.barrier()
-            dist.destroy_process_group()
+        group.barrier()
+        group.close()
         return
 
-    total_rays = n*world
+    table, ns = pack_system(system, g.l, g.n[0])
+    total_rays = int(counts.sum())
     ms_per_step = elapsed*1e3/args.steps
     value = total_rays*S*args.steps/elapsed
     from rayopt_amd._lib import F_ROTATED, F_REFRACT
@@ -450,15 +494,23 @@ def main():
     skipped_u = sum(1 for j in range(1, L)
                     if alias_on and not clip and not bends[j])
     alg_bytes = n*(56*S + 24*stored_i - 24*skipped_u + 48)  # one GPU's shard
-    kernel_ms = (ev_ms/args.steps if not (dist_mode and args.gather_every_step)
-                 else last_kernel_ms)
     achieved = alg_bytes/(kernel_ms*1e-3)/1e9
     prof = traffic_from_profile()
-    traffic = None
+    traffic = traffic_source = None
     if prof and prof.get("rays") == n and prof.get("clip") == clip and \
             prof.get("alias_i", 0) == int(alias_on):
         traffic = prof.get("hbm_bytes_per_launch")
+        traffic_source = ("profiles/traffic.json (rocprofv3 --pmc passes of "
+                          "this command on the GPU box, %s; not re-measured "
+                          "in this run)" % prof.get("profile", "committed"))
 
+    par = "ray shards x%d" % world
+    if dist_mode:
+        par += (", one process per GPU, host group over TCP (no PyTorch), "
+                "RCCL gather of y[L-1] to rank 0 %s (gather alone: %.2f ms)"
+                % ("in every step" if args.gather_every_step else
+                   "once, after the last step, inside the timed region",
+                   gather_ms))
     out = {
         "metric": "ray-surface-ops/sec",
         "value": value,
@@ -473,23 +525,19 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "double-Gauss (BASELINE configs[2]): L=%d elements, "
+            "workload": "double-Gauss (BASELINE configs[%d]): L=%d elements, "
                         "S=%d propagated surfaces, %d rays/GPU in 5 field "
-                        "bundles, clip=%s" % (L, S, n, clip),
+                        "bundles, clip=%s, one step = one "
+                        "GeometricTrace.propagate()" % (
+                            4 if args.total_rays == 10**8 else 2, L, S, n,
+                            clip),
             "rays_per_gpu": n,
+            "total_rays": total_rays,
             "surfaces": S,
             "clip": clip,
             "finite_fraction_at_image": finite,
             "settle_s": args.settle,
-            "parallelism": "ray shards x%d%s" % (
-                world, (", RCCL gather of y[L-1] to rank 0 %s (gather alone: "
-                        "%.2f ms%s)" % ("in every step"
-                                        if args.gather_every_step
-                                        else "once, after the last step, "
-                                        "inside the timed region", gather_ms,
-                                        ", via torch.distributed" if
-                                        torch_gather is not None else ""))
-                if dist_mode else ""),
+            "parallelism": par,
         },
         "roofline": {
             "bound": "hbm",
@@ -498,6 +546,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved/HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel": "rt_trace_kernel",
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
@@ -505,6 +554,13 @@ def main():
             "frac_of_achievable_6290": achieved/HBM_ACHIEVABLE_GBS,
         },
     }
+    if dist_mode:
+        out["gather_ms"] = gather_ms
+        out["kernel_ms_per_rank"] = per_rank_kernel_ms
+    if configs4 is not None:
+        out["configs4"] = configs4
+    if api is not None:
+        out["propagate_api"] = api
 
     if full_i is not None:
         e_full, k_full = full_i
@@ -517,7 +573,6 @@ def main():
             "frac": b_full/(k_full*1e-3)/1e9/HBM_PEAK_GBS,
             "note": "every row of i materialised (alias_i=0): 80 B per op",
         }
-
     if unclipped is not None:
         e_nc, k_nc = unclipped
         b_nc = n*(56*S + 24*stored_i + 48 - 24*sum(
@@ -532,50 +587,100 @@ def main():
                     "of stop and image are i rows bit for bit and are not "
                     "written",
         }
-
     if image_only is not None:
         e_img, k_img = image_only
         out["image_row_only"] = {
             "value": total_rays*S*args.steps/e_img,
             "kernel_ms": k_img,
-            "note": "propagate(keep=[-1]): all %d surfaces traced, only the "
-                    "image row stored (80 B/ray); FP64-VALU bound" % S,
+            "note": "propagate(keep=[0, -1]): all %d surfaces traced, only "
+                    "the image row stored (80 B/ray); FP64-VALU bound" % S,
         }
 
     if world == 1 and not dist_mode and args.cpu_sample > 0:
-        from oracle import trace_numpy as tn
-        m = min(args.cpu_sample, n)
-        ys, us = y[:m], u[:m]
-        tn.propagate(table, ys[:100000], us[:100000], clip=clip)   # warm
-        t0 = time.perf_counter()
-        Y, U, I, T = tn.propagate(table, ys, us, clip=clip)
-        dt = time.perf_counter() - t0
-        # the sample doubles as a parity check of the bench run itself
-        got = np.asarray(g.y[L - 1])[:m]
-        ref = Y[-1]
-        assert np.array_equal(np.isnan(got), np.isnan(ref))
-        fin = np.isfinite(ref)
-        assert (np.abs(got[fin] - ref[fin]) <=
-                1e-10*np.maximum(np.abs(ref[fin]), 1.)).all()
-        out["cpu_baseline"] = {
-            "value": m*S/dt,
-            "unit": "ray-surface-ops/s",
-            "cores": 1,
-            "kind": "port",
-            "sample": "first %d rays of the same workload, one "
-                      "propagate() of the numpy port (%.1f s); host has %d "
-                      "cores" % (m, dt, os.cpu_count()),
-        }
+        out["cpu_baseline"] = cpu_one_core(table, system, y, u, clip, S, g, L,
+                                           args.cpu_sample, g.l)
+        if cpu_all is not None:
+            out["cpu_baseline_all_cores"] = cpu_all
         try:
             out["cpu_baseline_c"] = cpu_c_oracle(table, y, u, clip, S, g, L)
         except Exception as err:      # a reported extra, never fatal
             out["cpu_baseline_c"] = {"error": repr(err)[:200]}
-    if cpu_procs is not None:
-        out["cpu_baseline_procs"] = cpu_procs
     emit(json.dumps(out))
     if dist_mode:
-        dist.barrier()
-        dist.destroy_process_group()
+        group.barrier()
+        group.close()
+
+
+def small_batch_latency(ra, system, device, n=10_000, reps=300):
+    """Wall time of one propagate() on a small batch: the launch-bound regime
+    of aiming iterations and merit evaluations, where the host path (re-pack,
+    table hand-over) decides."""
+    from rayopt_amd import prescriptions as P
+    y, u = ra.bundles.disc_bundle(n, BUNDLE_RADIUS, 5., 1,
+                                  P.DOUBLE_GAUSS_PUPIL_Z)
+    g = ra.GeometricTrace(system, device=device)
+    g.rays_given(y, u)
+    for _ in range(50):
+        g.propagate(clip=True)
+    g.engine.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.propagate(clip=True)
+    g.engine.sync()
+    wall = (time.perf_counter() - t0)/reps
+    return {"small_batch_rays": n, "small_batch_propagate_us": wall*1e6,
+            "small_batch_kernel_us": g.kernel_ms()*1e3}
+
+
+def run_configs4(ra, system, g, job, group, world, rank, args, clip,
+                 total=100_000_000):
+    """BASELINE configs[4]: 10^8 rays in total, sharded over the N GPUs; the
+    rays are built on the device (five field bundles per rank, pupil points
+    seeded per rank), results stay in HBM, one RCCL gather of y[L-1] to rank
+    0 after the last step inside the timed region."""
+    from rayopt_amd import distributed as D
+    from rayopt_amd import prescriptions as P
+    counts = D.shard_counts(total, world)
+    nf = len(FIELD_FRACTIONS)
+    m = int(counts[rank])//nf//64*64       # pupil points per field bundle
+    counts = np.array(group.broadcast(group.gather(m*nf)), dtype=np.int64)
+    rng = np.random.default_rng(7000 + rank)
+    r, phi = np.sqrt(rng.random(m)), 2*np.pi*rng.random(m)
+    yp = np.c_[r*np.cos(phi), r*np.sin(phi)]
+    fields = np.c_[np.zeros(nf), FIELD_FRACTIONS]
+    eng = g.engine
+    g.rays_fields(fields, yp, P.DOUBLE_GAUSS_PUPIL_Z, BUNDLE_RADIUS)
+    L = len(system)
+    S = L - 1
+    job.counts = counts
+    if rank == 0:
+        job.d_dst = eng.scratch(int(counts.sum())*3*8)
+
+    def step():
+        g.propagate(clip=clip)
+    elapsed, ev_ms, _ = job.timed(step, args.steps, args.warmup, True)
+    job.fence()
+    t0 = time.perf_counter()
+    job.gather()
+    job.fence()
+    gather_ms = group.allreduce_max((time.perf_counter() - t0)*1e3)
+    elapsed = group.allreduce_max(elapsed)
+    per_rank = group.gather(ev_ms/args.steps)
+    if rank != 0:
+        return None
+    tot = int(counts.sum())
+    return {
+        "workload": "BASELINE configs[4]: double-Gauss, %d rays in total "
+                    "over %d GPUs (%d per GPU), built on the device, RCCL "
+                    "gather of y[L-1] to rank 0 after the last step inside "
+                    "the timed region" % (tot, world, int(counts[0])),
+        "total_rays": tot,
+        "rays_per_gpu": int(counts[0]),
+        "ms_per_step": elapsed*1e3/args.steps,
+        "value": tot*S*args.steps/elapsed,
+        "gather_ms": gather_ms,
+        "kernel_ms_per_rank": per_rank,
+    }
 
 
 if __name__ == "__main__":

@@ -158,6 +158,43 @@ class GeometricTrace(Trace):
         self._engine = engine
         self._device = device
 
+    # -- Trace.propagate (rayopt/raytrace.py:31-35), evaluated lazily ------
+    # path / track / origins / mirrored are O(L) cumulative sums that cost as
+    # much host time as packing the table; most propagate() calls (merit
+    # evaluations, aiming iterations) never look at them.  propagate()
+    # snapshots what they are computed from -- the elements stay mutable --
+    # and the arrays are built on first access.
+    _LAZY = ("path", "track", "origins", "mirrored")
+
+    def _snapshot_geometry(self):
+        system = self.system
+        self._geometry = (
+            [el.offset for el in system], [el.distance for el in system],
+            [getattr(getattr(el, "material", None), "mirror", False)
+             for el in system])
+        d = self.__dict__
+        for name in self._LAZY:
+            d.pop(name, None)
+
+    def __getattr__(self, name):
+        # reached only when normal lookup fails
+        if name in GeometricTrace._LAZY and "_geometry" in self.__dict__:
+            offsets, distances, mirrors = self._geometry
+            if name == "path":              # rayopt/system.py:423-424
+                value = np.cumsum(distances)
+            elif name == "mirrored":        # :439-442
+                value = np.cumprod([-1 if m else 1 for m in mirrors])
+            else:                           # :414-415, :427-428
+                origins = self.__dict__.get("origins")
+                if origins is None:
+                    origins = np.cumsum(offsets, axis=0)
+                    self.__dict__["origins"] = origins
+                value = origins if name == "origins" else origins[:, 2]
+            self.__dict__[name] = value
+            return value
+        raise AttributeError("%r object has no attribute %r" % (
+            type(self).__name__, name))
+
     # -- storage ----------------------------------------------------------
     @property
     def engine(self):
@@ -662,7 +699,7 @@ class GeometricTrace(Trace):
         not written (no HBM traffic); reading them raises."""
         if not hasattr(self, "y"):
             raise ValueError("propagate: no rays; call rays_given() first")
-        super().propagate()
+        self._snapshot_geometry()
         if len(self.system) != self.length:
             raise ValueError("the system changed length since rays_given()")
         a, b = resolve_range(self.length, start, stop)

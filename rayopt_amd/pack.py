@@ -11,20 +11,46 @@ Every per-element scalar is evaluated here with the reference's own Python
 expression (cited per line) so that the float handed to the kernel is
 bit-identical to the one numpy would have broadcast.
 """
+import struct
+
 import numpy as np
 
 from ._lib import (SURFACE_DTYPE, RT_MAX_ASPH, RT_MAX_SURFACES, F_ROTATED,
                    F_CURVED, F_CONIC, F_ASPH, F_ALT, F_REFRACT, F_MIRROR)
 
 
-_SCALARS = ("c", "k", "kw", "kc2", "radius2", "mu", "muf", "smu", "mu2m1",
-            "n0", "nasph", "flags")
-_IDENTITY = np.eye(3).reshape(9)
+_IDENTITY = (1., 0., 0., 0., 1., 0., 0., 0., 1.)
+_NO_ASPH = (0.,)*(2*RT_MAX_ASPH)
+# rt_surface is 22 + 2*RT_MAX_ASPH doubles (c k kw kc2 radius2 mu muf smu
+# mu2m1 n0 offset[3] rot[9] asph[] dasph[]) followed by nasph, flags
+_ROW_FMT = "%ddiI" % (22 + 2*RT_MAX_ASPH)
+assert struct.calcsize("<" + _ROW_FMT) == SURFACE_DTYPE.itemsize
+assert [SURFACE_DTYPE.fields[f][1] for f in ("offset", "rot", "asph", "nasph",
+                                             "flags")] == \
+    [80, 104, 176, 176 + 16*RT_MAX_ASPH, 180 + 16*RT_MAX_ASPH]
+_STRUCTS = {}
+
+
+def _row_struct(length):
+    st = _STRUCTS.get(length)
+    if st is None:
+        st = _STRUCTS[length] = struct.Struct("<" + _ROW_FMT*length)
+    return st
+
+
+def _floats(v, n):
+    """``n`` Python floats of a small vector / matrix attribute."""
+    v = v.tolist() if hasattr(v, "tolist") else list(v)
+    if n == 9 and len(v) == 3:
+        v = v[0] + v[1] + v[2]
+    if len(v) != n:
+        raise ValueError("expected %d numbers, got %r" % (n, v))
+    return v
 
 
 def _sign(x):
     """np.sign for a Python float (NaN stays NaN)."""
-    return float(int(x > 0) - int(x < 0)) if x == x else x
+    return (1. if x > 0 else -1. if x < 0 else 0.) if x == x else x
 
 
 def resolve_range(length, start=1, stop=None):
@@ -51,20 +77,17 @@ def pack_system(system, wavelength, n_init, start=1, stop=None):
     n0 = float(n_init)
     if start >= 1:
         n[start - 1] = n0
-    # one Python pass collecting columns, then one assignment per field: the
-    # table is rebuilt on every propagate(), so this runs once per merit
-    # evaluation / aiming iteration and must stay in the tens of microseconds
-    offsets, rots, aspheres = [], [], []
-    cols = {name: [] for name in _SCALARS}
+    # one Python pass appending plain floats to ONE flat list, then a single
+    # struct.pack into the table's memory: the table is rebuilt on every
+    # propagate() (elements are mutable between calls,
+    # rayopt/geometric_trace.py:98-99), so this runs once per merit
+    # evaluation / aiming iteration and decides the wall time of small
+    # traces (list-of-lists -> ndarray conversions and per-field assignments
+    # cost several times more than the attribute reads themselves)
+    flat = []
+    extend = flat.extend
     for j, el in enumerate(system):
         flags = 0
-        # --- frame: TransformMixin (elements.py:120-154) ---
-        offsets.append(el.offset)
-        if getattr(el, "rotated", False):
-            flags |= F_ROTATED
-            rots.append(np.asarray(el.rot_normal, dtype=float).reshape(9))
-        else:
-            rots.append(_IDENTITY)
         # --- shape: Spheroid (elements.py:411-501) ---
         c = getattr(el, "curvature", 0.)
         k = getattr(el, "conic", 0.)
@@ -73,33 +96,22 @@ def pack_system(system, wavelength, n_init, start=1, stop=None):
             flags |= F_CURVED
         if k:                                  # `if not k:` :484
             flags |= F_CONIC
-        nasph = 0
-        if asph is not None:                   # elements.py:478
-            nasph = len(asph)
-            if nasph > RT_MAX_ASPH:
-                raise ValueError("element %d: %d aspheric terms, limit %d"
-                                 % (j, nasph, RT_MAX_ASPH))
-            flags |= F_ASPH
-            aspheres.append((j, asph))
         if getattr(el, "alternate_intersection", False):
             flags |= F_ALT                     # elements.py:497
         # --- index / Snell: Interface.get_n_mu (elements.py:283-289) ---
         mu = 1.
-        inside = start <= j < stop
-        before = n0 if inside else 1.
-        if inside:
+        before = 1.
+        if start <= j < stop:
+            before = n0
             if hasattr(el, "get_n_mu"):
-                nj, mu = el.get_n_mu(n0, wavelength)
-            else:                              # plain Element.propagate :230
-                nj, mu = n0, 1.
-            n[j] = nj
-            n0 = nj
+                n0, mu = el.get_n_mu(n0, wavelength)
+            # else: plain Element.propagate :230 leaves n and the ray alone
+            n[j] = n0
         if mu and mu != 1:                     # elements.py:313, :356
             flags |= F_REFRACT
             if mu == -1:                       # elements.py:363
                 flags |= F_MIRROR
-        for name, value in zip(_SCALARS, (
-                c, k,
+        extend((c, k,
                 1 + k,                         # kw, elements.py:489
                 (1 + k)*c**2,                  # kc2, elements.py:451,468
                 el.radius**2,                  # elements.py:207
@@ -107,15 +119,30 @@ def pack_system(system, wavelength, n_init, start=1, stop=None):
                 abs(mu),                       # muf, elements.py:358
                 _sign(mu),                     # smu, elements.py:366
                 mu**2 - 1,                     # mu2m1, elements.py:365
-                before, nasph, flags)):
-            cols[name].append(value)
-    table = np.zeros(length, dtype=SURFACE_DTYPE)
-    table["offset"] = np.asarray(offsets, dtype=float)
-    table["rot"] = rots
-    for name in _SCALARS:
-        table[name] = cols[name]
-    for j, asph in aspheres:
-        a = np.asarray(asph, dtype=float)
-        table["asph"][j, :len(a)] = a                              # :452-454
-        table["dasph"][j, :len(a)] = 2*(np.arange(len(a)) + 1)*a   # :471-472
+                before))
+        # --- frame: TransformMixin (elements.py:120-154) ---
+        extend(_floats(el.offset, 3))
+        if getattr(el, "rotated", False):
+            flags |= F_ROTATED
+            extend(_floats(el.rot_normal, 9))
+        else:
+            extend(_IDENTITY)
+        nasph = 0
+        if asph is None:                       # elements.py:478
+            extend(_NO_ASPH)
+        else:
+            nasph = len(asph)
+            if nasph > RT_MAX_ASPH:
+                raise ValueError("element %d: %d aspheric terms, limit %d"
+                                 % (j, nasph, RT_MAX_ASPH))
+            flags |= F_ASPH
+            a = [float(x) for x in asph]
+            pad = (0.,)*(RT_MAX_ASPH - nasph)
+            extend(a)                                              # :452-454
+            extend(pad)
+            extend([2*(q + 1)*x for q, x in enumerate(a)])          # :471-472
+            extend(pad)
+        extend((nasph, flags))
+    table = np.frombuffer(bytearray(_row_struct(length).pack(*flat)),
+                          dtype=SURFACE_DTYPE)
     return table, n

@@ -28,9 +28,9 @@ def check_line(out, steps, warmup):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.
     assert r["frac"] == pytest.approx(r["achieved"]/r["peak"])
-    rays, S = d["config"]["rays_per_gpu"], d["config"]["surfaces"]
+    S = d["config"]["surfaces"]
     assert d["value"] == pytest.approx(
-        rays*S*d["n_gpus"]/(d["ms_per_step"]*1e-3), rel=1e-6)
+        d["config"]["total_rays"]*S/(d["ms_per_step"]*1e-3), rel=1e-6)
     return d
 
 
@@ -38,15 +38,39 @@ def test_single_process_line():
     out = subprocess.check_output(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--rays", "200000",
          "--steps", "4", "--warmup", "1", "--cpu-sample", "50000",
-         "--settle", "0.05"], text=True, cwd=ROOT)
+         "--cpu-procs", "4", "--settle", "0.05"], text=True, cwd=ROOT)
     d = check_line(out, 4, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    a = d["cpu_baseline_all_cores"]
+    assert a["kind"] == "port" and a["cores"] == 4 and a["value"] > 0
+    cc = d["cpu_baseline_c"]
+    assert cc["range"][0] <= cc["value"] <= cc["range"][1]
+    assert cc["image_row_bit_identical_to_gpu"] is True
+    api = d["propagate_api"]
+    assert api["propagate_ms_per_step"] > 0 and api["small_batch_rays"] == 10**4
+    assert d["roofline"]["traffic"] is None or d["roofline"]["traffic_source"]
+    assert "GeometricTrace.propagate()" in d["config"]["workload"]
 
 
-def test_torchrun_single_rank_multi_process_path():
-    """The whole N>1 code path (torch rendezvous, RCCL communicator, gather
-    of the final intercepts inside the timed region) with one rank."""
+def test_self_spawned_single_rank_multi_process_path():
+    """The whole N>1 code path (host group, RCCL communicator, gather of the
+    final intercepts inside the timed region) with one rank, started the way
+    the driver starts it: `python bench.py --gpus 1`, no launcher, no torch."""
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1")
+    out = subprocess.check_output(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1",
+         "--rays", "200000", "--steps", "3", "--warmup", "1", "--settle",
+         "0"], text=True, cwd=ROOT, env=env, stderr=subprocess.DEVNULL)
+    d = check_line(out, 3, 1)
+    assert "RCCL gather" in d["config"]["parallelism"]
+    assert "no PyTorch" in d["config"]["parallelism"]
+    assert d["gather_ms"] > 0 and len(d["kernel_ms_per_rank"]) == 1
+    assert "cpu_baseline" not in d
+
+
+def test_under_torchrun_single_rank():
+    """Same, started by a per-GPU launcher (the contract's launch line)."""
     env = dict(os.environ, RT_BENCH_FORCE_DIST="1")
     out = subprocess.check_output(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -57,20 +81,14 @@ def test_torchrun_single_rank_multi_process_path():
         stderr=subprocess.DEVNULL)
     d = check_line(out, 3, 1)
     assert "RCCL gather" in d["config"]["parallelism"]
-    assert "cpu_baseline" not in d
 
 
-def test_torchrun_torch_gather_safety_net():
-    """Same, with the engine's communicator declared unavailable: the
-    exchange goes through torch.distributed on views of the device memory."""
-    env = dict(os.environ, RT_BENCH_FORCE_DIST="1",
-               RT_BENCH_FORCE_TORCH_GATHER="1")
-    out = subprocess.check_output(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-         "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-         "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus",
-         "1", "--rays", "200000", "--steps", "3", "--warmup", "1",
-         "--settle", "0"], text=True, cwd=ROOT, env=env,
-        stderr=subprocess.DEVNULL)
-    d = check_line(out, 3, 1)
-    assert "via torch.distributed" in d["config"]["parallelism"]
+def test_more_gpus_than_devices_is_a_clear_error():
+    import ctypes
+    from rayopt_amd import distributed as D
+    have = D.visible_devices()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
+                          "--gpus", str(have + 1)], cwd=ROOT, text=True,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert res.returncode != 0 and res.stdout.strip() == ""
+    assert "%d devices needed, %d visible" % (have + 1, have) in res.stderr

@@ -1,0 +1,161 @@
+"""Multi-process path on CPU: world_size 2 (and 3), no GPU, no PyTorch in the
+workers.  Covers the host logic of the N>1 path -- shard bounds, the host
+group (rendezvous, broadcast of the RCCL unique id, barrier, max of the
+timings), the self-spawning launcher of ``python bench.py --gpus N`` and the
+layout of the gathered buffer.  The workers use a stand-in for the GPU
+context (FakeEngine): the RCCL transfer itself (rt_gather_final with
+nranks > 1, rayopt_amd/csrc/rt_engine.hip) needs two GPUs and is NOT covered
+here -- it runs in ``bench.py --gpus N`` on a multi-GPU node only."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from rayopt_amd import distributed as D
+from rayopt_amd.distributed import (shard_bounds, shard_counts,
+                                    gather_offsets, split_gathered)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_partition():
+    for n in (1, 7, 64, 10**7, 10**8 + 3):
+        for w in (1, 2, 3, 8):
+            b = shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            c = shard_counts(n, w)
+            assert c.sum() == n and c.max() - c.min() <= 1
+            assert list(gather_offsets(c)) == [lo for lo, _ in b]
+    assert shard_counts(10**8, 8).tolist() == [12_500_000]*8   # configs[4]
+
+
+def test_split_gathered_layout():
+    counts = np.array([3, 2, 4])
+    total = counts.sum()
+    buf = np.arange(3*total, dtype=float)      # [component][global ray]
+    parts = split_gathered(buf, counts)
+    assert [p.shape for p in parts] == [(3, 3), (2, 3), (4, 3)]
+    assert parts[1][0].tolist() == [3., 3. + total, 3. + 2*total]
+
+
+def test_single_rank_group_is_trivial():
+    g = D.HostGroup(1, 0)
+    assert g.broadcast(b"x") == b"x" and g.gather(3) == [3]
+    assert g.allreduce_max(2.5) == 2.5
+    g.barrier()
+    g.close()
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, time
+    import numpy as np
+    sys.path.insert(0, %r)
+    assert "torch" not in sys.modules
+    from rayopt_amd import distributed as D
+    from rayopt_amd.bundles import disc_bundle
+
+    class FakeEngine:
+        # stands in for the GPU context: records what the host logic asks for
+        def comm_unique_id(self):
+            return bytes(range(128))
+        def comm_init(self, uid, nranks, rank):
+            self.args = (bytes(uid), nranks, rank)
+
+    world, rank, local = D.world_info()
+    if os.environ.get("RT_TEST_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    group = D.HostGroup(world, rank)
+    eng = FakeEngine()
+    assert D.init_engine_comm(eng, group) == (world, rank)
+    assert eng.args == (bytes(range(128)), world, rank)
+
+    # barrier really waits for the slowest rank
+    t0 = time.monotonic()
+    if rank == world - 1:
+        time.sleep(.3)
+    group.barrier()
+    assert time.monotonic() - t0 > .25
+    assert group.allreduce_max(10. + rank) == 10. + world - 1
+    assert group.allreduce_min(10. + rank) == 10.
+    assert group.broadcast("from-%%d" %% rank, src=world - 1) == \\
+        "from-%%d" %% (world - 1)
+
+    # shard a global batch, "trace" it locally (identity stand-in), gather the
+    # final rows the way the root lays them out, compare with the unsharded
+    n = 1001
+    y, u = disc_bundle(n, 3., 1., 0)
+    lo, hi = D.shard_bounds(n, world)[rank]
+    counts = D.shard_counts(n, world)
+    box = group.gather(y[lo:hi])
+    if rank == 0:
+        buf = np.concatenate([b.T for b in box], axis=1).ravel()
+        parts = D.split_gathered(buf, counts)
+        assert np.array_equal(np.concatenate(parts), y)
+    group.barrier()
+    group.close()
+    assert "torch" not in sys.modules
+    print("rank", rank, "ok", flush=True)
+""")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_spawned_workers_host_group(tmp_path, world, capfd):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    rc = D.spawn_workers(world, [sys.executable, str(script)],
+                         check_devices=False)
+    out = capfd.readouterr().out
+    assert rc == 0, out
+    for rank in range(world):
+        assert "rank %d ok" % rank in out
+
+
+def test_a_dying_rank_takes_the_job_down(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, RT_TEST_FAIL_RANK="1")
+    rc = D.spawn_workers(2, [sys.executable, str(script)], env=env,
+                         check_devices=False)
+    assert rc == 7
+
+
+def test_under_a_per_gpu_launcher(tmp_path):
+    """The environment `python -m torch.distributed.run` prepares (RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_PORT): the workers find each other through
+    the rendezvous file named after MASTER_PORT, without importing torch."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RT_RDZV_FILE", "RT_RDZV_TOKEN")}
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e,
+                                      stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
+
+
+def test_bench_needs_as_many_devices_as_gpus():
+    """`python bench.py --gpus 2` as typed: no launcher message, a clear
+    statement of what is missing (this container has no GPU at all)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2"], cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=120)
+    assert res.returncode != 0
+    assert res.stdout.strip() == ""
+    have = D.visible_devices()
+    if have < 2:
+        assert "2 devices needed, %d visible" % have in res.stderr
