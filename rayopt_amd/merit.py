@@ -19,81 +19,116 @@ import numpy as np
 from scipy.optimize import minimize
 
 
+# --------------------------------------------------------------------------
+# variables and operands
+#
+# The contract with optimize() is structural, so that objects written for the
+# reference (rayopt/optimize.py:24-93) can be handed to this optimize() and
+# the classes below to the reference's: a *variable* is anything with
+# ``get()``, ``set(value)``, ``bounds``, ``scale`` and ``init``; an *operand*
+# anything with ``get()`` and the three iterables ``get_objective()``,
+# ``get_equality()``, ``get_inequality()`` of callables that map the operand
+# vector to residuals (objective terms are squared and summed; equalities are
+# driven to zero, inequalities kept >= 0).
+# --------------------------------------------------------------------------
+
+class Affine:
+    """The residual map ``v -> gain*(v - offset) - shift`` of an operand
+    vector.  Every role an operand can play is one of these: a weighted
+    objective term (gain = weight), an equality (1, shift 0), a lower bound
+    ``v - offset >= lo`` (1, shift lo), an upper bound ``v - offset <= hi``
+    (-1, shift -hi)."""
+    __slots__ = ("gain", "offset", "shift")
+
+    def __init__(self, gain, offset, shift=0):
+        self.gain, self.offset, self.shift = gain, offset, shift
+
+    def __call__(self, v):
+        return self.gain*(v - self.offset) - self.shift
+
+    def __repr__(self):
+        return "Affine(%r*(v - %r) - %r)" % (self.gain, self.offset,
+                                             self.shift)
+
+
 class Variable:
-    """A degree of freedom: ``get()`` / ``set(value)``, box ``bounds`` and a
-    ``scale`` that normalises it for the minimiser (default: the width of the
-    box, which then has to be finite; rayopt/optimize.py:24-43)."""
+    """A degree of freedom of ``system`` (same constructor as
+    rayopt/optimize.py:24): box ``bounds``, a ``scale`` that normalises it
+    for the minimiser -- by default the width of the box, which then has to
+    be finite -- and the value ``init`` the search starts from (default: the
+    present one).  Either subclass it with ``get``/``set`` or pass the two
+    callables."""
     def __init__(self, system, bounds=(-np.inf, np.inf), scale=None,
-                 init=None):
-        self.system = system
-        self.bounds = bounds
+                 init=None, getter=None, setter=None):
+        lower, upper = bounds
         if scale is None:
-            scale = bounds[1] - bounds[0]
-            assert np.isfinite(scale), "give a scale or finite bounds"
-        self.scale = scale
-        self.init = self.get() if init is None else init
+            scale = upper - lower
+            if not np.isfinite(scale):
+                raise AssertionError(
+                    "Variable: without a scale the bounds must be finite "
+                    "(got %r)" % (bounds,))
+        if getter is not None:
+            self.get = getter
+        if setter is not None:
+            self.set = setter
+        self.system, self.bounds, self.scale = system, bounds, scale
+        self.init = init if init is not None else self.get()
 
     def get(self):
-        raise NotImplementedError
+        raise NotImplementedError("Variable.get: subclass or pass getter=")
 
     def set(self, value):
-        raise NotImplementedError
+        raise NotImplementedError("Variable.set: subclass or pass setter=")
 
 
 class PathVariable(Variable):
-    """The attribute / item reached by ``system.get_path(path)``, e.g.
-    ``(1, "curvature")`` (rayopt/optimize.py:46-55)."""
+    """The attribute or item ``system.get_path(path)`` reaches, e.g.
+    ``(1, "curvature")`` (rayopt/optimize.py:46)."""
     def __init__(self, system, path, *args, **kwargs):
         self.path = path
-        super().__init__(system, *args, **kwargs)
-
-    def get(self):
-        return self.system.get_path(self.path)
-
-    def set(self, value):
-        self.system.set_path(self.path, value)
+        Variable.__init__(
+            self, system, *args,
+            getter=lambda: system.get_path(path),
+            setter=lambda value: system.set_path(path, value), **kwargs)
 
 
 class Operand:
-    """A vector-valued quantity ``get()`` of the system and how it enters the
-    problem (rayopt/optimize.py:58-84): with a ``weight`` it adds
+    """A vector-valued quantity ``get()`` of the system and the roles it
+    plays (same constructor as rayopt/optimize.py:58): a ``weight`` adds
     ``sum((weight*(v - offset))**2)`` to the merit; ``min`` / ``max`` bound
-    ``v - offset`` from below / above; ``min == max`` makes it an equality
-    (as in the reference the equality is ``v - offset == 0`` whatever the
-    common value of ``min`` and ``max`` is)."""
+    ``v - offset`` from below / above; ``min == max`` pins ``v - offset`` to
+    ZERO whatever the common value is -- the reference's behaviour, kept."""
     def __init__(self, system, weight=None, offset=0, min=None, max=None):
-        self.system = system
-        self.weight = weight
-        self.offset = offset
-        self.min = min
-        self.max = max
+        self.system, self.weight, self.offset = system, weight, offset
+        self.min, self.max = min, max
 
     def get(self):
-        raise NotImplementedError
+        raise NotImplementedError("Operand.get: subclass, or use FuncOp")
 
     def get_objective(self):
-        if self.weight:
-            yield lambda v: self.weight*(v - self.offset)
+        return [Affine(self.weight, self.offset)] if self.weight else []
 
     def get_equality(self):
-        if self.min is not None and self.min == self.max:
-            yield lambda v: v - self.offset
+        pinned = self.min is not None and self.min == self.max
+        return [Affine(1, self.offset)] if pinned else []
 
     def get_inequality(self):
+        sides = []
         if self.min is not None:
-            yield lambda v: v - self.offset - self.min
+            sides.append(Affine(1, self.offset, self.min))
         if self.max is not None:
-            yield lambda v: self.max - (v - self.offset)
+            sides.append(Affine(-1, self.offset, -self.max))
+        return sides
 
 
 class FuncOp(Operand):
-    """``func(system)`` flattened (rayopt/optimize.py:87-93)."""
+    """``func(system)`` as a flat vector (rayopt/optimize.py:87)."""
     def __init__(self, system, func, *args, **kwargs):
-        super().__init__(system, *args, **kwargs)
+        Operand.__init__(self, system, *args, **kwargs)
         self.func = func
 
     def get(self):
-        return np.atleast_1d(self.func(self.system)).ravel()
+        return np.ravel(self.func(self.system))
 
 
 class SpotOperand(Operand):
@@ -270,8 +305,8 @@ class _Problem:
         system, every weighted operand can evaluate system variants."""
         system = self.operands[0].system
         return (not self.equality and not self.inequality and
-                all(isinstance(v, PathVariable) and v.system is system
-                    for v in self.variables) and
+                all(getattr(v, "path", None) is not None and
+                    v.system is system for v in self.variables) and
                 all(hasattr(self.operands[k], "get_variants") and
                     self.operands[k].system is system
                     for k, _ in self.objective))

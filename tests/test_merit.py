@@ -116,6 +116,45 @@ def test_optimize_takes_the_reference_iterates(constrained):
     del start
 
 
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+@pytest.mark.parametrize("constrained", [False, True])
+def test_variables_and_operands_are_interchangeable(constrained):
+    """The contract between optimize() and its arguments is structural: the
+    reference's own Variable/Operand objects run through merit.optimize, and
+    merit's through rayopt.optimize.optimize -- same optimum either way."""
+    ro = refshim.load()
+    import importlib
+    ref_opt = importlib.import_module("rayopt.optimize")
+    theirs = ro.system_from_yaml(SINGLET)
+    theirs.update()
+    rv, rp = make_problem(ref_opt, theirs, ro.GeometricTrace, constrained)
+    want = ref_opt.optimize(rv, rp)
+    # reference objects, our optimiser
+    theirs2 = ro.system_from_yaml(SINGLET)
+    theirs2.update()
+    rv2, rp2 = make_problem(ref_opt, theirs2, ro.GeometricTrace, constrained)
+    got = merit.optimize(rv2, rp2)
+    np.testing.assert_allclose(got.x, want.x, rtol=1e-9)
+    assert got.nit == want.nit
+    # our objects, the reference's optimiser
+    mine = ra.system_from_yaml(SINGLET)
+    mv, mp = make_problem(merit, mine, oracle_trace, constrained)
+    back = ref_opt.optimize(mv, mp)
+    np.testing.assert_allclose(back.x, want.x, rtol=1e-9)
+    assert back.nit == want.nit
+
+
+def test_variable_from_callables():
+    box = {"v": 2.}
+    var = merit.Variable(None, bounds=(0., 4.), getter=lambda: box["v"],
+                         setter=lambda x: box.update(v=x))
+    assert var.init == 2. and var.scale == 4.
+    var.set(3.)
+    assert var.get() == 3.
+    with pytest.raises(NotImplementedError):
+        merit.Variable(None, scale=1.)
+
+
 def test_each_point_is_traced_once():
     """merit, constraints and callback at the same x share one evaluation."""
     system = ra.system_from_yaml(SINGLET)
