@@ -51,59 +51,74 @@ class Affine:
                                              self.shift)
 
 
-class Variable:
+def _abstract(what):
+    def method(self, *args):
+        raise NotImplementedError("%s.%s: subclass %s, or pass the callable"
+                                  % (type(self).__name__, what,
+                                     type(self).__name__))
+    method.__name__ = what
+    return method
+
+
+class _Described:
+    """repr with the public attributes: what optimisation logs show."""
+    def __repr__(self):
+        public = ", ".join(
+            "%s=%r" % (k, v) for k, v in sorted(vars(self).items())
+            if k != "system" and not k.startswith("_") and not callable(v))
+        return "%s(%s)" % (type(self).__name__, public)
+
+
+class Variable(_Described):
     """A degree of freedom of ``system`` (same constructor as
     rayopt/optimize.py:24): box ``bounds``, a ``scale`` that normalises it
     for the minimiser -- by default the width of the box, which then has to
     be finite -- and the value ``init`` the search starts from (default: the
     present one).  Either subclass it with ``get``/``set`` or pass the two
     callables."""
+    get = _abstract("get")
+    set = _abstract("set")
+
     def __init__(self, system, bounds=(-np.inf, np.inf), scale=None,
                  init=None, getter=None, setter=None):
         lower, upper = bounds
-        if scale is None:
-            scale = upper - lower
-            if not np.isfinite(scale):
-                raise AssertionError(
-                    "Variable: without a scale the bounds must be finite "
-                    "(got %r)" % (bounds,))
+        width = upper - lower
+        if scale is None and not np.isfinite(width):
+            raise AssertionError(
+                "Variable: without a scale the bounds must be finite "
+                "(got %r)" % (bounds,))
         if getter is not None:
             self.get = getter
         if setter is not None:
             self.set = setter
-        self.system, self.bounds, self.scale = system, bounds, scale
+        self.system, self.bounds = system, bounds
+        self.scale = width if scale is None else scale
         self.init = init if init is not None else self.get()
-
-    def get(self):
-        raise NotImplementedError("Variable.get: subclass or pass getter=")
-
-    def set(self, value):
-        raise NotImplementedError("Variable.set: subclass or pass setter=")
 
 
 class PathVariable(Variable):
     """The attribute or item ``system.get_path(path)`` reaches, e.g.
     ``(1, "curvature")`` (rayopt/optimize.py:46)."""
-    def __init__(self, system, path, *args, **kwargs):
-        self.path = path
+    def __init__(self, system, path, bounds=(-np.inf, np.inf), scale=None,
+                 init=None):
+        self.path = tuple(path) if isinstance(path, list) else path
         Variable.__init__(
-            self, system, *args,
+            self, system, bounds, scale, init,
             getter=lambda: system.get_path(path),
-            setter=lambda value: system.set_path(path, value), **kwargs)
+            setter=lambda value: system.set_path(path, value))
 
 
-class Operand:
+class Operand(_Described):
     """A vector-valued quantity ``get()`` of the system and the roles it
     plays (same constructor as rayopt/optimize.py:58): a ``weight`` adds
     ``sum((weight*(v - offset))**2)`` to the merit; ``min`` / ``max`` bound
     ``v - offset`` from below / above; ``min == max`` pins ``v - offset`` to
     ZERO whatever the common value is -- the reference's behaviour, kept."""
+    get = _abstract("get")
+
     def __init__(self, system, weight=None, offset=0, min=None, max=None):
         self.system, self.weight, self.offset = system, weight, offset
         self.min, self.max = min, max
-
-    def get(self):
-        raise NotImplementedError("Operand.get: subclass, or use FuncOp")
 
     def get_objective(self):
         return [Affine(self.weight, self.offset)] if self.weight else []
@@ -113,18 +128,17 @@ class Operand:
         return [Affine(1, self.offset)] if pinned else []
 
     def get_inequality(self):
-        sides = []
-        if self.min is not None:
-            sides.append(Affine(1, self.offset, self.min))
-        if self.max is not None:
-            sides.append(Affine(-1, self.offset, -self.max))
-        return sides
+        # lower: v - offset - min >= 0;  upper: max - (v - offset) >= 0
+        return [Affine(sign, self.offset, sign*limit)
+                for sign, limit in ((1, self.min), (-1, self.max))
+                if limit is not None]
 
 
 class FuncOp(Operand):
     """``func(system)`` as a flat vector (rayopt/optimize.py:87)."""
-    def __init__(self, system, func, *args, **kwargs):
-        Operand.__init__(self, system, *args, **kwargs)
+    def __init__(self, system, func, weight=None, offset=0, min=None,
+                 max=None):
+        Operand.__init__(self, system, weight, offset, min, max)
         self.func = func
 
     def get(self):
