@@ -228,23 +228,37 @@ BASIC = {
 # --------------------------------------------------------------------------
 
 def _axis_angle(angle, axis):
-    """Rodrigues rotation matrix about ``axis`` (right-handed, 3x3)."""
-    d = np.asarray(axis, dtype=float)
-    d = d/np.linalg.norm(d)
+    """Rotation about ``axis`` by ``angle`` (Rodrigues), 3x3, evaluated in
+    the order the reference's ``rotation_matrix`` does -- cos on the
+    diagonal, + (1 - cos) d d^T, + sin [d]x -- so the entries carry the same
+    rounding (rayopt/transformations.py rotation_matrix, used at
+    rayopt/elements.py:147)."""
+    d = np.array(axis, dtype=float)
+    d /= math.sqrt(np.dot(d, d))
     ca, sa = math.cos(angle), math.sin(angle)
-    cross = np.array([[0., -d[2], d[1]], [d[2], 0., -d[0]], [-d[1], d[0], 0.]])
-    return ca*np.eye(3) + (1. - ca)*np.outer(d, d) + sa*cross
+    rot = np.diag([ca, ca, ca])
+    rot += np.outer(d, d)*(1. - ca)
+    d *= sa
+    rot += np.array([[0., -d[2], d[1]], [d[2], 0., -d[0]], [-d[1], d[0], 0.]])
+    return rot
 
 
 def _euler_rxyz(ax, ay, az):
-    """Rotating-frame x-y-z Euler matrix: Rx(ax) Ry(ay) Rz(az)."""
-    cx, sx = math.cos(ax), math.sin(ax)
-    cy, sy = math.cos(ay), math.sin(ay)
-    cz, sz = math.cos(az), math.sin(az)
-    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
-    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
-    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
-    return rx @ ry @ rz
+    """Rotating-frame x-y-z Euler matrix Rx(ax) Ry(ay) Rz(az) in closed
+    form.  The nine entries are the products the reference's
+    ``euler_matrix(ax, ay, az, "rxyz")`` forms (rayopt/transformations.py:
+    1047; "rxyz" = first axis z, odd parity, rotating frame: the angles enter
+    negated and in reverse order), term for term in Python floats, so that
+    ``rot_normal`` -- and with it every tilted trace -- equals the
+    reference's to the last bit rather than to 1e-17."""
+    s3, s2, s1 = math.sin(-az), math.sin(-ay), math.sin(-ax)
+    c3, c2, c1 = math.cos(-az), math.cos(-ay), math.cos(-ax)
+    c3c1, c3s1 = c3*c1, c3*s1
+    s3c1, s3s1 = s3*c1, s3*s1
+    return np.array([
+        [c2*c3, c2*s3, -s2],
+        [s2*c3s1 - s3c1, s2*s3s1 + c3c1, c2*s1],
+        [s2*c3c1 + s3s1, s2*s3c1 - c3s1, c2*c1]])
 
 
 class Pose:
@@ -281,15 +295,15 @@ class Pose:
         rot = np.eye(3)
         if not self.straight:
             axis = np.cross(u, (0, 0, 1.))
-            angle = math.asin(min(1., float(np.linalg.norm(axis))))
+            angle = np.arcsin(min(1., np.linalg.norm(axis)))
             if u[2] < 0:
-                angle = math.pi - angle
+                angle = np.pi - angle
             if np.allclose(axis, 0):
                 axis = (1., 0, 0)
             self.rot_axis = _axis_angle(angle, axis)
-            rot = rot @ self.rot_axis
+            rot = np.dot(rot, self.rot_axis)
         if not self.normal:
-            rot = rot @ _euler_rxyz(*self._angles)
+            rot = np.dot(rot, _euler_rxyz(*self._angles))
         self.rot_normal = rot
 
     distance = property(lambda self: self._distance,
