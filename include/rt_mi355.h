@@ -242,7 +242,10 @@ typedef struct rt_aim_args {
     int32_t rim;     /* 1: marginal rays graze the first limiting aperture
                         of elements 1..nsurf-2 instead of the stop */
     int32_t maxiter; /* per root find */
-    int32_t pad_;
+    int32_t no_chief; /* 1: keep the pupil distance of the seeds -- the
+                         object pupil is telecentric, or its `aim` flag is
+                         off and only the rim is aimed at
+                         (aim_chief, system.py:509-510) */
     double tol;      /* convergence: secant step / |margin| */
 } rt_aim_args;
 int rt_sizeof_aim_seed(void);
@@ -305,7 +308,9 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * "tile_rays" (measurement only: 0 = the documented SoA layout; TR = a power
  * of two: results are written tile-major [tile of TR rays][L][10][TR] so a
  * workgroup's whole output is one contiguous region; nothing can be read
- * back in that layout -- it exists to measure the store pattern).
+ * back in that layout -- it exists to measure the store pattern),
+ * "probe_store" (rt_probe pattern modes only: 0 plain stores, 1 non-temporal,
+ * 2 sc1 write-through, 3 sc0 sc1).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
 /*

@@ -50,7 +50,7 @@ AIM_SEED_DTYPE = np.dtype([
 ], align=True)
 
 AIM_ARGS_DTYPE = np.dtype([
-    ("stop", "i4"), ("rim", "i4"), ("maxiter", "i4"), ("pad_", "i4"),
+    ("stop", "i4"), ("rim", "i4"), ("maxiter", "i4"), ("no_chief", "i4"),
     ("tol", "f8"),
 ], align=True)
 

@@ -71,12 +71,29 @@ def start_pupil(system, l, z0=None, a0=None):
     return z0, a0
 
 
+def pupil_option(system, name, default=False):
+    """``system.object.pupil.<name>`` for this package's conjugates (a dict)
+    and the reference's (a Pupil object, rayopt/pupils.py:29-38)."""
+    pupil = getattr(system.object, "pupil", None)
+    if isinstance(pupil, dict):
+        return pupil.get(name, default)
+    return getattr(pupil, name, default)
+
+
 class FieldAimer:
-    """Aims F field points at once.  ``engine`` is injectable (tests)."""
+    """Aims F field points at once.  ``engine`` is injectable (tests).
+
+    ``aim``: None = as the reference decides (rayopt/system.py:507-531): the
+    chief ray is aimed only if ``object.pupil.aim`` is set and the pupil is
+    not telecentric, the marginal rays if ``aim`` is set or the rim is asked
+    for; an object pupil without the flag -- the reference's default --
+    launches from the first-order pupil as it is.  True = aim whatever the
+    flag says (the batched extension entry points)."""
 
     def __init__(self, system, l=None, engine=None, tol=1e-9, maxiter=60,
-                 on_device=True):
+                 on_device=True, aim=True):
         self.system = system
+        self.aim = aim
         self.l = system.wavelengths[0] if l is None else l
         self.trace = GeometricTrace(system, engine=engine)
         self.tol = tol
@@ -99,8 +116,7 @@ class FieldAimer:
         rad = self.system[stop].radius
         z0 = np.broadcast_to(np.asarray(z0, dtype=float), (len(yo),))
         todo = ~np.all(np.isclose(yo, 0), axis=1)   # on-axis: nothing to aim
-        obj = self.system.object
-        if obj.finite and _telecentric(obj):        # system.py:509-510
+        if not self._aims()[0]:                     # system.py:509-510
             todo[:] = False
         if not todo.any():
             return z0.copy()
@@ -188,6 +204,22 @@ class FieldAimer:
     def _start(self, l, z0=None, a0=None):
         return start_pupil(self.system, l, z0, a0)
 
+    def _aims(self, rim=False):
+        """(aim the chief ray, aim the marginal rays)."""
+        flag = bool(pupil_option(self.system, "aim")) if self.aim is None \
+            else bool(self.aim)
+        telecentric = bool(pupil_option(self.system, "telecentric"))
+        return flag and not telecentric, flag or bool(rim)
+
+    @staticmethod
+    def _unaimed(yo, z0, a0):
+        """The first-order pupil for every field (_aim_pupil with both
+        solvers returning their input, system.py:557-583)."""
+        z = np.broadcast_to(np.asarray(z0, dtype=float), (len(yo),)).copy()
+        r = np.broadcast_to(np.fabs(np.asarray(a0, dtype=float)), (len(yo),))
+        a = r[:, None, None]*np.array([[-1., -1.], [1., 1.]])
+        return z, a
+
     def _pupil_on_device(self, yo, wavelengths, starts, rim):
         """All fields at all wavelengths, all five root finds, one kernel
         (rt_aim_pupil): z (W,F), a (W,F,2,2)."""
@@ -204,6 +236,7 @@ class FieldAimer:
         args = np.zeros((), dtype=AIM_ARGS_DTYPE)
         args["stop"], args["rim"] = system.stop, bool(rim)
         args["maxiter"], args["tol"] = self.maxiter, self.tol
+        args["no_chief"] = not self._aims(rim)[0]
         seeds = np.concatenate([
             aim_seeds(system, yo, z0, a0, group)
             for group, (z0, a0) in enumerate(starts)])
@@ -221,6 +254,10 @@ class FieldAimer:
         a (W,F,2,2) -- in one launch where the engine aims on the device."""
         yo = np.atleast_2d(np.asarray(yo, dtype=float))
         starts = [self._start(l) for l in wavelengths]
+        if not self._aims(rim)[1]:
+            out = [self._unaimed(yo, z0, a0) for z0, a0 in starts]
+            return (np.array([z for z, _ in out]),
+                    np.array([a for _, a in out]))
         if self.on_device and hasattr(self.trace.engine, "aim_pupil"):
             return self._pupil_on_device(yo, wavelengths, starts, rim)
         keep = self.l
@@ -240,6 +277,8 @@ class FieldAimer:
         yo = np.atleast_2d(np.asarray(yo, dtype=float))
         nf = len(yo)
         z0, a0 = self._start(self.l, z0, a0)
+        if not self._aims(rim)[1]:
+            return self._unaimed(yo, z0, a0)
         if self.on_device and np.ndim(z0) == 0 and np.ndim(a0) == 0 \
                 and hasattr(self.trace.engine, "aim_pupil"):
             z, a = self._pupil_on_device(yo, [self.l],

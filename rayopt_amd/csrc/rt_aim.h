@@ -121,7 +121,7 @@ RT_HD int rt_aim_chief(const rt_surface *__restrict__ tab,
      * telecentric object, whose chief rays do not depend on the pupil
      * distance (aim_chief, system.py:509-510) */
     if ((fabs(sd->yo[0]) <= 1e-8 && fabs(sd->yo[1]) <= 1e-8) ||
-        (sd->finite && sd->telecentric))
+        (sd->finite && sd->telecentric) || g->no_chief)
         return 0;
     const double rad = sqrt(tab[g->stop].radius2);
     rt_field F;

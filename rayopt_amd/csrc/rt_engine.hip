@@ -93,6 +93,7 @@ struct rt_ctx {
     int pin_busy[2]; /* a DMA recorded in pin_done[k] may still use h_pin[k] */
     double *d_w;  /* ray weights, NULL = uniform 1/n */
     size_t w_cap;
+    int64_t w_n;  /* rays the weights were given for (must equal n) */
     double *d_partials; /* RT_RED_BLOCKS x 8 doubles + 16 reduced values */
     double *d_group;    /* rt_spot_stats: stats | partials */
     size_t group_cap;   /* doubles */
@@ -104,6 +105,7 @@ struct rt_ctx {
     int opt_fuse; /* build generated rays inside the first trace */
     int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
     int opt_tile; /* measurement only: tile-major result layout, rays/tile */
+    int opt_probe_store; /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
 
     /* rt_generate_rays: field frames | pupil points, and whether row 0 is
      * still to be built from them */
@@ -1127,6 +1129,10 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         if ((value != 0) != ctx->opt_fast)
             ctx->table_dirty = 1;
         ctx->opt_fast = value ? 1 : 0;
+    } else if (!strcmp(key, "probe_store")) {
+        if (value < 0 || value > 3)
+            return rt_fail(ctx, RT_ERR_ARG, "probe_store must be 0..3");
+        ctx->opt_probe_store = value;
     } else if (!strcmp(key, "tile_rays")) {
         /* measurement only: tile-major layout (rt_kernels.h, rt_lay); takes
          * effect with the next rt_reserve / rt_set_rays */
@@ -1186,7 +1192,16 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
         const rt_lay lay = rt_layout(ctx);
         const double *win = ctx->d_buf;
 #define RT_PROBE(IN, RP, SI)                                                  \
-    hipLaunchKernelGGL((rt_probe_pattern_kernel<IN, RP>), dim3(grid),         \
+    do {                                                                      \
+        switch (ctx->opt_probe_store) {                                       \
+        case 1: RT_PROBE_FL(IN, RP, SI, 1); break;                            \
+        case 2: RT_PROBE_FL(IN, RP, SI, 2); break;                            \
+        case 3: RT_PROBE_FL(IN, RP, SI, 3); break;                            \
+        default: RT_PROBE_FL(IN, RP, SI, 0); break;                           \
+        }                                                                     \
+    } while (0)
+#define RT_PROBE_FL(IN, RP, SI, FL)                                           \
+    hipLaunchKernelGGL((rt_probe_pattern_kernel<IN, RP, FL>), dim3(grid),     \
                        dim3(block), 0, ctx->stream, 1, L, win, lay, ld, SI)
         switch (mode) {
         case 0: RT_PROBE(0, 2, 1); break;
@@ -1195,6 +1210,7 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
         case 7: RT_PROBE(0, 1, 0); break;
         default: RT_PROBE(2, 1, 0); break;
         }
+#undef RT_PROBE_FL
 #undef RT_PROBE
         *bytes = (double)ld * ((mode >= 7 ? 56. : 80.) * (L - 1) +
                                ((mode == 0 || mode == 7) ? 48. : 0.));
@@ -1325,6 +1341,7 @@ int rt_set_weights(rt_ctx *ctx, const double *w)
             RT_HIP(ctx, hipFree(ctx->d_w));
         ctx->d_w = NULL;
         ctx->w_cap = 0;
+        ctx->w_n = 0;
         return RT_OK;
     }
     if ((size_t)ctx->n > ctx->w_cap) {
@@ -1337,6 +1354,7 @@ int rt_set_weights(rt_ctx *ctx, const double *w)
     RT_HIP(ctx, hipMemcpyAsync(ctx->d_w, w, ctx->n * sizeof(double),
                                hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->w_n = ctx->n;
     return RT_OK;
 }
 
@@ -1351,6 +1369,12 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
                        surf);
     if (rt_soa_only(ctx, who) != RT_OK)
         return RT_ERR_STATE;
+    if (ctx->d_w && ctx->w_n != ctx->n)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "%s: the weights on the device were set for a batch "
+                       "of %lld rays, this one has %lld: call rt_set_weights "
+                       "after seeding (NULL for uniform weights)", who,
+                       (long long)ctx->w_n, (long long)ctx->n);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_partials)
         RT_HIP(ctx, hipMalloc((void **)&ctx->d_partials,

@@ -313,7 +313,37 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
  * without its arithmetic, a linear fill and a 16-byte copy.  They calibrate
  * the memory-system ceiling the trace kernel is judged against.
  */
-template <int IN, int RP>
+/* store flavours of the pattern probe: 0 plain, 1 non-temporal, 2 sc1
+ * (write-through to memory, line dropped from the XCD's L2), 3 sc0 sc1 */
+template <int FL, typename V>
+__device__ __forceinline__ void rt_probe_store(V *p, V v)
+{
+    if constexpr (FL == 0) {
+        *p = v;
+    } else if constexpr (FL == 1) {
+        __builtin_nontemporal_store(v, p);
+    } else if constexpr (sizeof(V) == 8) {
+        if constexpr (FL == 2)
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p),
+                         "v"(v)
+                         : "memory");
+        else
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p),
+                         "v"(v)
+                         : "memory");
+    } else {
+        if constexpr (FL == 2)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p),
+                         "v"(v)
+                         : "memory");
+        else
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p),
+                         "v"(v)
+                         : "memory");
+    }
+}
+
+template <int IN, int RP, int FL>
 __global__ void rt_probe_pattern_kernel(int start, int stop,
                                         const double *__restrict__ in,
                                         rt_lay a, int64_t ld, int stored_i)
@@ -345,12 +375,16 @@ __global__ void rt_probe_pattern_kernel(int start, int stop,
         const int64_t row = s * a.ss + col;
         for (int c = 0; c < 3; ++c) {
             y[c] += u[c];
-            *reinterpret_cast<V *>(a.Y + row + c * a.cs) = y[c];
-            *reinterpret_cast<V *>(a.U + row + c * a.cs) = u[c];
+            rt_probe_store<FL>(reinterpret_cast<V *>(a.Y + row + c * a.cs),
+                               y[c]);
+            rt_probe_store<FL>(reinterpret_cast<V *>(a.U + row + c * a.cs),
+                               u[c]);
             if (stored_i)
-                *reinterpret_cast<V *>(a.I + row + c * a.cs) = u[c];
+                rt_probe_store<FL>(
+                    reinterpret_cast<V *>(a.I + row + c * a.cs), u[c]);
         }
-        *reinterpret_cast<V *>(a.T + s * a.ssT + col) = y[2];
+        rt_probe_store<FL>(reinterpret_cast<V *>(a.T + s * a.ssT + col),
+                           y[2]);
     }
 }
 

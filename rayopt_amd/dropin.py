@@ -59,8 +59,12 @@ def _device_pupil(reference_pupil, engine_factory):
         pup = self.object.pupil
         if stop not in (None, -1) or not pup.aim or kwargs:
             return reference_pupil(self, yo, l=l, stop=stop, **kwargs)
-        cache = self.__dict__.setdefault("_mi355_pupils", {})
-        key = (l, stop, float(yo[0]), float(yo[1]), float(pup.distance),
+        # kept inside the reference's own cache, under a key of its own, so
+        # that System.update() -- which clears _pupil_cache after any change
+        # of the prescription (rayopt/system.py:201-202) -- forgets these
+        # results together with the reference's
+        cache = self._pupil_cache.setdefault(("mi355", l, stop), {})
+        key = (float(yo[0]), float(yo[1]), float(pup.distance),
                float(pup.radius), len(self))
         if key not in cache:
             engine = engine_factory() if engine_factory else get_engine()

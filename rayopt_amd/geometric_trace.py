@@ -287,6 +287,8 @@ class GeometricTrace(Trace):
             l = self.system.wavelengths[0]
         if np.ndim(l) == 1:
             return self._rays_given_groups(y, u, np.asarray(l, float), w, ref)
+        if np.ndim(self.n) != 1:    # an earlier batch had one n per group
+            self.n = np.empty(self.length)
         if w is not None and np.shape(w) != (n,):
             raise ValueError("rays_given: w must have shape (%d,)" % n)
         self._uniform_w = w is None
@@ -416,11 +418,23 @@ class GeometricTrace(Trace):
             self.allocate(nrays)
         self._reset_bundles()
         self.l = self.system.wavelengths[0] if l is None else l
-        self.w = w
+        if np.ndim(self.l) != 0:
+            raise ValueError("rays_given_device takes one wavelength")
+        if np.ndim(self.n) != 1:
+            self.n = np.empty(self.length)
+        if w is not None and np.shape(w) != (nrays,):
+            raise ValueError("rays_given_device: w must have shape (%d,)"
+                             % nrays)
+        self._uniform_w = w is None
+        self.w = np.broadcast_to(np.ones(1)/nrays, (nrays,)) if w is None \
+            else np.asarray(w, dtype=float)
         self.ref = ref
         self.n[0] = self.system.refractive_index(self.l, 0)
         self._upload_table(1, None, self.n[0])
         self.engine.set_rays_device(d_y, d_u, nrays, layout)
+        # the device reductions (rms, refocus, spot_stats) read the weights
+        # of THIS batch: upload them, or drop those of an earlier one
+        self.engine.set_weights(None if self._uniform_w else self.w)
         for rows in (self.y, self.u, self.i, self.t):
             rows.invalidate(0, self.length)
 
@@ -486,7 +500,9 @@ class GeometricTrace(Trace):
         of ``rays_point`` (rayopt/geometric_trace.py:204-209): pupil pattern
         (``pupil_distribution``), aiming of every field on the GPU
         (:class:`rayopt_amd.aiming.FieldAimer`; ``aim=False`` uses the
-        paraxial entrance pupil), ray construction on the GPU, trace.  Ray
+        paraxial entrance pupil, ``aim=None`` does what the object pupil's
+        own ``aim`` flag says, as the reference's ``rays_point`` would), ray
+        construction on the GPU, trace.  Ray
         ``f*P + p`` belongs to field ``f``; ``self.w`` carries the quadrature
         weights of the pattern, normalised per field.
 
@@ -505,8 +521,9 @@ class GeometricTrace(Trace):
         alive = len(yp)
         packed = None
         if np.ndim(l) == 0:
-            if aim:
-                aimer = FieldAimer(self.system, l, self._aux_engine())
+            if aim or aim is None:
+                aimer = FieldAimer(self.system, l, self._aux_engine(),
+                                   aim=aim)
                 z, a = aimer.pupil(fields, rim=rim)
                 packed = aimer.packed
             else:
@@ -514,8 +531,9 @@ class GeometricTrace(Trace):
             copies = len(fields)
         else:
             l = np.asarray(l, dtype=float)
-            if aim:
-                aimer = FieldAimer(self.system, l[0], self._aux_engine())
+            if aim or aim is None:
+                aimer = FieldAimer(self.system, l[0], self._aux_engine(),
+                                   aim=aim)
                 z, a = aimer.pupils(fields, l, rim=rim)
                 packed = aimer.packed
             else:
@@ -586,12 +604,17 @@ class GeometricTrace(Trace):
             filter = not clip
         yp = np.atleast_2d(np.asarray(yp, dtype=float))
         l = self.system.wavelengths[0] if wavelength is None else wavelength
-        z, a = FieldAimer(self.system, l, self._aux_engine()).pupil(
-            [yo], rim=(stop == -1))
+        z, a = FieldAimer(self.system, l, self._aux_engine(),
+                          aim=None).pupil([yo], rim=(stop == -1))
         if filter:
-            am = np.fabs(a[0]).max()
-            c = np.sum(a[0], axis=0)/2
-            d = np.diff(a[0], axis=0)/2
+            # Pupil.map(filter=True) (rayopt/pupils.py:97-107) acts on the
+            # aperture as the conjugate hands it over: angles atan2(a, z) for
+            # an object at finite distance (rayopt/conjugates.py:146)
+            af = np.arctan2(a[0], z[0]) if self.system.object.finite \
+                else a[0]
+            am = np.fabs(af).max()
+            c = np.sum(af, axis=0)/2
+            d = np.diff(af, axis=0)/2
             inside = (np.square(yp*am - c)/np.square(d)).sum(1) <= 1
             yp = yp[inside]
             if weight is not None:
@@ -619,8 +642,8 @@ class GeometricTrace(Trace):
         ``axis`` (rayopt/geometric_trace.py:211-215)."""
         from .aiming import FieldAimer
         l = self.system.wavelengths[0] if wavelength is None else wavelength
-        z, a = FieldAimer(self.system, l, self._aux_engine()).pupil(
-            [yo], rim=True)
+        z, a = FieldAimer(self.system, l, self._aux_engine(),
+                          aim=None).pupil([yo], rim=True)
         yp = np.zeros((3, 2))
         yp[1:, axis] = a[0][:, axis]/np.fabs(a[0]).max()
         self.rays_fields([yo], yp, z, a, l)
@@ -638,7 +661,7 @@ class GeometricTrace(Trace):
         fields = np.linspace(0, 1, nrays)[:, None]*np.atleast_2d(yo)
         e = np.zeros((3, 2))
         e[(1, 2), (1, 0)] = eps
-        aimer = FieldAimer(self.system, l, self._aux_engine())
+        aimer = FieldAimer(self.system, l, self._aux_engine(), aim=None)
         z0, a = aimer.pupil([(0., 0.)])
         z = aimer.chief(fields, z0[0], np.fabs(a[0]).max())
         # built field-major on the device, re-ordered kind-major (a few
