@@ -41,6 +41,45 @@ class Trace:
         self.origins = self.system.origins
         self.mirrored = self.system.mirrored
 
+    def from_axis(self, y, i=None, ref=0):
+        """Points given along the folded optical axis -- ``y[k, ray]`` =
+        (x, y, z) with z the path length along the axis -- in the global
+        frame: every point is assigned to the element whose stretch of the
+        axis it lies on (``i``: the split indices, by default found from ray
+        ``ref``'s z against ``path``), shifted to that element's vertex and
+        turned by its axis rotation (rayopt/raytrace.py:38-54)."""
+        y = np.atleast_3d(y)
+        if i is None:
+            i = np.searchsorted(y[:, ref, 2], self.path)
+        pieces = []
+        for j, block in enumerate(np.vsplit(y, i)):
+            if block.ndim <= 1:
+                continue
+            j = min(j, self.length - 1)
+            flat = block.reshape(-1, 3) - (0., 0., self.path[j])
+            flat = self.origins[j] + self.system[j].from_axis(flat)
+            pieces.append(flat.reshape(block.shape))
+        return np.vstack(pieces)
+
+    def print_coeffs(self, coeff, labels, sum=True):
+        """Lines of a per-element table: index, element type letter, one
+        column per label; a totals row unless ``sum=False``
+        (rayopt/raytrace.py:56-63)."""
+        width = len(labels)
+        yield ("%2s %1s" + "% 10s"*width) % (("#", "T") + tuple(labels))
+        row = "%2s %1s" + "% 10.4g"*width
+        for j, values in enumerate(coeff):
+            letter = getattr(self.system[j], "typeletter", "S")
+            yield row % ((j, letter) + tuple(values))
+        if sum:
+            yield row % (("", "") + tuple(np.sum(coeff, axis=0)))
+
+    def align(self):
+        """Tilt the elements for the axial ray given the indices of the last
+        trace (``System.align``), then re-trace (rayopt/raytrace.py:65-67)."""
+        self.system.align(self.n)
+        self.propagate()
+
 
 class DeviceRows:
     """Lazy host view of one device-resident result array.
@@ -789,30 +828,31 @@ class GeometricTrace(Trace):
             el.radius = fn(self.engine.row_rmax(j), el.radius)
 
     def print_trace(self, rays=None):
-        """Text table per ray (default: the first three): index, track,
-        path relative to the axial path, intercept, direction
-        (rayopt/geometric_trace.py:242-255)."""
+        """Text table per ray: refractive index, track, path relative to the
+        axial path, intercept, direction per element
+        (rayopt/geometric_trace.py:242-255).  ``rays`` (extension): the ray
+        indices to print, default all as in the reference; a ray costs three
+        strided reads of L values from the device."""
         if np.ndim(self.l):
             raise NotImplementedError("one wavelength per table")
-        rays = range(min(3, self.nrays)) if rays is None else rays
         labels = ("n/track z/rel path/height x/height y/height z/"
                   "angle x/angle y/angle z").split("/")
-        head = ("%2s %1s" + "% 10s"*len(labels)) % (("#", "T") + tuple(labels))
-        for k in rays:
+        for k in (range(self.nrays) if rays is None else rays):
             y = self.engine.download_ray(RT_Y, k)
             u = self.engine.download_ray(RT_U, k)
             t = np.cumsum(self.engine.download_ray(RT_T, k)) - self.path
             yield "ray %i" % k
-            yield head
-            for j in range(self.length):
-                row = (self.n[j], self.path[j], t[j]) + tuple(y[j]) + \
-                    tuple(u[j])
-                letter = getattr(self.system[j], "typeletter", "S")
-                yield ("%2s %1s" + "% 10.4g"*len(row)) % ((j, letter) + row)
+            yield from self.print_coeffs(
+                np.column_stack([self.n, self.path, t, y, u]), labels,
+                sum=False)
             yield ""
 
+    def text(self):
+        """rayopt/geometric_trace.py:257-258."""
+        return self.print_trace()
+
     def __str__(self):
-        return "\n".join(self.print_trace())
+        return "\n".join(self.text())
 
     def _image_pupil(self):
         pupil = self.system.image.pupil

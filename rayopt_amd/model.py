@@ -228,18 +228,26 @@ BASIC = {
 # --------------------------------------------------------------------------
 
 def _axis_angle(angle, axis):
-    """Rotation about ``axis`` by ``angle`` (Rodrigues), 3x3, evaluated in
-    the order the reference's ``rotation_matrix`` does -- cos on the
-    diagonal, + (1 - cos) d d^T, + sin [d]x -- so the entries carry the same
-    rounding (rayopt/transformations.py rotation_matrix, used at
-    rayopt/elements.py:147)."""
+    """Rotation about ``axis`` by ``angle`` (Rodrigues), 3x3:
+    ``R[i][j] = (delta_ij cos + d_i d_j (1 - cos)) + eps_ikj d_k sin``.
+    Each entry is summed in that order -- diagonal term, then the projector
+    term, then the cross-product term -- which is the order the reference's
+    ``rotation_matrix`` accumulates them in (used at rayopt/elements.py:147),
+    so the entries carry the same rounding."""
     d = np.array(axis, dtype=float)
-    d /= math.sqrt(np.dot(d, d))
+    d = (d/math.sqrt(np.dot(d, d))).tolist()
     ca, sa = math.cos(angle), math.sin(angle)
-    rot = np.diag([ca, ca, ca])
-    rot += np.outer(d, d)*(1. - ca)
-    d *= sa
-    rot += np.array([[0., -d[2], d[1]], [d[2], 0., -d[0]], [-d[1], d[0], 0.]])
+    # (k, sign) of the cross-product matrix [d]x entry (i, j)
+    cross = {(0, 1): (2, -1.), (0, 2): (1, 1.), (1, 0): (2, 1.),
+             (1, 2): (0, -1.), (2, 0): (1, -1.), (2, 1): (0, 1.)}
+    rot = np.empty((3, 3))
+    for i in range(3):
+        for j in range(3):
+            entry = (ca if i == j else 0.) + (d[i]*d[j])*(1. - ca)
+            if i != j:
+                k, sign = cross[i, j]
+                entry = entry + sign*(d[k]*sa)
+            rot[i, j] = entry
     return rot
 
 
@@ -259,6 +267,25 @@ def _euler_rxyz(ax, ay, az):
         [c2*c3, c2*s3, -s2],
         [s2*c3s1 - s3c1, s2*s3s1 + c3c1, c2*s1],
         [s2*c3c1 + s3s1, s2*s3c1 - c3s1, c2*c1]])
+
+
+def _euler_angles_rxyz(rot):
+    """Inverse of :func:`_euler_rxyz`: the angles ``(ax, ay, az)`` of a
+    rotation matrix.  With s_k = sin(-a_k), c_k = cos(-a_k) the matrix reads
+    ``[[c2 c3, c2 s3, -s2], [., ., c2 s1], [., ., c2 c1]]``, so ax and az
+    follow from the ratios in the last column / first row and ay from -s2
+    against c2 = hypot(R12, R22); at the pole (c2 = 0) only ax + az is
+    defined and az is set to 0 (the convention of the reference's
+    ``euler_from_matrix(rot, "rxyz")``, rayopt/elements.py:117)."""
+    c2 = math.sqrt(rot[2][2]*rot[2][2] + rot[1][2]*rot[1][2])
+    if c2 > 4.*np.finfo(float).eps:
+        a_x = math.atan2(rot[1][2], rot[2][2])
+        a_z = math.atan2(rot[0][1], rot[0][0])
+    else:                       # gimbal lock: all of ax + az goes to az
+        a_x = 0.
+        a_z = math.atan2(-rot[1][0], rot[1][1])
+    a_y = math.atan2(-rot[0][2], c2)
+    return -a_x, -a_y, -a_z
 
 
 class Pose:
@@ -305,6 +332,26 @@ class Pose:
         if not self.normal:
             rot = np.dot(rot, _euler_rxyz(*self._angles))
         self.rot_normal = rot
+
+    def align(self, direction, mu):
+        """Tilt the element so that a ray arriving along this element's
+        ``direction`` leaves along ``direction`` after refraction with index
+        ratio ``mu`` (or reflection): the surface normal is put along
+        ``mu*incident - excident`` (Snell in vector form;
+        rayopt/elements.py:103-118, called by ``System.align``)."""
+        incident = self._direction
+        normal = mu*incident - np.asarray(direction, dtype=float)
+        if mu < 1:
+            normal = -normal
+        if np.allclose(normal, 0):
+            normal = np.array([0., 0., 1.])
+        normal = normal/np.linalg.norm(normal)
+        axis = np.cross(incident, normal)
+        tilt = np.arcsin(np.linalg.norm(axis))
+        if np.allclose(axis, 0):
+            axis = (1., 0., 0.)
+        self.update(self._distance, self._direction,
+                    _euler_angles_rxyz(_axis_angle(tilt, axis).T))
 
     distance = property(lambda self: self._distance,
                         lambda self, d: self.update(d, self._direction,
@@ -586,6 +633,17 @@ class System(list):
     @property
     def track(self):
         return self.origins[:, 2]
+
+    def align(self, n):
+        """Tilt every element for the axial ray: element j is aligned to
+        send its incident axis into the direction of element j+1, given the
+        indices ``n[j]`` behind the elements; the image is left untilted
+        (rayopt/system.py:430-436)."""
+        before = n[0]
+        for j in range(len(self) - 1):
+            self[j].align(self[j + 1].direction, before/n[j])
+            before = n[j]
+        self[-1].angles = (0., 0., 0.)
 
     @property
     def mirrored(self):
