@@ -56,18 +56,57 @@ def entrance_pupil(system, l=None):
     return b/a, system[stop].radius/a
 
 
+def exit_pupil(system, l=None):
+    """(distance from the vertex of the image surface, radius) of the
+    paraxial image of the stop in image space: the two basis rays
+    (y, n u) = (1, 0), (0, 1) leaving the stop are carried through elements
+    stop+1 .. L-1; the first row (a, b) of the INVERSE of that matrix gives
+    distance = b n_last / a and radius = stop radius / a -- what the
+    reference stores in ``system.image.pupil`` (``update_conjugates``,
+    rayopt/paraxial_trace.py:336-341) and ``GeometricTrace.opd`` takes its
+    default reference-sphere radius from (rayopt/geometric_trace.py:113)."""
+    if l is None:
+        l = system.wavelengths[0]
+    stop = system.stop
+    n_prev = system.refractive_index(l, stop)
+    rays = np.array([[1., 0.], [0., 1.]])        # (y, n u) for two rays
+    for el in system[stop + 1:]:
+        rays[:, 0] += el.distance*rays[:, 1]/n_prev
+        c = getattr(el, "curvature", 0.)
+        asph = getattr(el, "aspherics", None)
+        if asph:
+            c = c + 2*asph[0]
+        if getattr(getattr(el, "material", None), "mirror", False):
+            rays[:, 1] += 2*c*rays[:, 0]
+            continue
+        if not hasattr(el, "get_n_mu"):
+            continue
+        n_next, _ = el.get_n_mu(n_prev, l)
+        rays[:, 1] -= rays[:, 0]*c*(n_next - n_prev)
+        n_prev = n_next
+    a, b = np.linalg.inv(rays.T)[0]
+    return b*n_prev/a, system[stop].radius/a
+
+
 def start_pupil(system, l, z0=None, a0=None):
-    """Starting pupil (distance, aperture) at wavelength ``l``: the paraxial
-    image of the stop; a specified object pupil radius is the starting
-    aperture, as in the reference (Pupil.update only tracks it if
-    update_radius)."""
+    """Starting pupil (distance, aperture): what the reference reads from
+    ``system.object.pupil`` (rayopt/system.py:562-565) -- the distance the
+    last ``update()`` stored (or the user pinned), else the paraxial image
+    of the stop evaluated now; a specified object pupil radius is the
+    starting aperture, as in the reference (``Pupil.update`` only tracks it
+    if ``update_radius``), else the paraxial one.  ``l`` is the wavelength
+    of the on-the-fly evaluation."""
     if z0 is None or a0 is None:
-        zp, ap = entrance_pupil(system, l)
         spec = getattr(system.object, "pupil", None)
-        given = spec.get("radius") if isinstance(spec, dict) else \
-            getattr(spec, "radius", None)
+        get = spec.get if isinstance(spec, dict) else \
+            (lambda key: getattr(spec, key, None))
+        zp, given = get("distance"), get("radius")
+        if (z0 is None and zp is None) or (a0 is None and not given):
+            zq, ap = entrance_pupil(system, l)
+            zp = zq if zp is None else zp
+            given = given or ap
         z0 = zp if z0 is None else z0
-        a0 = (given or ap) if a0 is None else a0
+        a0 = given if a0 is None else a0
     return z0, a0
 
 

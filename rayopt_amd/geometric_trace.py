@@ -855,10 +855,19 @@ class GeometricTrace(Trace):
         return "\n".join(self.text())
 
     def _image_pupil(self):
+        """(telecentric, distance) of the image-side pupil: the reference's
+        Pupil object as its paraxial update left it, or -- this package's
+        conjugates -- the distance the last ``System.update()`` stored there
+        (or the user pinned), else the paraxial exit pupil at the system's
+        first wavelength evaluated now (rayopt/paraxial_trace.py:326-341)."""
         pupil = self.system.image.pupil
-        if isinstance(pupil, dict):
-            return bool(pupil.get("telecentric", False)), pupil.get("distance")
-        return bool(pupil.telecentric), pupil.distance
+        if not isinstance(pupil, dict):
+            return bool(pupil.telecentric), pupil.distance
+        telecentric = bool(pupil.get("telecentric", False))
+        if pupil.get("distance") is not None or telecentric:
+            return telecentric, pupil.get("distance")
+        from .aiming import exit_pupil
+        return False, exit_pupil(self.system)[0]
 
     def opd_rays(self, radius=None, after=-2, image=-1):
         """Per-ray optical path difference on the reference sphere centred

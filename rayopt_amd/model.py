@@ -581,8 +581,32 @@ class System(list):
                 "elements": [e.dict() for e in self]}
 
     def update(self):
-        """Nothing to solve: pickups/solves/paraxial data are host-side
-        design tools outside the accelerated path."""
+        """The part of rayopt's ``System.update()`` (rayopt/system.py:
+        201-211) the traced path reads afterwards: the first-order pupils.
+        The paraxial images of the stop in object and image space, at the
+        first wavelength, are stored in ``object.pupil`` / ``image.pupil``
+        under the reference's rules (``Pupil.update``, rayopt/pupils.py:
+        43-47: ``distance`` unless ``update_distance`` is off, ``radius``
+        only if ``update_radius`` is on) -- what
+        ``ParaxialTrace.update_conjugates`` does (rayopt/paraxial_trace.py:
+        326-341).  Unaimed launches (``object.pupil.aim`` off) and the
+        default reference sphere of ``opd()`` use the stored values until
+        the next ``update()``, as in the reference; without any ``update()``
+        they are evaluated on the fly.  Pickups, solves and the paraxial
+        trace itself are design tools outside the accelerated path."""
+        from .aiming import entrance_pupil, exit_pupil
+        l = self.wavelengths[0]
+        try:
+            found = ((self.object, entrance_pupil(self, l)),
+                     (self.image, exit_pupil(self, l)))
+        except (ZeroDivisionError, IndexError, np.linalg.LinAlgError):
+            return self
+        for conjugate, (distance, radius) in found:
+            pupil = conjugate.pupil
+            if pupil.get("update_distance", True) and np.isfinite(distance):
+                pupil["distance"] = float(distance)
+            if pupil.get("update_radius", False) and np.isfinite(radius):
+                pupil["radius"] = float(radius)
         return self
 
     def _walk(self, path):

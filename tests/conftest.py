@@ -25,8 +25,8 @@ def pytest_configure(config):
 def golden_names():
     return sorted(os.path.basename(p)[:-4]
                   for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                  if not os.path.basename(p).startswith(("kat_", "aim_",
-                                                         "consumers_")))
+                  if not os.path.basename(p).startswith(
+                      ("kat_", "aim_", "consumers_", "analysis_")))
 
 
 def consumer_golden_names():
