@@ -48,8 +48,9 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                 not re-measured in this run (counters need rocprofv3) but
                 taken from the committed profile named in ``traffic_source``.
   propagate_api the public call against the bare engine call (Engine.trace
-                in the same timed loop) and the wall time of one propagate()
-                on a 10^4-ray batch, where the host path decides
+                in the same timed loop); with --extras also the wall time of
+                one propagate() on a 10^4-ray batch, where the host path
+                decides
   full_i / unclipped / image_row_only   (--extras) other store modes
   cpu_baseline  the numpy port of the reference path (oracle/trace_numpy.py,
                 same whole-array numpy operations as rayopt) timed on this
@@ -465,7 +466,10 @@ def main():
                        "(re-pack + table hand-over + launch); "
                        "engine_trace = the bare rt_trace call in the same "
                        "timed loop"}
-        api.update(small_batch_latency(ra, system, local_rank))
+        if args.extras:     # launches of another batch size: kept out of
+            # the default command so that every rt_trace_kernel launch a
+            # profiler sees there is the headline workload
+            api.update(small_batch_latency(ra, system, local_rank))
 
     configs4 = None
     if dist_mode and world > 1 and not args.no_configs4 and \

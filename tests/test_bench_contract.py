@@ -38,7 +38,8 @@ def test_single_process_line():
     out = subprocess.check_output(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--rays", "200000",
          "--steps", "4", "--warmup", "1", "--cpu-sample", "50000",
-         "--cpu-procs", "4", "--settle", "0.05"], text=True, cwd=ROOT)
+         "--cpu-procs", "4", "--settle", "0.05", "--extras"], text=True,
+        cwd=ROOT)
     d = check_line(out, 4, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
