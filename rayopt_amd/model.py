@@ -55,8 +55,12 @@ class Material:
         catalogue database: ``None``, a Material, a float (constant index), an
         ``(nd, vd)`` tuple or ``"nd/vd"`` string (Abbe model), and the basic
         names ``vacuum``, ``air``, ``mirror`` (optionally ``basic/<name>``);
-        other names (``N-BK7``, ``schott/N-BK7``) resolve in the ``.agf``
-        catalogues loaded with :func:`rayopt_amd.catalog.load_agf`.
+        other names (``N-BK7``, ``schott/N-BK7``) resolve in the catalogue
+        files loaded with :func:`rayopt_amd.catalog.load_agf` and then, as
+        ``[source/][catalog/]name``, in the glass library
+        (:mod:`rayopt_amd.library`: the user's rayopt ``library.sqlite`` if
+        there is one, else the built-in table of refractiveindex.info
+        formulas -- ``SCHOTT-SK|N-SK16``).
         """
         if spec is None or isinstance(spec, Material):
             return spec
@@ -86,9 +90,20 @@ class Material:
         glass = catalogs.find(text)
         if glass is not None:
             return glass
-        raise KeyError("material %r: not in a loaded glass catalogue "
-                       "(rayopt_amd.catalog.load_agf); or give a numeric "
-                       "index or an 'nd/vd' pair" % (spec,))
+        # [source/][catalog/]name in the glass library, as the reference
+        # resolves it (rayopt/material.py:104-115)
+        from .library import Library
+        name = parts[-1]
+        catalog = parts[-2] if len(parts) > 1 else None
+        source = parts[-3] if len(parts) > 2 else None
+        try:
+            return Library.one().get("material", name, catalog, source)
+        except KeyError:
+            raise KeyError(
+                "material %r: not in a loaded glass catalogue "
+                "(rayopt_amd.catalog.load_agf) nor in the glass library "
+                "(rayopt_amd.library); or give a numeric index or an "
+                "'nd/vd' pair" % (spec,)) from None
 
 
 class ConstantIndex(Material):
