@@ -47,8 +47,11 @@ def test_material_make():
     assert ra.Material.make("mirror").mirror
     assert ra.Material.make("basic/air").refractive_index(587.56e-9) == \
         pytest.approx(1.000277, abs=2e-6)
+    # catalogue names resolve in the glass library (tests/test_library.py)
+    assert ra.Material.make("SCHOTT-SK|N-SK16").refractive_index(
+        587.56e-9) == pytest.approx(1.62041, abs=1e-5)
     with pytest.raises(KeyError):
-        ra.Material.make("SCHOTT-SK|N-SK16")
+        ra.Material.make("NO-SUCH|GLASS")
 
 
 def test_get_n_mu_and_system_index():
