@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))       # tests/: random_systems
 
 from oracle import refshim  # noqa: E402
 from cases import cases  # noqa: E402
@@ -50,7 +51,10 @@ def main():
     import scipy
     meta = "rayopt@/root/reference numpy %s scipy %s" % (np.__version__,
                                                          scipy.__version__)
+    only = sys.argv[1:]          # name prefixes: regenerate just those cases
     for case in cases():
+        if only and not case["name"].startswith(tuple(only)):
+            continue
         g = run_reference(ro, case)
         path = os.path.join(HERE, case["name"] + ".npz")
         np.savez_compressed(
@@ -62,6 +66,8 @@ def main():
             case["name"], g.y.shape[0], g.y.shape[1],
             np.isnan(g.u[1:, :, 0]).mean()))
 
+    if only:
+        return
     # --- consumers: rms / refocus / opd(resample=0) from the reference ---
     from cases import consumer_cases
     for case in consumer_cases():

@@ -28,7 +28,12 @@ def test_c_oracle_matches_reference_golden(name):
         if exact:
             assert np.array_equal(x, want, equal_nan=True), (name, label)
         else:
-            assert_parity(x, want, 1e-12, "%s.%s" % (name, label))
+            # tilted_seed_*: the worst-conditioned of 1796 random tilted
+            # systems (tests/tools/soak_tilted.py), where summing the 3x3
+            # products in index order instead of through BLAS shows at up to
+            # 2.4e-11 -- the contract is 1e-10
+            rtol = 1e-10 if name.startswith("tilted_seed_") else 1e-12
+            assert_parity(x, want, rtol, "%s.%s" % (name, label))
 
 
 @pytest.mark.parametrize("seed", range(40))
