@@ -310,7 +310,13 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * workgroup's whole output is one contiguous region; nothing can be read
  * back in that layout -- it exists to measure the store pattern),
  * "probe_store" (rt_probe pattern modes only: 0 plain stores, 1 non-temporal,
- * 2 sc1 write-through, 3 sc0 sc1).
+ * 2 sc1 write-through, 3 sc0 sc1),
+ * "compact" (clipped-ray compaction: 0 = never, the default; 1 = traces that
+ * drop rows (rt_set_keep_rows) run the compacting kernel -- rays whose
+ * direction is NaN are retired, their remaining kept rows filled with NaN,
+ * and the survivors of a 256-ray workgroup are packed into fewer wavefronts
+ * with ballots and an LDS exchange; 2 = every trace.  Results are identical
+ * to the plain kernel's, NaN payloads aside).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
 /*

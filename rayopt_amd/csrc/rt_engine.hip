@@ -106,6 +106,8 @@ struct rt_ctx {
     int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
     int opt_tile; /* measurement only: tile-major result layout, rays/tile */
     int opt_probe_store; /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
+    int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
+    int last_compact; /* the last trace ran the compacting kernel */
 
     /* rt_generate_rays: field frames | pupil points, and whether row 0 is
      * still to be built from them */
@@ -252,6 +254,22 @@ static int rt_gen_flush(rt_ctx *c)
                        !c->opt_alias);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
+}
+
+/* the compacting variant pays (one barrier per element) only where dead rays
+ * are wasted FP64 issue, i.e. where rows are traced but not stored */
+static bool rt_use_compact(const rt_ctx *c, int start, int stop)
+{
+    if (!c->opt_compact || c->opt_r != 1 || c->opt_nt || c->opt_xcd)
+        return false;
+    if (c->ngroups > 1 && (c->n / c->ngroups) % RT_CB)
+        return false; /* a 256-ray tile would straddle two tables */
+    if (c->opt_compact == 2)
+        return true;
+    for (int s = start; s < stop; ++s)
+        if (c->h_stage[s].flags & RT_F_NOSTORE)
+            return true;
+    return false;
 }
 
 template <int R, bool NT, bool XCD>
@@ -1004,13 +1022,15 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
     /* a generated batch that no one has looked at yet is built inside this
      * launch (default kernel variant, from the first element on) */
     const bool fused = ctx->gen_pending && start == 1 && start < stop &&
-                       ctx->opt_r == 1 && !ctx->opt_nt && !ctx->opt_xcd;
+                       ctx->opt_r == 1 && !ctx->opt_nt && !ctx->opt_xcd &&
+                       !rt_use_compact(ctx, start, stop);
     if (!fused) {
         int rc = rt_gen_flush(ctx);
         if (rc != RT_OK)
             return rc;
     }
     RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
+    ctx->last_compact = 0;
     if (fused) {
         const int block = ctx->opt_block;
         ctx->gen_pending = 0;
@@ -1025,6 +1045,16 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
                            ctx->gen_np, ctx->gen_n, ctx->gen_s0,
                            !ctx->opt_alias);
         RT_HIP(ctx, hipGetLastError());
+    } else if (start < stop && rt_use_compact(ctx, start, stop)) {
+        const unsigned grid = (unsigned)((ctx->ld + RT_CB - 1) / RT_CB);
+        hipLaunchKernelGGL(rt_trace_compact_kernel, dim3(grid), dim3(RT_CB),
+                           0, ctx->stream, ctx->d_surf, start, stop, clip,
+                           rt_layout(ctx), ctx->ld,
+                           ctx->ngroups > 1 ? ctx->n / ctx->ngroups
+                                            : (int64_t)0,
+                           ctx->nsurf);
+        RT_HIP(ctx, hipGetLastError());
+        ctx->last_compact = 1;
     } else if (start < stop) {
         const int key = ctx->opt_r * 4 + ctx->opt_nt * 2 + ctx->opt_xcd;
         switch (key) {
@@ -1129,6 +1159,10 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         if ((value != 0) != ctx->opt_fast)
             ctx->table_dirty = 1;
         ctx->opt_fast = value ? 1 : 0;
+    } else if (!strcmp(key, "compact")) {
+        if (value < 0 || value > 2)
+            return rt_fail(ctx, RT_ERR_ARG, "compact must be 0, 1 or 2");
+        ctx->opt_compact = value;
     } else if (!strcmp(key, "probe_store")) {
         if (value < 0 || value > 3)
             return rt_fail(ctx, RT_ERR_ARG, "probe_store must be 0..3");

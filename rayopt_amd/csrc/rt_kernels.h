@@ -259,6 +259,126 @@ __global__ void rt_trace_gen_kernel(const rt_surface *__restrict__ surf,
     rt_march<1, false>(surf, 1, stop, clip, a, col, y, u);
 }
 
+/*
+ * Clipped-ray compaction (BASELINE north_star: "wavefront ballots for ...
+ * clipped-ray compaction").  A ray whose direction has become NaN -- clipped
+ * by an aperture (rayopt/elements.py:206-209), missed surface, TIR, Newton
+ * failure -- is NaN in every array of every later element, so there is
+ * nothing left to compute for it; with rows that are all stored the kernel is
+ * bound by those stores and a dead ray costs exactly what a live one does
+ * (measured: profiles/r02_probes, part C), but when rows are NOT stored
+ * (rt_set_keep_rows: merit functions keep the image row) the kernel is bound
+ * by FP64 issue and dead lanes are wasted issue slots.  This variant retires
+ * dead rays -- their remaining kept rows are filled with NaN at once -- and,
+ * whenever that frees a whole wavefront of the 256-ray workgroup, packs the
+ * surviving rays into the low lanes: 64-bit ballots + popcounts give every
+ * survivor its slot, the state (y, u and the ray's column) moves through LDS,
+ * and the emptied wavefronts only keep the barriers company.  A ray keeps
+ * its column, so results land where the plain kernel puts them, bit for bit.
+ */
+#define RT_CB 256
+
+__device__ __forceinline__ void rt_fill_nan_rows(
+    const rt_surface *__restrict__ surf, int from, int stop, const rt_lay &a,
+    int64_t col)
+{
+    for (int s = from; s < stop; ++s) {
+        const unsigned f = surf[s].flags;
+        if (f & RT_F_NOSTORE)
+            continue;
+        const int64_t row = s * a.ss + col;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.Y[row + c * a.cs] = RT_NAN;
+            if (!(f & RT_F_SKIP_U))
+                a.U[row + c * a.cs] = RT_NAN;
+            if (f & RT_F_STORE_I)
+                a.I[row + c * a.cs] = RT_NAN;
+        }
+        a.T[s * a.ssT + col] = RT_NAN;
+    }
+}
+
+__global__ void __launch_bounds__(RT_CB)
+rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
+                        int stop, int clip, rt_lay a, int64_t ld,
+                        int64_t group_rays, int nsurf)
+{
+    __shared__ int cnt[2][RT_CB / 64]; /* by element parity: a wavefront may
+                                          still read round k while another
+                                          already writes round k + 1 */
+    __shared__ double sm[6][RT_CB];
+    __shared__ int smi[RT_CB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t tile0 = (int64_t)blockIdx.x * RT_CB;
+    if (group_rays) /* a tile never straddles two groups (host checks) */
+        surf += (tile0 / group_rays) * nsurf;
+    bool has = tile0 + tid < ld;
+    int idx = tid; /* the ray's column inside the tile */
+    double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
+    if (has)
+        rt_load_state<1>(a, start - 1, rt_col(a, tile0 + idx), y, u);
+    {
+        const rt_surface *S0 = surf + (start - 1);
+        rt_leave<1>(S0, S0->flags, y, u);
+    }
+    int nwaves = RT_CB / 64; /* wavefronts that may still hold rays */
+    for (int s = start; s < stop; ++s) {
+        /* retire the rays that died at the previous element */
+        if (has && !(u[0][0] == u[0][0])) {
+            rt_fill_nan_rows(surf, s, stop, a, rt_col(a, tile0 + idx));
+            has = false;
+        }
+        /* survivors per wavefront -> can a whole wavefront be freed? */
+        const unsigned long long mine = __ballot(has);
+        if (wave < nwaves && lane == 0)
+            cnt[s & 1][wave] = __popcll(mine);
+        __syncthreads();
+        int total = 0, before = 0, used = 0;
+        for (int w = 0; w < nwaves; ++w) {
+            const int c = cnt[s & 1][w];
+            before += w < wave ? c : 0;
+            total += c;
+            used += c > 0;
+        }
+        const int need = (total + 63) >> 6;
+        if (need < used) { /* workgroup-uniform */
+            if (has) {
+                const int dst =
+                    before + __popcll(mine & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    sm[c][dst] = y[0][c];
+                    sm[3 + c][dst] = u[0][c];
+                }
+                smi[dst] = idx;
+            }
+            __syncthreads();
+            has = tid < total;
+            if (has) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    y[0][c] = sm[c][tid];
+                    u[0][c] = sm[3 + c][tid];
+                }
+                idx = smi[tid];
+            }
+            nwaves = need;
+            __syncthreads(); /* sm is rewritten by the next compaction */
+        }
+        const rt_surface *S = surf + s;
+        const unsigned flags = S->flags;
+        if (RT_WAVE_ANY(has)) {
+            double iv[1][3], t[1];
+            rt_step<1>(S, flags, clip, y, u, iv, t);
+            if (has)
+                rt_store_rows<1, false>(flags, s, a,
+                                        rt_col(a, tile0 + idx), y, u, iv, t);
+            rt_leave<1>(S, flags, y, u);
+        }
+    }
+}
+
 /* rays_given: AoS (n,3) staging -> SoA row 0 of Y,U,I and T[0] = 0 */
 __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
                                    const double *__restrict__ u_aos,

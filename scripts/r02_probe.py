@@ -129,7 +129,7 @@ def part_c(n):
     system = ra.system_from_yaml(P.DOUBLE_GAUSS)
     S = len(system) - 1
     fields = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in (0, .35, .5, .7, 1.)]
-    for scale in (1., 1.5, 2.):
+    for scale in (1., 1.15, 1.3, 1.5, 2.):
         y, u = multi_field_bundle(n, 17.*scale, fields, 0,
                                   P.DOUBLE_GAUSS_PUPIL_Z)
         g = ra.GeometricTrace(system)
@@ -142,6 +142,13 @@ def part_c(n):
         r = dict(part="C", bundle_radius_scale=scale, dead_fraction=frac)
         r["random_full_ms"] = kernel_ms(g, True, reps=20)
         r["random_image_only_ms"] = kernel_ms(g, True, reps=20, keep=[0, -1])
+        # the compacting kernel (rt_set_option "compact"), same random order
+        g.engine.set_option("compact", 1)
+        r["random_image_only_compact_ms"] = kernel_ms(g, True, reps=20,
+                                                      keep=[0, -1])
+        g.engine.set_option("compact", 2)
+        r["random_full_compact_ms"] = kernel_ms(g, True, reps=20)
+        g.engine.set_option("compact", 0)
         # ideal compaction: the same rays, the dead ones contiguous, ordered
         # by the surface they die at
         key = np.where(dead, dead_at, 10**6)

@@ -919,3 +919,60 @@ def test_two_thousand_variants_one_launch():
 def test_grouped_partial_propagation_gpu():
     from test_host_model import _grouped_partial_checks
     _grouped_partial_checks(lambda s: ra.GeometricTrace(s))
+
+
+# -- clipped-ray compaction (rt_set_option "compact") --------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1., 1.6])
+@pytest.mark.parametrize("keep", [None, [-1], [3, 7, -1]])
+def test_compacting_kernel_gives_the_plain_kernels_results(scale, keep):
+    """Dead rays retired, survivors packed into fewer wavefronts: every kept
+    row identical to the plain kernel's, bit for bit, NaN masks included;
+    over-filled bundle (most rays vignette at different elements) and the
+    nominal one; all rows, the image row, a few rows."""
+    from rayopt_amd import prescriptions as P
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    fields = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in (0, .35, .5, .7, 1.)]
+    y, u = ra.bundles.multi_field_bundle(200_003, 17.*scale, fields, 5,
+                                         P.DOUBLE_GAUSS_PUPIL_Z)
+    y[::1000] = np.nan                      # dead on arrival
+    L = len(system)
+    rows = range(1, L) if keep is None else [range(L)[k] for k in keep]
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    g.propagate(clip=True, keep=keep)
+    want = {(name, j): np.array(getattr(g, name)[j])
+            for name in "yuit" for j in rows}
+    g.engine.set_option("compact", 2 if keep is None else 1)
+    try:
+        g.propagate(clip=True, keep=keep)
+        for (name, j), ref in want.items():
+            got = np.asarray(getattr(g, name)[j])
+            assert np.array_equal(got, ref, equal_nan=True), (name, j)
+        dead = np.isnan(want["u", L - 1][:, 0]).mean()
+        assert dead > (.5 if scale > 1 else .001)
+    finally:
+        g.engine.set_option("compact", 0)
+
+
+@pytest.mark.gpu
+def test_compacting_kernel_with_ray_groups_and_aspheres():
+    """Groups with their own surface table (three wavelengths, tiles never
+    straddle a group) and the Newton path under compaction."""
+    from rayopt_amd import prescriptions as P
+    system = ra.system_from_yaml(P.ASPHERE_PHONE)
+    y, u = ra.bundles.disc_bundle(25_600, 0.9, 20., 3)   # overfills the stop
+    y[:, 1] -= 0.5*np.tan(np.radians(20.))
+    g = ra.GeometricTrace(system)
+    ls = [587.56e-9, 486.13e-9, 656.27e-9]
+    g.rays_given(y, u, l=ls)
+    g.propagate(clip=True, keep=[-1])
+    want = np.array(g.y[-1])
+    assert .2 < np.isnan(want[:, 0]).mean() < .95
+    g.engine.set_option("compact", 1)
+    try:
+        g.propagate(clip=True, keep=[-1])
+        assert np.array_equal(np.asarray(g.y[-1]), want, equal_nan=True)
+    finally:
+        g.engine.set_option("compact", 0)
