@@ -33,10 +33,30 @@ LAMBDA_D, LAMBDA_C, LAMBDA_F = 587.56e-9, 656.27e-9, 486.13e-9
 # materials: scalar n(lambda), evaluated on the host once per (element, l)
 # --------------------------------------------------------------------------
 
-class Material:
+class Stamped:
+    """Counts attribute assignments in ``_stamp``.  The surface table is
+    re-packed on every ``propagate()`` because elements are mutable between
+    calls (rayopt/geometric_trace.py:98-99); the packer keeps an element's
+    row as long as its stamp, its material's stamp and the values it cannot
+    see being changed in place (aspheric coefficients, dispersion
+    coefficients) are the same (rayopt_amd/pack.py).  Names starting with
+    ``_pack`` are the packer's own notes and do not count."""
+    _stamp = 0
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name[:5] != "_pack":
+            object.__setattr__(self, "_stamp", self._stamp + 1)
+
+
+class Material(Stamped):
     """Refractive medium; ``mirror`` marks a reflecting coating."""
     solid = True
     mirror = False
+
+    def _pack_key(self):
+        """What identifies n(lambda) of this medium to the packer's cache."""
+        return id(self), self._stamp
 
     def __init__(self, name="-", solid=True, mirror=False):
         self.name = name
@@ -222,6 +242,11 @@ class DispersionGlass(Material):
         self.typ = typ
         self.coefficients = np.atleast_1d(np.asarray(coefficients, float))
 
+    def _pack_key(self):
+        c = self.coefficients
+        return (id(self), self._stamp,
+                c.tobytes() if hasattr(c, "tobytes") else tuple(c))
+
     def refractive_index(self, wavelength):
         n = DISPERSION[self.typ](wavelength/1e-6, self.coefficients)
         return -n if self.mirror else n
@@ -303,7 +328,7 @@ def _euler_angles_rxyz(rot):
     return -a_x, -a_y, -a_z
 
 
-class Pose:
+class Pose(Stamped):
     """Placement of an element relative to the previous one.
 
     ``offset = distance*direction`` is expressed in the global, unrotated
@@ -328,8 +353,13 @@ class Pose:
         self._distance, self._direction = distance, u
         self._offset = distance*u
         self._angles = np.array(angles, dtype=float)
-        self.straight = bool(np.allclose(u, (0, 0, 1.)))
-        self.normal = bool(np.allclose(self._angles, 0.))
+        # np.allclose(u, (0, 0, 1)) and np.allclose(angles, 0) of the
+        # reference (rayopt/elements.py:135-136), on Python floats: this runs
+        # whenever a distance changes (refocus, thickness variables)
+        ux, uy, uz = u.tolist()
+        self.straight = (abs(ux) <= 1e-8 and abs(uy) <= 1e-8 and
+                         abs(uz - 1.) <= 1e-8 + 1e-5)
+        self.normal = all(abs(a) <= 1e-8 for a in self._angles.tolist())
         self.rotated = not (self.straight and self.normal)
         self.rot_axis = self.rot_normal = None
         if not self.rotated:

@@ -38,6 +38,31 @@ def _row_struct(length):
     return st
 
 
+def _note(el):
+    """What would have to change for the packed row of ``el`` to change, or
+    False if that cannot be told (an element or material of another
+    package)."""
+    stamp = getattr(el, "_stamp", None)
+    if stamp is None:
+        return False
+    mat = getattr(el, "material", None)
+    if mat is None:
+        mkey = None
+    elif hasattr(mat, "_pack_key"):
+        mkey = mat._pack_key()
+    else:
+        return False
+    asph = getattr(el, "aspherics", None)
+    return stamp, mkey, None if asph is None else tuple(asph)
+
+
+def _notes(system):
+    if not hasattr(system, "__dict__"):
+        return None
+    notes = tuple([_note(el) for el in system])
+    return None if False in notes else notes
+
+
 def _floats(v, n):
     """``n`` Python floats of a small vector / matrix attribute."""
     v = v.tolist() if hasattr(v, "tolist") else list(v)
@@ -84,9 +109,36 @@ def pack_system(system, wavelength, n_init, start=1, stop=None):
     # evaluation / aiming iteration and decides the wall time of small
     # traces (list-of-lists -> ndarray conversions and per-field assignments
     # cost several times more than the attribute reads themselves)
+    # --- nothing touched since the last call with these arguments: the same
+    # table (every element and material of this package counts its attribute
+    # assignments, model.Stamped; values that can change in place -- aspheric
+    # and dispersion coefficients -- are part of the note)
+    notes = _notes(system)
+    whole = None
+    if notes is not None:
+        whole = (wavelength, float(n_init), start, stop, notes)
+        kept = system.__dict__.get("_pack_table")
+        if kept is not None and kept[0] == whole:
+            return (np.frombuffer(bytearray(kept[1]), dtype=SURFACE_DTYPE),
+                    kept[2].copy())
     flat = []
     extend = flat.extend
     for j, el in enumerate(system):
+        inside = start <= j < stop
+        # --- an element this package made that has not been touched since
+        # its row was last built: the same row (model.Stamped)
+        slot = None
+        note = notes[j] if notes is not None else _note(el)
+        if note is not False:
+            slot = (wavelength, n0 if inside else None)
+            rows = el.__dict__.get("_pack_rows")
+            hit = rows.get(slot) if rows is not None else None
+            if hit is not None and hit[0] == note:
+                extend(hit[1])
+                if inside:
+                    n[j] = n0 = hit[2]
+                continue
+        first = len(flat)
         flags = 0
         # --- shape: Spheroid (elements.py:411-501) ---
         c = getattr(el, "curvature", 0.)
@@ -101,7 +153,7 @@ def pack_system(system, wavelength, n_init, start=1, stop=None):
         # --- index / Snell: Interface.get_n_mu (elements.py:283-289) ---
         mu = 1.
         before = 1.
-        if start <= j < stop:
+        if inside:
             before = n0
             if hasattr(el, "get_n_mu"):
                 n0, mu = el.get_n_mu(n0, wavelength)
@@ -143,6 +195,13 @@ def pack_system(system, wavelength, n_init, start=1, stop=None):
             extend([2*(q + 1)*x for q, x in enumerate(a)])          # :471-472
             extend(pad)
         extend((nasph, flags))
-    table = np.frombuffer(bytearray(_row_struct(length).pack(*flat)),
-                          dtype=SURFACE_DTYPE)
+        if slot is not None:
+            rows = el.__dict__.get("_pack_rows")
+            if rows is None or len(rows) > 16:
+                rows = el.__dict__["_pack_rows"] = {}
+            rows[slot] = (note, tuple(flat[first:]), n0)
+    packed = _row_struct(length).pack(*flat)
+    table = np.frombuffer(bytearray(packed), dtype=SURFACE_DTYPE)
+    if whole is not None:
+        system.__dict__["_pack_table"] = (whole, packed, n.copy())
     return table, n
