@@ -192,10 +192,23 @@ class GeometricTrace(Trace):
     u[i]: outgoing/excidence direction after surface
     all in i-surface normal coordinates relative to vertex
     """
-    def __init__(self, system, engine=None, device=None):
+    def __init__(self, system, engine=None, device=None, **options):
+        """``options`` (extension): engine options applied to this trace's
+        context (``rt_set_option``), e.g. ``fast_asphere=True`` -- even
+        aspheres on the FMA / rcp / rsq arithmetic, results within the 1e-8
+        contract for iterated aspheres instead of bit-identical to the
+        reference -- or ``compact=1``, the clipped-ray compacting kernel for
+        traces that do not store every row."""
         super().__init__(system)
         self._engine = engine
         self._device = device
+        self._options = dict(options)
+        if engine is not None:
+            self._apply_options()
+
+    def _apply_options(self):
+        for key, value in self._options.items():
+            self._engine.set_option(key, int(value))
 
     # -- Trace.propagate (rayopt/raytrace.py:31-35), evaluated lazily ------
     # path / track / origins / mirrored are O(L) cumulative sums that cost as
@@ -239,6 +252,7 @@ class GeometricTrace(Trace):
     def engine(self):
         if self._engine is None:
             self._engine = Engine(self._device)   # raises without GPU/.so
+            self._apply_options()
         return self._engine
 
     def allocate(self, nrays):

@@ -14,12 +14,12 @@ from rayopt_amd.bundles import disc_bundle, multi_field_bundle
 from rayopt_amd.pack import pack_system
 
 
-def run(name, system, y, u, l, clip, reps=60):
-    g = ra.GeometricTrace(system)
+def run(name, system, y, u, l, clip, reps=60, keep=None, **options):
+    g = ra.GeometricTrace(system, **options)
     g.rays_given(y, u, l)
     ms = []
     for k in range(reps):       # the first ~50 launches ride the clock ramp
-        g.propagate(clip=clip)
+        g.propagate(clip=clip, keep=keep)
         ms.append(g.kernel_ms())
     ms = float(np.median(ms[-10:]))
     n, S = y.shape[0], len(system) - 1
@@ -31,9 +31,13 @@ def run(name, system, y, u, l, clip, reps=60):
                                    if not bends[j])
     nbytes = n*(56*S + 24*stored_i - 24*skipped_u + 48)
     dead = float(np.isnan(np.asarray(g.u[-1])[:, 0]).mean())
-    print(json.dumps(dict(config=name, rays=n, surfaces=S, clip=clip,
-                          kernel_ms=ms, ops_per_s=n*S/ms*1e3,
-                          GBs=nbytes/ms/1e6, dead_fraction=dead)), flush=True)
+    rec = dict(config=name, rays=n, surfaces=S, clip=clip, kernel_ms=ms,
+               ops_per_s=n*S/ms*1e3, dead_fraction=dead)
+    if keep is None:
+        rec["GBs"] = nbytes/ms/1e6
+    rec.update(options)
+    print(json.dumps(rec), flush=True)
+    g.engine.close()
 
 
 def main():
@@ -52,7 +56,19 @@ def main():
     for deg in (0., 17.5):
         y, u = disc_bundle(10**7, 0.6, deg, 3)
         y[:, 1] -= 0.5*np.tan(np.radians(deg))
-        run("C4 asphere 1e7 field %.1f deg" % deg, s, y, u, None, True)
+        run("C4 asphere 1e7 field %.1f deg, exact Newton (bit-identical to "
+            "the reference)" % deg, s, y, u, None, True)
+        run("C4 asphere 1e7 field %.1f deg, fast_asphere (1e-8 contract)"
+            % deg, s, y, u, None, True, fast_asphere=1)
+    # over-filled C3 (bundle radius x1.5: 55 % of the rays vignette): every
+    # row stored, image row only, image row only with the compacting kernel
+    s = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = multi_field_bundle(10**7, 17.*1.5, th, 0, P.DOUBLE_GAUSS_PUPIL_Z)
+    run("C3 overfilled x1.5, all rows", s, y, u, None, True)
+    run("C3 overfilled x1.5, image row only", s, y, u, None, True,
+        keep=[0, -1])
+    run("C3 overfilled x1.5, image row only, compacting kernel", s, y, u,
+        None, True, keep=[0, -1], compact=1)
     s = ra.system_from_yaml(P.TORTURE)
     run("torture (tilts, conics, mirror) 1e7", s, *disc_bundle(10**7, 9., 2., 1),
         None, True)
