@@ -239,14 +239,19 @@ class Job:
         self.counts, self.d_dst = counts, d_dst
         self.L = len(g.system)
 
+    exchange = True
+
     def gather(self):
         from rayopt_amd._lib import RT_Y
-        self.eng.gather_final(RT_Y, self.L - 1, self.counts, 0, self.d_dst)
+        if self.exchange:
+            self.eng.gather_final(RT_Y, self.L - 1, self.counts, 0,
+                                  self.d_dst)
 
     def fence(self):
         self.eng.sync()
         if self.dist:
-            self.eng.comm_sync()
+            if self.exchange:
+                self.eng.comm_sync()
             self.group.barrier()
 
     def timed(self, step, steps, warmup, final_gather):
@@ -316,11 +321,21 @@ def main():
     if not launched and args.gpus > 1:
         # plain `python bench.py --gpus N`: one worker per GPU, this process
         # only waits (rank 0's JSON line goes to the inherited stdout)
-        raise SystemExit(D.spawn_workers(args.gpus))
+        raise SystemExit(D.spawn_workers(
+            args.gpus,
+            check_devices=not os.environ.get("RT_BENCH_SHARE_DEVICE")))
     world, rank, local_rank = D.world_info()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # RT_BENCH_SHARE_DEVICE=1 (tests only): every rank opens device 0 and the
+    # RCCL exchange is left out -- RCCL refuses two ranks on one device -- so
+    # that the host side of the N>1 path (spawn, host group, per-rank
+    # bookkeeping, the configs[4] leg) can run on a one-GPU box.  The line
+    # it prints is marked "test_mode" and is not a measurement.
+    share = bool(os.environ.get("RT_BENCH_SHARE_DEVICE"))
     have = D.visible_devices()
+    if share:
+        local_rank = 0
     if local_rank >= have:
         raise SystemExit("--gpus %d: %d devices needed, %d visible"
                          % (args.gpus, max(world, local_rank + 1), have))
@@ -374,10 +389,12 @@ def main():
     # there is an exchange); no fallback: without it the job fails
     d_dst = 0
     if dist_mode:
-        D.init_engine_comm(eng, group)
+        if not share:
+            D.init_engine_comm(eng, group)
         if rank == 0:
             d_dst = eng.scratch(int(counts.sum())*3*8)
     job = Job(args, group, g, counts, d_dst)
+    job.exchange = not share
 
     mode = {"clip": clip}
 
@@ -448,7 +465,7 @@ def main():
     ylast = np.asarray(g.y[L - 1])
     ulast = np.asarray(g.u[L - 1])
     finite = float(np.isfinite(ulast[:, 0]).mean())
-    if dist_mode and rank == 0:
+    if dist_mode and rank == 0 and job.exchange:
         gathered = eng.copy_to_host(d_dst, int(counts.sum())*3*8)
         gathered = gathered.reshape(3, -1)
         mine = gathered[:, :n].T
@@ -561,6 +578,10 @@ def main():
     if dist_mode:
         out["gather_ms"] = gather_ms
         out["kernel_ms_per_rank"] = per_rank_kernel_ms
+        if share:
+            out["test_mode"] = ("RT_BENCH_SHARE_DEVICE: all ranks on device "
+                                "0, RCCL exchange left out -- not a "
+                                "measurement")
     if configs4 is not None:
         out["configs4"] = configs4
     if api is not None:

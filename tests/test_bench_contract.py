@@ -93,3 +93,23 @@ def test_more_gpus_than_devices_is_a_clear_error():
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert res.returncode != 0 and res.stdout.strip() == ""
     assert "%d devices needed, %d visible" % (have + 1, have) in res.stderr
+
+
+def test_two_ranks_host_side_on_one_device():
+    """The host side of N = 2 -- self-spawned workers, host group, per-rank
+    bookkeeping, the configs[4] leg -- with both ranks on the one device of
+    this box and the RCCL exchange left out (RCCL refuses two ranks on one
+    device); what remains unexecuted is rt_gather_final with nranks > 1."""
+    env = dict(os.environ, RT_BENCH_SHARE_DEVICE="1")
+    out = subprocess.check_output(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+         "--rays", "200000", "--steps", "3", "--warmup", "1", "--settle",
+         "0"], text=True, cwd=ROOT, env=env, stderr=subprocess.DEVNULL,
+        timeout=600)
+    d = check_line(out, 3, 1)
+    assert d["n_gpus"] == 2 and "test_mode" in d
+    assert d["config"]["total_rays"] == 400000
+    assert len(d["kernel_ms_per_rank"]) == 2
+    c4 = d["configs4"]
+    assert c4["total_rays"] > 99_000_000 and len(c4["kernel_ms_per_rank"]) == 2
+    assert c4["value"] > 0
