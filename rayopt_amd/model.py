@@ -21,6 +21,7 @@ Only state and O(L) scalar geometry live here.  The per-ray arithmetic
 (intercept, clip, refract, frame changes) is *not* implemented on the host:
 it runs in the HIP kernel (csrc/rt_math.h) and nowhere else in this package.
 """
+import itertools
 import math
 
 import numpy as np
@@ -33,20 +34,29 @@ LAMBDA_D, LAMBDA_C, LAMBDA_F = 587.56e-9, 656.27e-9, 486.13e-9
 # materials: scalar n(lambda), evaluated on the host once per (element, l)
 # --------------------------------------------------------------------------
 
+_STAMPS = itertools.count(1)
+
+
 class Stamped:
-    """Counts attribute assignments in ``_stamp``.  The surface table is
-    re-packed on every ``propagate()`` because elements are mutable between
-    calls (rayopt/geometric_trace.py:98-99); the packer keeps an element's
-    row as long as its stamp, its material's stamp and the values it cannot
-    see being changed in place (aspheric coefficients, dispersion
-    coefficients) are the same (rayopt_amd/pack.py).  Names starting with
-    ``_pack`` are the packer's own notes and do not count."""
+    """Every attribute assignment gives the object a new ``_stamp``, drawn
+    from ONE process-wide counter -- so a stamp is never seen twice, not on
+    the same object after a change and not on another object (a new element
+    that happens to reuse the address and construction history of a deleted
+    one included).  The surface table is re-packed on every ``propagate()``
+    because elements are mutable between calls
+    (rayopt/geometric_trace.py:98-99); the packer keeps an element's row as
+    long as its stamp, its material's stamp and the values it cannot see
+    being changed in place (aspheric coefficients, dispersion coefficients)
+    are the same (rayopt_amd/pack.py).  A copy (``copy.deepcopy``) starts
+    with the stamp of its original, whose content it shares at that moment.
+    Names starting with ``_pack`` are the packer's own notes and do not
+    count."""
     _stamp = 0
 
     def __setattr__(self, name, value):
         object.__setattr__(self, name, value)
         if name[:5] != "_pack":
-            object.__setattr__(self, "_stamp", self._stamp + 1)
+            object.__setattr__(self, "_stamp", next(_STAMPS))
 
 
 class Material(Stamped):
@@ -56,7 +66,7 @@ class Material(Stamped):
 
     def _pack_key(self):
         """What identifies n(lambda) of this medium to the packer's cache."""
-        return id(self), self._stamp
+        return (self._stamp,)
 
     def __init__(self, name="-", solid=True, mirror=False):
         self.name = name
@@ -244,7 +254,7 @@ class DispersionGlass(Material):
 
     def _pack_key(self):
         c = self.coefficients
-        return (id(self), self._stamp,
+        return (self._stamp,
                 c.tobytes() if hasattr(c, "tobytes") else tuple(c))
 
     def refractive_index(self, wavelength):

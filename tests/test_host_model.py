@@ -274,3 +274,60 @@ def test_grouped_partial_propagation_host_logic():
     from fake_engine import OracleEngine
     _grouped_partial_checks(
         lambda s: ra.GeometricTrace(s, engine=OracleEngine()))
+
+
+def test_packed_rows_are_never_stale():
+    """pack_system keeps rows while nothing was assigned to; every way the
+    prescription can change must be seen (rayopt/geometric_trace.py:98-99:
+    elements are mutable between propagate() calls)."""
+    import copy
+    import gc
+    from rayopt_amd.pack import pack_system
+    from rayopt_amd.model import Spheroid
+    s = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    l = s.wavelengths[0]
+
+    def table():
+        return pack_system(s, l, 1.)
+
+    t0, n0 = table()
+    t1, n1 = table()
+    assert t0.tobytes() == t1.tobytes() and np.array_equal(n0, n1)
+    t1["c"][2] = 99.                        # the caller's copy is its own
+    assert table()[0].tobytes() == t0.tobytes()
+    s[3].curvature *= 1.5
+    assert table()[0]["c"][3] == t0["c"][3]*1.5
+    s[4].distance += 1.
+    assert table()[0]["offset"][4][2] == t0["offset"][4][2] + 1.
+    s[2].material = ra.Material.make(1.7)
+    t, n = table()
+    assert n[2] == 1.7 and t["n0"][3] == 1.7
+    s[2].material.n = 1.71                  # the material object itself
+    t, n = table()
+    assert n[2] == 1.71 and t["n0"][3] == 1.71
+    s[5].aspherics = [0., 1e-6]
+    assert table()[0]["nasph"][5] == 2
+    s[5].aspherics[1] = 2e-6                # in place, no assignment
+    assert table()[0]["asph"][5][1] == 2e-6
+    # an element replaced by a NEW object built the same way, possibly at
+    # the same address: never the old row
+    for curvature in (0.01, 0.02, 0.03):
+        s[7] = Spheroid(curvature=curvature, distance=3.777, material=1.62041,
+                        radius=16.468)
+        gc.collect()
+        assert table()[0]["c"][7] == curvature
+    # other wavelength, other start index, another system built from this one
+    assert pack_system(s, 486e-9, 1.)[0].tobytes() == table()[0].tobytes()
+    dispersive = ra.system_from_yaml(ra.prescriptions.COOKE % dict(
+        air=1.0, sk16="1.62041/60.32", f2="1.62004/36.37"))
+    a = pack_system(dispersive, 486.13e-9, 1.)[1]
+    b = pack_system(dispersive, 656.27e-9, 1.)[1]
+    assert a[1] != b[1]
+    assert pack_system(dispersive, 486.13e-9, 1.)[1][1] == a[1]
+    twin = copy.deepcopy(s)
+    assert pack_system(twin, l, 1.)[0].tobytes() == table()[0].tobytes()
+    twin[1].curvature = 0.5
+    assert pack_system(twin, l, 1.)[0]["c"][1] == 0.5
+    assert table()[0]["c"][1] != 0.5
+    s.append(Spheroid(distance=1.))
+    assert len(table()[0]) == len(t0) + 1
