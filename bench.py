@@ -333,12 +333,17 @@ def main():
     # bookkeeping, the configs[4] leg) can run on a one-GPU box.  The line
     # it prints is marked "test_mode" and is not a measurement.
     share = bool(os.environ.get("RT_BENCH_SHARE_DEVICE"))
-    have = D.visible_devices()
     if share:
         local_rank = 0
-    if local_rank >= have:
-        raise SystemExit("--gpus %d: %d devices needed, %d visible"
-                         % (args.gpus, max(world, local_rank + 1), have))
+
+    def check_device():
+        # opens the HIP runtime: only after the forked CPU leg (N = 1)
+        have = D.visible_devices()
+        if local_rank >= have:
+            raise SystemExit("--gpus %d: %d devices needed, %d visible"
+                             % (args.gpus, max(world, local_rank + 1), have))
+    if world > 1:
+        check_device()
 
     sys.stdout.flush()
     real_stdout = os.dup(1)
@@ -376,6 +381,8 @@ def main():
             cpu_all = cpu_port_on_processes(system, y, u, clip, procs)
         except Exception as err:      # a reported extra, never fatal
             cpu_all = {"error": repr(err)[:200]}
+    if world == 1:
+        check_device()
     g = ra.GeometricTrace(system, device=local_rank)
     eng = g.engine
     for kv in args.option:
