@@ -203,6 +203,13 @@ class GeometricTrace(Trace):
         self._engine = engine
         self._device = device
         self._options = dict(options)
+        # "device": all fields aimed by one kernel, iterated to 1e-9;
+        # "reference": rayopt's own procedure and tolerances, field by field
+        # (rayopt_amd/aiming_reference.py) -- for numbers that must match
+        # rayopt's
+        self._aiming = self._options.pop("aiming", "device")
+        if self._aiming not in ("device", "reference"):
+            raise ValueError("aiming must be 'device' or 'reference'")
         if engine is not None:
             self._apply_options()
 
@@ -645,6 +652,18 @@ class GeometricTrace(Trace):
             raise ValueError("lost must be 'nan' or 'omit'")
         return r
 
+    def _pupil(self, yo, l, rim=False, given=None):
+        """(z (1,), a (1,2,2)) of one field, by the configured aiming;
+        ``given``: the caller's wavelength argument, None if defaulted."""
+        if self._aiming == "reference":
+            from .aiming_reference import reference_aimer
+            z, a = reference_aimer(self.system, self._aux_engine(), l,
+                                   -1 if rim else None, given).pupil(yo)
+            return np.array([z]), a[None]
+        from .aiming import FieldAimer
+        return FieldAimer(self.system, l, self._aux_engine(),
+                          aim=None).pupil([yo], rim=rim)
+
     def rays(self, yo, yp, wavelength=None, stop=None, filter=None,
              clip=False, weight=None, ref=0):
         """One field point ``yo`` through the pupil coordinates ``yp`` (P,2):
@@ -657,8 +676,7 @@ class GeometricTrace(Trace):
             filter = not clip
         yp = np.atleast_2d(np.asarray(yp, dtype=float))
         l = self.system.wavelengths[0] if wavelength is None else wavelength
-        z, a = FieldAimer(self.system, l, self._aux_engine(),
-                          aim=None).pupil([yo], rim=(stop == -1))
+        z, a = self._pupil(yo, l, rim=(stop == -1), given=wavelength)
         if filter:
             # Pupil.map(filter=True) (rayopt/pupils.py:97-107) acts on the
             # aperture as the conjugate hands it over: angles atan2(a, z) for
@@ -695,8 +713,7 @@ class GeometricTrace(Trace):
         ``axis`` (rayopt/geometric_trace.py:211-215)."""
         from .aiming import FieldAimer
         l = self.system.wavelengths[0] if wavelength is None else wavelength
-        z, a = FieldAimer(self.system, l, self._aux_engine(),
-                          aim=None).pupil([yo], rim=True)
+        z, a = self._pupil(yo, l, rim=True, given=wavelength)
         yp = np.zeros((3, 2))
         yp[1:, axis] = a[0][:, axis]/np.fabs(a[0]).max()
         self.rays_fields([yo], yp, z, a, l)
@@ -714,9 +731,22 @@ class GeometricTrace(Trace):
         fields = np.linspace(0, 1, nrays)[:, None]*np.atleast_2d(yo)
         e = np.zeros((3, 2))
         e[(1, 2), (1, 0)] = eps
-        aimer = FieldAimer(self.system, l, self._aux_engine(), aim=None)
-        z0, a = aimer.pupil([(0., 0.)])
-        z = aimer.chief(fields, z0[0], np.fabs(a[0]).max())
+        if self._aiming == "reference":
+            # field after field, each chief ray started from the previous
+            # field's pupil distance (rayopt/geometric_trace.py:223-226)
+            from .aiming_reference import reference_aimer
+            aimer = reference_aimer(self.system, self._aux_engine(), l, None,
+                                    wavelength)
+            zk, p = aimer.pupil((0., 0.))
+            z, a = [], p[None]
+            for field in fields:
+                zk = aimer.chief(field, zk, np.fabs(p).max())
+                z.append(zk)
+            z = np.array(z)
+        else:
+            aimer = FieldAimer(self.system, l, self._aux_engine(), aim=None)
+            z0, a = aimer.pupil([(0., 0.)])
+            z = aimer.chief(fields, z0[0], np.fabs(a[0]).max())
         # built field-major on the device, re-ordered kind-major (a few
         # dozen rays: the reference's layout is part of the contract)
         self.rays_fields(fields, e, z, a[0], l)

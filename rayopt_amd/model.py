@@ -650,6 +650,7 @@ class System(list):
         they are evaluated on the fly.  Pickups, solves and the paraxial
         trace itself are design tools outside the accelerated path."""
         from .aiming import entrance_pupil, exit_pupil
+        self.__dict__.pop("_reference_aimers", None)    # their guess caches
         l = self.wavelengths[0]
         try:
             found = ((self.object, entrance_pupil(self, l)),

@@ -1,0 +1,96 @@
+"""aiming="reference": rayopt's own aiming procedure (solvers, tolerances,
+guess cache, call order; rayopt/system.py:466-593, rayopt/cachend.py:84-105)
+with the one-ray traces on the engine -- aimed pupils and the bundles
+launched from them MATCH the reference's instead of agreeing to its 1e-3."""
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd.aiming_reference import ReferenceAimer
+from rayopt_amd.prescriptions import cooke, ASPHERE_PHONE
+from oracle import refshim
+
+from fake_engine import OracleEngine
+
+pytestmark = pytest.mark.skipif(not refshim.available(),
+                                reason="no /root/reference")
+COOKE = cooke().replace("radius: 20.", "radius: 0.364")
+FINITE = COOKE.replace(
+    "object: {angle_deg: 20, pupil: {radius: 6.25, aim: True}}",
+    "object: {type: finite, radius: 8., pupil: {radius: 6.25, aim: True}}"
+).replace("- {roc: 21.25, distance: 5.0,", "- {roc: 21.25, distance: 60.,")
+
+
+def both(text):
+    ro = refshim.load()
+    rs = ro.system_from_yaml(text)
+    rs.update()
+    ms = ra.system_from_yaml(text)
+    ms.update()
+    return ro, rs, ms
+
+
+@pytest.mark.parametrize("text", [COOKE, FINITE])
+@pytest.mark.parametrize("stop", [None, -1])
+def test_pupils_match_the_reference(text, stop):
+    ro, rs, ms = both(text)
+    aimer = ReferenceAimer(ms, OracleEngine(), stop=stop)
+    # the order matters: every field is seeded from the ones before it
+    for yo in ((0, 1.), (0, .7), (0, 0.), (.6, .8), (0, .35), (0, 1.)):
+        zr, ar = rs.pupil(yo, stop=stop)
+        zm, am = aimer.pupil(yo)
+        assert zm == pytest.approx(zr, rel=1e-11, abs=1e-11)
+        np.testing.assert_allclose(am, ar, rtol=1e-11, atol=1e-12)
+    assert aimer.evaluations > 50
+
+
+@pytest.mark.parametrize("text", [COOKE, FINITE])
+def test_generators_match_the_reference(text):
+    ro, rs, ms = both(text)
+    r = ro.GeometricTrace(rs)
+    g = ra.GeometricTrace(ms, engine=OracleEngine(), aiming="reference")
+    for kind, args, kw in (
+            ("rays_point", ((0, 1.),),
+             dict(nrays=21, distribution="hexapolar", filter=False)),
+            ("rays_point", ((0, .7),), dict(nrays=30, distribution="tee",
+                                            clip=True)),
+            ("rays_clipping", ((0, 1.),), {}),
+            ("rays_line", ((0, 1.),), dict(nrays=5)),
+            ("rays_point", ((0, 0.),), dict(nrays=13, distribution="square"))):
+        getattr(r, kind)(*args, **kw)
+        getattr(g, kind)(*args, **kw)
+        assert g.nrays == r.nrays, kind
+        for name in "yu":
+            a, b = np.asarray(getattr(g, name)), getattr(r, name)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (kind, name)
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-9,
+                                       equal_nan=True, err_msg=kind)
+    assert g.rms() == pytest.approx(r.rms(), rel=1e-8)
+
+
+def test_update_forgets_the_guess_cache():
+    ro, rs, ms = both(COOKE)
+    g = ra.GeometricTrace(ms, engine=OracleEngine(), aiming="reference")
+    g.rays_point((0, 1.), nrays=5)
+    assert ms.__dict__["_reference_aimers"]
+    ms[ms.stop].radius /= 2
+    rs[rs.stop].radius /= 2
+    ms.update()
+    rs.update()
+    assert "_reference_aimers" not in ms.__dict__
+    g.rays_point((0, 1.), nrays=5)
+    r = ro.GeometricTrace(rs)
+    r.rays_point((0, 1.), nrays=5)
+    np.testing.assert_allclose(np.asarray(g.y[0]), r.y[0], atol=1e-9)
+
+
+def test_aspheres_agree_through_the_newton_path():
+    text = ASPHERE_PHONE.replace("pupil: {radius: 0.6}",
+                                 "pupil: {radius: 0.6, aim: True}")
+    ro, rs, ms = both(text)
+    aimer = ReferenceAimer(ms, OracleEngine())
+    for yo in ((0, 1.), (0, .5)):
+        zr, ar = rs.pupil(yo)
+        zm, am = aimer.pupil(yo)
+        assert zm == pytest.approx(zr, rel=1e-9)
+        np.testing.assert_allclose(am, ar, rtol=1e-9)

@@ -32,6 +32,11 @@ TOL = {"double_gauss": dict(launch=1e-7, image=1e-7, opd=1e-5, psf=1e-5),
 RIM_TOL = 3e-2
 
 
+# the same with aiming="reference": rayopt's own aiming procedure on the
+# engine -- the aimed systems then match as tightly as the unaimed one
+EXACT = dict(launch=1e-8, image=1e-7, opd=1e-4, psf=1e-4)
+
+
 def load(name):
     with np.load(os.path.join(GOLDEN, "analysis_%s.npz" % name)) as z:
         g = {k: z[k] for k in z.files}
@@ -60,9 +65,9 @@ def close(got, want, atol, what):
         what, np.abs(got[ok] - want[ok]).max())
 
 
-def replay(name, make_trace):
+def replay(name, make_trace, tol=None):
     g = load(name)
-    tol = TOL[name]
+    tol = TOL[name] if tol is None else tol
     system = ra.system_from_yaml(g["yaml"])
     system.update()             # Analysis.run starts with it (:77-78)
     traces, checked, quadrature = {}, {}, {}
@@ -159,7 +164,7 @@ def replay(name, make_trace):
             assert len(set(pick)) == len(pick) and call["stride"] == 1
         # rays_clipping aims at the rim whatever the aim flag says
         # (rayopt/system.py:530-531): solver tolerance there
-        rim = method == "rays_clipping"
+        rim = method == "rays_clipping" and tol is not EXACT
         launch = max(tol["launch"], RIM_TOL) if rim else tol["launch"]
         image = max(tol["image"], RIM_TOL) if rim else tol["image"]
         close(np.asarray(t.y[0])[pick], g[key + "_y0"], launch,
@@ -184,7 +189,21 @@ def test_analysis_replay_on_the_engine_double(name):
                                                   engine=OracleEngine()))
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_analysis_replay_with_the_reference_aiming(name):
+    from fake_engine import OracleEngine
+    replay(name, lambda system: ra.GeometricTrace(
+        system, engine=OracleEngine(), aiming="reference"), EXACT)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_analysis_replay_on_the_device(name):
     replay(name, lambda system: ra.GeometricTrace(system))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_analysis_replay_on_the_device_with_the_reference_aiming(name):
+    replay(name, lambda system: ra.GeometricTrace(system, aiming="reference"),
+           EXACT)
