@@ -316,7 +316,9 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * direction is NaN are retired, their remaining kept rows filled with NaN,
  * and the survivors of a 256-ray workgroup are packed into fewer wavefronts
  * with ballots and an LDS exchange; 2 = every trace.  Results are identical
- * to the plain kernel's, NaN payloads aside).
+ * to the plain kernel's, NaN payloads aside), "compact_every" (k: the
+ * survivors of a workgroup are counted -- one barrier -- at every k-th element
+ * only; default 1).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
 /*

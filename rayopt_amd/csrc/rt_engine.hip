@@ -107,6 +107,7 @@ struct rt_ctx {
     int opt_tile; /* measurement only: tile-major result layout, rays/tile */
     int opt_probe_store; /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
+    int opt_compact_every; /* survivors are counted at every k-th element */
     int last_compact; /* the last trace ran the compacting kernel */
 
     /* rt_generate_rays: field frames | pupil points, and whether row 0 is
@@ -331,6 +332,7 @@ int rt_create(int device, rt_ctx **out)
     c->opt_block = 256;
     c->opt_alias = 1;
     c->opt_fuse = 1;
+    c->opt_compact_every = 1;
 #define RT_HIP_C(call)                                                        \
     do {                                                                      \
         hipError_t e_ = (call);                                               \
@@ -1052,7 +1054,7 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
                            rt_layout(ctx), ctx->ld,
                            ctx->ngroups > 1 ? ctx->n / ctx->ngroups
                                             : (int64_t)0,
-                           ctx->nsurf);
+                           ctx->nsurf, ctx->opt_compact_every);
         RT_HIP(ctx, hipGetLastError());
         ctx->last_compact = 1;
     } else if (start < stop) {
@@ -1163,6 +1165,10 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         if (value < 0 || value > 2)
             return rt_fail(ctx, RT_ERR_ARG, "compact must be 0, 1 or 2");
         ctx->opt_compact = value;
+    } else if (!strcmp(key, "compact_every")) {
+        if (value < 1 || value > 64)
+            return rt_fail(ctx, RT_ERR_ARG, "compact_every must be in [1, 64]");
+        ctx->opt_compact_every = value;
     } else if (!strcmp(key, "probe_store")) {
         if (value < 0 || value > 3)
             return rt_fail(ctx, RT_ERR_ARG, "probe_store must be 0..3");

@@ -302,7 +302,7 @@ __device__ __forceinline__ void rt_fill_nan_rows(
 __global__ void __launch_bounds__(RT_CB)
 rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
                         int stop, int clip, rt_lay a, int64_t ld,
-                        int64_t group_rays, int nsurf)
+                        int64_t group_rays, int nsurf, int every)
 {
     __shared__ int cnt[2][RT_CB / 64]; /* by element parity: a wavefront may
                                           still read round k while another
@@ -329,20 +329,25 @@ rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
             rt_fill_nan_rows(surf, s, stop, a, rt_col(a, tile0 + idx));
             has = false;
         }
-        /* survivors per wavefront -> can a whole wavefront be freed? */
+        /* survivors per wavefront -> can a whole wavefront be freed?  The
+         * question costs a workgroup barrier, so it is asked only at every
+         * `every`-th element (uniform across the workgroup) */
+        const bool ask = (s - start) % every == every - 1 && nwaves > 1;
         const unsigned long long mine = __ballot(has);
-        if (wave < nwaves && lane == 0)
-            cnt[s & 1][wave] = __popcll(mine);
-        __syncthreads();
-        int total = 0, before = 0, used = 0;
-        for (int w = 0; w < nwaves; ++w) {
-            const int c = cnt[s & 1][w];
-            before += w < wave ? c : 0;
-            total += c;
-            used += c > 0;
+        int total = 0, before = 0, used = 0, need = RT_CB / 64;
+        if (ask) {
+            if (wave < nwaves && lane == 0)
+                cnt[s & 1][wave] = __popcll(mine);
+            __syncthreads();
+            for (int w = 0; w < nwaves; ++w) {
+                const int c = cnt[s & 1][w];
+                before += w < wave ? c : 0;
+                total += c;
+                used += c > 0;
+            }
+            need = (total + 63) >> 6;
         }
-        const int need = (total + 63) >> 6;
-        if (need < used) { /* workgroup-uniform */
+        if (ask && need < used) { /* workgroup-uniform */
             if (has) {
                 const int dst =
                     before + __popcll(mine & ((1ull << lane) - 1ull));

@@ -146,8 +146,11 @@ def part_c(n):
         g.engine.set_option("compact", 1)
         r["random_image_only_compact_ms"] = kernel_ms(g, True, reps=20,
                                                       keep=[0, -1])
-        g.engine.set_option("compact", 2)
-        r["random_full_compact_ms"] = kernel_ms(g, True, reps=20)
+        for every in (2, 3, 4, 6, 64):
+            g.engine.set_option("compact_every", every)
+            r["random_image_only_compact_every%d_ms" % every] = kernel_ms(
+                g, True, reps=20, keep=[0, -1])
+        g.engine.set_option("compact_every", 1)
         g.engine.set_option("compact", 0)
         # ideal compaction: the same rays, the dead ones contiguous, ordered
         # by the surface they die at
