@@ -31,12 +31,15 @@ def time_reference(y, u, wavelength, clip, want_image_row=None,
     system = ro.system_from_yaml(text)
     m = min(len(y), max_rays)
     trace = ro.GeometricTrace(system)
-    trace.rays_given(y[:100000], u[:100000], wavelength)
-    trace.propagate(clip=clip)                      # warm
+    warm = min(100000, max(1, m//10))
+    trace.rays_given(y[:warm], u[:warm], wavelength)
+    with np.errstate(all="ignore"):
+        trace.propagate(clip=clip)                  # warm
     trace = ro.GeometricTrace(system)
     trace.rays_given(y[:m], u[:m], wavelength)
     t0 = time.perf_counter()
-    trace.propagate(clip=clip)
+    with np.errstate(all="ignore"):
+        trace.propagate(clip=clip)
     dt = time.perf_counter() - t0
     S = len(system) - 1
     same = None

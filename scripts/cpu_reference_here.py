@@ -32,10 +32,32 @@ def main():
             "kind": "port", "seconds": dt, "rays": n}
     ref = ref_timing.time_reference(y, u, l, True, want_image_row=Y[-1],
                                     max_rays=n)
-    print(json.dumps({"host_cores": os.cpu_count(), "port": port,
-                      "reference": ref,
-                      "port_over_reference": (port["value"]/ref["value"]
-                                              if ref else None)}, indent=1))
+    out = {"host_cores": os.cpu_count(), "port": port, "reference": ref,
+           "port_over_reference": (port["value"]/ref["value"]
+                                   if ref else None)}
+    # the asphere config -- the reference solves every ray
+    # with its own scipy.optimize.newton call (rayopt/elements.py:333-349)
+    asph = ra.system_from_yaml(P.ASPHERE_PHONE)
+    la = asph.wavelengths[0]
+    ta, _ = pack_system(asph, la, asph.refractive_index(la, 0))
+    Sa = len(asph) - 1
+    m = 200_000
+    ya, ua = ra.bundles.disc_bundle(m, 0.6, 17.5, 3)
+    ya[:, 1] -= 0.5*np.tan(np.radians(17.5))
+    tn.propagate(ta, ya[:1000], ua[:1000], clip=True)
+    t0 = time.perf_counter()
+    Ya = tn.propagate(ta, ya, ua, clip=True)[0]
+    dt = time.perf_counter() - t0
+    out["asphere_port"] = {"value": m*Sa/dt, "rays": m, "seconds": dt,
+                           "note": "C4, numpy port (masked vector Newton)"}
+    k = 3000
+    refa = ref_timing.time_reference(ya[:k], ua[:k], la, True,
+                                     want_image_row=None, max_rays=k,
+                                     prescription=P.ASPHERE_PHONE)
+    if refa:
+        refa["note"] = "C4, rayopt itself: one scipy newton call per ray"
+    out["asphere_reference"] = refa
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
