@@ -261,7 +261,8 @@ static int rt_gen_flush(rt_ctx *c)
  * are wasted FP64 issue, i.e. where rows are traced but not stored */
 static bool rt_use_compact(const rt_ctx *c, int start, int stop)
 {
-    if (!c->opt_compact || c->opt_r != 1 || c->opt_nt || c->opt_xcd)
+    if (!c->opt_compact || c->opt_r != 1 || c->opt_nt || c->opt_xcd ||
+        c->opt_tile)
         return false;
     if (c->ngroups > 1 && (c->n / c->ngroups) % RT_CB)
         return false; /* a 256-ray tile would straddle two tables */

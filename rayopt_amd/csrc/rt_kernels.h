@@ -278,25 +278,20 @@ __global__ void rt_trace_gen_kernel(const rt_surface *__restrict__ surf,
  */
 #define RT_CB 256
 
-__device__ __forceinline__ void rt_fill_nan_rows(
-    const rt_surface *__restrict__ surf, int from, int stop, const rt_lay &a,
-    int64_t col)
+/* NaN into the rows of element s for one column (flags say which exist) */
+__device__ __forceinline__ void rt_store_nan_row(unsigned f, int s,
+                                                 const rt_lay &a, int64_t col)
 {
-    for (int s = from; s < stop; ++s) {
-        const unsigned f = surf[s].flags;
-        if (f & RT_F_NOSTORE)
-            continue;
-        const int64_t row = s * a.ss + col;
+    const int64_t row = s * a.ss + col;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            a.Y[row + c * a.cs] = RT_NAN;
-            if (!(f & RT_F_SKIP_U))
-                a.U[row + c * a.cs] = RT_NAN;
-            if (f & RT_F_STORE_I)
-                a.I[row + c * a.cs] = RT_NAN;
-        }
-        a.T[s * a.ssT + col] = RT_NAN;
+    for (int c = 0; c < 3; ++c) {
+        a.Y[row + c * a.cs] = RT_NAN;
+        if (!(f & RT_F_SKIP_U))
+            a.U[row + c * a.cs] = RT_NAN;
+        if (f & RT_F_STORE_I)
+            a.I[row + c * a.cs] = RT_NAN;
     }
+    a.T[s * a.ssT + col] = RT_NAN;
 }
 
 __global__ void __launch_bounds__(RT_CB)
@@ -309,67 +304,77 @@ rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
                                           already writes round k + 1 */
     __shared__ double sm[6][RT_CB];
     __shared__ int smi[RT_CB];
+    __shared__ unsigned short gone[RT_CB]; /* column -> first element whose
+                                              rows are NaN (0: alive) */
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t tile0 = (int64_t)blockIdx.x * RT_CB;
     if (group_rays) /* a tile never straddles two groups (host checks) */
         surf += (tile0 / group_rays) * nsurf;
-    bool has = tile0 + tid < ld;
+    /* SoA (the only layout this kernel is launched for): the tile's columns
+     * are consecutive */
+    const int64_t col0 = tile0;
+    const bool exists = tile0 + tid < ld;
+    bool has = exists;
     int idx = tid; /* the ray's column inside the tile */
+    gone[tid] = 0;
     double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
     if (has)
-        rt_load_state<1>(a, start - 1, rt_col(a, tile0 + idx), y, u);
+        rt_load_state<1>(a, start - 1, col0 + idx, y, u);
     {
         const rt_surface *S0 = surf + (start - 1);
         rt_leave<1>(S0, S0->flags, y, u);
     }
     int nwaves = RT_CB / 64; /* wavefronts that may still hold rays */
     for (int s = start; s < stop; ++s) {
-        /* retire the rays that died at the previous element */
+        /* retire the rays that died at the previous element: their later
+         * kept rows are NaN, written below when those rows come up */
         if (has && !(u[0][0] == u[0][0])) {
-            rt_fill_nan_rows(surf, s, stop, a, rt_col(a, tile0 + idx));
+            gone[idx] = (unsigned short)s; /* a wavefront that is still at
+                                              the rows of element s-1 reads
+                                              "not yet" */
             has = false;
         }
         /* survivors per wavefront -> can a whole wavefront be freed?  The
          * question costs a workgroup barrier, so it is asked only at every
          * `every`-th element (uniform across the workgroup) */
         const bool ask = (s - start) % every == every - 1 && nwaves > 1;
-        const unsigned long long mine = __ballot(has);
-        int total = 0, before = 0, used = 0, need = RT_CB / 64;
         if (ask) {
+            const unsigned long long mine = __ballot(has);
             if (wave < nwaves && lane == 0)
                 cnt[s & 1][wave] = __popcll(mine);
             __syncthreads();
+            int total = 0, before = 0, used = 0;
             for (int w = 0; w < nwaves; ++w) {
                 const int c = cnt[s & 1][w];
                 before += w < wave ? c : 0;
                 total += c;
                 used += c > 0;
             }
-            need = (total + 63) >> 6;
-        }
-        if (ask && need < used) { /* workgroup-uniform */
-            if (has) {
-                const int dst =
-                    before + __popcll(mine & ((1ull << lane) - 1ull));
+            const int need = (total + 63) >> 6;
+            if (need < used) { /* workgroup-uniform */
+                if (has) {
+                    const int dst =
+                        before + __popcll(mine & ((1ull << lane) - 1ull));
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    sm[c][dst] = y[0][c];
-                    sm[3 + c][dst] = u[0][c];
+                    for (int c = 0; c < 3; ++c) {
+                        sm[c][dst] = y[0][c];
+                        sm[3 + c][dst] = u[0][c];
+                    }
+                    smi[dst] = idx;
                 }
-                smi[dst] = idx;
-            }
-            __syncthreads();
-            has = tid < total;
-            if (has) {
+                __syncthreads();
+                has = tid < total;
+                if (has) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    y[0][c] = sm[c][tid];
-                    u[0][c] = sm[3 + c][tid];
+                    for (int c = 0; c < 3; ++c) {
+                        y[0][c] = sm[c][tid];
+                        u[0][c] = sm[3 + c][tid];
+                    }
+                    idx = smi[tid];
                 }
-                idx = smi[tid];
+                nwaves = need;
+                __syncthreads(); /* sm is rewritten by the next compaction */
             }
-            nwaves = need;
-            __syncthreads(); /* sm is rewritten by the next compaction */
         }
         const rt_surface *S = surf + s;
         const unsigned flags = S->flags;
@@ -377,9 +382,16 @@ rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
             double iv[1][3], t[1];
             rt_step<1>(S, flags, clip, y, u, iv, t);
             if (has)
-                rt_store_rows<1, false>(flags, s, a,
-                                        rt_col(a, tile0 + idx), y, u, iv, t);
+                rt_store_rows<1, false>(flags, s, a, col0 + idx, y, u, iv, t);
             rt_leave<1>(S, flags, y, u);
+        }
+        if (!(flags & RT_F_NOSTORE)) {
+            /* a kept row: the columns of retired rays get their NaN from the
+             * thread that owns the column, next to the survivors' stores */
+            __syncthreads();
+            const int from = gone[tid];
+            if (exists && from && from <= s)
+                rt_store_nan_row(flags, s, a, col0 + tid);
         }
     }
 }
