@@ -318,7 +318,7 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * with ballots and an LDS exchange; 2 = every trace.  Results are identical
  * to the plain kernel's, NaN payloads aside), "compact_every" (k: the
  * survivors of a workgroup are counted -- one barrier -- at every k-th element
- * only; default 1).
+ * only; default 4, the measured optimum: asking costs ~0.5 us per workgroup).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
 /*

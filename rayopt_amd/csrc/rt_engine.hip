@@ -333,7 +333,7 @@ int rt_create(int device, rt_ctx **out)
     c->opt_block = 256;
     c->opt_alias = 1;
     c->opt_fuse = 1;
-    c->opt_compact_every = 1;
+    c->opt_compact_every = 4; /* measured best, profiles/r02_probes */
 #define RT_HIP_C(call)                                                        \
     do {                                                                      \
         hipError_t e_ = (call);                                               \
