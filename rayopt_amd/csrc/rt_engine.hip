@@ -1219,7 +1219,7 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
                        "rt_probe: the linear fills address the SoA layout");
     /* rows 1..L-1 of the four arrays; row 0 (the input rays) is preserved */
     RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
-    if (mode == 0 || (mode >= 5 && mode <= 8)) {
+    if (mode == 0 || (mode >= 5 && mode <= 9)) {
         /* the trace kernel's store pattern without its arithmetic, in the
          * layout in force (SoA or tile_rays):
          *   0  80 B/op, 16-byte stores, 48 B/ray input read from HBM
@@ -1249,12 +1249,14 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
         case 5: RT_PROBE(1, 2, 1); break;
         case 6: RT_PROBE(2, 2, 1); break;
         case 7: RT_PROBE(0, 1, 0); break;
+        case 9: RT_PROBE(3, 1, 0); break; /* 7 with non-temporal loads */
         default: RT_PROBE(2, 1, 0); break;
         }
 #undef RT_PROBE_FL
 #undef RT_PROBE
         *bytes = (double)ld * ((mode >= 7 ? 56. : 80.) * (L - 1) +
-                               ((mode == 0 || mode == 7) ? 48. : 0.));
+                               ((mode == 0 || mode == 7 || mode == 9) ? 48.
+                                                                       : 0.));
     } else if (mode == 1) {
         double total = 0.;
         for (int w = RT_Y; w <= RT_T; ++w) {
