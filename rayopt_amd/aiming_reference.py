@@ -194,7 +194,13 @@ def reference_aimer(system, engine, l, stop, given=None):
     for "the default"): the reference keys its cache on that
     (rayopt/system.py:586), so a bundle requested without a wavelength and
     one requested at the first wavelength have separate guess histories."""
-    cache = system.__dict__.setdefault("_reference_aimers", {})
+    home = getattr(system, "_pupil_cache", None)
+    if isinstance(home, dict):
+        # a rayopt System: live inside its own cache, which its update()
+        # clears (rayopt/system.py:201-202), under a key of our own
+        cache = home.setdefault("rayopt_amd reference aimers", {})
+    else:
+        cache = system.__dict__.setdefault("_reference_aimers", {})
     key = (given, stop)
     if key not in cache:
         cache[key] = ReferenceAimer(system, engine, l, stop)

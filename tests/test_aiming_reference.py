@@ -94,3 +94,20 @@ def test_aspheres_agree_through_the_newton_path():
         zm, am = aimer.pupil(yo)
         assert zm == pytest.approx(zr, rel=1e-9)
         np.testing.assert_allclose(am, ar, rtol=1e-9)
+
+
+def test_on_a_rayopt_system_the_cache_lives_in_its_pupil_cache():
+    """GeometricTrace(rayopt_system, aiming="reference"): the solved fields
+    are dropped when rayopt's own System.update() clears _pupil_cache."""
+    ro, rs, ms = both(COOKE)
+    g = ra.GeometricTrace(rs, engine=OracleEngine(), aiming="reference")
+    r = ro.GeometricTrace(rs)
+    g.rays_point((0, 1.), nrays=5)
+    assert "rayopt_amd reference aimers" in rs._pupil_cache
+    rs[rs.stop].radius /= 2
+    rs.update()
+    assert "rayopt_amd reference aimers" not in rs._pupil_cache
+    g.rays_point((0, 1.), nrays=5)
+    r.rays_point((0, 1.), nrays=5)
+    np.testing.assert_allclose(np.asarray(g.y[0]), r.y[0], atol=1e-9)
+    np.testing.assert_allclose(np.asarray(g.y[-1]), r.y[-1], atol=1e-9)
