@@ -159,3 +159,26 @@ def test_bench_needs_as_many_devices_as_gpus():
     have = D.visible_devices()
     if have < 2:
         assert "2 devices needed, %d visible" % have in res.stderr
+
+
+def test_under_torch_distributed_run(tmp_path):
+    """The contract's launch line for N > 1 -- `python -m
+    torch.distributed.run --nproc-per-node 2 ...` -- around the torch-free
+    workers: they take RANK / LOCAL_RANK / WORLD_SIZE from it and meet
+    through the MASTER_PORT-named rendezvous file (the launcher's own store
+    occupies that port)."""
+    pytest.importorskip("torch")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RT_RDZV_FILE", "RT_RDZV_TOKEN")}
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(script)], env=env, text=True,
+        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:]
+    assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
