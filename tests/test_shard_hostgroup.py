@@ -99,7 +99,8 @@ WORKER = textwrap.dedent("""
     group.barrier()
     group.close()
     assert "torch" not in sys.modules
-    print("rank", rank, "ok", flush=True)
+    sys.stdout.write("rank %%d ok\\n" %% rank)     # one write: ranks share a pipe
+    sys.stdout.flush()
 """)
 
 
