@@ -153,12 +153,13 @@ class HostGroup:
                     conn, _ = server.accept()
                 except socket.timeout:
                     continue
-                conn.settimeout(timeout)
+                conn.settimeout(5.)     # a stranger must not hold rank 0 up
                 try:
                     hello = _recv(conn)
                 except Exception:
                     conn.close()
                     continue
+                conn.settimeout(timeout)
                 if (not isinstance(hello, tuple) or hello[0] != _MAGIC or
                         hello[1] != token or
                         not 1 <= hello[2] < self.world or
