@@ -1257,6 +1257,24 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
         *bytes = (double)ld * ((mode >= 7 ? 56. : 80.) * (L - 1) +
                                ((mode == 0 || mode == 7 || mode == 9) ? 48.
                                                                        : 0.));
+    } else if (mode == 10 || mode == 11 || mode == 12) {
+        /* 56 B pattern, K = 2 / 4 / 8 rays per lane one after the other,
+         * inputs loaded up front */
+        const int block = ctx->opt_block;
+        const int K = mode == 10 ? 2 : (mode == 11 ? 4 : 8);
+        const unsigned grid =
+            (unsigned)((ld + (int64_t)block * K - 1) / ((int64_t)block * K));
+        const rt_lay lay = rt_layout(ctx);
+        if (K == 2)
+            hipLaunchKernelGGL(rt_probe_seq_kernel<2>, dim3(grid), dim3(block),
+                               0, ctx->stream, 1, L, lay, ld);
+        else if (K == 4)
+            hipLaunchKernelGGL(rt_probe_seq_kernel<4>, dim3(grid), dim3(block),
+                               0, ctx->stream, 1, L, lay, ld);
+        else
+            hipLaunchKernelGGL(rt_probe_seq_kernel<8>, dim3(grid), dim3(block),
+                               0, ctx->stream, 1, L, lay, ld);
+        *bytes = (double)ld * (56. * (L - 1) + 48.);
     } else if (mode == 1) {
         double total = 0.;
         for (int w = RT_Y; w <= RT_T; ++w) {

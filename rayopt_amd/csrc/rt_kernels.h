@@ -530,6 +530,44 @@ __global__ void rt_probe_pattern_kernel(int start, int stop,
     }
 }
 
+/* the 56 B pattern with K rays per lane marched ONE AFTER THE OTHER, all
+ * K inputs loaded up front: K times fewer, K times larger read bursts per
+ * workgroup (does clustering the reads in time make them cheaper among the
+ * saturated writes?) */
+template <int K>
+__global__ void rt_probe_seq_kernel(int start, int stop, rt_lay a, int64_t ld)
+{
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x * K + threadIdx.x;
+    double y[K][3], u[K][3];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = base + (int64_t)k * blockDim.x;
+        const int64_t col = rt_col(a, j < ld ? j : 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            y[k][c] = a.Y[(start - 1) * a.ss + c * a.cs + col];
+            u[k][c] = a.U[(start - 1) * a.ss + c * a.cs + col];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = base + (int64_t)k * blockDim.x;
+        if (j >= ld)
+            continue;
+        const int64_t col = rt_col(a, j);
+        for (int s = start; s < stop; ++s) {
+            const int64_t row = s * a.ss + col;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                y[k][c] += u[k][c];
+                a.Y[row + c * a.cs] = y[k][c];
+                a.U[row + c * a.cs] = u[k][c];
+            }
+            a.T[s * a.ssT + col] = y[k][2];
+        }
+    }
+}
+
 __global__ void rt_probe_fill_kernel(double *__restrict__ dst, int64_t n2)
 {
     typedef double v2 __attribute__((ext_vector_type(2)));

@@ -13,7 +13,10 @@ g.rays_given(y, u)
 for _ in range(60):
     g.propagate(clip=True)
 for rep in range(3):
-    for mode, name in ((7, "plain loads"), (9, "non-temporal loads"), (8, "no read")):
+    for mode, name in ((7, "plain loads"), (9, "non-temporal loads"),
+                       (10, "2 rays per lane in sequence, inputs up front"),
+                       (11, "4 rays per lane in sequence"),
+                       (12, "8 rays per lane in sequence"), (8, "no read")):
         t = []
         for _ in range(10):
             ms, b = g.engine.probe(mode)
