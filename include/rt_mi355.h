@@ -328,7 +328,9 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value);
  * 16-byte store per lane, 4 = same, non-temporal; 5 / 6 = mode 0 with the
  * 48 B/ray input read from an L2-resident window / not at all; 7 / 8 = the
  * default kernel's own pattern (56 B per op, 8-byte stores) with / without
- * the input read.  Modes 0 and 5-8 honour "tile_rays" and "block".  Returns
+ * the input read; 9 = mode 7 with non-temporal loads; 10 / 11 / 12 = mode 7
+ * with 2 / 4 / 8 rays per lane marched one after the other, inputs loaded up
+ * front.  Modes 0 and 5-12 honour "tile_rays" and "block".  Returns
  * kernel time and the bytes moved.  Overwrites rows >= 1.
  */
 int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes);
