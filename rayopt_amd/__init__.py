@@ -11,6 +11,9 @@ from .model import (System, Element, Interface, Spheroid, Pose, Material,
 from .formats import (system_from_yaml, system_from_json, system_from_dict,
                       system_to_yaml, system_to_json)
 from .geometric_trace import GeometricTrace, Trace, DeviceRows
+from .library import Library
+
+FullTrace = GeometricTrace      # the reference's alias (geometric_trace.py:262)
 from .engine import Engine, get_engine
 from ._lib import EngineError
 from . import prescriptions, bundles, pupil, merit, catalog
@@ -20,6 +23,7 @@ __all__ = [
     "ConstantIndex", "AbbeGlass", "Conjugate", "make_element",
     "system_from_yaml", "system_from_json", "system_from_dict",
     "system_to_yaml", "system_to_json", "GeometricTrace", "Trace",
-    "DeviceRows", "Engine", "get_engine", "EngineError", "prescriptions",
+    "DeviceRows", "FullTrace", "Library", "Engine", "get_engine",
+    "EngineError", "prescriptions",
     "bundles", "pupil", "merit", "catalog",
 ]

@@ -731,6 +731,61 @@ class System(list):
                                          "mirror", False) else 1
                            for el in self])
 
+    # -- launch side of the path: pupils and launch rays ----------------------
+    def pupil(self, yo, l=None, stop=None, aiming="device", engine=None):
+        """``(z, a)``: distance of the aimed pupil of field ``yo`` from the
+        vertex of the first element and its apertures
+        ``[[-sag, -mer], [+sag, +mer]]`` (rayopt/system.py:585-593).  Chief and
+        marginal rays are aimed as the object pupil's ``aim`` flag says
+        (``stop=-1``: marginal rays to the rim of the limiting aperture).
+        ``aiming="device"``: the batched kernel, iterated to 1e-9;
+        ``"reference"``: rayopt's own solvers, tolerances and guess cache
+        (rayopt_amd/aiming_reference.py)."""
+        if stop not in (None, -1):
+            raise NotImplementedError("pupil(): stop is None or -1")
+        if engine is None:
+            from .engine import get_engine
+            engine = get_engine()
+        wavelength = self.wavelengths[0] if l is None else l
+        if aiming == "reference":
+            from .aiming_reference import reference_aimer
+            return reference_aimer(self, engine, wavelength, stop, l).pupil(yo)
+        from .aiming import FieldAimer
+        z, a = FieldAimer(self, wavelength, engine, aim=None).pupil(
+            [yo], rim=(stop == -1))
+        return float(z[0]), a[0]
+
+    def aim(self, yo, yp=None, z=None, a=None, filter=True, l=None,
+            engine=None):
+        """Launch rays ``(y, u)`` -- host arrays (N,3) -- of field ``yo``
+        through the normalised pupil coordinates ``yp`` (default: the chief
+        ray), for the pupil ``(z, a)`` (default: the first-order pupil):
+        ``System.aim`` of the reference (rayopt/system.py:503-504 ->
+        ``Conjugate.aim``, rayopt/conjugates.py:137-166,236-255).  The rays
+        are built by the device's generation kernel; ``filter`` drops the
+        pupil points outside the aimed ellipse (``Pupil.map``)."""
+        from .aiming import start_pupil
+        from .geometric_trace import GeometricTrace
+        if engine is None:
+            from .engine import get_engine
+            engine = get_engine()
+        wavelength = self.wavelengths[0] if l is None else l
+        if z is None or a is None:
+            z0, a0 = start_pupil(self, wavelength)
+            z = z0 if z is None else z
+            a = a0*np.array([[-1., -1.], [1., 1.]]) if a is None else a
+        yp = np.zeros((1, 2)) if yp is None else np.atleast_2d(
+            np.asarray(yp, dtype=float))
+        if filter and np.ndim(a) == 2:
+            af = np.arctan2(a, z) if self.object.finite else np.asarray(a)
+            am = np.fabs(af).max()
+            centre, half = np.sum(af, axis=0)/2, np.diff(af, axis=0)/2
+            yp = yp[(np.square(yp*am - centre)/np.square(half)).sum(1) <= 1]
+        trace = GeometricTrace(self, engine=engine)
+        trace.rays_fields([yo], yp, [z], np.asarray(a, dtype=float)[None]
+                          if np.ndim(a) == 2 else a, wavelength)
+        return np.array(trace.y[0]), np.array(trace.u[0])
+
     def propagate(self, y, u, n, l, start=1, stop=None, clip=False):
         """Generator with the reference's contract (system.py:459-464):
         yields ``(y, u, n, i, t)`` per element of ``self[start:stop]``.

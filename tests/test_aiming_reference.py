@@ -111,3 +111,33 @@ def test_on_a_rayopt_system_the_cache_lives_in_its_pupil_cache():
     r.rays_point((0, 1.), nrays=5)
     np.testing.assert_allclose(np.asarray(g.y[0]), r.y[0], atol=1e-9)
     np.testing.assert_allclose(np.asarray(g.y[-1]), r.y[-1], atol=1e-9)
+
+
+@pytest.mark.parametrize("text", [COOKE, FINITE])
+def test_system_pupil_and_aim_methods(text):
+    """System.pupil / System.aim of this package's System
+    (rayopt/system.py:503-504, 585-593): launch rays for a given pupil equal
+    the reference's to rounding; the aimed pupil to the reference's tolerance
+    by the kernel, to 1e-11 by the reference procedure."""
+    ro, rs, ms = both(text)
+    eng = OracleEngine()
+    yp = np.array([(0, 0), (0, .5), (.5, 0), (-.7, .7), (0, -1.), (.9, .9)])
+    for yo in ((0, 1.), (.6, .8)):
+        zr, ar = rs.pupil(yo)
+        for filt in (True, False):
+            yr, ur = rs.aim(yo, yp, zr, ar, filter=filt)
+            ym, um = ms.aim(yo, yp, zr, ar, filter=filt, engine=eng)
+            assert ym.shape == yr.shape
+            np.testing.assert_allclose(ym, yr, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(um, ur, rtol=0, atol=1e-12)
+        y1, u1 = ms.aim(yo, None, zr, ar, engine=eng)          # chief ray
+        yr1, ur1 = rs.aim(yo, None, zr, ar)
+        np.testing.assert_allclose(np.c_[y1, u1], np.c_[yr1, ur1],
+                                   atol=1e-12)
+        zm, am = ms.pupil(yo, engine=eng)
+        assert zm == pytest.approx(zr, rel=3e-3)
+        np.testing.assert_allclose(am, ar, rtol=3e-3)
+        zm, am = ms.pupil(yo, aiming="reference", engine=OracleEngine())
+        assert zm == pytest.approx(zr, rel=1e-10)
+        np.testing.assert_allclose(am, ar, rtol=1e-10)
+    assert ra.FullTrace is ra.GeometricTrace

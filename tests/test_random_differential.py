@@ -83,3 +83,67 @@ def test_gpu_vs_oracle_random_systems(seed):
         for rows, b in zip((g.y, g.u, g.i, g.t), want):
             assert_parity(np.asarray(rows[1:]), b, rtol, "seed %d" % seed)
         assert np.array_equal(g.n[1:], ns[1:])
+
+
+ASPHERIC_SEEDS = [s for s in range(200) if has_asphere(random_prescription(s))]
+
+
+@pytest.mark.parametrize("seed", ASPHERIC_SEEDS[:30])
+def test_fast_asphere_arithmetic_on_random_systems(seed, hostemu):
+    """RT_F_FAST on the host build of the kernel arithmetic against the exact
+    path of the same header, random aspheric systems (tilts, conics, mirrors,
+    up to five terms): 1e-8 contract, identical NaN masks."""
+    from rayopt_amd._lib import F_ASPH, F_FAST
+    p = random_prescription(seed)
+    system = ra.system_from_dict(copy.deepcopy(p))
+    y, u = random_rays(seed, 600, p)
+    table, _ = pack_system(system, 587.56e-9,
+                           system.refractive_index(587.56e-9, 0))
+    fast = table.copy()
+    fast["flags"] = np.where(fast["flags"] & F_ASPH, fast["flags"] | F_FAST,
+                             fast["flags"])
+    for clip in (True, False):
+        a = hostemu(table, y, u, 1, len(table), clip, 1)
+        b = hostemu(fast, y, u, 1, len(table), clip, 1)
+        for x, w in zip(b, a):
+            assert_parity(x, w, RTOL_ASPHERE, "seed %d" % seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", ASPHERIC_SEEDS[:30])
+def test_gpu_fast_asphere_and_compaction_on_random_systems(seed):
+    """The opt-in kernel variants on random aspheric systems: fast arithmetic
+    within the asphere contract of the oracle, and the compacting kernel
+    bit-identical to the plain one (every row and the image row only)."""
+    p = random_prescription(seed)
+    system = ra.system_from_dict(copy.deepcopy(p))
+    n = 20011
+    y, u = random_rays(seed, n, p)
+    table, ns = pack_system(system, 587.56e-9,
+                            system.refractive_index(587.56e-9, 0))
+    want = tn.propagate(table, y, u, clip=True)
+    g = ra.GeometricTrace(system, fast_asphere=True)
+    try:
+        g.rays_given(y, u)
+        g.propagate(clip=True)
+        for rows, b in zip((g.y, g.u, g.i, g.t), want):
+            assert_parity(np.asarray(rows[1:]), b, RTOL_ASPHERE,
+                          "fast seed %d" % seed)
+    finally:
+        g.engine.set_option("fast_asphere", 0)
+    g.propagate(clip=True)
+    plain = [np.array(np.asarray(r[1:])) for r in (g.y, g.u, g.i, g.t)]
+    g.engine.set_option("compact", 2)
+    g.engine.set_option("compact_every", 1)
+    try:
+        g.propagate(clip=True)
+        for rows, b in zip((g.y, g.u, g.i, g.t), plain):
+            assert np.array_equal(np.asarray(rows[1:]), b, equal_nan=True), \
+                seed
+        g.engine.set_option("compact", 1)
+        g.propagate(clip=True, keep=[-1])
+        assert np.array_equal(np.asarray(g.y[-1]), plain[0][-1],
+                              equal_nan=True), seed
+    finally:
+        g.engine.set_option("compact", 0)
+        g.engine.set_option("compact_every", 4)
