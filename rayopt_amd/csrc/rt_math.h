@@ -223,6 +223,13 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
  *     forms).
  * Results agree with the exact path to ~1e-13 (tests: <= 1e-9 asserted,
  * identical NaN masks on the asphere goldens).
+ *
+ * The same primitives are NOT offered for planes, spheres and conics: tried
+ * (round 2), the closed form on FMA / rcp / rsq stays ~1e-14 from the exact
+ * path on ordinary systems but reached 1.9e-9 on the worst-conditioned of
+ * the random tilted systems (tests/golden/tilted_seed_4200) -- outside the
+ * 1e-10 contract of the closed form, which the exact path meets there only
+ * because it repeats numpy's operations in numpy's order.
  */
 RT_HD double rt_fma(double a, double b, double c)
 {
@@ -238,10 +245,13 @@ RT_HD double rt_rcp_fast(double x)
 #else
     double r = 1. / x;
 #endif
+    double q = r;
 #pragma unroll
     for (int k = 0; k < STEPS; ++k)
-        r = rt_fma(r, rt_fma(-x, r, 1.), r);
-    return r;
+        q = rt_fma(q, rt_fma(-x, q, 1.), q);
+    /* 1/0 = +-inf and 1/inf = 0 as IEEE division has them: the refinement
+     * would turn the seed's inf / 0 into NaN */
+    return (x == 0. || x - x != 0.) ? r : q;
 }
 
 /* sqrt(w) and 1/sqrt(w) together (coupled Goldschmidt steps on the hardware
