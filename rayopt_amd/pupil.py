@@ -57,55 +57,89 @@ def _disc_quadrature(x, w):
     return rs, ps, ws
 
 
+# --------------------------------------------------------------------------
+# the patterns: name -> function(nrays, rng) -> (ref, xy, weight)
+#
+# A pattern is a set of normalised pupil coordinates, the index of its
+# reference ray and, for the quadrature rules, weights.  Ray counts, ordering
+# and the reference index are part of the contract with the reference
+# (rayopt/utils.py:117-199): Analysis indexes into the bundles it requests
+# (rayopt/analysis.py:236-249 splits a "tee" fan at ``ref``).
+# --------------------------------------------------------------------------
+
+def _fan(lo, n, axis):
+    """n points from lo to 1 along one pupil axis (0 sagittal, 1 meridional)."""
+    xy = np.zeros((n, 2))
+    xy[:, axis] = np.linspace(lo, 1, n)
+    return xy
+
+
+def _half_meridional(n, rng):
+    return 0, _fan(0, n, 1), None
+
+
+def _meridional(n, rng):
+    return 0, _fan(-1, n - n % 2 + 1, 1), None
+
+
+def _sagittal(n, rng):
+    n -= n % 2
+    return n//2, _fan(-1, n + 1, 0), None
+
+
+def _cross(n, rng):
+    n -= n % 4
+    arm = n//2 + 1
+    return n//4, np.r_[_fan(-1, arm, 1), _fan(-1, arm, 0)], None
+
+
+def _tee(n, rng):
+    half = (n - 2)//3
+    return (2*half + 1,
+            np.r_[_fan(-1, 2*half + 1, 1), _fan(0, half + 1, 0)], None)
+
+
+def _random(n, rng):
+    rng = np.random.default_rng() if rng is None else rng
+    r, phi = rng.random((2, n))
+    z = np.exp(2j*np.pi*phi)*np.sqrt(r)
+    return 0, np.r_[[[0., 0.]], np.c_[z.real, z.imag]], None
+
+
+def _hexapolar(n, rng):
+    rings = int(np.sqrt(n/3. - 1/12.) - 1/2.)
+    parts = [np.zeros((1, 2))]
+    for ring in range(1, rings + 1):         # 6, 12, 18 ... points per ring
+        a = np.linspace(0, 2*np.pi, 6*ring, endpoint=False)
+        # (sin a * ring)/rings, in this order: the reference's rounding
+        parts.append(np.c_[np.sin(a)*ring/rings, np.cos(a)*ring/rings])
+    return 0, np.concatenate(parts), None
+
+
+def _quadrature(nodes):
+    def pattern(n, rng):
+        r, phi, weight = _disc_quadrature(*nodes(int(np.sqrt(n) + 1)))
+        return 0, np.c_[r*np.cos(phi), r*np.sin(phi)], weight
+    return pattern
+
+
+PATTERNS = {
+    "half-meridional": _half_meridional, "meridional": _meridional,
+    "sagittal": _sagittal, "cross": _cross, "tee": _tee, "random": _random,
+    "square": lambda n, rng: (0, _grid_in_circle(n), None),
+    "triangular": lambda n, rng: (0, _grid_in_circle(n, stagger=True), None),
+    "hexapolar": _hexapolar,
+    "radau": _quadrature(_radau_nodes), "lobatto": _quadrature(_lobatto_nodes),
+}
+
+
 def pupil_distribution(distribution, nrays, rng=None):
     """Return ``(ref, xy, weight)``: index of the reference ray, (n,2)
     coordinates, weights (None unless a quadrature rule)."""
-    d, n = distribution, nrays
-    ref, weight = 0, None
-    lin = np.linspace
-    if n == 1:
-        xy = np.zeros((1, 2))
-    elif d == "half-meridional":
-        xy = np.c_[np.zeros(n), lin(0, 1, n)]
-    elif d == "meridional":
-        n -= n % 2
-        xy = np.c_[np.zeros(n + 1), lin(-1, 1, n + 1)]
-    elif d == "sagittal":
-        n -= n % 2
-        ref = n//2
-        xy = np.c_[lin(-1, 1, n + 1), np.zeros(n + 1)]
-    elif d == "cross":
-        n -= n % 4
-        ref = n//4
-        h = n//2 + 1
-        xy = np.r_[np.c_[np.zeros(h), lin(-1, 1, h)],
-                   np.c_[lin(-1, 1, h), np.zeros(h)]]
-    elif d == "tee":
-        n = (n - 2)//3
-        ref = 2*n + 1
-        xy = np.r_[np.c_[np.zeros(2*n + 1), lin(-1, 1, 2*n + 1)],
-                   np.c_[lin(0, 1, n + 1), np.zeros(n + 1)]]
-    elif d == "random":
-        rng = np.random.default_rng() if rng is None else rng
-        r, phi = rng.random((2, n))
-        z = np.exp(2j*np.pi*phi)*np.sqrt(r)
-        xy = np.r_[[[0., 0.]], np.c_[z.real, z.imag]]
-    elif d == "square":
-        xy = _grid_in_circle(n)
-    elif d == "triangular":
-        xy = _grid_in_circle(n, stagger=True)
-    elif d == "hexapolar":
-        rings = int(np.sqrt(n/3. - 1/12.) - 1/2.)
-        parts = [np.zeros((1, 2))]
-        for i in range(1, rings + 1):
-            a = lin(0, 2*np.pi, 6*i, endpoint=False)
-            parts.append(np.c_[np.sin(a)*i/rings, np.cos(a)*i/rings])
-        xy = np.concatenate(parts)
-    elif d in ("radau", "lobatto"):
-        k = int(np.sqrt(n) + 1)
-        x, w = _radau_nodes(k) if d == "radau" else _lobatto_nodes(k)
-        r, p, weight = _disc_quadrature(x, w)
-        xy = np.c_[r*np.cos(p), r*np.sin(p)]
-    else:
-        raise ValueError("unknown ray distribution", d)
-    return ref, xy, weight
+    if nrays == 1:
+        return 0, np.zeros((1, 2)), None
+    try:
+        pattern = PATTERNS[distribution]
+    except KeyError:
+        raise ValueError("unknown ray distribution", distribution) from None
+    return pattern(nrays, rng)
