@@ -32,54 +32,92 @@ def _glass(args):
     return AbbeGlass(nd, vd if vd else float("inf"), name=args[0])
 
 
+class _ZmxParse:
+    """What is known while walking a ``.zmx`` file: the system so far (its
+    last element is the surface the next operands apply to) and the
+    thickness that will precede the next ``SURF``."""
+    def __init__(self):
+        self.system = System()
+        self.system.append(Spheroid(material=BASIC["air"]))
+        self.system.wavelengths = []
+        self.thickness = 0.
+
+    @property
+    def surface(self):
+        return self.system[-1]
+
+
+def _unit(st, words, rest):
+    st.system.scale = UNITS[words[0].upper()]
+
+
+def _name(st, words, rest):
+    st.system.description = rest.strip().strip('"') if words else ""
+
+
+def _surface(st, words, rest):
+    st.system.append(Spheroid(distance=st.thickness, material=BASIC["air"]))
+
+
+def _attribute(name):
+    def action(st, words, rest):
+        setattr(st.surface, name, float(words[0]))   # "INFINITY" -> inf
+    return action
+
+
+def _thickness(st, words, rest):
+    st.thickness = float(words[0])
+
+
+def _material(st, words, rest):
+    st.surface.material = _glass(words)
+
+
+def _even_asphere_term(st, words, rest):
+    # PARM i = coefficient of r^(2 i); PARM 0 is not a polynomial term
+    term, value = int(words[0]) - 1, float(words[1])
+    if term >= 0:
+        terms = st.surface.aspherics or []
+        terms += [0.]*(term + 1 - len(terms))
+        terms[term] = value
+        st.surface.aspherics = terms
+
+
+def _stop(st, words, rest):
+    st.surface.stop = True
+    st.system.stop = len(st.system) - 1
+
+
+def _wavelengths(st, words, rest):
+    st.system.wavelengths = [float(w)*1e-6 for w in words]
+
+
+def _wavelength_entry(st, words, rest):
+    # WAVM index micrometres weight
+    if float(words[2]) > 0 or not st.system.wavelengths:
+        st.system.wavelengths.append(float(words[1])*1e-6)
+
+
+ACTIONS = {
+    "UNIT": _unit, "NAME": _name, "SURF": _surface,
+    "CURV": _attribute("curvature"), "DIAM": _attribute("radius"),
+    "CONI": _attribute("conic"), "DISZ": _thickness, "GLAS": _material,
+    "PARM": _even_asphere_term, "STOP": _stop, "WAVL": _wavelengths,
+    "WAVM": _wavelength_entry,
+    # MIRR 2 is a substrate flag, not a mirror: nothing to do
+}
+
+
 def zmx_to_system(text):
-    air = BASIC["air"]
-    s = System()
-    s.append(Spheroid(material=air))
-    s.wavelengths = []
-    thickness = 0.
-    for raw in text.splitlines():
-        parts = raw.strip().split(None, 1)
-        if not parts:
-            continue
-        cmd = parts[0]
-        args = parts[1].split() if len(parts) == 2 else []
-        el = s[-1]
-        if cmd == "UNIT":
-            s.scale = UNITS[args[0].upper()]
-        elif cmd == "NAME":
-            s.description = parts[1].strip().strip('"') if args else ""
-        elif cmd == "SURF":
-            s.append(Spheroid(distance=thickness, material=air))
-        elif cmd == "CURV":
-            el.curvature = float(args[0])
-        elif cmd == "DISZ":
-            thickness = float(args[0])       # "INFINITY" -> inf
-        elif cmd == "DIAM":
-            el.radius = float(args[0])
-        elif cmd == "GLAS":
-            el.material = _glass(args)
-        elif cmd == "MIRR" and args and int(float(args[0])) == 2:
-            pass                             # substrate flag, not a mirror
-        elif cmd == "CONI":
-            el.conic = float(args[0])
-        elif cmd == "PARM":
-            i, v = int(args[0]) - 1, float(args[1])
-            if i < 0:
-                continue
-            if el.aspherics is None:
-                el.aspherics = []
-            while len(el.aspherics) <= i:
-                el.aspherics.append(0.)
-            el.aspherics[i] = v
-        elif cmd == "STOP":
-            el.stop = True
-            s.stop = len(s) - 1
-        elif cmd == "WAVL":
-            s.wavelengths = [float(w)*1e-6 for w in args]
-        elif cmd == "WAVM":
-            if float(args[2]) > 0 or not s.wavelengths:
-                s.wavelengths.append(float(args[1])*1e-6)
-    if not s.wavelengths:
-        s.wavelengths = [587.56e-9]
-    return s
+    """Parse the text of a ``.zmx`` file (or an open file)."""
+    if hasattr(text, "read"):
+        text = text.read()
+    st = _ZmxParse()
+    for line in text.splitlines():
+        opcode, _, rest = line.strip().partition(" ")
+        action = ACTIONS.get(opcode)
+        if action is not None:
+            action(st, rest.split(), rest)
+    if not st.system.wavelengths:
+        st.system.wavelengths = [587.56e-9]
+    return st.system
