@@ -3,19 +3,28 @@
  * sequential geometric ray-trace engine.
  *
  * Kernel design (MI355X first):
- *  - one lane owns R adjacent rays (R = 2 by default -> 16-byte global
- *    accesses, 1 KiB per wave instruction) and keeps their state (y, u) in
- *    VGPRs across the whole surface loop: the fused march reads 48 B per ray
- *    once and writes 80 B per ray-surface op, nothing is ever re-read;
+ *  - one lane owns one ray (R = 1: 8-byte global accesses, 512 B per wave
+ *    instruction; 2 or 4 adjacent rays per lane are template variants) and
+ *    keeps its state (y, u) in VGPRs across the whole surface loop: the fused
+ *    march reads 48 B per ray once and writes 56-80 B per ray-surface op,
+ *    nothing is ever re-read;
  *  - results are SoA [surface][component][ray] so every store instruction of
- *    a wave covers one contiguous, 1 KiB aligned segment;
+ *    a wave covers one contiguous, 512 B aligned segment; rows that are bit
+ *    for bit another row (i[j] = u[j-1] without tilts, u[j] = i[j] where
+ *    nothing bends or clips) are served, not stored;
  *  - the surface table is wave-uniform: it is read with scalar loads
  *    (s_load_dwordx*) through the scalar cache into SGPRs, costing no VGPRs
- *    and no LDS traffic; all per-surface branches are scalar branches;
+ *    and no LDS traffic; all per-surface branches are scalar branches; it is
+ *    double buffered on the device so a changed table never drains the stream;
  *  - the even-asphere Newton solve is the only divergent loop; its trip count
- *    is decided per wavefront with a 64-bit ballot (rt_math.h);
+ *    is decided per wavefront with a 64-bit ballot (rt_math.h); an opt-in fast
+ *    arithmetic (FMA, rcp/rsq, one reciprocal per iterate) takes it off the
+ *    FP64-issue wall;
+ *  - a wavefront whose rays are all dead stores NaN rows without evaluating
+ *    the element; an opt-in kernel compacts the survivors of a workgroup into
+ *    fewer wavefronts (ballots + LDS) for traces that keep few rows;
  *  - FP64 VALU only: the path is elementwise, there is no contraction to put
- *    on MFMA.  Bound: HBM write bandwidth (80 B / ray-surface op).
+ *    on MFMA.  Bound: HBM write bandwidth (56-80 B / ray-surface op).
  *
  * No CPU fallback lives here: every entry point either runs on the GPU or
  * returns an error.
