@@ -47,6 +47,24 @@ def main():
         s = ra.system_from_yaml(P.cooke(l))
         run("C2 cooke 1e6 l=%.0fnm" % (l*1e9), s,
             *disc_bundle(10**6, 5.5, 5., 0), l, True)
+    # C2 as ONE launch: the same 10^6 rays at the three wavelengths (ray
+    # groups, one surface table each) through the dispersive prescription
+    s = ra.system_from_yaml(P.COOKE % dict(air=1.0, sk16="1.62041/60.32",
+                                           f2="1.62004/36.37"))
+    y, u = disc_bundle(10**6 - 10**6 % 64, 5.5, 5., 0)
+    g = ra.GeometricTrace(s)
+    g.rays_given(y, u, l=[587.56e-9, 656.27e-9, 486.13e-9])
+    ms = []
+    for k in range(60):
+        g.propagate(clip=True)
+        ms.append(g.kernel_ms())
+    ms = float(np.median(ms[-10:]))
+    n3, S = 3*len(y), len(s) - 1
+    print(json.dumps(dict(config="C2 cooke, 3 wavelengths x 1e6 rays in ONE "
+                          "launch", rays=n3, surfaces=S, clip=True,
+                          kernel_ms=ms, ops_per_s=n3*S/ms*1e3,
+                          GBs=n3*(56*S + 48)/ms/1e6)), flush=True)
+    g.engine.close()
     s = ra.system_from_yaml(P.DOUBLE_GAUSS)
     th = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in (0, .35, .5, .7, 1.)]
     y, u = multi_field_bundle(10**7, 17., th, 0, P.DOUBLE_GAUSS_PUPIL_Z)
