@@ -924,9 +924,10 @@ def test_grouped_partial_propagation_gpu():
 # -- clipped-ray compaction (rt_set_option "compact") --------------------------
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("slots", [0, 2, 3, 4])
 @pytest.mark.parametrize("scale", [1., 1.6])
 @pytest.mark.parametrize("keep", [None, [-1], [3, 7, -1]])
-def test_compacting_kernel_gives_the_plain_kernels_results(scale, keep):
+def test_compacting_kernel_gives_the_plain_kernels_results(scale, keep, slots):
     """Dead rays retired, survivors packed into fewer wavefronts: every kept
     row identical to the plain kernel's, bit for bit, NaN masks included;
     over-filled bundle (most rays vignette at different elements) and the
@@ -944,7 +945,10 @@ def test_compacting_kernel_gives_the_plain_kernels_results(scale, keep):
     g.propagate(clip=True, keep=keep)
     want = {(name, j): np.array(getattr(g, name)[j])
             for name in "yuit" for j in rows}
+    # slots = 0: the workgroup variant (ballot counts exchanged through LDS
+    # at a barrier); 2..4: the wave-private pool of slots x 64 rays
     g.engine.set_option("compact", 2 if keep is None else 1)
+    g.engine.set_option("compact_slots", slots)
     try:
         g.propagate(clip=True, keep=keep)
         for (name, j), ref in want.items():
@@ -954,10 +958,12 @@ def test_compacting_kernel_gives_the_plain_kernels_results(scale, keep):
         assert dead > (.5 if scale > 1 else .001)
     finally:
         g.engine.set_option("compact", 0)
+        g.engine.set_option("compact_slots", 0)
 
 
 @pytest.mark.gpu
-def test_compacting_kernel_with_ray_groups_and_aspheres():
+@pytest.mark.parametrize("slots", [0, 4])
+def test_compacting_kernel_with_ray_groups_and_aspheres(slots):
     """Groups with their own surface table (three wavelengths, tiles never
     straddle a group) and the Newton path under compaction."""
     from rayopt_amd import prescriptions as P
@@ -971,8 +977,10 @@ def test_compacting_kernel_with_ray_groups_and_aspheres():
     want = np.array(g.y[-1])
     assert .2 < np.isnan(want[:, 0]).mean() < .95
     g.engine.set_option("compact", 1)
+    g.engine.set_option("compact_slots", slots)
     try:
         g.propagate(clip=True, keep=[-1])
         assert np.array_equal(np.asarray(g.y[-1]), want, equal_nan=True)
     finally:
         g.engine.set_option("compact", 0)
+        g.engine.set_option("compact_slots", 0)
