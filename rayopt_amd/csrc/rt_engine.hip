@@ -117,7 +117,6 @@ struct rt_ctx {
     int opt_probe_store; /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
     int opt_compact_every; /* survivors are counted at every k-th element */
-    int opt_compact_slots; /* 0: workgroup variant; 2..4: wave-private pool */
     int last_compact; /* the last trace ran the compacting kernel */
 
     /* rt_generate_rays: field frames | pupil points, and whether row 0 is
@@ -274,10 +273,8 @@ static bool rt_use_compact(const rt_ctx *c, int start, int stop)
     if (!c->opt_compact || c->opt_r != 1 || c->opt_nt || c->opt_xcd ||
         c->opt_tile)
         return false;
-    if (c->ngroups > 1 &&
-        (c->n / c->ngroups) % (c->opt_compact_slots ? 64 * c->opt_compact_slots
-                                                    : RT_CB))
-        return false; /* a tile would straddle two tables */
+    if (c->ngroups > 1 && (c->n / c->ngroups) % RT_CB)
+        return false; /* a 256-ray tile would straddle two tables */
     if (c->opt_compact == 2)
         return true;
     for (int s = start; s < stop; ++s)
@@ -1060,27 +1057,6 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
                            ctx->gen_np, ctx->gen_n, ctx->gen_s0,
                            !ctx->opt_alias);
         RT_HIP(ctx, hipGetLastError());
-    } else if (start < stop && rt_use_compact(ctx, start, stop) &&
-               ctx->opt_compact_slots) {
-        /* barrier-free variant: one wavefront, a pool of SLOTS x 64 rays */
-        const int slots = ctx->opt_compact_slots;
-        const unsigned grid =
-            (unsigned)((ctx->ld + 64 * slots - 1) / (64 * slots));
-        const int64_t gr = ctx->ngroups > 1 ? ctx->n / ctx->ngroups
-                                            : (int64_t)0;
-#define RT_POOL(N)                                                            \
-    hipLaunchKernelGGL(rt_trace_pool_kernel<N>, dim3(grid), dim3(64), 0,      \
-                       ctx->stream, ctx->d_surf, start, stop, clip,           \
-                       rt_layout(ctx), ctx->ld, gr, ctx->nsurf)
-        if (slots == 2)
-            RT_POOL(2);
-        else if (slots == 3)
-            RT_POOL(3);
-        else
-            RT_POOL(4);
-#undef RT_POOL
-        RT_HIP(ctx, hipGetLastError());
-        ctx->last_compact = 1;
     } else if (start < stop && rt_use_compact(ctx, start, stop)) {
         const unsigned grid = (unsigned)((ctx->ld + RT_CB - 1) / RT_CB);
         hipLaunchKernelGGL(rt_trace_compact_kernel, dim3(grid), dim3(RT_CB),
@@ -1199,10 +1175,6 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         if (value < 0 || value > 2)
             return rt_fail(ctx, RT_ERR_ARG, "compact must be 0, 1 or 2");
         ctx->opt_compact = value;
-    } else if (!strcmp(key, "compact_slots")) {
-        if (value != 0 && (value < 2 || value > 4))
-            return rt_fail(ctx, RT_ERR_ARG, "compact_slots must be 0, 2, 3, 4");
-        ctx->opt_compact_slots = value;
     } else if (!strcmp(key, "compact_every")) {
         if (value < 1 || value > 64)
             return rt_fail(ctx, RT_ERR_ARG, "compact_every must be in [1, 64]");

@@ -396,135 +396,6 @@ rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
     }
 }
 
-/*
- * Compaction without barriers: a wavefront owns a POOL of SLOTS x 64 rays in
- * LDS (y, u and the ray's column) and marches the whole pool through an
- * element, 64 rays at a time, before going on to the next element.  Dead rays
- * stay where they are until the survivors fit into one slot less; then the
- * pool is packed in place -- slot after slot, every survivor moves down to
- * prefix + popcount(ballot below its lane) -- and from there on the wavefront
- * makes one pass less per element.  No other wavefront is involved, so there
- * is nothing to wait for: LDS operations of one wavefront execute in order.
- * Rows of dead rays are written as in rt_trace_compact_kernel, by the lane
- * that owns the column, when the row comes up.
- */
-template <int SLOTS>
-__global__ void __launch_bounds__(64)
-rt_trace_pool_kernel(const rt_surface *__restrict__ surf, int start, int stop,
-                     int clip, rt_lay a, int64_t ld, int64_t group_rays,
-                     int nsurf)
-{
-    constexpr int T = 64 * SLOTS;
-    __shared__ double st[6][T];
-    __shared__ unsigned short colof[T]; /* pool position -> column in the tile */
-    __shared__ unsigned short gone[T];  /* column -> first element whose rows
-                                           are NaN (0: alive) */
-    const int lane = threadIdx.x;
-    const int64_t tile0 = (int64_t)blockIdx.x * T;
-    if (group_rays)
-        surf += (tile0 / group_rays) * nsurf;
-    int nrays = (int)((ld - tile0) < T ? (ld - tile0) : T);
-    {
-        const rt_surface *S0 = surf + (start - 1);
-        const unsigned f0 = S0->flags;
-#pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            const int p = k * 64 + lane;
-            gone[p] = 0;
-            if (p < nrays) {
-                double y[1][3], u[1][3];
-                rt_load_state<1>(a, start - 1, tile0 + p, y, u);
-                rt_leave<1>(S0, f0, y, u);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    st[c][p] = y[0][c];
-                    st[3 + c][p] = u[0][c];
-                }
-                colof[p] = (unsigned short)p;
-                if (!(u[0][0] == u[0][0]))
-                    gone[p] = (unsigned short)start; /* dead on arrival */
-            }
-        }
-    }
-    for (int s = start; s < stop; ++s) {
-        const rt_surface *S = surf + s;
-        const unsigned flags = S->flags;
-        int alive = 0;
-        for (int k = 0; k * 64 < nrays; ++k) { /* wave-uniform trip count */
-            const int p = k * 64 + lane;
-            const bool has = p < nrays;
-            double y[1][3], u[1][3];
-            int col = 0;
-            if (has) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    y[0][c] = st[c][p];
-                    u[0][c] = st[3 + c][p];
-                }
-                col = colof[p];
-            }
-            const bool live = has && u[0][0] == u[0][0];
-            if (RT_WAVE_ANY(live)) {
-                double iv[1][3], t[1];
-                rt_step<1>(S, flags, clip, y, u, iv, t);
-                if (live)
-                    rt_store_rows<1, false>(flags, s, a, tile0 + col, y, u,
-                                            iv, t);
-                rt_leave<1>(S, flags, y, u);
-                const bool still = live && u[0][0] == u[0][0];
-                if (live) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        st[c][p] = y[0][c];
-                        st[3 + c][p] = u[0][c];
-                    }
-                    if (!still)
-                        gone[col] = (unsigned short)(s + 1);
-                }
-                alive += __popcll(__ballot(still));
-            }
-        }
-        if (!(flags & RT_F_NOSTORE)) {
-            /* a kept row: NaN for the columns whose ray is gone */
-#pragma unroll
-            for (int k = 0; k < SLOTS; ++k) {
-                const int c = k * 64 + lane;
-                const int from = gone[c];
-                if (tile0 + c < ld && from && from <= s)
-                    rt_store_nan_row(flags, s, a, tile0 + c);
-            }
-        }
-        /* pack the pool when that saves a pass */
-        if (alive <= ((nrays + 63) / 64 - 1) * 64 && alive < nrays) {
-            int base = 0;
-            for (int k = 0; k * 64 < nrays; ++k) {
-                const int p = k * 64 + lane;
-                double v[6];
-                int col = 0;
-                bool live = false;
-                if (p < nrays) {
-#pragma unroll
-                    for (int c = 0; c < 6; ++c)
-                        v[c] = st[c][p];
-                    col = colof[p];
-                    live = v[3] == v[3];
-                }
-                const unsigned long long m = __ballot(live);
-                if (live) {
-                    const int dst =
-                        base + __popcll(m & ((1ull << lane) - 1ull));
-#pragma unroll
-                    for (int c = 0; c < 6; ++c)
-                        st[c][dst] = v[c];
-                    colof[dst] = (unsigned short)col;
-                }
-                base += __popcll(m);
-            }
-            nrays = base;
-        }
-    }
-}
-
 /* rays_given: AoS (n,3) staging -> SoA row 0 of Y,U,I and T[0] = 0 */
 __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
                                    const double *__restrict__ u_aos,

@@ -146,16 +146,11 @@ def part_c(n):
         g.engine.set_option("compact", 1)
         r["random_image_only_compact_ms"] = kernel_ms(g, True, reps=20,
                                                       keep=[0, -1])
-        for every in (4, 64):
+        for every in (2, 3, 4, 6, 64):
             g.engine.set_option("compact_every", every)
             r["random_image_only_compact_every%d_ms" % every] = kernel_ms(
                 g, True, reps=20, keep=[0, -1])
-        g.engine.set_option("compact_every", 4)
-        for slots in (2, 3, 4):     # wave-private pool, no barriers
-            g.engine.set_option("compact_slots", slots)
-            r["random_image_only_pool%d_ms" % slots] = kernel_ms(
-                g, True, reps=20, keep=[0, -1])
-        g.engine.set_option("compact_slots", 0)
+        g.engine.set_option("compact_every", 1)
         g.engine.set_option("compact", 0)
         # ideal compaction: the same rays, the dead ones contiguous, ordered
         # by the surface they die at

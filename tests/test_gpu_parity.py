@@ -924,10 +924,9 @@ def test_grouped_partial_propagation_gpu():
 # -- clipped-ray compaction (rt_set_option "compact") --------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("slots", [0, 2, 3, 4])
 @pytest.mark.parametrize("scale", [1., 1.6])
 @pytest.mark.parametrize("keep", [None, [-1], [3, 7, -1]])
-def test_compacting_kernel_gives_the_plain_kernels_results(scale, keep, slots):
+def test_compacting_kernel_gives_the_plain_kernels_results(scale, keep):
     """Dead rays retired, survivors packed into fewer wavefronts: every kept
     row identical to the plain kernel's, bit for bit, NaN masks included;
     over-filled bundle (most rays vignette at different elements) and the
@@ -945,10 +944,7 @@ def test_compacting_kernel_gives_the_plain_kernels_results(scale, keep, slots):
     g.propagate(clip=True, keep=keep)
     want = {(name, j): np.array(getattr(g, name)[j])
             for name in "yuit" for j in rows}
-    # slots = 0: the workgroup variant (ballot counts exchanged through LDS
-    # at a barrier); 2..4: the wave-private pool of slots x 64 rays
     g.engine.set_option("compact", 2 if keep is None else 1)
-    g.engine.set_option("compact_slots", slots)
     try:
         g.propagate(clip=True, keep=keep)
         for (name, j), ref in want.items():
@@ -958,12 +954,10 @@ def test_compacting_kernel_gives_the_plain_kernels_results(scale, keep, slots):
         assert dead > (.5 if scale > 1 else .001)
     finally:
         g.engine.set_option("compact", 0)
-        g.engine.set_option("compact_slots", 0)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("slots", [0, 4])
-def test_compacting_kernel_with_ray_groups_and_aspheres(slots):
+def test_compacting_kernel_with_ray_groups_and_aspheres():
     """Groups with their own surface table (three wavelengths, tiles never
     straddle a group) and the Newton path under compaction."""
     from rayopt_amd import prescriptions as P
@@ -977,10 +971,8 @@ def test_compacting_kernel_with_ray_groups_and_aspheres(slots):
     want = np.array(g.y[-1])
     assert .2 < np.isnan(want[:, 0]).mean() < .95
     g.engine.set_option("compact", 1)
-    g.engine.set_option("compact_slots", slots)
     try:
         g.propagate(clip=True, keep=[-1])
         assert np.array_equal(np.asarray(g.y[-1]), want, equal_nan=True)
     finally:
         g.engine.set_option("compact", 0)
-        g.engine.set_option("compact_slots", 0)
