@@ -115,6 +115,9 @@ struct rt_ctx {
     int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
     int opt_tile; /* measurement only: tile-major result layout, rays/tile */
     int opt_probe_store; /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
+    void *d_probe_in; /* rt_probe modes 13/14: input rows of their own */
+    size_t probe_in_bytes;
+    int probe_in_uc;
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
     int opt_compact_every; /* survivors are counted at every k-th element */
     int last_compact; /* the last trace ran the compacting kernel */
@@ -416,6 +419,8 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_group);
     if (ctx->d_gen)
         (void)hipFree(ctx->d_gen);
+    if (ctx->d_probe_in)
+        (void)hipFree(ctx->d_probe_in);
     if (ctx->d_opd_ref)
         (void)hipFree(ctx->d_opd_ref);
     for (int k = 0; k < 2; ++k) {
@@ -1228,7 +1233,7 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
                        "rt_probe: the linear fills address the SoA layout");
     /* rows 1..L-1 of the four arrays; row 0 (the input rays) is preserved */
     RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
-    if (mode == 0 || (mode >= 5 && mode <= 9)) {
+    if (mode == 0 || (mode >= 5 && mode <= 9) || mode == 13 || mode == 14) {
         /* the trace kernel's store pattern without its arithmetic, in the
          * layout in force (SoA or tile_rays):
          *   0  80 B/op, 16-byte stores, 48 B/ray input read from HBM
@@ -1236,11 +1241,34 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
          *   7  56 B/op (i served from u), 8-byte stores like the default
          *      kernel, input from HBM                     8  same, no read */
         const int block = ctx->opt_block;
-        const int rp = mode >= 7 ? 1 : 2;
+        const int rp = mode >= 7 ? 1 : 2; /* 7..14: one ray per lane */
         const unsigned grid =
             (unsigned)((ld / rp + block - 1) / block);
         const rt_lay lay = rt_layout(ctx);
         const double *win = ctx->d_buf;
+        if (mode == 13 || mode == 14) {
+            /* 7 with the input rows in their own allocation: 13 = uncached
+             * (MTYPE UC: reads bypass the L2), 14 = ordinary device memory */
+            const size_t need = (size_t)6 * ld * sizeof(double);
+            if (ctx->probe_in_bytes != need || ctx->probe_in_uc != (mode == 13)) {
+                if (ctx->d_probe_in)
+                    (void)hipFree(ctx->d_probe_in);
+                ctx->d_probe_in = NULL;
+                ctx->probe_in_bytes = 0;
+                if (mode == 13)
+                    RT_HIP(ctx, hipExtMallocWithFlags(&ctx->d_probe_in, need,
+                                                      hipDeviceMallocUncached));
+                else
+                    RT_HIP(ctx, hipMalloc(&ctx->d_probe_in, need));
+                RT_HIP(ctx, hipMemsetAsync(ctx->d_probe_in, 0, need,
+                                           ctx->stream));
+                ctx->probe_in_bytes = need;
+                ctx->probe_in_uc = mode == 13;
+                RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
+            }
+            win = (const double *)ctx->d_probe_in;
+        }
 #define RT_PROBE(IN, RP, SI)                                                  \
     do {                                                                      \
         switch (ctx->opt_probe_store) {                                       \
@@ -1259,13 +1287,15 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
         case 6: RT_PROBE(2, 2, 1); break;
         case 7: RT_PROBE(0, 1, 0); break;
         case 9: RT_PROBE(3, 1, 0); break; /* 7 with non-temporal loads */
+        case 13:
+        case 14: RT_PROBE(4, 1, 0); break;
         default: RT_PROBE(2, 1, 0); break;
         }
 #undef RT_PROBE_FL
 #undef RT_PROBE
         *bytes = (double)ld * ((mode >= 7 ? 56. : 80.) * (L - 1) +
-                               ((mode == 0 || mode == 7 || mode == 9) ? 48.
-                                                                       : 0.));
+                               ((mode == 0 || mode == 7 || mode == 9 ||
+                                 mode >= 13) ? 48. : 0.));
     } else if (mode == 10 || mode == 11 || mode == 12) {
         /* 56 B pattern, K = 2 / 4 / 8 rays per lane one after the other,
          * inputs loaded up front */

@@ -502,6 +502,10 @@ __global__ void rt_probe_pattern_kernel(int start, int stop,
                 a.Y + (start - 1) * a.ss + c * a.cs + col));
             u[c] = __builtin_nontemporal_load(reinterpret_cast<const V *>(
                 a.U + (start - 1) * a.ss + c * a.cs + col));
+        } else if constexpr (IN == 4) { /* from a separate buffer `in`,
+                                           [6][ld] (uncached allocation) */
+            y[c] = *reinterpret_cast<const V *>(in + (int64_t)c * ld + j);
+            u[c] = *reinterpret_cast<const V *>(in + (int64_t)(3 + c) * ld + j);
         } else if constexpr (IN == 1) { /* from a 3 MB window that stays in
                                            L2 */
             const int64_t k = j & 0xffff;

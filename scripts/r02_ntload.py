@@ -16,7 +16,10 @@ for rep in range(3):
     for mode, name in ((7, "plain loads"), (9, "non-temporal loads"),
                        (10, "2 rays per lane in sequence, inputs up front"),
                        (11, "4 rays per lane in sequence"),
-                       (12, "8 rays per lane in sequence"), (8, "no read")):
+                       (12, "8 rays per lane in sequence"),
+                       (13, "input rows in an UNCACHED allocation"),
+                       (14, "input rows in a separate ordinary allocation"),
+                       (8, "no read")):
         t = []
         for _ in range(10):
             ms, b = g.engine.probe(mode)
