@@ -330,7 +330,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value);
  * default kernel's own pattern (56 B per op, 8-byte stores) with / without
  * the input read; 9 = mode 7 with non-temporal loads; 10 / 11 / 12 = mode 7
  * with 2 / 4 / 8 rays per lane marched one after the other, inputs loaded up
- * front.  Modes 0 and 5-12 honour "tile_rays" and "block".  Returns
+ * front; 13 / 14 = mode 7 with the input rows in an uncached / an ordinary
+ * allocation of their own.  Modes 0 and 5-14 honour "tile_rays" and "block".  Returns
  * kernel time and the bytes moved.  Overwrites rows >= 1.
  */
 int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes);
