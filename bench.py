@@ -338,7 +338,15 @@ def main():
 
     def check_device():
         # opens the HIP runtime: only after the forked CPU leg (N = 1)
+        nonlocal local_rank
         have = D.visible_devices()
+        if have == 1 and world > 1 and local_rank and any(
+                os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES",
+                                            "ROCR_VISIBLE_DEVICES",
+                                            "CUDA_VISIBLE_DEVICES")):
+            # the launcher masks the devices per rank: ours is device 0 (two
+            # ranks that really share one GPU are refused by RCCL below)
+            local_rank = 0
         if local_rank >= have:
             raise SystemExit("--gpus %d: %d devices needed, %d visible"
                              % (args.gpus, max(world, local_rank + 1), have))
