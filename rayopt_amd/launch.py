@@ -30,14 +30,16 @@ def _frame(u, z):
 
 
 def _sag0(element, y):
-    """-surface_sag of element 0 at the object point (z of the object
-    surface), Spheroid.surface_sag rayopt/elements.py:440-455."""
+    """-surface_sag of element 0 at the object point(s) ``y`` ((3,) or
+    (F,3)) (z of the object surface), Spheroid.surface_sag
+    rayopt/elements.py:440-455."""
+    y = np.asarray(y)
     c = getattr(element, "curvature", 0.)
     asph = getattr(element, "aspherics", None)
     if not c and asph is None:
-        return -y[2]
-    r2 = y[0]*y[0] + y[1]*y[1]
-    e = y[2]
+        return -y[..., 2]
+    r2 = y[..., 0]*y[..., 0] + y[..., 1]*y[..., 1]
+    e = y[..., 2]
     if c:
         k = getattr(element, "conic", 0.)
         e = e - c*r2/(1 + np.sqrt(1 - (1 + k)*c**2*r2))
@@ -51,32 +53,41 @@ def _sag0(element, y):
 
 
 def _direction(yo, angle, projection):
-    """Unit direction of field ``yo`` (fractional, 2,) for an object at
-    infinity with semi-angle ``angle`` (InfiniteConjugate.map,
-    rayopt/conjugates.py:208-234)."""
+    """Unit directions of the fields ``yo`` (fractional, (F,2) or (2,)) for
+    an object at infinity with semi-angle ``angle`` (InfiniteConjugate.map,
+    rayopt/conjugates.py:208-234); every field at once, entry by entry the
+    arithmetic of the one-field call."""
+    yo = np.asarray(yo, dtype=float)
+    u = np.empty(yo.shape[:-1] + (3,))
     if projection == "rectilinear":
-        y = yo*np.tan(angle)
-        u = np.array((y[0], y[1], 1.))
-        return u/np.sqrt(np.square(u).sum(-1))
+        u[..., :2] = yo*np.tan(angle)
+        u[..., 2] = 1.
+        return u/np.sqrt(np.square(u).sum(-1))[..., None]
     if projection == "stereographic":
         y = yo*(2*np.tan(angle/2))
         r = np.square(y).sum(-1)/4
-        return np.array((y[0], y[1], 1 - r))/(r + 1)
+        u[..., :2] = y
+        u[..., 2] = 1 - r
+        return u/(r + 1)[..., None]
     if projection == "equisolid":
         y = yo*(2*np.sin(angle/2))
         r = np.square(y).sum(-1)
-        y = y*np.sqrt(1 - r/4)
-        return np.array((y[0], y[1], 1 - r/2))
+        u[..., :2] = y*np.sqrt(1 - r/4)[..., None]
+        u[..., 2] = 1 - r/2
+        return u
     if projection == "orthographic":
         y = yo*np.sin(angle)
-        r = np.square(y).sum(-1)
-        return np.array((y[0], y[1], np.sqrt(1 - r)))
+        u[..., :2] = y
+        u[..., 2] = np.sqrt(1 - np.square(y).sum(-1))
+        return u
     if projection == "equidistant":
         y = yo*angle
         behind = np.square(y).sum(-1) > (np.pi/2)**2
         y = np.sin(y)
         z = np.sqrt(np.square(y).sum(-1))
-        return np.array((y[0], y[1], -z if behind else z))
+        u[..., :2] = y
+        u[..., 2] = np.where(behind, -z, z)
+        return u
     raise NotImplementedError("projection %r" % projection)
 
 
@@ -107,14 +118,13 @@ def field_frames(system, yo, z, a):
     axis = np.zeros((nf, 3))
     axis[:, 2] = z
     if not obj.finite:
-        u = np.array([_direction(yo[f], obj.angle, projection)
-                      for f in range(nf)])
+        u = _direction(yo, obj.angle, projection)
         out["am"] = np.fabs(a).max((1, 2))
         out["base"] = axis - z[:, None]*u
     else:
         y = np.zeros((nf, 3))
         y[:, :2] = -yo*obj.radius
-        y[:, 2] = [_sag0(system[0], yf) for yf in y]
+        y[:, 2] = _sag0(system[0], y)
         u = axis if _telecentric(obj) else axis - y
         out["finite"] = 1
         out["flip"] = z < 0
@@ -145,14 +155,13 @@ def aim_seeds(system, yo, z0, a0, group=0):
     out = np.zeros(len(yo), dtype=AIM_SEED_DTYPE)
     out["yo"] = yo
     out["z0"], out["a0"], out["group"] = z0, a0, group
-    for f in range(len(yo)):
-        if not obj.finite:
-            out[f]["dir"] = _direction(yo[f], obj.angle, projection)
-        else:
-            y = np.zeros(3)
-            y[:2] = -yo[f]*obj.radius
-            y[2] = _sag0(system[0], y)
-            out[f]["finite"] = 1
-            out[f]["telecentric"] = _telecentric(obj)
-            out[f]["point"] = y
+    if not obj.finite:
+        out["dir"] = _direction(yo, obj.angle, projection)
+    else:
+        y = np.zeros((len(yo), 3))
+        y[:, :2] = -yo*obj.radius
+        y[:, 2] = _sag0(system[0], y)
+        out["finite"] = 1
+        out["telecentric"] = _telecentric(obj)
+        out["point"] = y
     return out

@@ -133,13 +133,27 @@ PATTERNS = {
 }
 
 
+_PATTERN_CACHE = {}
+
+
 def pupil_distribution(distribution, nrays, rng=None):
     """Return ``(ref, xy, weight)``: index of the reference ray, (n,2)
-    coordinates, weights (None unless a quadrature rule)."""
+    coordinates, weights (None unless a quadrature rule).  The deterministic
+    patterns are computed once per ``(distribution, nrays)`` -- a merit
+    function asks for the same one at every evaluation -- and handed out as
+    copies."""
     if nrays == 1:
         return 0, np.zeros((1, 2)), None
     try:
         pattern = PATTERNS[distribution]
     except KeyError:
         raise ValueError("unknown ray distribution", distribution) from None
-    return pattern(nrays, rng)
+    if distribution == "random":
+        return pattern(nrays, rng)
+    key = distribution, nrays
+    if key not in _PATTERN_CACHE:
+        if len(_PATTERN_CACHE) > 64:
+            _PATTERN_CACHE.clear()
+        _PATTERN_CACHE[key] = pattern(nrays, rng)
+    ref, xy, weight = _PATTERN_CACHE[key]
+    return ref, xy.copy(), None if weight is None else weight.copy()
