@@ -100,6 +100,8 @@ struct rt_ctx {
     void *h_pin[2]; /* pinned staging for large pageable copies */
     hipEvent_t pin_done[2];
     int pin_busy[2]; /* a DMA recorded in pin_done[k] may still use h_pin[k] */
+    char *h_aim; /* pinned: rt_aim_pupil's tables | seeds out, z | a | status in */
+    size_t h_aim_bytes;
     double *d_w;  /* ray weights, NULL = uniform 1/n */
     size_t w_cap;
     int64_t w_n;  /* rays the weights were given for (must equal n) */
@@ -406,6 +408,8 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_scratch);
     if (ctx->d_user)
         (void)hipFree(ctx->d_user);
+    if (ctx->h_aim)
+        (void)hipHostFree(ctx->h_aim);
     for (int i = 0; i < 2; ++i)
         if (ctx->h_pin[i]) {
             (void)hipHostFree(ctx->h_pin[i]);
@@ -860,37 +864,56 @@ int rt_aim_pupil(rt_ctx *ctx, const rt_aim_seed *seeds, int nfields,
                            "rt_aim_pupil: field %d names table %d of %d", f,
                            seeds[f].group, ctx->ngroups);
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    /* scratch: tables | seeds | z | a | status, each 256-byte aligned */
+    /* scratch: tables | seeds | z | a | status, each 256-byte aligned; the
+     * same layout in one pinned host buffer, so that a call costs one copy
+     * in, the kernel, one copy out */
     const size_t ntab = (size_t)ctx->nsurf * ctx->ngroups;
     const size_t tb = (sizeof(rt_surface) * ntab + 255) / 256 * 256;
     const size_t sb = (sizeof(rt_aim_seed) * nfields + 255) / 256 * 256;
     const size_t zb = (sizeof(double) * nfields + 255) / 256 * 256;
     const size_t ab = (sizeof(double) * 4 * nfields + 255) / 256 * 256;
     const size_t cb = (sizeof(int32_t) * nfields + 255) / 256 * 256;
-    int rc = rt_need_scratch(ctx, tb + sb + zb + ab + cb);
+    const size_t all = tb + sb + zb + ab + cb;
+    int rc = rt_need_scratch(ctx, all);
     if (rc != RT_OK)
         return rc;
-    char *base = (char *)ctx->d_scratch;
+    if (all > ctx->h_aim_bytes) {
+        if (ctx->h_aim)
+            (void)hipHostFree(ctx->h_aim);
+        ctx->h_aim = NULL;
+        ctx->h_aim_bytes = 0;
+        const size_t want = all + all / 2;
+        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_aim, want));
+        ctx->h_aim_bytes = want;
+    }
+    char *base = (char *)ctx->d_scratch, *host = ctx->h_aim;
     rt_surface *d_tab = (rt_surface *)base;
     rt_aim_seed *d_seeds = (rt_aim_seed *)(base + tb);
     double *d_z = (double *)(base + tb + sb);
     double *d_a = (double *)(base + tb + sb + zb);
     int32_t *d_status = (int32_t *)(base + tb + sb + zb + ab);
-    RT_HIP(ctx, hipMemcpyAsync(d_tab, ctx->h_surf, sizeof(rt_surface) * ntab,
-                               hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(d_seeds, seeds, sizeof(rt_aim_seed) * nfields,
-                               hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(rt_aim_kernel, dim3((unsigned)((nfields + 63) / 64)),
-                       dim3(64), 0, ctx->stream, d_tab, ctx->nsurf, d_seeds,
-                       nfields, *args, d_z, d_a, d_status);
+    memcpy(host, ctx->h_surf, sizeof(rt_surface) * ntab);
+    memcpy(host + tb, seeds, sizeof(rt_aim_seed) * nfields);
+    RT_HIP(ctx, hipMemcpyAsync(base, host, tb + sb, hipMemcpyHostToDevice,
+                               ctx->stream));
+    /* one wavefront per field while they are all resident at once, 16
+     * fields per wavefront beyond that (rt_kernels.h) */
+    if (nfields <= 32768)
+        hipLaunchKernelGGL(rt_aim_kernel<true>, dim3((unsigned)nfields),
+                           dim3(4), 0, ctx->stream, d_tab, ctx->nsurf, d_seeds,
+                           nfields, *args, d_z, d_a, d_status);
+    else
+        hipLaunchKernelGGL(rt_aim_kernel<false>,
+                           dim3((unsigned)(((int64_t)nfields * 4 + 63) / 64)),
+                           dim3(64), 0, ctx->stream, d_tab, ctx->nsurf,
+                           d_seeds, nfields, *args, d_z, d_a, d_status);
     RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipMemcpyAsync(z, d_z, sizeof(double) * nfields,
-                               hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(a, d_a, sizeof(double) * 4 * nfields,
-                               hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(status, d_status, sizeof(int32_t) * nfields,
+    RT_HIP(ctx, hipMemcpyAsync(host + tb + sb, base + tb + sb, zb + ab + cb,
                                hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(z, host + tb + sb, sizeof(double) * nfields);
+    memcpy(a, host + tb + sb + zb, sizeof(double) * 4 * nfields);
+    memcpy(status, host + tb + sb + zb + ab, sizeof(int32_t) * nfields);
     return RT_OK;
 }
 

@@ -634,25 +634,66 @@ __global__ void rt_generate_kernel(const rt_field *__restrict__ fields,
     a.T[col] = 0.;
 }
 
-/* batched aiming: one lane per field runs System.pupil start to finish
- * (rt_aim.h); the table, seeds and results live in the scratch buffer */
-__global__ void rt_aim_kernel(const rt_surface *__restrict__ tab, int nsurf,
+/*
+ * System.pupil for F fields: FOUR lanes per field.  Every lane of a field
+ * repeats the chief-ray solve (same arithmetic, same result), then lane m
+ * runs ONE of the four marginal root finds -- m = 0..3 in the order the
+ * sequential rt_aim_field takes them (+mer, -mer, +sag, -sag) -- so the
+ * longest dependent chain is chief + one marginal instead of chief + four.
+ * The lanes then agree on what the sequential code would have returned: the
+ * status of the first solve that failed, NaN for it and for every later
+ * entry.  Bit-identical to rt_aim_field (tests/hostemu runs that one).
+ *
+ * UNIFORM: one field per workgroup (4 lanes of one wavefront): the field's
+ * surface table is wave-uniform and is read with scalar loads, like the trace
+ * kernel's -- the one-ray traces are chains of dependent table reads, and
+ * per-lane vector loads of the table were what the solve waited for.
+ * !UNIFORM: 16 fields per wavefront, for batches so large that one wavefront
+ * per field would not be resident at once; the table is read per lane.
+ */
+template <bool UNIFORM>
+__global__ void __launch_bounds__(64) rt_aim_kernel(const rt_surface *__restrict__ tab, int nsurf,
                               const rt_aim_seed *__restrict__ seeds, int nf,
                               rt_aim_args args, double *__restrict__ z,
                               double *__restrict__ a,
                               int32_t *__restrict__ status)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = t >> 2, m = t & 3;
     if (f >= nf)
         return;
     const rt_aim_seed sd = seeds[f];
-    double zf, af[2][2];
-    status[f] = rt_aim_field(tab + (int64_t)sd.group * nsurf, nsurf, &sd,
-                             &args, &zf, af);
-    z[f] = zf;
-    for (int i = 0; i < 2; ++i)
-        for (int k = 0; k < 2; ++k)
-            a[(f * 2 + i) * 2 + k] = af[i][k];
+    const int group =
+        UNIFORM ? __builtin_amdgcn_readfirstlane(sd.group) : sd.group;
+    const rt_surface *__restrict__ tabf = tab + (int64_t)group * nsurf;
+    double zf;
+    const int rc = rt_aim_chief(tabf, &sd, &args, fabs(sd.a0), &zf);
+    const int axis = 1 - (m >> 1), sign = 1 - (m & 1);
+    int rcm = 0;
+    double val = NAN;
+    if (!rc) {
+        const double e = 2 * sign - 1.;
+        double x;
+        rcm = rt_aim_marginal(tabf, nsurf, &sd, &args, zf, axis == 0 ? e : 0.,
+                              axis == 1 ? e : 0., &x);
+        if (!rcm)
+            val = e * fabs(x);
+    }
+    int st = rc;
+    bool unreached = rc != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int rk = __shfl(rcm, k, 4);
+        if (!st && rk)
+            st = rk;
+        if (k < m && rk)
+            unreached = true;
+    }
+    a[(f * 2 + sign) * 2 + axis] = unreached ? NAN : val;
+    if (m == 0) {
+        z[f] = zf;
+        status[f] = st;
+    }
 }
 
 /* ------------------------------------------------------------------ */
