@@ -276,9 +276,8 @@ class FieldAimer:
         args["stop"], args["rim"] = system.stop, bool(rim)
         args["maxiter"], args["tol"] = self.maxiter, self.tol
         args["no_chief"] = not self._aims(rim)[0]
-        seeds = np.concatenate([
-            aim_seeds(system, yo, z0, a0, group)
-            for group, (z0, a0) in enumerate(starts)])
+        seeds = aim_seeds(system, yo, [z0 for z0, _ in starts],
+                          [a0 for _, a0 in starts], range(len(starts)))
         z, a, status = engine.aim_pupil(seeds, args)
         if status.any():
             bad = int(np.flatnonzero(status)[0])

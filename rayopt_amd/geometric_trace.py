@@ -523,9 +523,7 @@ class GeometricTrace(Trace):
         else:
             l = np.asarray(l, dtype=float)
             groups = len(l)
-            fields = np.concatenate([
-                field_frames(self.system, yo, z[g], a[g])
-                for g in range(groups)])
+            fields = field_frames(self.system, yo, z, a, groups)
             per = len(fields)//groups*yp.shape[0]
             if per % 64:
                 raise ValueError(

@@ -98,21 +98,50 @@ def _telecentric(obj):
     return bool(pupil.telecentric)
 
 
-def field_frames(system, yo, z, a):
+def _cross(a, b):
+    """``np.cross`` of (...,3) arrays, the same products and differences,
+    without its axis shuffling."""
+    out = np.empty(np.broadcast(a, b).shape)
+    out[..., 0] = a[..., 1]*b[..., 2] - a[..., 2]*b[..., 1]
+    out[..., 1] = a[..., 2]*b[..., 0] - a[..., 0]*b[..., 2]
+    out[..., 2] = a[..., 0]*b[..., 1] - a[..., 1]*b[..., 0]
+    return out
+
+
+_SIGNS = np.array(((-1., -1.), (1., 1.)))
+
+
+def _apertures(a, nf):
+    """Pupil apertures as (F,2,2): from a scalar radius, (F,) radii, one
+    (2,2) ``[[-sag,-mer],[+sag,+mer]]`` or (F,2,2)."""
+    a = np.asarray(a, dtype=float)
+    if a.ndim <= 1:     # scalar radius, or one radius per field
+        a = a[..., None, None]*_SIGNS
+    return np.broadcast_to(a, (nf, 2, 2))
+
+
+def field_frames(system, yo, z, a, groups=None):
     """``FIELD_DTYPE`` array, one entry per row of ``yo`` (F,2) fractional
     object coordinates.  ``z``: pupil distance(s) from the vertex of element
     0, scalar or (F,); ``a``: pupil aperture(s): scalar radius, (F,) radii,
-    (2,2) ``[[-sag,-mer],[+sag,+mer]]`` or (F,2,2)."""
+    (2,2) ``[[-sag,-mer],[+sag,+mer]]`` or (F,2,2).
+
+    ``groups=G``: ``z`` and ``a`` are sequences of G such entries (one per
+    wavelength / variant) and the result holds G*F frames, group-major --
+    the concatenation of the G single calls, built in one go."""
     obj = system.object
     projection = getattr(obj, "projection", None) or \
         getattr(obj, "extra", {}).get("projection", "rectilinear")
     yo = np.atleast_2d(np.asarray(yo, dtype=float))
+    if groups is not None:
+        per = yo.shape[0]
+        z = np.concatenate([np.broadcast_to(np.asarray(zg, dtype=float),
+                                            (per,)) for zg in z])
+        a = np.concatenate([_apertures(ag, per) for ag in a])
+        yo = np.tile(yo, (groups, 1))
     nf = yo.shape[0]
     z = np.broadcast_to(np.asarray(z, dtype=float), (nf,))
-    a = np.asarray(a, dtype=float)
-    if a.ndim <= 1:     # scalar radius, or one radius per field
-        a = a[..., None, None]*np.array(((-1., -1.), (1., 1.)))
-    a = np.broadcast_to(a, (nf, 2, 2))
+    a = _apertures(a, nf)
     out = np.zeros(nf, dtype=FIELD_DTYPE)
     out["z"] = z
     axis = np.zeros((nf, 3))
@@ -132,9 +161,9 @@ def field_frames(system, yo, z, a):
         out["base"] = y
     # sagittal / meridional unit vectors about the axis (0, 0, z), all
     # fields at once (_frame)
-    s = np.cross(u, axis)
+    s = _cross(u, axis)
     s[np.all(s == 0, axis=1)] = (1., 0., 0.)
-    m = np.cross(u, s)
+    m = _cross(u, s)
     out["u"] = u
     out["s"] = s/np.sqrt(np.square(s).sum(-1))[:, None]
     out["m"] = m/np.sqrt(np.square(m).sum(-1))[:, None]
@@ -147,21 +176,29 @@ def aim_seeds(system, yo, z0, a0, group=0):
     a field at infinity in the object's projection; object point of a finite
     field), from which the device rebuilds :func:`field_frames` for every
     trial distance; the starting pupil ``z0, a0`` and the surface table
-    (wavelength) ``group`` the fields are aimed at."""
+    (wavelength) ``group`` the fields are aimed at.
+
+    ``z0, a0, group`` may be sequences of G values: the result then holds
+    G*F seeds, group-major (every field once per table)."""
     obj = system.object
     projection = getattr(obj, "projection", None) or \
         getattr(obj, "extra", {}).get("projection", "rectilinear")
     yo = np.atleast_2d(np.asarray(yo, dtype=float))
-    out = np.zeros(len(yo), dtype=AIM_SEED_DTYPE)
+    per = len(yo)
+    out = np.zeros(per, dtype=AIM_SEED_DTYPE)
     out["yo"] = yo
-    out["z0"], out["a0"], out["group"] = z0, a0, group
     if not obj.finite:
         out["dir"] = _direction(yo, obj.angle, projection)
     else:
-        y = np.zeros((len(yo), 3))
+        y = np.zeros((per, 3))
         y[:, :2] = -yo*obj.radius
         y[:, 2] = _sag0(system[0], y)
         out["finite"] = 1
         out["telecentric"] = _telecentric(obj)
         out["point"] = y
+    if np.ndim(group):
+        out = np.tile(out, len(group))
+        z0, a0, group = (np.repeat(np.asarray(v), per)
+                         for v in (z0, a0, group))
+    out["z0"], out["a0"], out["group"] = z0, a0, group
     return out

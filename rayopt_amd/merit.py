@@ -181,8 +181,10 @@ class SpotOperand(Operand):
         t.rays_points(self.fields, wavelength=l, nrays=self.nrays,
                       distribution=self.distribution, clip=self.clip,
                       aim=self.aim, keep=[-1])
-        self.kernel_ms.append(t.kernel_ms())
         r = t.rms_fields(lost=self.lost).ravel()
+        # after the reduction has been waited for: the trace's events are
+        # complete by then and the query costs no round trip of its own
+        self.kernel_ms.append(t.kernel_ms())
         return np.where(np.isfinite(r), r, self.penalty)
 
     def get_variants(self, systems):
