@@ -448,6 +448,81 @@ def test_aiming_kernel_gpu():
         FieldAimer(system, maxiter=2).pupil([(0, 0), (0, 1.)])
 
 
+def _seeds_and_args(system, fields, engine, rim=False, maxiter=60,
+                    wavelengths=None):
+    """What FieldAimer hands rt_aim_pupil, with the tables uploaded."""
+    from rayopt_amd._lib import AIM_ARGS_DTYPE
+    from rayopt_amd.aiming import start_pupil
+    from rayopt_amd.launch import aim_seeds
+    from rayopt_amd.pack import pack_system
+    ls = [system.wavelengths[0]] if wavelengths is None else wavelengths
+    engine.upload_system(np.stack([
+        pack_system(system, l, system.refractive_index(l, 0))[0]
+        for l in ls]))
+    starts = [start_pupil(system, l) for l in ls]
+    seeds = aim_seeds(system, fields, [z for z, _ in starts],
+                      [a for _, a in starts], range(len(ls)))
+    args = np.zeros((), dtype=AIM_ARGS_DTYPE)
+    args["stop"], args["rim"] = system.stop, rim
+    args["maxiter"], args["tol"] = maxiter, 1e-9
+    return seeds, args
+
+
+@pytest.mark.gpu
+def test_aiming_kernel_equals_its_host_build_bit_for_bit():
+    """The device kernel gives four lanes to a field (one marginal solve
+    each); tests/hostemu runs the sequential rt_aim_field of the same
+    header.  Same z, a and status, bit for bit -- also where solves fail
+    (which entries are NaN, which status wins) and with the fields of
+    several wavelengths (tables) in one launch."""
+    from fake_engine import OracleEngine
+    rng = np.random.default_rng(3)
+    fields = np.r_[[[0., 0.]], rng.uniform(-.7, .7, (40, 2))]
+    for name, text in AIM_SYSTEMS.items():
+        system = ra.system_from_yaml(text)
+        for rim in (False, True):
+            for maxiter in (60, 6, 3, 1):
+                dev, emu = ra.get_engine(), OracleEngine()
+                seeds, args = _seeds_and_args(system, fields, dev, rim,
+                                              maxiter)
+                _seeds_and_args(system, fields, emu, rim, maxiter)
+                got = dev.aim_pupil(seeds, args)
+                want = emu.aim_pupil(seeds, args)
+                for g, w, what in zip(got, want, ("z", "a", "status")):
+                    assert np.array_equal(g, w, equal_nan=True), \
+                        (name, rim, maxiter, what)
+                if maxiter == 60:
+                    assert not got[2].any()
+    assert_some_failed = False
+    system = ra.system_from_yaml(DISPERSIVE_COOKE)
+    dev, emu = ra.get_engine(), OracleEngine()
+    seeds, args = _seeds_and_args(system, fields, dev, False, 5,
+                                  system.wavelengths)
+    _seeds_and_args(system, fields, emu, False, 5, system.wavelengths)
+    got, want = dev.aim_pupil(seeds, args), emu.aim_pupil(seeds, args)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w, equal_nan=True)
+    assert_some_failed = got[2].any() and not got[2].all()
+    assert assert_some_failed, "maxiter=5 should fail some fields only"
+
+
+@pytest.mark.gpu
+def test_aiming_kernel_large_batches_take_the_packed_kernel():
+    """Beyond 32768 fields the launch packs 16 fields into a wavefront and
+    reads the tables per lane: the same values as one wavefront per field."""
+    system = ra.system_from_yaml(DISPERSIVE_COOKE)
+    rng = np.random.default_rng(4)
+    fields = rng.uniform(-.7, .7, (12000, 2))
+    engine = ra.get_engine()
+    seeds, args = _seeds_and_args(system, fields, engine, False, 60,
+                                  system.wavelengths)       # 36000 seeds
+    z, a, status = engine.aim_pupil(seeds, args)
+    assert not status.any()
+    pick = rng.choice(len(seeds), 3000, replace=False)
+    zs, as_, st = engine.aim_pupil(seeds[pick], args)
+    assert np.array_equal(z[pick], zs) and np.array_equal(a[pick], as_)
+
+
 def _pupils_checks(engine_factory):
     """Every field at every wavelength in one launch equals one aimer per
     wavelength, value for value; the host-loop form agrees."""
