@@ -333,6 +333,10 @@ def main():
     # bookkeeping, the configs[4] leg) can run on a one-GPU box.  The line
     # it prints is marked "test_mode" and is not a measurement.
     share = bool(os.environ.get("RT_BENCH_SHARE_DEVICE"))
+    # ... unless RT_TRANSPORT_LIBRARY names a stand-in for librccl.so (the
+    # shared-memory transport of tests/stubs): then the engine's gather runs
+    # as it is, nranks > 1 branch included, and rank 0 checks every shard
+    stand_in = os.environ.get("RT_TRANSPORT_LIBRARY", "")
     if share:
         local_rank = 0
 
@@ -404,12 +408,12 @@ def main():
     # there is an exchange); no fallback: without it the job fails
     d_dst = 0
     if dist_mode:
-        if not share:
+        if not share or stand_in:
             D.init_engine_comm(eng, group)
         if rank == 0:
             d_dst = eng.scratch(int(counts.sum())*3*8)
     job = Job(args, group, g, counts, d_dst)
-    job.exchange = not share
+    job.exchange = not share or bool(stand_in)
 
     mode = {"clip": clip}
 
@@ -487,7 +491,16 @@ def main():
         assert np.array_equal(mine, ylast, equal_nan=True), \
             "gathered shard 0 differs from the local result"
         assert np.isfinite(gathered).mean() > 0.9
-        del gathered
+    if dist_mode and stand_in and job.exchange:
+        # test mode: every rank's image row travels over the host group too
+        # and rank 0 compares the whole gathered buffer with it
+        rows = group.gather(ylast)
+        if rank == 0:
+            for have, want in zip(D.split_gathered(gathered, counts), rows):
+                assert np.array_equal(have, want, equal_nan=True), \
+                    "a gathered shard differs from its rank's result"
+        del rows
+    gathered = None
 
     api = None
     if engine_leg is not None and rank == 0:
@@ -595,8 +608,15 @@ def main():
         out["kernel_ms_per_rank"] = per_rank_kernel_ms
         if share:
             out["test_mode"] = ("RT_BENCH_SHARE_DEVICE: all ranks on device "
-                                "0, RCCL exchange left out -- not a "
-                                "measurement")
+                                "0, %s -- not a measurement" % (
+                                    "rt_gather_final run over the stand-in "
+                                    "transport %s, every gathered shard "
+                                    "checked" % os.path.basename(stand_in)
+                                    if stand_in else
+                                    "RCCL exchange left out"))
+        elif stand_in:
+            out["test_mode"] = ("RT_TRANSPORT_LIBRARY=%s replaces RCCL -- "
+                                "not a measurement" % stand_in)
     if configs4 is not None:
         out["configs4"] = configs4
     if api is not None:

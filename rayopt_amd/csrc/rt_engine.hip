@@ -1774,11 +1774,25 @@ static int rt_rccl_load(rt_ctx *ctx)
 {
     if (g_rccl.lib)
         return RT_OK;
-    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib)
-        lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib)
-        return rt_fail(ctx, RT_ERR_RCCL, "dlopen(librccl.so): %s", dlerror());
+    /* RT_TRANSPORT_LIBRARY names another library with RCCL's entry points:
+     * no fallback (if it is set it must load); the GPU tests point it at a
+     * shared-memory stand-in so that several ranks sharing one device --
+     * which RCCL refuses -- run the nranks > 1 branch below */
+    const char *other = getenv("RT_TRANSPORT_LIBRARY");
+    void *lib;
+    if (other && *other) {
+        lib = dlopen(other, RTLD_NOW | RTLD_LOCAL);
+        if (!lib)
+            return rt_fail(ctx, RT_ERR_RCCL, "dlopen(%s): %s", other,
+                           dlerror());
+    } else {
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib)
+            lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib)
+            return rt_fail(ctx, RT_ERR_RCCL, "dlopen(librccl.so): %s",
+                           dlerror());
+    }
 #define RT_SYM(field, name)                                                   \
     do {                                                                      \
         *(void **)(&g_rccl.field) = dlsym(lib, name);                         \
