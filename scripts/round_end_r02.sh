@@ -31,6 +31,9 @@ say "forced-dist under torch.distributed.run, gather every step rc=$?"; cat "$OU
 RT_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 2 --steps 5 --warmup 1 --settle 0 \
    > "$OUT/bench_two_ranks_one_device_TEST_MODE.json" 2> "$OUT/bench_two_ranks.err"
 say "two ranks on one device (host side only, test mode) rc=$?"; cat "$OUT/bench_two_ranks_one_device_TEST_MODE.json" | tee -a "$OUT/summary.txt"
+RT_BENCH_SHARE_DEVICE=1 RT_TRANSPORT_LIBRARY=$REPO/tests/stubs/librt_shm_transport.so timeout 900 python bench.py --gpus 2 --rays 2000000 --steps 5 --warmup 1 --settle 0 --no-configs4 \
+   > "$OUT/bench_two_ranks_stand_in_transport_TEST_MODE.json" 2> "$OUT/bench_two_ranks_stand_in.err"
+say "two ranks on one device, rt_gather_final over the shared-memory stand-in for RCCL (test mode) rc=$?"; cat "$OUT/bench_two_ranks_stand_in_transport_TEST_MODE.json" | tee -a "$OUT/summary.txt"
 timeout 300 python scripts/r02_probe.py D > "$OUT/host_overhead.jsonl" 2>&1
 say "host overhead rc=$?"; cat "$OUT/host_overhead.jsonl" | tee -a "$OUT/summary.txt"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- \

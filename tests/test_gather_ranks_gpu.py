@@ -78,13 +78,20 @@ WORKER = textwrap.dedent("""
                     if not np.array_equal(parts[r], box[r], equal_nan=True):
                         bad.append((rnd, which, r))
                 assert np.isfinite(have[root]).mean() > .5
-    # two gathers queued back to back without a wait in between (the second
-    # snapshot must not overtake the first transfer): Y then T of one trace
-    if rank == root:
-        d1 = eng.scratch((total*3 + total)*8)
+    # the row is snapshotted when the gather is issued: a trace of other rays
+    # queued right behind it must not change what arrives
+    want = group.gather(np.asarray(g.y[L - 1]))
+    y, u = disc_bundle(n, 12., 3., 999 + rank)
     eng.gather_final(RT_Y, L - 1, counts, root, d3)
-    g.propagate(clip=True)          # rewrites the rows while "in flight"
+    g.rays_given(y, u)
+    g.propagate(clip=True)
     eng.comm_sync()
+    have = group.gather(
+        eng.copy_to_host(d3, total*3*8) if rank == root else None)
+    if rank == 0:
+        for r, part in enumerate(D.split_gathered(have[root], counts, 3)):
+            if not np.array_equal(part, want[r], equal_nan=True):
+                bad.append(("snapshot", r))
     group.barrier()
     if rank == 0:
         assert not bad, bad
