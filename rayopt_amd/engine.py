@@ -302,6 +302,9 @@ class Engine:
             counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), root,
             ctypes.c_void_p(d_dst)), "rt_gather_final")
 
+    def comm_destroy(self):
+        self._check(self.lib.rt_comm_destroy(self.ctx), "rt_comm_destroy")
+
     def comm_sync(self):
         self._check(self.lib.rt_comm_sync(self.ctx), "rt_comm_sync")
 

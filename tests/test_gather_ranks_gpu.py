@@ -77,7 +77,8 @@ WORKER = textwrap.dedent("""
                 for r in range(world):
                     if not np.array_equal(parts[r], box[r], equal_nan=True):
                         bad.append((rnd, which, r))
-                assert np.isfinite(have[root]).mean() > .5
+                if not np.isfinite(have[root]).any():
+                    bad.append((rnd, which, 'nothing finite'))
     # the row is snapshotted when the gather is issued: a trace of other rays
     # queued right behind it must not change what arrives
     want = group.gather(np.asarray(g.y[L - 1]))

@@ -3,9 +3,10 @@ workers.  Covers the host logic of the N>1 path -- shard bounds, the host
 group (rendezvous, broadcast of the RCCL unique id, barrier, max of the
 timings), the self-spawning launcher of ``python bench.py --gpus N`` and the
 layout of the gathered buffer.  The workers use a stand-in for the GPU
-context (FakeEngine): the RCCL transfer itself (rt_gather_final with
-nranks > 1, rayopt_amd/csrc/rt_engine.hip) needs two GPUs and is NOT covered
-here -- it runs in ``bench.py --gpus N`` on a multi-GPU node only."""
+context (FakeEngine); the engine's own gather (rt_gather_final with
+nranks > 1, rayopt_amd/csrc/rt_engine.hip) is covered on the device by
+tests/test_gather_ranks_gpu.py over a stand-in transport; RCCL itself with
+several ranks runs in ``bench.py --gpus N`` on a multi-GPU node only."""
 import os
 import socket
 import subprocess
