@@ -413,7 +413,11 @@ int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out);
  * exchange is the gather of the last-surface intercepts to a root rank
  * (RCCL over xGMI): grouped ncclSend/ncclRecv, direct peer->root links, no
  * ring.  id is a 128-byte ncclUniqueId created on rank 0 and distributed by
- * the host (any out-of-band channel).
+ * the host (any out-of-band channel).  librccl.so is bound at first use;
+ * the environment variable RT_TRANSPORT_LIBRARY names another library with
+ * RCCL's entry points to bind instead (it must load: there is no fallback) --
+ * the GPU tests use a shared-memory stand-in to run several ranks on one
+ * device, which RCCL refuses.
  */
 int rt_comm_unique_id(void *id128);
 int rt_comm_init(rt_ctx *ctx, const void *id128, int nranks, int rank);

@@ -116,6 +116,8 @@ struct rt_ctx {
     int opt_fuse; /* build generated rays inside the first trace */
     int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
     int opt_tile; /* measurement only: tile-major result layout, rays/tile */
+    int opt_uniform_fix; /* measurement only: input components read as if
+                            wave-uniform (6-bit mask) */
     int opt_probe_store; /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
     void *d_probe_in; /* rt_probe modes 13/14: input rows of their own */
     size_t probe_in_bytes;
@@ -299,7 +301,8 @@ static void rt_launch(rt_ctx *c, int start, int stop, int clip)
                        dim3(block), (size_t)c->opt_lds, c->stream, c->d_surf,
                        start, stop, clip, rt_layout(c), c->ld, nblocks,
                        c->ngroups > 1 ? c->n / c->ngroups : (int64_t)0,
-                       c->nsurf);
+                       c->nsurf, (const unsigned *)NULL,
+                       (unsigned)(start == 1 ? c->opt_uniform_fix : 0));
 }
 
 extern "C" {
@@ -1207,6 +1210,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         if (value < 1 || value > 64)
             return rt_fail(ctx, RT_ERR_ARG, "compact_every must be in [1, 64]");
         ctx->opt_compact_every = value;
+    } else if (!strcmp(key, "uniform_fix")) {
+        ctx->opt_uniform_fix = value & 63;
     } else if (!strcmp(key, "probe_store")) {
         if (value < 0 || value > 3)
             return rt_fail(ctx, RT_ERR_ARG, "probe_store must be 0..3");

@@ -119,6 +119,28 @@ __device__ __forceinline__ void rt_load_state(const rt_lay &a, int srow,
     }
 }
 
+/*
+ * The same for one ray per lane where some components of the input rows are
+ * known to hold ONE bit pattern across the wavefront's 64 rays (bit c of
+ * `m`: Y component c, bit 3+c: U component c): those are read from the
+ * wavefront's first column -- one request instead of eight cache lines.
+ * Bundles from a field point at infinity share their direction, bundles from
+ * an object point share their origin (rayopt/conjugates.py:137-166,236-255),
+ * so half or more of the 48 B/ray input is of this kind.
+ */
+__device__ __forceinline__ void rt_load_state_uniform(
+    const rt_lay &a, int srow, int64_t col, int64_t col0, unsigned m,
+    double (&y)[1][3], double (&u)[1][3])
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double *py = a.Y + srow * a.ss + c * a.cs;
+        const double *pu = a.U + srow * a.ss + c * a.cs;
+        y[0][c] = py[(m >> c) & 1 ? col0 : col];
+        u[0][c] = pu[(m >> (3 + c)) & 1 ? col0 : col];
+    }
+}
+
 /* the rows of one element for the R rays at column `col` */
 template <int R, bool NT>
 __device__ __forceinline__ void rt_store_rows(
@@ -197,7 +219,8 @@ template <int R, bool NT, bool XCD>
 __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
                                 int stop, int clip, rt_lay a, int64_t ld,
                                 int64_t nblocks, int64_t group_rays,
-                                int nsurf)
+                                int nsurf, const unsigned *__restrict__ uni,
+                                unsigned ufix)
 {
     const int64_t chunk = rt_chunk<XCD>(nblocks);
     const int64_t j = (chunk * blockDim.x + threadIdx.x) * R;
@@ -213,7 +236,20 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
     }
     const int64_t col = rt_col(a, j);
     double y[R][3], u[R][3];
-    rt_load_state<R>(a, start - 1, col, y, u);
+    if constexpr (R == 1) {
+        if (uni || ufix) {
+            /* per 64-ray tile: which input components are wave-uniform */
+            const int tile = __builtin_amdgcn_readfirstlane(
+                (int)((j - (int64_t)(threadIdx.x & 63)) >> 6));
+            const unsigned m = uni ? uni[tile] : ufix;
+            rt_load_state_uniform(a, start - 1, col,
+                                  rt_col(a, (int64_t)tile << 6), m, y, u);
+        } else {
+            rt_load_state<R>(a, start - 1, col, y, u);
+        }
+    } else {
+        rt_load_state<R>(a, start - 1, col, y, u);
+    }
     rt_march<R, NT>(surf, start, stop, clip, a, col, y, u);
 }
 

@@ -14,7 +14,7 @@ from bench import workload_rays
 
 DEFAULTS = dict(rays_per_thread=1, nontemporal=0, xcd_remap=0, block=256,
                 lds_pad=0,
-                alias_i=1)
+                alias_i=1, uniform_fix=0)
 
 
 def main():
@@ -31,18 +31,19 @@ def main():
     g = ra.GeometricTrace(system)
     g.rays_given(y, u)
     eng = g.engine
-    g.propagate(clip=True)
+    for _ in range(int(os.environ.get("RT_AB_SETTLE", 300))):
+        g.propagate(clip=True)      # clocks settle (~50-300 launches)
     ref = [np.array(np.asarray(r[-1])) for r in (g.y, g.u, g.t)]
     ref_mid = np.array(np.asarray(g.y[5]))
     times = {json.dumps(v): [] for v in variants}
-    for rnd in range(3):
+    for rnd in range(int(os.environ.get("RT_AB_ROUNDS", 3))):
         for v in variants:
             opts = dict(DEFAULTS)
             opts.update(v)
             for k, val in opts.items():
                 eng.set_option(k, val)
             g.propagate(clip=True)
-            if rnd == 0:
+            if rnd == 0 and not os.environ.get("RT_AB_NOCHECK"):
                 for rows, want in zip((g.y, g.u, g.t), ref):
                     assert np.array_equal(np.asarray(rows[-1]), want,
                                           equal_nan=True), v
