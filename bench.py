@@ -44,9 +44,11 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                 tilted (rayopt/system.py:461,464), so by default the engine
                 serves those rows of `i` from `u` instead of writing them
                 again; the double-Gauss has no tilted element -> 56 B.
-                ``traffic`` = HBM bytes per launch from PMC counters; it is
-                not re-measured in this run (counters need rocprofv3) but
-                taken from the committed profile named in ``traffic_source``.
+                ``traffic`` = HBM bytes per launch from PMC counters,
+                measured in this run at N = 1 (two rocprofv3 --pmc passes of
+                a 3-launch child run of this command; --traffic), or, where
+                rocprofv3 cannot run, taken from the committed profile;
+                ``traffic_source`` says which.
   propagate_api the public call against the bare engine call (Engine.trace
                 in the same timed loop); with --extras also the wall time of
                 one propagate() on a 10^4-ray batch, where the host path
@@ -224,6 +226,74 @@ def traffic_from_profile():
         return None
 
 
+def _profiled_from_outside(env):
+    """True when this process already runs under a profiler (rocprofv3 / the
+    rocprofiler-sdk tool library): a counter session nested inside another
+    one is not attempted."""
+    keys = ("ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH",
+            "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_KERNEL_TRACE")
+    return any(env.get(k) for k in keys) or \
+        "rocprofiler-sdk-tool" in env.get("LD_PRELOAD", "")
+
+
+def traffic_live(n, clip, timeout=240.):
+    """HBM bytes per launch of rt_trace_kernel on THIS box, now: two
+    `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, TCC budget) of a
+    short run of this very command -- same workload, same kernel, 3 launches
+    -- with the guide's gfx950 correction (FETCH_SIZE tallies 128-B requests
+    at 64 B: doubled; both counters are KiB).  Returns (bytes, detail) or
+    raises; the caller falls back to the committed profile."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith(("ROCP", "ROCPROF"))}
+    env.update(TMPDIR="/tmp", RT_BENCH_CHILD="1")
+    work = tempfile.mkdtemp(prefix="rt_bench_pmc_", dir="/tmp")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rays", str(n),
+           "--steps", "2", "--warmup", "1", "--settle", "0", "--cpu-sample",
+           "0", "--cpu-procs", "0", "--no-api-leg", "--traffic", "off"]
+    if not clip:
+        cmd.append("--no-clip")
+    kib, launches = {}, {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            res = subprocess.run(
+                [exe, "--kernel-trace", "--pmc", counter, "--output-format",
+                 "csv", "-d", out, "--"] + cmd, cwd="/tmp", env=env,
+                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                timeout=timeout)
+            if res.returncode != 0:
+                raise RuntimeError("rocprofv3 --pmc %s: rc %d: %s" % (
+                    counter, res.returncode, res.stderr[-300:]))
+            vals = []
+            for path in glob.glob(os.path.join(
+                    out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if "rt_trace_kernel" in row.get("Kernel_Name", "") \
+                                and row.get("Counter_Name") == counter:
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                raise RuntimeError("no %s rows for rt_trace_kernel" % counter)
+            kib[counter] = sum(vals)/len(vals)
+            launches[counter] = len(vals)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    fetch = kib["FETCH_SIZE"]*1024*2
+    write = kib["WRITE_SIZE"]*1024
+    return fetch + write, {
+        "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+        "launches": [launches["FETCH_SIZE"], launches["WRITE_SIZE"]]}
+
+
 # --------------------------------------------------------------------------
 # timed loops
 # --------------------------------------------------------------------------
@@ -305,6 +375,13 @@ def main():
                     help="also time the full_i (80 B/op), unclipped and "
                          "image-row-only modes (separate timed loops, "
                          "reported as extra objects)")
+    ap.add_argument("--traffic", choices=("live", "profile", "off"),
+                    default="live",
+                    help="roofline.traffic: 'live' = two rocprofv3 --pmc "
+                         "passes of a short run of this command on this box "
+                         "(N = 1 only; falls back to 'profile' if rocprofv3 "
+                         "cannot run), 'profile' = the committed "
+                         "profiles/traffic.json, 'off' = null")
     ap.add_argument("--no-api-leg", action="store_true",
                     help="skip the propagate_api comparison legs")
     ap.add_argument("--gather-every-step", action="store_true",
@@ -544,8 +621,27 @@ def main():
                     if alias_on and not clip and not bends[j])
     alg_bytes = n*(56*S + 24*stored_i - 24*skipped_u + 48)  # one GPU's shard
     achieved = alg_bytes/(kernel_ms*1e-3)/1e9
-    prof = traffic_from_profile()
-    traffic = traffic_source = None
+    traffic = traffic_source = traffic_detail = None
+    plain_kernel = alias_on and not args.option
+    if args.traffic == "live" and world == 1 and not dist_mode and \
+            plain_kernel and not os.environ.get("RT_BENCH_CHILD") and \
+            not _profiled_from_outside(os.environ):
+        try:
+            t0 = time.perf_counter()
+            traffic, traffic_detail = traffic_live(n, clip)
+            traffic_source = (
+                "measured in this run: rocprofv3 --kernel-trace --pmc "
+                "FETCH_SIZE / WRITE_SIZE (separate passes, %d + %d launches "
+                "of this workload in a child process, %.0f s), FETCH_SIZE "
+                "x2 per MI355X_MICROARCH.md (gfx950)" % (
+                    traffic_detail["launches"][0],
+                    traffic_detail["launches"][1],
+                    time.perf_counter() - t0))
+        except Exception as err:
+            log("[bench] live traffic measurement failed: %r" % (err,))
+            traffic = None
+    prof = traffic_from_profile() if (traffic is None and
+                                      args.traffic != "off") else None
     if prof and prof.get("rays") == n and prof.get("clip") == clip and \
             prof.get("alias_i", 0) == int(alias_on):
         traffic = prof.get("hbm_bytes_per_launch")
@@ -596,6 +692,7 @@ def main():
             "frac": achieved/HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_source,
+            "traffic_detail": traffic_detail,
             "kernel": "rt_trace_kernel",
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,

@@ -50,7 +50,13 @@ def test_single_process_line():
     assert cc["image_row_bit_identical_to_gpu"] is True
     api = d["propagate_api"]
     assert api["propagate_ms_per_step"] > 0 and api["small_batch_rays"] == 10**4
-    assert d["roofline"]["traffic"] is None or d["roofline"]["traffic_source"]
+    r = d["roofline"]
+    assert r["traffic"] is None or r["traffic_source"]
+    # the counters are read in this very run (two rocprofv3 --pmc passes of a
+    # child run): what the kernel moved is what the algorithm needs
+    assert r["traffic_source"].startswith("measured in this run"), r
+    assert r["traffic"] == pytest.approx(r["algorithmic_bytes_per_launch"],
+                                         rel=0.05)
     assert "GeometricTrace.propagate()" in d["config"]["workload"]
 
 
