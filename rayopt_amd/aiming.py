@@ -101,6 +101,9 @@ def start_pupil(system, l, z0=None, a0=None):
         get = spec.get if isinstance(spec, dict) else \
             (lambda key: getattr(spec, key, None))
         zp, given = get("distance"), get("radius")
+        if isinstance(spec, dict) and zp is not None:
+            from .design import pupil_radius    # slope / na / fno pupils
+            given = pupil_radius(spec)
         if (z0 is None and zp is None) or (a0 is None and not given):
             zq, ap = entrance_pupil(system, l)
             zp = zq if zp is None else zp

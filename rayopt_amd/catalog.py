@@ -66,8 +66,10 @@ def parse_agf(text):
             glass = DispersionGlass(AGF_FORMULAS[formula - 1], [],
                                     name=args[0])
             glass.glasscode = _number(args[2]) if len(args) > 2 else None
-            glass.nd = _number(args[3]) if len(args) > 3 else None
-            glass.vd = _number(args[4]) if len(args) > 4 else None
+            # the catalogue's stated values (nd / vd themselves are
+            # computed from the formula, model.Material)
+            glass.nd_stated = _number(args[3]) if len(args) > 3 else None
+            glass.vd_stated = _number(args[4]) if len(args) > 4 else None
             glass.status = int(_number(args[6])) if len(args) > 6 else None
             glasses[glass.name] = glass
         elif glass is None or cmd == "CC":
@@ -109,8 +111,8 @@ def parse_glc(text):
         glass = DispersionGlass(
             GLC_FORMULAS[kind],
             [_number(f) for f in fields[14:14 + count]], name=name)
-        glass.nd, glass.vd, glass.density = (_number(f)
-                                             for f in fields[1:4])
+        glass.nd_stated, glass.vd_stated, glass.density = (
+            _number(f) for f in fields[1:4])
         glasses[name] = glass
     return glasses
 

@@ -56,7 +56,7 @@ def book():
 
 def test_published_indices(book):
     bk7 = book.find("N-BK7")
-    assert bk7.typ == "sellmeier_squared" and bk7.nd == 1.5168
+    assert bk7.typ == "sellmeier_squared" and bk7.nd_stated == 1.5168
     assert bk7.glasscode == 517642.251 and bk7.status == 1
     assert bk7.comment == "Schott borosilicate crown"
     assert (bk7.lambda_min, bk7.lambda_max) == (0.3, 2.5)
@@ -163,7 +163,7 @@ def test_glc_catalogue(tmp_path):
         1.5168, abs=2e-5)
     assert g["SELLT"].refractive_index(LINES[0]) == pytest.approx(
         1.5168, abs=2e-5)
-    assert g["SELLT"].density == 2.51 and g["SELLT"].vd == 64.17
+    assert g["SELLT"].density == 2.51 and g["SELLT"].vd_stated == 64.17
     path = tmp_path / "mycat.glc"
     path.write_text(GLC)
     try:

@@ -1,0 +1,159 @@
+"""Design-time housekeeping of a System (rayopt_amd/design.py) against the
+live reference: the reference's own Cooke fixture (pickups, validators, an
+aimed radius pupil, catalogue glasses) and numeric prescriptions."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd import design
+from oracle import refshim
+
+# rayopt/test/test_raytrace.py:30-57, verbatim prescription text
+COOKE = """
+description: 'oslo cooke triplet example 50mm f/4 20deg'
+wavelengths: [587.56e-9, 656.27e-9, 486.13e-9]
+object: {angle_deg: 20, pupil: {radius: 6.25, aim: True}}
+image: {type: finite, pupil: {radius: 0, update_radius: True}}
+elements:
+- {material: air}
+- {roc: 21.25, distance: 5.0, material: SCHOTT-SK|N-SK16, radius: 6.5}
+- {roc: -158.65, distance: 2.0, material: air, radius: 6.5}
+- {roc: -20.25, distance: 6.0, material: SCHOTT-F|N-F2, radius: 5.0}
+- {roc: 19.6, distance: 1.0, material: air, radius: 5.0}
+- {material: air, radius: 4.75}
+- {roc: 141.25, distance: 6.0, material: SCHOTT-SK|N-SK16, radius: 6.5}
+- {roc: -17.285, distance: 2.0, material: air, radius: 6.5}
+- {distance: 42.95, radius: 0.364}
+stop: 5
+pickups:
+- {get: [1, radius], set: [2, radius]}
+- {get: [3, radius], set: [4, radius]}
+- {get: [6, radius], set: [7, radius]}
+validators:
+- {get: [edge_y, 2], minimum: .5}
+- {get: [2, distance], minimum: .5}
+- {get: [edge_y, 4], minimum: .5}
+- {get: [4, distance], minimum: .5}
+- {get: [edge_y, 7], minimum: .5}
+- {get: [7, distance], minimum: .5}
+"""
+
+NUMERIC = """
+description: numeric doublet with an asphere and a mirror
+object: {angle_deg: 3, pupil: {radius: 4.}}
+elements:
+- {material: 1.0}
+- {roc: 30., distance: 2., material: 1.5168/64.17, radius: 6.}
+- {roc: -25., distance: 3., material: 1.62/36.4, radius: 5.,
+   aspherics: [0., 1.0e-5, -2.0e-8]}
+- {roc: -90., distance: 1.5, material: 1.0, radius: 5.5, conic: -0.3}
+- {distance: 5., radius: 4., material: 1.0}
+- {roc: -200., distance: 40., material: mirror, radius: 8.}
+- {distance: -38., radius: 3.}
+stop: 4
+"""
+
+
+def reference_with_library():
+    ro = refshim.load()
+    try:
+        from rayopt.library import Library as RefLibrary
+        path = os.path.join(refshim.REFERENCE_ROOT, "rayopt", "library.sqlite")
+        RefLibrary._one = RefLibrary("sqlite:///%s" % path)
+    except Exception as err:
+        pytest.skip("reference library not usable here: %r" % (err,))
+    return ro
+
+
+def test_pupil_kinds():
+    for spec, radius in (
+            ({"radius": 2.5, "distance": 10.}, 2.5),
+            ({"type": "slope", "slope": .25, "distance": 10.}, 2.5),
+            ({"na": .1, "distance": 10.}, 10*.1/np.sqrt(1 - .01)),
+            ({"fno": 4., "distance": 8., "refractive_index": 1.2},
+             8*(1/9.6)/np.sqrt(1 - (1/9.6)**2))):
+        assert design.pupil_radius(spec) == pytest.approx(radius, rel=1e-15)
+        other = dict(spec)
+        design.pupil_set_radius(other, 3.)
+        assert design.pupil_radius(other) == pytest.approx(3., rel=1e-14)
+        assert set(other) == set(spec)          # stored in its own quantity
+    assert design.pupil_radius({}) is None
+
+
+def test_code_in_a_prescription_is_refused_not_run():
+    s = ra.system_from_yaml(ra.prescriptions.SINGLET)
+    for attr, entry in (("pickups", {"get_eval": "1/0", "set": [1, "radius"]}),
+                        ("validators", {"exec": "import os"}),
+                        ("solves", {"get_func": "f", "set": [1, "distance"]})):
+        setattr(s, attr, [entry])
+        with pytest.raises(ValueError, match="Python source"):
+            s.update()
+        setattr(s, attr, [])
+
+
+def test_pickups_solves_validators():
+    s = ra.system_from_yaml(COOKE)
+    s[1].radius = 6.
+    s.update()
+    assert s[2].radius == 6.                   # picked up
+    s[2].distance = .2
+    with pytest.raises(ValueError, match="< 0.5"):
+        s.validate()
+    edges, s.validators = s.validators[::2], s.validators[1::2]
+    with pytest.raises(ValueError, match="0.2 < 0.5"):
+        s.validate()
+    s.validate(fix=True)
+    assert s[2].distance == .5
+    s.validators += edges
+    s[2].distance = 2.
+    s.validate()
+    # a solve: move the image plane until the edge gap in front of it is 40
+    s.solves = [{"get": ["edge_y", 8], "set": [8, "distance"], "target": 40.}]
+    s.update()
+    assert s.edge_y[8] == pytest.approx(40., abs=1e-7)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+def test_text_edges_and_editing_like_the_reference():
+    ro = reference_with_library()
+    for text in (COOKE, NUMERIC):
+        a, b = ra.system_from_yaml(text), ro.system_from_yaml(text)
+        a.update()
+        b.update()
+        assert str(a) == str(b)
+        assert a.fields == b.fields
+        np.testing.assert_allclose(a.edge_y, b.edge_y, rtol=1e-14)
+        np.testing.assert_allclose(a.edge_x, b.edge_x, rtol=1e-14)
+        assert list(a.groups()) == list(b.groups())
+        for op in (lambda s: s.rescale(25.4), lambda s: s.resize_convex(),
+                   lambda s: s.reverse(), lambda s: s.rescale()):
+            op(a)
+            op(b)
+            assert a.scale == pytest.approx(b.scale, rel=1e-15)
+            for ea, eb in zip(a, b):
+                for key in ("distance", "radius", "curvature", "conic"):
+                    if hasattr(eb, key):
+                        assert getattr(ea, key) == pytest.approx(
+                            getattr(eb, key), rel=1e-15), key
+                if getattr(eb, "aspherics", None) is not None:
+                    np.testing.assert_allclose(ea.aspherics, eb.aspherics,
+                                               rtol=1e-15)
+                assert str(design._label(getattr(ea, "material", None))) == \
+                    str(getattr(eb, "material", None))
+            assert a.object.finite == b.object.finite
+            np.testing.assert_allclose(a.edge_y, b.edge_y, rtol=1e-13)
+        assert str(a).splitlines()[8:] == str(b).splitlines()[8:]
+
+
+@pytest.mark.skipif(not refshim.available(), reason="no /root/reference")
+def test_default_fields_follow_the_object():
+    ro = refshim.load()
+    for obj in ({"angle_deg": 0.}, {"angle_deg": 2.},
+                {"type": "finite", "radius": 0.}, {"type": "finite",
+                                                   "radius": 1.}):
+        kw = dict(elements=[{}, {"distance": 1.}], object=obj)
+        assert ra.System(**copy.deepcopy(kw)).fields == \
+            ro.System(**copy.deepcopy(kw)).fields
