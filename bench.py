@@ -236,7 +236,7 @@ def _profiled_from_outside(env):
         "rocprofiler-sdk-tool" in env.get("LD_PRELOAD", "")
 
 
-def traffic_live(n, clip, timeout=240.):
+def traffic_live(n, clip, timeout=120.):
     """HBM bytes per launch of rt_trace_kernel on THIS box, now: two
     `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE and
     WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, TCC budget) of a
