@@ -105,6 +105,11 @@ class Material(Stamped):
             return "%s/%s" % (self.catalog, self.name)
         return self.name
 
+    def spec(self):
+        """What a prescription file holds for this medium: something
+        :meth:`make` turns into an equal material again."""
+        return str(self)
+
     @staticmethod
     def make(spec):
         """Same dispatch as rayopt's Material.make for the forms that need no
@@ -132,13 +137,18 @@ class Material(Stamped):
             return ConstantIndex(spec)
         if type(spec) is tuple:
             return AbbeGlass(spec[0], spec[1])
+        if isinstance(spec, (int, np.integer, np.floating)):
+            return ConstantIndex(float(spec))
         text = str(spec)
         parts = text.split("/")
-        if len(parts) == 2:
+        if len(parts) <= 2:                      # "n" or "n/v"
             try:
-                return AbbeGlass(float(parts[0]), float(parts[1]))
+                numbers = [float(part) for part in parts]
             except ValueError:
                 pass
+            else:
+                return (AbbeGlass(*numbers) if len(numbers) == 2
+                        else ConstantIndex(numbers[0]))
         key = parts[-1].lower()
         if (len(parts) == 1 or parts[-2].lower() == "basic") and key in BASIC:
             return BASIC[key]
@@ -174,6 +184,11 @@ class ConstantIndex(Material):
         if self.name and self.name != "-":
             return super().__str__()
         return repr(self.n)
+
+    def spec(self):
+        if self.name and self.name != "-":
+            return super().spec()
+        return float(self.n)
 
 
 class AbbeGlass(Material):
@@ -295,6 +310,17 @@ class DispersionGlass(Material):
         if self.name and self.name != "-":      # a catalogue glass
             return super().__str__()
         return "%s%r" % (self.typ, [float(c) for c in self.coefficients])
+
+    def spec(self):
+        if self.name and self.name != "-":
+            return super().spec()
+        dat = {"typ": self.typ,
+               "coefficients": [float(c) for c in self.coefficients]}
+        if not self.solid:
+            dat["solid"] = False
+        if self.mirror:
+            dat["mirror"] = True
+        return dat
 
 
 BASIC = {
@@ -553,7 +579,8 @@ class Interface(Element):
     def dict(self):
         dat = super().dict()
         if self.material is not None:
-            dat["material"] = str(self.material)
+            spec = getattr(self.material, "spec", None)
+            dat["material"] = spec() if spec else str(self.material)
         return dat
 
     def edge_sag(self, axis=1):

@@ -157,3 +157,37 @@ def test_default_fields_follow_the_object():
         kw = dict(elements=[{}, {"distance": 1.}], object=obj)
         assert ra.System(**copy.deepcopy(kw)).fields == \
             ro.System(**copy.deepcopy(kw)).fields
+
+
+def test_prescriptions_written_out_read_back():
+    """rayopt/test/test_yaml.py: dump -> load, YAML and JSON.  Here the copy
+    must also trace the same: its packed surface table is the original's bit
+    for bit (a given `direction` is re-normalised on loading, one ulp)."""
+    from rayopt_amd.pack import pack_system
+    cases = dict(ra.prescriptions.ALL, cooke_glasses=COOKE, numeric=NUMERIC)
+    for name, text in cases.items():
+        a = ra.system_from_yaml(text)
+        for dump, load in ((ra.system_to_yaml, ra.system_from_yaml),
+                           (ra.system_to_json, ra.system_from_json)):
+            b = load(dump(a))
+            assert len(b) == len(a) and b.stop == a.stop
+            for l in a.wavelengths:
+                ta, na = pack_system(a, l, a.refractive_index(l, 0))
+                tb, nb = pack_system(b, l, b.refractive_index(l, 0))
+                assert np.array_equal(na, nb), name
+                if "direction" in text:
+                    for field in ta.dtype.names:
+                        np.testing.assert_allclose(
+                            tb[field], ta[field], rtol=0, atol=1e-15)
+                else:
+                    assert ta.tobytes() == tb.tobytes(), name
+                    assert a.dict() == b.dict(), name
+    # materials given by numbers stay numbers, whatever way they were spelled
+    for spec, index in ((1.5, 1.5), ("1.5", 1.5), (np.float64(1.25), 1.25),
+                        (2, 2.)):
+        m = ra.Material.make(spec)
+        assert m.refractive_index(5e-7) == index and m.spec() == index
+    m = ra.Material.make({"typ": "sellmeier", "coefficients": [1., .01, .2,
+                                                               .05]})
+    again = ra.Material.make(m.spec())
+    assert again.refractive_index(6e-7) == m.refractive_index(6e-7)
