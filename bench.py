@@ -53,6 +53,9 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                 in the same timed loop); with --extras also the wall time of
                 one propagate() on a 10^4-ray batch, where the host path
                 decides
+  generated_batch   the same bundles built on the device (rays_fields): a
+                re-trace rebuilds its launch rays in registers instead of
+                reading row 0 -- own timed loop, value / kernel_ms / achieved
   full_i / unclipped / image_row_only   (--extras) other store modes
   cpu_baseline  the numpy port of the reference path (oracle/trace_numpy.py,
                 same whole-array numpy operations as rayopt) timed on this
@@ -502,13 +505,7 @@ def main():
     def step_engine():          # the bare C-ABI call, table already there
         eng.trace(1, 0, mode["clip"])
 
-    if args.settle > 0:         # setup, not part of W or K
-        g.propagate(clip=clip)
-        t_end = time.perf_counter() + args.settle
-        while time.perf_counter() < t_end:
-            for _ in range(10):
-                eng.trace(1, 0, clip)
-            eng.sync()
+    settle(g, args.settle, clip)    # setup, not part of W or K
 
     final_gather = dist_mode and not args.gather_every_step
     plain = not dist_mode and not args.option
@@ -592,6 +589,10 @@ def main():
             # the default command so that every rt_trace_kernel launch a
             # profiler sees there is the headline workload
             api.update(small_batch_latency(ra, system, local_rank))
+
+    generated = None
+    if not dist_mode and plain and not args.no_api_leg:
+        generated = run_generated(ra, system, local_rank, n, clip, args)
 
     configs4 = None
     if dist_mode and world > 1 and not args.no_configs4 and \
@@ -716,6 +717,8 @@ def main():
                                 "not a measurement" % stand_in)
     if configs4 is not None:
         out["configs4"] = configs4
+    if generated is not None:
+        out["generated_batch"] = generated
     if api is not None:
         out["propagate_api"] = api
 
@@ -789,6 +792,66 @@ def small_batch_latency(ra, system, device, n=10_000, reps=300):
             "small_batch_kernel_us": g.kernel_ms()*1e3}
 
 
+def settle(g, seconds, clip):
+    """Untimed launches until the device runs at its sustained clocks: the
+    host work of a setup phase (ray generation, uploads) lets them drop, and
+    the first ~50 launches after it are ~10 % slower."""
+    if seconds <= 0:
+        return
+    eng = g.engine
+    g.propagate(clip=clip)
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        for _ in range(10):
+            eng.trace(1, 0, clip)
+        eng.sync()
+
+
+def run_generated(ra, system, device, n, clip, args):
+    """The same workload with the bundles built on the device (five field
+    points x n/5 pupil points, `rays_fields`: the counterpart of the
+    reference's rays_point entry) instead of handed over with rays_given.
+    Every timed step is the public propagate() on the resident batch; a
+    re-trace of a generated batch builds its launch rays again in registers
+    rather than read row 0, so the launch moves 56 B per ray-surface op and
+    16 B per pupil point."""
+    from rayopt_amd import prescriptions as P
+    nf = len(FIELD_FRACTIONS)
+    m = n//nf//64*64
+    rng = np.random.default_rng(7000)
+    r, phi = np.sqrt(rng.random(m)), 2*np.pi*rng.random(m)
+    yp = np.c_[r*np.cos(phi), r*np.sin(phi)]
+    fields = np.c_[np.zeros(nf), FIELD_FRACTIONS]
+    g = ra.GeometricTrace(system, device=device)
+    g.rays_fields(fields, yp, P.DOUBLE_GAUSS_PUPIL_Z, BUNDLE_RADIUS)
+    job = Job(args, None, g, None, 0)
+    g.propagate(clip=clip)      # the first trace writes row 0 as well
+    settle(g, args.settle, clip)
+
+    def step():
+        g.propagate(clip=clip)
+    elapsed, ev_ms, _ = job.timed(step, args.steps, args.warmup, False)
+    S = len(system) - 1
+    rays = m*nf
+    kernel_ms = ev_ms/args.steps
+    alg = rays*56*S + m*16
+    ulast = np.asarray(g.u[S])
+    return {
+        "workload": "the same five field bundles built on the device "
+                    "(rays_fields, %d rays), one step = one "
+                    "GeometricTrace.propagate() re-tracing the resident "
+                    "batch" % rays,
+        "rays": rays,
+        "value": rays*S*args.steps/elapsed,
+        "ms_per_step": elapsed*1e3/args.steps,
+        "kernel_ms": kernel_ms,
+        "algorithmic_bytes_per_launch": alg,
+        "achieved": alg/(kernel_ms*1e-3)/1e9,
+        "frac": alg/(kernel_ms*1e-3)/1e9/HBM_PEAK_GBS,
+        "finite_fraction_at_image": float(np.isfinite(ulast[:, 0]).mean()),
+    }
+
+
 def run_configs4(ra, system, g, job, group, world, rank, args, clip,
                  total=100_000_000):
     """BASELINE configs[4]: 10^8 rays in total, sharded over the N GPUs; the
@@ -815,6 +878,7 @@ def run_configs4(ra, system, g, job, group, world, rank, args, clip,
 
     def step():
         g.propagate(clip=clip)
+    settle(g, args.settle, clip)
     elapsed, ev_ms, _ = job.timed(step, args.steps, args.warmup, True)
     job.fence()
     t0 = time.perf_counter()

@@ -131,6 +131,10 @@ struct rt_ctx {
     void *d_gen;
     size_t gen_bytes, gen_fpad;
     int gen_pending, gen_nf;
+    int gen_live; /* row 0 still holds exactly what d_gen describes: a trace
+                     from element 1 may rebuild the rays instead of reading
+                     them */
+    int opt_regen;
     int64_t gen_np, gen_n;
     rt_surface gen_s0;
     /* per row of I: 0 = materialised, 1 = identical to U[j-1], 2 = to U[j] */
@@ -350,6 +354,7 @@ int rt_create(int device, rt_ctx **out)
     c->opt_block = 256;
     c->opt_alias = 1;
     c->opt_fuse = 1;
+    c->opt_regen = 1;
     c->opt_compact_every = 4; /* measured best, profiles/r02_probes */
 #define RT_HIP_C(call)                                                        \
     do {                                                                      \
@@ -532,9 +537,12 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     const int64_t quantum = ctx->opt_tile ? ctx->opt_tile : 64;
     const int64_t ld = (nrays + quantum - 1) / quantum * quantum;
     if (ld == ctx->ld && ctx->buf_nsurf == ctx->nsurf && ctx->d_buf) {
+        if (nrays != ctx->n)
+            ctx->gen_live = 0;
         ctx->n = nrays;
         return RT_OK;
     }
+    ctx->gen_live = 0;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld;
@@ -603,6 +611,7 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
     ctx->u_alias[0] = 0;
     ctx->valid[0] = 1;
     ctx->gen_pending = 0; /* these rays replace a generated batch */
+    ctx->gen_live = 0;
     return RT_OK;
 }
 
@@ -830,6 +839,7 @@ int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
     /* row 0 is built by the first trace (rt_trace_gen_kernel), or by
      * rt_gen_flush as soon as anything else asks for it */
     ctx->gen_pending = 1;
+    ctx->gen_live = 1;
     ctx->traced = 1;
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0;
     ctx->u_alias[0] = 0;
@@ -947,6 +957,8 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
         if (rc != RT_OK)
             return rc;
     }
+    if (surf == 0 && which != RT_I && which != RT_T)
+        ctx->gen_live = 0; /* the launch rays are the caller's from here on */
     if (which == RT_I)
         ctx->i_alias[surf] = 0; /* now holds its own data */
     if (which == RT_U)
@@ -1064,9 +1076,15 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
     }
     /* a generated batch that no one has looked at yet is built inside this
      * launch (default kernel variant, from the first element on) */
-    const bool fused = ctx->gen_pending && start == 1 && start < stop &&
-                       ctx->opt_r == 1 && !ctx->opt_nt && !ctx->opt_xcd &&
-                       !rt_use_compact(ctx, start, stop);
+    const bool gen_kernel = start == 1 && start < stop && ctx->opt_r == 1 &&
+                            !ctx->opt_nt && !ctx->opt_xcd &&
+                            !rt_use_compact(ctx, start, stop);
+    const bool fused = ctx->gen_pending && gen_kernel;
+    /* a later trace of the same generated batch builds the rays again in
+     * registers (same frames, same arithmetic: the values row 0 holds)
+     * rather than read 48 B per ray among the saturated stores */
+    const bool regen = !ctx->gen_pending && ctx->gen_live && ctx->opt_regen &&
+                       ctx->opt_fuse && gen_kernel && ctx->valid[0];
     if (!fused) {
         int rc = rt_gen_flush(ctx);
         if (rc != RT_OK)
@@ -1074,7 +1092,7 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
     }
     RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
     ctx->last_compact = 0;
-    if (fused) {
+    if (fused || regen) {
         const int block = ctx->opt_block;
         ctx->gen_pending = 0;
         hipLaunchKernelGGL(rt_trace_gen_kernel,
@@ -1086,7 +1104,7 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
                            ctx->nsurf, (const rt_field *)ctx->d_gen,
                            (const double *)((char *)ctx->d_gen + ctx->gen_fpad),
                            ctx->gen_np, ctx->gen_n, ctx->gen_s0,
-                           !ctx->opt_alias);
+                           !ctx->opt_alias, fused ? 1 : 0);
         RT_HIP(ctx, hipGetLastError());
     } else if (start < stop && rt_use_compact(ctx, start, stop)) {
         const unsigned grid = (unsigned)((ctx->ld + RT_CB - 1) / RT_CB);
@@ -1198,6 +1216,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         ctx->table_dirty = 1;
     } else if (!strcmp(key, "fuse_generate")) {
         ctx->opt_fuse = value ? 1 : 0;
+    } else if (!strcmp(key, "regenerate")) {
+        ctx->opt_regen = value ? 1 : 0;
     } else if (!strcmp(key, "fast_asphere")) {
         if ((value != 0) != ctx->opt_fast)
             ctx->table_dirty = 1;
@@ -1734,6 +1754,8 @@ int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
     int rc = rt_gen_flush(ctx);
     if (rc != RT_OK)
         return rc;
+    if (surf == 0)
+        ctx->gen_live = 0; /* the caller may write through the pointer */
     *out = rt_row(ctx, which, surf);
     return RT_OK;
 }

@@ -259,7 +259,9 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
  * written from there and the march goes on -- the generated batch never
  * makes the round trip through HBM that a separate generation kernel plus
  * the 48 B/ray input read would cost (the read is the expensive kind:
- * profiles/r01_probes/ab_store_order.log (9)).
+ * profiles/r01_probes/ab_store_order.log (9)).  Later traces of the same
+ * batch from element 1 (store0 = 0) build the rays again the same way --
+ * the values row 0 holds, bit for bit -- instead of reading them.
  */
 __global__ void rt_trace_gen_kernel(const rt_surface *__restrict__ surf,
                                     int stop, int clip, rt_lay a, int64_t ld,
@@ -267,7 +269,7 @@ __global__ void rt_trace_gen_kernel(const rt_surface *__restrict__ surf,
                                     const rt_field *__restrict__ fields,
                                     const double *__restrict__ pupil,
                                     int64_t npupil, int64_t n, rt_surface S0,
-                                    int store_i0)
+                                    int store_i0, int store0)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
@@ -284,14 +286,16 @@ __global__ void rt_trace_gen_kernel(const rt_surface *__restrict__ surf,
                         &S0, y, u);
     }
     const int64_t col = rt_col(a, j);
+    if (store0) { /* first trace of the batch; later ones leave row 0 alone */
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        a.Y[c * a.cs + col] = y[0][c];
-        a.U[c * a.cs + col] = u[0][c];
-        if (store_i0)
-            a.I[c * a.cs + col] = u[0][c];
+        for (int c = 0; c < 3; ++c) {
+            a.Y[c * a.cs + col] = y[0][c];
+            a.U[c * a.cs + col] = u[0][c];
+            if (store_i0)
+                a.I[c * a.cs + col] = u[0][c];
+        }
+        a.T[col] = 0.;
     }
-    a.T[col] = 0.;
     rt_march<1, false>(surf, 1, stop, clip, a, col, y, u);
 }
 

@@ -58,6 +58,9 @@ def test_single_process_line():
     assert r["traffic"] == pytest.approx(r["algorithmic_bytes_per_launch"],
                                          rel=0.05)
     assert "GeometricTrace.propagate()" in d["config"]["workload"]
+    gb = d["generated_batch"]
+    assert gb["value"] > 0 and gb["rays"] == 200000
+    assert gb["finite_fraction_at_image"] > .9
 
 
 def test_self_spawned_single_rank_multi_process_path():

@@ -176,3 +176,53 @@ def test_generation_fused_into_the_first_trace():
     for name in "yuit":
         assert np.array_equal(np.asarray(getattr(g1, name)),
                               np.asarray(getattr(g0, name)), equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_retrace_of_a_generated_batch_rebuilds_the_rays():
+    """A second propagate() of a device-generated batch builds the launch
+    rays again in registers instead of reading row 0 (rt_trace: `regen`):
+    same rows bit for bit as with the option off, row 0 untouched, also after
+    the system changed between the traces; once the caller replaces a launch
+    row, that row is what is traced."""
+    from rayopt_amd.prescriptions import COOKE
+    from rayopt_amd.aiming import FieldAimer
+    from rayopt_amd._lib import RT_Y
+    text = COOKE % dict(air=1.0, sk16="1.62041/60.32", f2="1.62004/36.37")
+    fields = np.c_[np.zeros(4), np.linspace(0, 1, 4)]
+    ref, yp, w = ra.pupil.pupil_distribution("hexapolar", 2500)
+
+    def run(regen):
+        system = ra.system_from_yaml(text)
+        z, a = FieldAimer(system).pupil(fields)
+        g = ra.GeometricTrace(system)
+        g.engine.set_option("regenerate", regen)
+        g.rays_fields(fields, yp, z, a)
+        g.propagate(clip=True)
+        first = {k: np.array(np.asarray(getattr(g, k))) for k in "yuit"}
+        g.propagate(clip=True)              # the re-trace
+        again = {k: np.array(np.asarray(getattr(g, k))) for k in "yuit"}
+        system[3].curvature *= 1.01         # another system, same rays
+        system[0].curvature = 1e-3          # not what the rays were built on
+        g.propagate(clip=False)
+        moved = {k: np.array(np.asarray(getattr(g, k))) for k in "yuit"}
+        # the caller's own launch heights from here on
+        y0 = np.ascontiguousarray(first["y"][0].T)*.5
+        g.engine.upload_row(RT_Y, 0, y0)
+        for rows in (g.y, g.u, g.i, g.t):
+            rows.invalidate(0, g.length)
+        g.propagate(clip=False)
+        halved = {k: np.array(np.asarray(getattr(g, k))) for k in "yuit"}
+        return first, again, moved, halved
+
+    on, off = run(1), run(0)
+    for a, b in zip(on, off):
+        for k in "yuit":
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+    first, again, moved, halved = on
+    for k in "yuit":
+        assert np.array_equal(first[k], again[k], equal_nan=True)
+        assert np.array_equal(first[k][0], moved[k][0], equal_nan=True)
+    assert not np.array_equal(first["y"][-1], moved["y"][-1], equal_nan=True)
+    assert np.array_equal(halved["y"][0], first["y"][0]*.5)
+    assert not np.array_equal(halved["y"][-1], moved["y"][-1], equal_nan=True)
