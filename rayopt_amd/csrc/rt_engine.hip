@@ -118,6 +118,7 @@ struct rt_ctx {
     int opt_tile; /* measurement only: tile-major result layout, rays/tile */
     int opt_uniform_fix; /* measurement only: input components read as if
                             wave-uniform (6-bit mask) */
+    int opt_gate_log2, opt_gate_window; /* measurement only: read windows */
     int opt_probe_store; /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
     void *d_probe_in; /* rt_probe modes 13/14: input rows of their own */
     size_t probe_in_bytes;
@@ -306,7 +307,9 @@ static void rt_launch(rt_ctx *c, int start, int stop, int clip)
                        start, stop, clip, rt_layout(c), c->ld, nblocks,
                        c->ngroups > 1 ? c->n / c->ngroups : (int64_t)0,
                        c->nsurf, (const unsigned *)NULL,
-                       (unsigned)(start == 1 ? c->opt_uniform_fix : 0));
+                       (unsigned)(start == 1 ? c->opt_uniform_fix : 0),
+                       c->opt_gate_log2 ? (1u << c->opt_gate_log2) - 1u : 0u,
+                       (unsigned)c->opt_gate_window);
 }
 
 extern "C" {
@@ -1230,6 +1233,12 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         if (value < 1 || value > 64)
             return rt_fail(ctx, RT_ERR_ARG, "compact_every must be in [1, 64]");
         ctx->opt_compact_every = value;
+    } else if (!strcmp(key, "gate_log2")) {
+        if (value < 0 || value > 20)
+            return rt_fail(ctx, RT_ERR_ARG, "gate_log2 must be in [0, 20]");
+        ctx->opt_gate_log2 = value;
+    } else if (!strcmp(key, "gate_window")) {
+        ctx->opt_gate_window = value < 1 ? 1 : value;
     } else if (!strcmp(key, "uniform_fix")) {
         ctx->opt_uniform_fix = value & 63;
     } else if (!strcmp(key, "probe_store")) {

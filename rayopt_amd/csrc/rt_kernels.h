@@ -220,7 +220,8 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
                                 int stop, int clip, rt_lay a, int64_t ld,
                                 int64_t nblocks, int64_t group_rays,
                                 int nsurf, const unsigned *__restrict__ uni,
-                                unsigned ufix)
+                                unsigned ufix, unsigned gate_mask,
+                                unsigned gate_window)
 {
     const int64_t chunk = rt_chunk<XCD>(nblocks);
     const int64_t j = (chunk * blockDim.x + threadIdx.x) * R;
@@ -235,6 +236,13 @@ __global__ void rt_trace_kernel(const rt_surface *__restrict__ surf, int start,
         surf += (int64_t)g * nsurf;
     }
     const int64_t col = rt_col(a, j);
+    if (gate_mask) {
+        /* measurement: input reads only inside chip-wide time windows (the
+         * 100 MHz reference counter is the same on every CU) */
+        while (((unsigned)__builtin_amdgcn_s_memrealtime() & gate_mask) >=
+               gate_window)
+            __builtin_amdgcn_s_sleep(2);
+    }
     double y[R][3], u[R][3];
     if constexpr (R == 1) {
         if (uni || ufix) {

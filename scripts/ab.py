@@ -14,7 +14,7 @@ from bench import workload_rays
 
 DEFAULTS = dict(rays_per_thread=1, nontemporal=0, xcd_remap=0, block=256,
                 lds_pad=0,
-                alias_i=1, uniform_fix=0)
+                alias_i=1, uniform_fix=0, gate_log2=0, gate_window=1)
 
 
 def main():
