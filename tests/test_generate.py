@@ -202,6 +202,12 @@ def test_retrace_of_a_generated_batch_rebuilds_the_rays():
         first = {k: np.array(np.asarray(getattr(g, k))) for k in "yuit"}
         g.propagate(clip=True)              # the re-trace
         again = {k: np.array(np.asarray(getattr(g, k))) for k in "yuit"}
+        g.propagate(stop=4, clip=True)      # ... of the first elements only
+        g.propagate(start=4, clip=True)
+        halves = {k: np.array(np.asarray(getattr(g, k))) for k in "yuit"}
+        for k in "yuit":
+            assert np.array_equal(halves[k][4:], again[k][4:], equal_nan=True)
+            assert np.array_equal(halves[k][:1], again[k][:1], equal_nan=True)
         system[3].curvature *= 1.01         # another system, same rays
         system[0].curvature = 1e-3          # not what the rays were built on
         g.propagate(clip=False)
