@@ -34,6 +34,12 @@ say "two ranks on one device (host side only, test mode) rc=$?"; cat "$OUT/bench
 RT_BENCH_SHARE_DEVICE=1 RT_TRANSPORT_LIBRARY=$REPO/tests/stubs/librt_shm_transport.so timeout 900 python bench.py --gpus 2 --rays 2000000 --steps 5 --warmup 1 --settle 0 --no-configs4 \
    > "$OUT/bench_two_ranks_stand_in_transport_TEST_MODE.json" 2> "$OUT/bench_two_ranks_stand_in.err"
 say "two ranks on one device, rt_gather_final over the shared-memory stand-in for RCCL (test mode) rc=$?"; cat "$OUT/bench_two_ranks_stand_in_transport_TEST_MODE.json" | tee -a "$OUT/summary.txt"
+timeout 300 python scripts/regen_ab.py > "$OUT/regen_ab.txt" 2>&1
+say "re-trace of a generated batch, rays rebuilt vs read rc=$?"; cat "$OUT/regen_ab.txt" | tee -a "$OUT/summary.txt"
+for ex in end_to_end spot_report optimize_spot tolerance_monte_carlo; do
+  timeout 300 python examples/$ex.py > "$OUT/example_$ex.log" 2>&1
+  say "examples/$ex.py rc=$?"; tail -2 "$OUT/example_$ex.log" | tee -a "$OUT/summary.txt"
+done
 timeout 300 python scripts/r02_probe.py D > "$OUT/host_overhead.jsonl" 2>&1
 say "host overhead rc=$?"; cat "$OUT/host_overhead.jsonl" | tee -a "$OUT/summary.txt"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- \
