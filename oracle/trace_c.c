@@ -125,14 +125,19 @@ static double intercept(const rt_surface *s, const double y[3],
     return -(d + g) / e;
 }
 
-/* v @ R (inverse: v @ R.T), rayopt/elements.py:156-175 */
+/* v @ R (inverse: v @ R.T), rayopt/elements.py:156-175.  np.dot of an
+ * (N,3) array with a 3x3 matrix is a BLAS dgemm: the inner index is summed
+ * in order with fused multiply-adds (verified entry by entry against exact
+ * rational arithmetic for numpy's OpenBLAS, N >= 2), hence the explicit
+ * fma() here while everything else is compiled with -ffp-contract=off. */
 static void rotate(const double r[9], int inverse, double v[3])
 {
     double o[3];
     for (int j = 0; j < 3; ++j)
-        o[j] = inverse ? (v[0] * r[3 * j] + v[1] * r[3 * j + 1]) +
-                             v[2] * r[3 * j + 2]
-                       : (v[0] * r[j] + v[1] * r[3 + j]) + v[2] * r[6 + j];
+        o[j] = inverse ? fma(v[2], r[3 * j + 2],
+                             fma(v[1], r[3 * j + 1], v[0] * r[3 * j]))
+                       : fma(v[2], r[6 + j],
+                             fma(v[1], r[3 + j], v[0] * r[j]));
     v[0] = o[0];
     v[1] = o[1];
     v[2] = o[2];

@@ -59,6 +59,29 @@ def load_golden(name):
     return g
 
 
+def blas_follows_fma_chain():
+    """Does THIS host's np.dot of an (N,3) array with a 3x3 matrix sum the
+    inner index in order with fused multiply-adds, as the kernel does
+    (rt_math.h: rt_dot3)?  Checked against exact rational arithmetic.  True
+    for numpy's OpenBLAS on x86-64 with FMA3 (where the goldens were made);
+    where it is, the numpy oracle -- and the reference -- are matched bit for
+    bit on tilted elements too, elsewhere to ~1e-14."""
+    from fractions import Fraction as F
+    rng = np.random.default_rng(11)
+    r = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    y = rng.normal(size=(37, 3))*10
+    for m in (r, r.T):
+        got = np.dot(y, m)
+        for i in range(len(y)):
+            for j in range(3):
+                acc = float(F(y[i, 0])*F(m[0, j]))
+                acc = float(F(acc) + F(y[i, 1])*F(m[1, j]))
+                acc = float(F(acc) + F(y[i, 2])*F(m[2, j]))
+                if acc != got[i, j]:
+                    return False
+    return True
+
+
 def case_rtol(g):
     return RTOL_ASPHERE if "aspherics" in g["yaml"] else RTOL_SPHERICAL
 

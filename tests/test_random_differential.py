@@ -16,10 +16,14 @@ from rayopt_amd.pack import pack_system
 from oracle import trace_numpy as tn
 from oracle import refshim
 
-from conftest import assert_parity, RTOL_SPHERICAL, RTOL_ASPHERE
+from conftest import (assert_parity, RTOL_SPHERICAL, RTOL_ASPHERE,
+                      blas_follows_fma_chain)
 from random_systems import random_prescription, random_rays
 
 SEEDS = list(range(60))
+# the numpy oracle's 3x3 products go through this host's BLAS: bit-identity
+# through tilted elements is asserted where that BLAS sums as the kernel does
+EXACT_TILTS = blas_follows_fma_chain()
 
 
 def has_asphere(p):
@@ -64,6 +68,10 @@ def test_oracle_and_kernel_math_vs_live_reference(seed, hostemu):
         rtol = RTOL_ASPHERE if has_asphere(p) else RTOL_SPHERICAL
         for a, b in zip(emu, want):
             assert_parity(a, b, rtol, "kernel math seed %d" % seed)
+            if not has_asphere(p) and (EXACT_TILTS or not tilted(p)):
+                # closed-form surfaces: the reference's values bit for bit,
+                # through tilted elements as well
+                assert np.array_equal(a, b, equal_nan=True), seed
 
 
 @pytest.mark.gpu
@@ -82,6 +90,9 @@ def test_gpu_vs_oracle_random_systems(seed):
         rtol = RTOL_ASPHERE if has_asphere(p) else RTOL_SPHERICAL
         for rows, b in zip((g.y, g.u, g.i, g.t), want):
             assert_parity(np.asarray(rows[1:]), b, rtol, "seed %d" % seed)
+            if not has_asphere(p) and (EXACT_TILTS or not tilted(p)):
+                assert np.array_equal(np.asarray(rows[1:]), b,
+                                      equal_nan=True), seed
         assert np.array_equal(g.n[1:], ns[1:])
 
 
