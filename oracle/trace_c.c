@@ -86,7 +86,8 @@ static double newton_intercept(const rt_surface *s, const double y[3],
         if (fval == 0)
             return p0;
         normal(s, x, q);
-        const double fder = (q[0] * u[0] + q[1] * u[1]) + q[2] * u[2];
+        /* np.dot of a (1,3) with a (3,1) array (:342): the BLAS chain */
+        const double fder = fma(q[2], u[2], fma(q[1], u[1], q[0] * u[0]));
         if (fder == 0)
             return NAN;
         const double p = p0 - fval / fder;

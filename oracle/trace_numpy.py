@@ -34,6 +34,54 @@ F_ROTATED, F_CURVED, F_CONIC, F_ASPH, F_ALT, F_REFRACT, F_MIRROR = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40)
 
 
+def _two_sum(a, b):
+    s = a + b
+    bb = s - a
+    return s, (a - (s - bb)) + (b - bb)
+
+
+def _two_product(a, b):
+    """a*b = p + e exactly (Dekker / Veltkamp, no hardware fma needed)."""
+    p = a*b
+    c = 134217729.                       # 2^27 + 1
+    ah = a*c
+    ah = ah - (ah - a)
+    al = a - ah
+    bh = b*c
+    bh = bh - (bh - b)
+    bl = b - bh
+    return p, ((ah*bh - p) + ah*bl + al*bh) + al*bl
+
+
+def fma(a, b, c):
+    """Correctly rounded a*b + c on arrays, from IEEE + - * alone (Boldo and
+    Melquiond, "Emulation of a FMA and correctly rounded sums", 2008: the
+    small terms are added with rounding to odd, which makes the final
+    rounding that of the exact sum).  The reference reaches fused
+    multiply-adds through BLAS -- np.dot of a (1,3) with a (3,1) array in
+    Interface.intercept's fprime (rayopt/elements.py:342) sums
+    fma(q2, u2, fma(q1, u1, q0*u0)); checked against exact rational
+    arithmetic -- and numpy itself has no fma.  Finite, non-extreme operands
+    (no overflow / underflow of the partial terms), NaN in NaN out."""
+    a, b, c = np.broadcast_arrays(np.asarray(a, float), np.asarray(b, float),
+                                  np.asarray(c, float))
+    uh, ul = _two_product(a, b)
+    th, tl = _two_sum(c, uh)
+    v, err = _two_sum(tl, ul)
+    # round-to-odd of tl + ul: if inexact and v came out even, its odd
+    # neighbour on the side of the error is the one
+    bits = v.view(np.int64) if v.flags.c_contiguous else \
+        np.ascontiguousarray(v).view(np.int64)
+    inexact = (err != 0) & np.isfinite(v)
+    even = (bits & 1) == 0
+    toward = np.where(err > 0, np.inf, -np.inf)
+    v = np.where(inexact & even, np.nextafter(v, toward), v)
+    out = th + v
+    # infinities (and anything the error-free steps turned into NaN): the
+    # plain expression has the right special value
+    return np.where(np.isfinite(out), out, a*b + c)
+
+
 def _rot(s):
     return np.asarray(s["rot"], dtype=float).reshape(3, 3)
 
@@ -118,7 +166,11 @@ def newton_intercept(s, y, u, tol=1e-7, maxiter=5):
             fval = surface_sag(s, xyz)
             zero = fval == 0
             out[idx[zero]] = pi[zero]
-            fder = (surface_normal(s, xyz)*ui).sum(1)
+            # np.dot(normal (1,3), ui.T (3,1)) (:342): a BLAS call, which
+            # sums in order with fused multiply-adds
+            q = surface_normal(s, xyz)
+            fder = fma(q[:, 2], ui[:, 2],
+                       fma(q[:, 1], ui[:, 1], q[:, 0]*ui[:, 0]))
             dzero = (fder == 0) & ~zero      # "Derivative was zero" -> NaN
             p = pi - fval/fder
             fin = np.isfinite(p) & np.isfinite(pi)

@@ -191,8 +191,10 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
                 continue;
             }
             const double e = rt_normal_e(S, flags, r2, root);
+            /* np.dot(normal, u.T) of a (1,3) and a (3,1) array (:342):
+             * BLAS, i.e. the fused chain of rt_dot3 */
             const double fder =
-                ((px * e) * u[r][0] + (py * e) * u[r][1]) + 1. * u[r][2];
+                rt_dot3(px * e, py * e, 1., u[r][0], u[r][1], u[r][2]);
             if (fder == 0.) {
                 live[r] = false; /* "Derivative was zero" -> NaN */
                 continue;

@@ -52,12 +52,12 @@ def test_matches_reference_golden(name):
                   gold["start"], gold["stop"])
     want = [gold[k][a:b] for k in "yuit"]
     compare(g, want, a, b, case_rtol(gold), name)
-    if "aspherics" not in gold["yaml"]:
-        # plane / sphere / conic, tilted or not: the reference's values to
-        # the last bit (the 3x3 products follow the dgemm's fused chain)
-        for rows, ref, label in zip((g.y, g.u, g.i, g.t), want, "yuit"):
-            assert np.array_equal(np.asarray(rows[a:b]), ref,
-                                  equal_nan=True), (name, label)
+    # ... and to the last bit: plane / sphere / conic, tilted or not (the 3x3
+    # products follow the dgemm's fused chain), iterated aspheres (scipy's
+    # Newton operation for operation, BLAS-summed derivative included)
+    for rows, ref, label in zip((g.y, g.u, g.i, g.t), want, "yuit"):
+        assert np.array_equal(np.asarray(rows[a:b]), ref,
+                              equal_nan=True), (name, label)
     assert np.array_equal(g.n[:b], gold["n"][:b])
     # row 0 is what rays_given stored
     assert np.array_equal(g.y[0], gold["y0"])

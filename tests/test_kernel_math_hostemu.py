@@ -25,7 +25,6 @@ def test_kernel_math_matches_reference(hostemu, name, rays_per_lane):
     for label, got, want in (("y", Y, g["y"]), ("u", U, g["u"]),
                              ("i", I, g["i"]), ("t", T, g["t"])):
         assert_parity(got, want[a:b], rtol, "%s.%s" % (name, label))
-        if "aspherics" not in g["yaml"]:
-            # closed-form surfaces, tilted ones included: bit for bit
-            assert np.array_equal(got, want[a:b], equal_nan=True), \
-                (name, label)
+        # and in fact bit for bit: closed-form surfaces, tilted elements,
+        # the Newton solve of the aspheres
+        assert np.array_equal(got, want[a:b], equal_nan=True), (name, label)

@@ -24,17 +24,13 @@ def test_c_oracle_matches_reference_golden(name):
     table, ns = pack_system(system, g["l"],
                             system.refractive_index(g["l"], 0), a, b)
     got = build_c.propagate(table, g["y0"], g["u0"], a, b, g["clip"])
-    # closed-form surfaces are bit for bit the reference's, tilted elements
-    # included (the worst-conditioned of 1796 random tilted systems,
-    # tilted_seed_*, among them): the 3x3 products follow the dgemm's chain
-    # of fused multiply-adds.  Aspheres: scipy's Newton restated, 1e-12.
-    exact = "aspherics" not in g["yaml"]
+    # bit for bit the reference's: closed-form surfaces, tilted elements (the
+    # worst-conditioned of 1796 random tilted systems, tilted_seed_*, among
+    # them) and the Newton solve of the aspheres -- the 3x3 products and the
+    # Newton derivative follow the chain of fused multiply-adds the reference
+    # gets from BLAS
     for label, x, want in zip("yuit", got, (g["y"], g["u"], g["i"], g["t"])):
-        want = want[a:b]
-        if exact:
-            assert np.array_equal(x, want, equal_nan=True), (name, label)
-        else:
-            assert_parity(x, want, 1e-12, "%s.%s" % (name, label))
+        assert np.array_equal(x, want[a:b], equal_nan=True), (name, label)
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -51,7 +47,7 @@ def test_c_oracle_matches_numpy_oracle_on_random_systems(seed):
         with np.errstate(all="ignore"):
             b = tn.propagate(table, y, u, clip=clip)
         for x, w in zip(a, b):
-            if asph or (tilted and not EXACT_TILTS):
+            if tilted and not EXACT_TILTS:
                 assert_parity(x, w, 1e-11, "seed %d" % seed)
             else:
                 assert np.array_equal(x, w, equal_nan=True), seed

@@ -29,18 +29,15 @@ def oracle_on_case(g):
 def test_oracle_matches_reference_golden(name):
     g = load_golden(name)
     system, a, b, ns, (Y, U, I, T) = oracle_on_case(g)
-    # bit-exact -- tilted and decentred elements included: the host model
-    # forms rot_normal with the reference's own products
-    # (rayopt_amd/model.py _euler_rxyz / _axis_angle) -- unless Newton is
-    # involved (the scipy loop is restated in masked vector form)
-    exact = "aspherics" not in g["yaml"]
+    # bit-exact, all of it: tilted and decentred elements (the host model
+    # forms rot_normal with the reference's own products,
+    # rayopt_amd/model.py _euler_rxyz / _axis_angle) and the iterated
+    # aspheres (scipy's scalar Newton restated operation for operation, its
+    # derivative summed with the fused chain the reference reaches through
+    # BLAS, oracle/trace_numpy.py: fma)
     for label, got, want in (("y", Y, g["y"]), ("u", U, g["u"]),
                              ("i", I, g["i"]), ("t", T, g["t"])):
-        want = want[a:b]
-        if exact:
-            assert np.array_equal(got, want, equal_nan=True), (name, label)
-        else:
-            assert_parity(got, want, 1e-12, "%s.%s" % (name, label))
+        assert np.array_equal(got, want[a:b], equal_nan=True), (name, label)
     assert np.array_equal(ns[a:b], g["n"][a:b])
     # rows the reference did not trace were poisoned by the generator
     assert np.isnan(g["t"][b:]).all()

@@ -54,10 +54,7 @@ def test_oracle_and_kernel_math_vs_live_reference(seed, hostemu):
         got = tn.propagate(table, y, u, clip=clip)
         assert np.array_equal(ns[1:], g.n[1:])
         for a, b in zip(got, want):
-            if has_asphere(p):
-                assert_parity(a, b, 1e-11, "oracle seed %d" % seed)
-            else:
-                assert np.array_equal(a, b, equal_nan=True), seed
+            assert np.array_equal(a, b, equal_nan=True), seed
         # (2) this package's host model packs the same system
         table2, _ = pack_system(mine, g.l, g.n[0])
         for f in table.dtype.names:
@@ -68,9 +65,9 @@ def test_oracle_and_kernel_math_vs_live_reference(seed, hostemu):
         rtol = RTOL_ASPHERE if has_asphere(p) else RTOL_SPHERICAL
         for a, b in zip(emu, want):
             assert_parity(a, b, rtol, "kernel math seed %d" % seed)
-            if not has_asphere(p) and (EXACT_TILTS or not tilted(p)):
-                # closed-form surfaces: the reference's values bit for bit,
-                # through tilted elements as well
+            if EXACT_TILTS or not tilted(p):
+                # the reference's values bit for bit, through tilted elements
+                # and iterated aspheres as well
                 assert np.array_equal(a, b, equal_nan=True), seed
 
 
@@ -90,7 +87,7 @@ def test_gpu_vs_oracle_random_systems(seed):
         rtol = RTOL_ASPHERE if has_asphere(p) else RTOL_SPHERICAL
         for rows, b in zip((g.y, g.u, g.i, g.t), want):
             assert_parity(np.asarray(rows[1:]), b, rtol, "seed %d" % seed)
-            if not has_asphere(p) and (EXACT_TILTS or not tilted(p)):
+            if EXACT_TILTS or not tilted(p):
                 assert np.array_equal(np.asarray(rows[1:]), b,
                                       equal_nan=True), seed
         assert np.array_equal(g.n[1:], ns[1:])
