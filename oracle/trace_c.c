@@ -10,10 +10,11 @@
  * host cores with OpenMP (measured: 8e6 ray-surface-ops/s on one core, 1e8 on
  * 8), which lets the GPU tests compare EVERY ray of a full-size (10^7 rays)
  * trace instead of a subsample.  Pinned like the numpy oracle: bit-identical to the
- * reference's golden vectors for plane/sphere/conic surfaces
- * (tests/test_oracle_c.py), 1e-12 for the restated scipy Newton loop.
- * Compile with -ffp-contract=off (numpy never fuses a*b+c).  Never linked
- * into or called by the product.
+ * reference's golden vectors -- plane/sphere/conic surfaces, tilted elements
+ * and the restated scipy Newton loop of the aspheres (tests/test_oracle_c.py).
+ * Compile with -ffp-contract=off (numpy never fuses a*b+c); the two places
+ * where the reference goes through BLAS, which does, spell their fma() out.
+ * Never linked into or called by the product.
  *
  * Table layout: struct rt_surface of include/rt_mi355.h.
  */

@@ -16,9 +16,9 @@ Parity pinning: this oracle is validated (tests/test_oracle_golden.py)
 
 It deliberately performs the same whole-array numpy operations, in the same
 order, as the reference (AoS ``(N,3)`` float64 arrays, one temporary per
-ufunc), so (i) its results are bit-identical to the reference's for
-sphere/conic/plane surfaces and (ii) its timing is representative of the
-reference's numpy path.  It consumes the same ``rt_surface`` table as the GPU
+ufunc), so (i) its results are bit-identical to the reference's -- for every
+surface type, tilted elements and iterated aspheres included -- and (ii) its
+timing is representative of the reference's numpy path.  It consumes the same ``rt_surface`` table as the GPU
 kernel (a numpy structured array, see include/rt_mi355.h).
 
 The one place where the reference is not numpy is the even-asphere intercept:
@@ -26,7 +26,9 @@ a Python loop over rays calling ``scipy.optimize.newton``
 (rayopt/elements.py:333-349).  That algorithm lives in SciPy (not vendored;
 1.15.3 in the build container; ``setup.py`` pins no version); its scalar
 Newton-Raphson branch is restated here in masked, vectorised form
-(``newton_intercept``) and checked ray-for-ray against the real thing.
+(``newton_intercept``) and checked ray-for-ray, bit for bit, against the real
+thing; its derivative is a BLAS dot in the reference (np.dot of a (1,3) with a
+(3,1) array), i.e. a chain of fused multiply-adds, reproduced with ``fma``.
 """
 import numpy as np
 
