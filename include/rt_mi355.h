@@ -297,6 +297,9 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * "fuse_generate" (1 = the first trace after rt_generate_rays builds the
  * rays in registers and writes row 0 itself, the default; 0 = a separate
  * generation kernel writes row 0 and the trace reads it),
+ * "regenerate" (1 = default: later traces of a generated batch from element 1
+ * build the launch rays again in registers -- the values row 0 holds, bit for
+ * bit -- as long as row 0 is what the generator wrote; 0 = they read row 0),
  * "lds_pad" (bytes of unused dynamic LDS per workgroup: caps the resident
  * workgroups per CU for occupancy experiments; default 0),
  * "fast_asphere" (0 = default: even aspheres reproduce the reference's Newton
@@ -318,7 +321,11 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * with ballots and an LDS exchange; 2 = every trace.  Results are identical
  * to the plain kernel's, NaN payloads aside), "compact_every" (k: the
  * survivors of a workgroup are counted -- one barrier -- at every k-th element
- * only; default 4, the measured optimum: asking costs ~0.5 us per workgroup).
+ * only; default 4, the measured optimum: asking costs ~0.5 us per workgroup),
+ * "uniform_fix" (measurement only, results are wrong unless the data happen to
+ * be so: 6-bit mask of input components read from the wavefront's first
+ * column), "gate_log2" / "gate_window" (measurement only: input reads wait
+ * for chip-wide windows of the 100 MHz reference counter).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
 /*
