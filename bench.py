@@ -261,10 +261,10 @@ def traffic_live(n, clip, timeout=120.):
     work = tempfile.mkdtemp(prefix="rt_bench_pmc_", dir="/tmp")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rays", str(n),
            "--steps", "2", "--warmup", "1", "--settle", "0", "--cpu-sample",
-           "0", "--cpu-procs", "0", "--no-api-leg", "--traffic", "off"]
+           "0", "--cpu-procs", "0", "--no-engine-leg", "--traffic", "off"]
     if not clip:
         cmd.append("--no-clip")
-    kib, launches = {}, {}
+    kib, launches, gen = {}, {}, {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(work, counter)
@@ -276,25 +276,40 @@ def traffic_live(n, clip, timeout=120.):
             if res.returncode != 0:
                 raise RuntimeError("rocprofv3 --pmc %s: rc %d: %s" % (
                     counter, res.returncode, res.stderr[-300:]))
-            vals = []
+            vals, regen = [], []
             for path in glob.glob(os.path.join(
                     out, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
-                    for row in csv.DictReader(f):
-                        if "rt_trace_kernel" in row.get("Kernel_Name", "") \
-                                and row.get("Counter_Name") == counter:
-                            vals.append(float(row["Counter_Value"]))
+                    rows = [row for row in csv.DictReader(f)
+                            if row.get("Counter_Name") == counter]
+                rows.sort(key=lambda row: int(row.get("Dispatch_Id", 0)))
+                for row in rows:
+                    name = row.get("Kernel_Name", "")
+                    if "rt_trace_kernel" in name:
+                        vals.append(float(row["Counter_Value"]))
+                    elif "rt_trace_gen_kernel" in name:
+                        regen.append(float(row["Counter_Value"]))
             if not vals:
                 raise RuntimeError("no %s rows for rt_trace_kernel" % counter)
             kib[counter] = sum(vals)/len(vals)
             launches[counter] = len(vals)
+            # the generated batch: its first launch writes row 0 as well;
+            # the re-traces are what the leg times
+            if len(regen) > 1:
+                gen[counter] = sum(regen[1:])/len(regen[1:])
     finally:
         shutil.rmtree(work, ignore_errors=True)
     fetch = kib["FETCH_SIZE"]*1024*2
     write = kib["WRITE_SIZE"]*1024
-    return fetch + write, {
-        "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
-        "launches": [launches["FETCH_SIZE"], launches["WRITE_SIZE"]]}
+    detail = {"fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+              "launches": [launches["FETCH_SIZE"], launches["WRITE_SIZE"]]}
+    if len(gen) == 2:
+        detail["generated_batch"] = {
+            "fetch_bytes_corrected_x2": gen["FETCH_SIZE"]*1024*2,
+            "write_bytes": gen["WRITE_SIZE"]*1024,
+            "hbm_bytes_per_launch": gen["FETCH_SIZE"]*1024*2 +
+            gen["WRITE_SIZE"]*1024}
+    return fetch + write, detail
 
 
 # --------------------------------------------------------------------------
@@ -385,6 +400,8 @@ def main():
                          "(N = 1 only; falls back to 'profile' if rocprofv3 "
                          "cannot run), 'profile' = the committed "
                          "profiles/traffic.json, 'off' = null")
+    ap.add_argument("--no-engine-leg", action="store_true",
+                    help="skip the bare-engine comparison leg only")
     ap.add_argument("--no-api-leg", action="store_true",
                     help="skip the propagate_api comparison legs")
     ap.add_argument("--gather-every-step", action="store_true",
@@ -532,7 +549,7 @@ def main():
         e_full, ev_full, _ = job.timed(step, args.steps, args.warmup, False)
         full_i = (e_full, ev_full/args.steps)
         eng.set_option("alias_i", 1)
-    if not args.no_api_leg and not dist_mode:
+    if not args.no_api_leg and not args.no_engine_leg and not dist_mode:
         g.propagate(clip=clip)
         e_eng, ev_eng, _ = job.timed(step_engine, args.steps, args.warmup,
                                      False)
@@ -718,6 +735,12 @@ def main():
     if configs4 is not None:
         out["configs4"] = configs4
     if generated is not None:
+        counted = (traffic_detail or {}).pop("generated_batch", None)
+        if counted:     # the same counter passes saw this leg's kernel too
+            generated["traffic"] = counted["hbm_bytes_per_launch"]
+            generated["traffic_detail"] = {
+                k: counted[k] for k in ("fetch_bytes_corrected_x2",
+                                        "write_bytes")}
         out["generated_batch"] = generated
     if api is not None:
         out["propagate_api"] = api
