@@ -836,8 +836,10 @@ def run_generated(ra, system, device, n, clip, args):
     reference's rays_point entry) instead of handed over with rays_given.
     Every timed step is the public propagate() on the resident batch; a
     re-trace of a generated batch builds its launch rays again in registers
-    rather than read row 0, so the launch moves 56 B per ray-surface op and
-    16 B per pupil point."""
+    rather than read row 0, so the launch writes 56 B per ray-surface op and
+    reads 16 B per ray: the pupil coordinates (a pupil point is shared by
+    the five fields, but its five uses are a fifth of the launch apart, so
+    the L2 sees it five times -- what the fetch counter confirms)."""
     from rayopt_amd import prescriptions as P
     nf = len(FIELD_FRACTIONS)
     m = n//nf//64*64
@@ -857,7 +859,7 @@ def run_generated(ra, system, device, n, clip, args):
     S = len(system) - 1
     rays = m*nf
     kernel_ms = ev_ms/args.steps
-    alg = rays*56*S + m*16
+    alg = rays*(56*S + 16)
     ulast = np.asarray(g.u[S])
     return {
         "workload": "the same five field bundles built on the device "
