@@ -1,0 +1,101 @@
+"""Full-size traces against the reference itself, by digest.
+
+tests/golden/digests.json holds SHA-256 digests of what the UNMODIFIED
+reference computed for the BASELINE configs at sizes it finishes in seconds
+(C1 10^4, C2 10^6 rays x 3 wavelengths, C3 10^6 rays in five fields clipped
+and unclipped, C4 2*10^4 rays through six Newton-solved aspheres, the
+tilted / folded torture system 2*10^5 rays): every value of y, u, i, t of
+every traced row (generator: tests/golden/make_digests.py).  Equal digests =
+every one of up to 1.2*10^8 values equal to the reference's, bit for bit --
+no oracle in between.  Here: the numpy oracle, the C oracle and the host build
+of the kernel arithmetic; under -m gpu: the device."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd.pack import pack_system
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import digest_cases as dc  # noqa: E402
+
+with open(os.path.join(os.path.dirname(__file__), "golden",
+                       "digests.json")) as f:
+    DIGESTS = json.load(f)
+CASES = {c["name"]: c for c in dc.cases()}
+NAMES = sorted(CASES)
+# the asphere case is ~6 s in the numpy oracle (masked vector Newton) and the
+# 10^6-ray ones ~3 s each: kept, the whole file stays under a minute on CPU
+
+
+def rows_from(arrays, L):
+    def rows_of(k, j):
+        if j >= L:
+            raise IndexError
+        return arrays[k][j - 1]
+    return rows_of
+
+
+def check_inputs(name):
+    case, want = CASES[name], DIGESTS[name]
+    y, u = case["rays"]
+    if dc.digest_inputs(y, u) != want["inputs"]:
+        pytest.skip("this host builds other launch rays than the recording "
+                    "host did (numpy / libm differ): the digest of the "
+                    "results cannot be compared")
+    return case, want, y, u
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_inputs_reproduce(name):
+    case, want = CASES[name], DIGESTS[name]
+    assert dc.digest_inputs(*case["rays"]) == want["inputs"], \
+        "launch rays differ from the recording host's"
+
+
+@pytest.mark.parametrize("engine", ["numpy oracle", "C oracle",
+                                    "kernel arithmetic, host build"])
+@pytest.mark.parametrize("name", NAMES)
+def test_cpu_restatements_equal_the_reference_by_digest(name, engine,
+                                                        hostemu):
+    from oracle import trace_numpy as tn, build_c
+    case, want, y, u = check_inputs(name)
+    if engine != "C oracle" and want["rays"] > 300_000 and \
+            "unclipped" in name:
+        pytest.skip("one 10^6-ray double-Gauss case per slow engine")
+    system = ra.system_from_yaml(case["yaml"])
+    table, ns = pack_system(system, case["l"],
+                            system.refractive_index(case["l"], 0))
+    with np.errstate(all="ignore"):
+        if engine == "numpy oracle":
+            Y, U, I, T = tn.propagate(table, y, u, clip=case["clip"])
+        elif engine == "C oracle":
+            Y, U, I, T = build_c.propagate(table, y, u, clip=case["clip"])
+        else:
+            Y, U, I, T = hostemu(table, y, u, 1, len(table), case["clip"], 1)
+    got = dc.digest_rows(rows_from(dict(y=Y, u=U, i=I, t=T), len(system)))
+    assert got == want["results"], name
+    assert int(np.isnan(U[-1][:, 0]).sum()) == want["dead_at_image"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_device_equals_the_reference_by_digest(name):
+    case, want, y, u = check_inputs(name)
+    system = ra.system_from_yaml(case["yaml"])
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u, case["l"])
+    g.propagate(clip=case["clip"])
+    arrays = {"y": g.y, "u": g.u, "i": g.i, "t": g.t}
+    L = len(system)
+
+    def rows_of(k, j):
+        if j >= L:
+            raise IndexError
+        return np.asarray(arrays[k][j])
+    assert dc.digest_rows(rows_of) == want["results"], name
+    assert int(np.isnan(np.asarray(g.u[-1])[:, 0]).sum()) == \
+        want["dead_at_image"]
