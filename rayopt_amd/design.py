@@ -107,7 +107,8 @@ def pupil_text(pupil):
     label, key = {"radius": ("Radius", "radius"), "slope": ("Slope", "slope"),
                   "na": ("NA", "na"),
                   "fno": ("F-Number", "fno")}[pupil_kind(pupil)]
-    yield "%s: %g" % (label, pupil.get(key, 0.))
+    value = pupil.get(key)
+    yield "%s: %g" % (label, 0. if value is None else value)
 
 
 def conjugate_text(conjugate):
