@@ -28,64 +28,85 @@ from .geometric_trace import GeometricTrace
 from .launch import _telecentric
 
 
+def _element_matrix(el, n0, l):
+    """(index behind the element, its 4x4 first-order matrix acting on
+    (x, y, n u_x, n u_y)): a transfer over the element's distance, then --
+    for a surface -- refraction or reflection at incidence ``angles[0]`` in
+    the form of Massey and Siegman (Appl. Opt. 8, 975) and the turn by
+    ``angles[2]`` about the axis, entry by entry and product by product as
+    the reference forms them (rayopt/elements.py:223-228, 300-304, 503-542):
+    the first-order pupils below are the reference's to the last bit, and
+    with them every aimed bundle of ``aiming="reference"``."""
+    transfer = np.eye(4)
+    transfer[0, 2] = transfer[1, 3] = el.distance/n0
+    material = getattr(el, "material", None)
+    n = n0 if material is None else el.refractive_index(l)
+    if not hasattr(el, "curvature"):
+        return n, transfer
+    c = el.curvature
+    if el.aspherics is not None:
+        c = c + 2*el.aspherics[0]
+    angles = np.asarray(el.angles, dtype=float)
+    cos_i = np.cos(angles[0])
+    bend = np.eye(4)
+    if material is not None:
+        if material.mirror:
+            bend[2, 0] = 2*c*cos_i
+            bend[3, 1] = 2*c/cos_i
+        else:
+            mu = n/n0
+            p = np.sqrt(mu**2 + cos_i**2 - 1)
+            bend[1, 1] = p/(mu*cos_i)
+            bend[2, 0] = n0*c*(cos_i - p)
+            bend[3, 1] = mu*bend[2, 0]/(cos_i*p)
+            bend[3, 3] = 1/bend[1, 1]
+    m = np.dot(bend, transfer)
+    cos_t, sin_t = np.cos(angles[2]), np.sin(angles[2])
+    turn = np.eye(4)
+    turn[:2, :2] = turn[2:, 2:] = np.array([[cos_t, -sin_t],
+                                            [sin_t, -cos_t]])
+    return n, np.dot(turn, np.dot(m, turn.T))
+
+
+def first_order_matrix(system, l, start=1, stop=None):
+    """(index behind the last element, product of the element matrices of
+    ``system[start:stop]``) -- rayopt/system.py:399-410."""
+    n = system.refractive_index(l, start - 1)
+    m = np.eye(4)
+    for el in system[start:stop]:
+        n, mi = _element_matrix(el, n, l)
+        m = np.dot(mi, m)
+    return n, m
+
+
 def entrance_pupil(system, l=None):
-    """(distance from the vertex of element 0, radius) of the paraxial image
-    of the stop in object space: y-nu trace of two rays through elements
-    1..stop (untilted elements)."""
+    """(distance from the vertex of element 0, radius) of the first-order
+    image of the stop in object space, from the meridional 2x2 block of the
+    matrix object -> stop: what ``ParaxialTrace.update_conjugates`` hands
+    ``system.object`` (rayopt/paraxial_trace.py:326-334)."""
     if l is None:
         l = system.wavelengths[0]
     stop = system.stop
-    n0 = system.refractive_index(l, 0)
-    rays = np.array([[1., 0.], [0., 1.]])        # (y, n u) for two rays
-    n_prev = n0
-    for el in system[1:stop + 1]:
-        rays[:, 0] += el.distance*rays[:, 1]/n_prev
-        c = getattr(el, "curvature", 0.)
-        asph = getattr(el, "aspherics", None)
-        if asph:
-            c = c + 2*asph[0]
-        if getattr(getattr(el, "material", None), "mirror", False):
-            # reflection as the reference's paraxial matrix has it
-            # (rayopt/elements.py:517-520): u' = u + 2 c y, index unchanged
-            rays[:, 1] += 2*c*rays[:, 0]
-            continue
-        n_next, _ = el.get_n_mu(n_prev, l)
-        rays[:, 1] -= rays[:, 0]*c*(n_next - n_prev)
-        n_prev = n_next
-    a, b = rays[0, 0], rays[1, 0]*n0
+    _, m = first_order_matrix(system, l, stop=stop + 1)
+    a, b = m[1::2, 1::2][0]
+    b *= system.refractive_index(l, 0)
     return b/a, system[stop].radius/a
 
 
 def exit_pupil(system, l=None):
     """(distance from the vertex of the image surface, radius) of the
-    paraxial image of the stop in image space: the two basis rays
-    (y, n u) = (1, 0), (0, 1) leaving the stop are carried through elements
-    stop+1 .. L-1; the first row (a, b) of the INVERSE of that matrix gives
-    distance = b n_last / a and radius = stop radius / a -- what the
-    reference stores in ``system.image.pupil`` (``update_conjugates``,
-    rayopt/paraxial_trace.py:336-341) and ``GeometricTrace.opd`` takes its
-    default reference-sphere radius from (rayopt/geometric_trace.py:113)."""
+    first-order image of the stop in image space: first row of the inverse
+    of the meridional block stop -> image -- what the reference stores in
+    ``system.image.pupil`` (rayopt/paraxial_trace.py:336-341) and
+    ``GeometricTrace.opd`` takes its default reference-sphere radius from
+    (rayopt/geometric_trace.py:113)."""
     if l is None:
         l = system.wavelengths[0]
     stop = system.stop
-    n_prev = system.refractive_index(l, stop)
-    rays = np.array([[1., 0.], [0., 1.]])        # (y, n u) for two rays
-    for el in system[stop + 1:]:
-        rays[:, 0] += el.distance*rays[:, 1]/n_prev
-        c = getattr(el, "curvature", 0.)
-        asph = getattr(el, "aspherics", None)
-        if asph:
-            c = c + 2*asph[0]
-        if getattr(getattr(el, "material", None), "mirror", False):
-            rays[:, 1] += 2*c*rays[:, 0]
-            continue
-        if not hasattr(el, "get_n_mu"):
-            continue
-        n_next, _ = el.get_n_mu(n_prev, l)
-        rays[:, 1] -= rays[:, 0]*c*(n_next - n_prev)
-        n_prev = n_next
-    a, b = np.linalg.inv(rays.T)[0]
-    return b*n_prev/a, system[stop].radius/a
+    n, m = first_order_matrix(system, l, start=stop + 1)
+    a, b = np.linalg.inv(m[1::2, 1::2])[0]
+    b *= n
+    return b/a, system[stop].radius/a
 
 
 def start_pupil(system, l, z0=None, a0=None):
