@@ -34,9 +34,10 @@ RIM_TOL = 3e-2
 
 # the same with aiming="reference": rayopt's own aiming procedure on the
 # engine.  The aimed pupils are then the reference's bit for bit and so are
-# the traces; what is left is the last bit of the pupil PATTERN's
-# coordinates (rayopt_amd/pupil.py restates rayopt/utils.py:117-199 with its
-# own expressions: launch heights differ by <= 5e-15) and, on the device, the
+# the traces; what is left is the last bit of the Radau / Lobatto
+# quadrature nodes (np.roots of the recording host there, numpy.polynomial
+# here: launch heights differ by <= 5e-15; the other sampling patterns are
+# bit-identical arrays) and, on the device, the
 # summation order of the reductions behind refocus() and opd()
 EXACT = dict(launch=1e-13, image=1e-12, opd=1e-10, psf=1e-10)
 EXACT_DEVICE = dict(launch=1e-13, image=1e-12, refocus=1e-9, opd=1e-6,
