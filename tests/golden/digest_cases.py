@@ -91,6 +91,17 @@ def _cases():
                rays=lambda: bundle(2*10**5, 12., 2., 3))
 
 
+GENERATED = dict(name="generated_double_gauss_5_fields_1e6",
+                 yaml=P.DOUBLE_GAUSS, l=587.56e-9, clip=True,
+                 fields=[(0., 0.), (0., .35), (0., .5), (0., .7), (0., 1.)],
+                 z=P.DOUBLE_GAUSS_PUPIL_Z, a=17.,
+                 pupil=lambda: disc_points(200_000, 77)*.95)
+"""Bundles the reference builds with System.aim(yo, yp, z, a, filter=False)
+(rayopt/system.py:504, rayopt/conjugates.py:236-255) field by field and hands
+to rays_given; here built on the device (rays_fields), first trace fused with
+the generation, re-traces rebuilding the rays."""
+
+
 def digest_rows(rows_of):
     """SHA-256 over rows 1..L-1 of y, u, i (each (N,3) C-contiguous) and t
     ((N,)), in that order; ``rows_of(name, j)`` returns the row."""

@@ -60,6 +60,32 @@ def main():
             "reference_seconds": round(dt, 2),
         }
         print(case["name"], out[case["name"]], flush=True)
+    gen = dc.GENERATED
+    if not only or gen["name"] in only:
+        s = ro.system_from_yaml(gen["yaml"])
+        yp = gen["pupil"]()
+        a = gen["a"]*np.array(((-1., -1.), (1., 1.)))
+        ys, us = zip(*[s.aim(np.array(yo), yp, gen["z"], a, filter=False)
+                       for yo in gen["fields"]])
+        y, u = np.concatenate(ys), np.concatenate(us)
+        g = ro.GeometricTrace(s)
+        g.rays_given(y, u, gen["l"])
+        with np.errstate(all="ignore"):
+            g.propagate(clip=gen["clip"])
+        arrays = {"y": g.y, "u": g.u, "i": g.i, "t": g.t}
+        L = len(s)
+
+        def rows_of(k, j):
+            if j >= L:
+                raise IndexError
+            return arrays[k][j]
+        out[gen["name"]] = {
+            "rays": int(y.shape[0]), "elements": L, "clip": gen["clip"],
+            "inputs": dc.digest_inputs(yp, np.array(gen["fields"])),
+            "launch": dc.digest_inputs(g.y[0], g.u[0]),
+            "results": dc.digest_rows(rows_of),
+            "dead_at_image": int(np.isnan(g.u[-1][:, 0]).sum())}
+        print(gen["name"], out[gen["name"]], flush=True)
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 

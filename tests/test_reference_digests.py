@@ -132,3 +132,47 @@ def test_three_wavelengths_in_one_launch_equal_the_reference_by_digest():
                 raise IndexError
             return np.asarray(arrays[key][j])[k*n:(k + 1)*n]
         assert dc.digest_rows(rows_of) == DIGESTS[name]["results"], name
+
+
+def _generated(make_trace):
+    gen, want = dc.GENERATED, DIGESTS[dc.GENERATED["name"]]
+    yp = gen["pupil"]()
+    if dc.digest_inputs(yp, np.array(gen["fields"])) != want["inputs"]:
+        pytest.skip("other pupil points than on the recording host")
+    system = ra.system_from_yaml(gen["yaml"])
+    g = make_trace(system)
+    g.rays_fields(np.array(gen["fields"]), yp, gen["z"], gen["a"], gen["l"])
+    L = len(system)
+    for what in ("first trace: generation fused into it",
+                 "re-trace: launch rays rebuilt, row 0 not read",
+                 "re-trace again"):
+        g.propagate(clip=gen["clip"])
+        arrays = {"y": g.y, "u": g.u, "i": g.i, "t": g.t}
+
+        def rows_of(k, j):
+            if j >= L:
+                raise IndexError
+            return np.asarray(arrays[k][j])
+        assert dc.digest_inputs(np.asarray(g.y[0]), np.asarray(g.u[0])) == \
+            want["launch"], what
+        assert dc.digest_rows(rows_of) == want["results"], what
+    return g
+
+
+def test_generated_bundles_equal_the_reference_by_digest_on_the_double():
+    """rays_fields (five fields x 2*10^5 pupil points) + propagate against
+    what the reference computes from System.aim + rays_given + propagate:
+    launch rays and every traced value, by digest (engine double: the numpy
+    oracle's generation and trace)."""
+    from fake_engine import OracleEngine
+    _generated(lambda system: ra.GeometricTrace(system,
+                                                engine=OracleEngine()))
+
+
+@pytest.mark.gpu
+def test_generated_bundles_equal_the_reference_by_digest_on_the_device():
+    """The same on the device: rays built by the kernel (first trace), rebuilt
+    by every re-trace -- bit for bit the reference's bundles and results."""
+    g = _generated(lambda system: ra.GeometricTrace(system))
+    assert int(np.isnan(np.asarray(g.u[-1])[:, 0]).sum()) == \
+        DIGESTS[dc.GENERATED["name"]]["dead_at_image"]
