@@ -221,30 +221,28 @@ class DesignMixin:
     def groups(self):
         """Index lists of the lens groups: gas, solids, (mirror, solids)*,
         gas -- or a mirror on its own."""
-        group = []
-        for i, el in enumerate(self):
-            if hasattr(el, "material"):
-                mat = el.material
-                if getattr(mat, "solid", False):
-                    group.append(i)
-                elif group or getattr(mat, "mirror", False):
-                    group.append(i)
-                    yield group
-                    group = []
-            elif group:
-                group.append(i)
-        if group:
-            yield group
+        open_group = []
+        for index, element in enumerate(self):
+            if not hasattr(element, "material"):    # a plane without medium
+                if open_group:
+                    open_group.append(index)
+                continue
+            medium = element.material
+            if getattr(medium, "solid", False):
+                open_group.append(index)
+            elif open_group or getattr(medium, "mirror", False):
+                yield open_group + [index]
+                open_group = []
+        if open_group:
+            yield open_group
 
     def edge_thickness(self, axis=1):
         """Axial gap in front of every element measured at the rim
         (element radius) instead of the vertex."""
-        gaps, before = [], 0.
-        for el in self:
-            here = el.edge_sag(axis) if hasattr(el, "edge_sag") else 0.
-            gaps.append(el.distance - here + before)
-            before = here
-        return np.array(gaps)
+        rim = np.array([el.edge_sag(axis) if hasattr(el, "edge_sag") else 0.
+                        for el in self])
+        vertex = np.array([el.distance for el in self])
+        return (vertex - rim) + np.concatenate([[0.], rim[:-1]])
 
     @property
     def edge_y(self):
@@ -257,44 +255,43 @@ class DesignMixin:
     def resize_convex(self):
         """Make the convex side of a lens at least as large as the surface
         that closes it (a lens can then be edged from one side)."""
-        opened, c_opened = None, None
-        for el in self[1:-1]:
-            if not hasattr(el, "material"):
+        front = None            # (surface that opened a solid, its curvature)
+        for surface in self[1:-1]:
+            if not hasattr(surface, "material"):
                 continue
-            c = getattr(el, "curvature", 0)
-            solid = (not el.material) or el.material.solid
-            if opened is not None:
-                r = max(el.radius, opened.radius)
-                if c <= 0:
-                    el.radius = r
-                if c_opened > 0:
-                    opened.radius = r
-                opened = None
-            if solid:
-                opened, c_opened = el, c
+            curvature = getattr(surface, "curvature", 0)
+            if front is not None:
+                opener, opened_with = front
+                larger = max(surface.radius, opener.radius)
+                if curvature <= 0:          # closes convex (or flat)
+                    surface.radius = larger
+                if opened_with > 0:         # opened convex
+                    opener.radius = larger
+            starts_solid = (not surface.material) or surface.material.solid
+            front = (surface, curvature) if starts_solid else None
 
     def reverse(self):
         """Turn the system around: the element order, every surface, the
         material behind each surface and the distances swap ends; object and
         image change places."""
-        gaps = [el.distance for el in self] + [0.]
-        media = [None] + [getattr(el, "material", None) for el in self]
-        for i, el in enumerate(self):
-            el.reverse()
-            el.distance = gaps[i + 1]
-            el.material = media[i]
-        self.object, self.image = self.image, self.object
+        count = len(self)
+        distance_behind = [self[i + 1].distance if i + 1 < count else 0.
+                           for i in range(count)]
+        medium_before = [getattr(self[i - 1], "material", None) if i else None
+                         for i in range(count)]
+        for element, gap, medium in zip(self, distance_behind, medium_before):
+            element.reverse()
+            element.distance = gap
+            element.material = medium
         self[:] = self[::-1]
+        self.object, self.image = self.image, self.object
 
     def rescale(self, scale=None):
         """Multiply every length by ``scale`` (default: to millimetres)."""
-        if scale is None:
-            scale = self.scale/1e-3
-        self.scale /= scale
-        for el in self:
-            el.rescale(scale)
-        self.object.rescale(scale)
-        self.image.rescale(scale)
+        factor = self.scale/1e-3 if scale is None else scale
+        for part in (*self, self.object, self.image):
+            part.rescale(factor)
+        self.scale = self.scale/factor
 
     # -- text -------------------------------------------------------------------
     def base_text(self):
