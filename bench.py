@@ -139,6 +139,20 @@ def cpu_port_on_processes(system, y, u, clip, procs):
                       "the numpy port each (%.2f s)" % (len(y), procs, dt)}
 
 
+def host_cpu():
+    """'model name, N logical cores' of this host."""
+    model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return "%s, %d logical cores" % (model, os.cpu_count() or 0)
+
+
 def cpu_one_core(table, system, y, u, clip, S, g, L, sample, l):
     """One propagate() of the numpy port -- or of rayopt itself where
     /root/reference exists -- on one core; doubles as a parity check of the
@@ -162,6 +176,11 @@ def cpu_one_core(table, system, y, u, clip, S, g, L, sample, l):
         "sample": "first %d rays of the same workload, one propagate() of "
                   "the numpy port (%.1f s); host has %d cores" % (
                       m, dt, os.cpu_count()),
+        "host": host_cpu(),
+        # the port is the reference's arithmetic bit for bit (tests/): so is
+        # what the GPU just computed in the timed loop
+        "image_row_bit_identical_to_gpu": bool(
+            np.array_equal(got, ref, equal_nan=True)),
     }
     from oracle import ref_timing
     ref = ref_timing.time_reference(ys, us, l, clip, want_image_row=Y[-1])

@@ -43,6 +43,7 @@ def test_single_process_line():
     d = check_line(out, 4, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert c["image_row_bit_identical_to_gpu"] is True and "cores" in c["host"]
     a = d["cpu_baseline_all_cores"]
     assert a["kind"] == "port" and a["cores"] == 4 and a["value"] > 0
     cc = d["cpu_baseline_c"]
