@@ -1,0 +1,161 @@
+"""Stateful fuzz of the engine's bookkeeping on the GPU: the same random
+sequence of calls -- seedings (host rays, weights, device-built bundles),
+partial and full traces with and without clipping and kept-row subsets, reads
+of single rows in random order, changes of the System between traces, kernel
+options flipped on the device side only -- is applied to a GeometricTrace on
+the device and to one on the numpy engine double, and after every step every
+row the double holds must be bit for bit what the device holds.
+
+What it is after: rows served instead of stored (i from u, u from i), rows
+detached before their source is overwritten, keep masks, host-side row caches
+invalidated at the right time, a generated batch rebuilt instead of read.
+
+    python tests/tools/fuzz_state.py 0 200 [ops per sequence]
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import rayopt_amd as ra
+from fake_engine import OracleEngine
+from random_systems import random_prescription, random_rays
+
+SIZES = (1, 63, 64, 65, 777, 4099)
+OPTIONS = (("alias_i", (0, 1)), ("regenerate", (0, 1)),
+           ("fuse_generate", (0, 1)), ("rays_per_thread", (1, 2, 4)),
+           ("nontemporal", (0, 1)), ("compact", (0, 1, 2)))
+DEFAULTS = dict(alias_i=1, regenerate=1, fuse_generate=1, rays_per_thread=1,
+                nontemporal=0, compact=0)
+
+
+def compare(dev, cpu, log):
+    L = cpu.length
+    for name in "yuit":
+        a, b = getattr(dev, name), getattr(cpu, name)
+        for j in range(L):
+            if not cpu.engine.valid[j]:
+                continue
+            x, w = np.asarray(a[j]), np.asarray(b[j])
+            if not np.array_equal(x, w, equal_nan=True):
+                raise AssertionError("%s[%d] differs after: %s" % (
+                    name, j, " | ".join(log[-6:])))
+    if not np.array_equal(np.asarray(dev.n), np.asarray(cpu.n),
+                          equal_nan=True):
+        raise AssertionError("n differs after: " + " | ".join(log[-6:]))
+
+
+def sequence(seed, nops):
+    rng = np.random.default_rng(seed)
+    p = random_prescription(seed)
+    system = ra.system_from_dict(copy.deepcopy(p))
+    L = len(system)
+    dev = ra.GeometricTrace(system)
+    cpu = ra.GeometricTrace(system, engine=OracleEngine())
+    eng = dev.engine
+    for k, v in DEFAULTS.items():
+        eng.set_option(k, v)
+    log, seeded = [], False
+    try:
+        for _ in range(nops):
+            op = rng.choice(["given", "fields", "prop", "prop", "prop",
+                             "read", "opt", "mutate"])
+            if not seeded and op not in ("given", "fields"):
+                op = "given"
+            if op == "given":
+                n = int(rng.choice(SIZES))
+                y, u = random_rays(int(rng.integers(1 << 30)), n, p)
+                w = None
+                if rng.random() < .3:
+                    w = rng.random(n)
+                    w /= w.sum()
+                for t in (dev, cpu):
+                    t.rays_given(y, u, w=w)
+                seeded = True
+                log.append("given n=%d w=%s" % (n, w is not None))
+            elif op == "fields":
+                nf = int(rng.integers(1, 5))
+                m = int(rng.choice((64, 200, 333)))
+                if (nf*m) % 1 == 0:
+                    fields = rng.uniform(-1, 1, (nf, 2))
+                    yp = rng.uniform(-.6, .6, (m, 2))
+                    rad = min(float(e.radius) for e in system[1:-1]
+                              if np.isfinite(e.radius))
+                    for t in (dev, cpu):
+                        t.rays_fields(fields, yp, 40., .5*rad)
+                    seeded = True
+                    log.append("fields %dx%d" % (nf, m))
+            elif op == "prop":
+                valid = [j for j in range(L - 1) if cpu.engine.valid[j]]
+                start = int(rng.choice(valid)) + 1
+                stop = None if rng.random() < .5 else \
+                    int(rng.integers(start, L + 1))
+                clip = bool(rng.random() < .5)
+                keep = None
+                if rng.random() < .3:
+                    keep = sorted(set(int(x) for x in rng.integers(
+                        0, L, int(rng.integers(1, L)))))
+                for t in (dev, cpu):
+                    t.propagate(start=start, stop=stop, clip=clip, keep=keep)
+                log.append("prop %d:%s clip=%s keep=%s" % (start, stop, clip,
+                                                           keep))
+            elif op == "read":
+                j = int(rng.integers(0, L))
+                name = "yuit"[int(rng.integers(4))]
+                if cpu.engine.valid[j]:
+                    x = np.asarray(getattr(dev, name)[j])
+                    w = np.asarray(getattr(cpu, name)[j])
+                    assert np.array_equal(x, w, equal_nan=True), \
+                        "read %s[%d] after: %s" % (name, j,
+                                                   " | ".join(log[-6:]))
+                log.append("read %s[%d]" % (name, j))
+                continue
+            elif op == "opt":
+                key, values = OPTIONS[int(rng.integers(len(OPTIONS)))]
+                value = int(rng.choice(values))
+                eng.set_option(key, value)
+                log.append("%s=%d" % (key, value))
+                continue
+            elif op == "mutate":
+                j = int(rng.integers(1, L))
+                el = system[j]
+                what = rng.choice(["distance", "curvature", "radius"])
+                if what == "curvature" and hasattr(el, "curvature"):
+                    el.curvature *= 1. + 1e-3*rng.normal()
+                elif what == "radius" and np.isfinite(el.radius):
+                    el.radius *= 1. + 1e-2*rng.normal()
+                else:
+                    el.distance = el.distance*(1. + 1e-3*rng.normal())
+                log.append("mutate %d %s" % (j, what))
+                continue
+            compare(dev, cpu, log)
+    finally:
+        for k, v in DEFAULTS.items():
+            eng.set_option(k, v)
+    return len(log)
+
+
+def main():
+    lo, hi = int(sys.argv[1]), int(sys.argv[2])
+    nops = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+    bad = steps = 0
+    for seed in range(lo, hi):
+        try:
+            with np.errstate(all="ignore"):
+                steps += sequence(seed, nops)
+        except AssertionError as err:
+            bad += 1
+            print("FAIL seed %d: %s" % (seed, str(err)[:400]), flush=True)
+        except Exception as err:
+            bad += 1
+            print("ERROR seed %d: %r" % (seed, err), flush=True)
+    print("state fuzz %d..%d: %d steps, %d failing sequences" % (
+        lo, hi, steps, bad))
+
+
+if __name__ == "__main__":
+    main()
