@@ -40,6 +40,12 @@ class OracleEngine:
         self.valid = np.zeros(L, dtype=bool)
         self.valid[0] = True
 
+    def upload_row(self, which, surf, src_soa):
+        """rt_upload_row: (ncomp, n) SoA data into row ``surf``."""
+        src = np.asarray(src_soa, dtype=float)
+        self.rows[which][surf] = src if which == RT_T else src.T
+        self.valid[surf] = True
+
     def set_weights(self, w):
         self.w = None if w is None else np.array(w)
 

@@ -67,7 +67,7 @@ def sequence(seed, nops):
     try:
         for _ in range(nops):
             op = rng.choice(["given", "fields", "prop", "prop", "prop",
-                             "read", "opt", "mutate"])
+                             "read", "opt", "mutate", "upload"])
             if not seeded and op not in ("given", "fields"):
                 op = "given"
             if op == "given":
@@ -124,6 +124,22 @@ def sequence(seed, nops):
                 eng.set_option(key, value)
                 log.append("%s=%d" % (key, value))
                 continue
+            elif op == "upload":
+                # the caller's own data into one row of one array: rows that
+                # were being served from it must keep what they showed
+                j = int(rng.integers(0, L))
+                if not cpu.engine.valid[j]:
+                    continue
+                which = int(rng.integers(4))
+                n = cpu.nrays
+                data = rng.normal(size=(1 if which == 3 else 3, n))
+                if which == 3:
+                    data = data[0]
+                for t in (dev, cpu):
+                    t.engine.upload_row(which, j, data)
+                    for rows in (t.y, t.u, t.i, t.t):
+                        rows.invalidate(0, L)
+                log.append("upload %s[%d]" % ("yuit"[which], j))
             elif op == "mutate":
                 j = int(rng.integers(1, L))
                 el = system[j]
