@@ -955,6 +955,13 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
         if (rc != RT_OK)
             return rc;
     }
+    if (which == RT_U && ctx->i_alias[surf] == 2) {
+        /* i[0] is u[0] at seeding time (geometric_trace.py:67), a copy in
+         * the reference: it keeps the old directions */
+        int rc = rt_detach(ctx, RT_I, surf);
+        if (rc != RT_OK)
+            return rc;
+    }
     if (which == RT_I && ctx->u_alias[surf]) {
         int rc = rt_detach(ctx, RT_U, surf);
         if (rc != RT_OK)
