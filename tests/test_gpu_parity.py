@@ -981,3 +981,25 @@ def test_compacting_kernel_with_ray_groups_and_aspheres():
         assert np.array_equal(np.asarray(g.y[-1]), want, equal_nan=True)
     finally:
         g.engine.set_option("compact", 0)
+
+
+def test_replacing_a_launch_row_leaves_the_rows_it_served_alone():
+    """i[0] = u[0] at seeding time is a COPY in the reference
+    (rayopt/geometric_trace.py:67); on the device I[0] is served from U[0]
+    until U[0] is replaced (rt_upload_row) -- then it must keep the old
+    directions.  Found by tests/tools/fuzz_state.py."""
+    from rayopt_amd._lib import RT_U
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = _c3_rays(1000)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    other = np.ascontiguousarray(u[::-1].T)
+    g.engine.upload_row(RT_U, 0, other)
+    for rows in (g.y, g.u, g.i, g.t):
+        rows.invalidate(0, g.length)
+    assert np.array_equal(np.asarray(g.u[0]), other.T)
+    assert np.array_equal(np.asarray(g.i[0]), u)
+    g.propagate(clip=True)
+    want, _ = oracle_trace(system, y, other.T, g.l, True)
+    compare(g, want, 1, 13, RTOL_SPHERICAL, "replaced u[0]")
+    assert np.array_equal(np.asarray(g.i[0]), u)
