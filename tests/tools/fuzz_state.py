@@ -67,7 +67,7 @@ def sequence(seed, nops):
     try:
         for _ in range(nops):
             op = rng.choice(["given", "fields", "prop", "prop", "prop",
-                             "read", "opt", "mutate", "upload"])
+                             "read", "opt", "mutate", "upload", "reduce"])
             if not seeded and op not in ("given", "fields"):
                 op = "given"
             if op == "given":
@@ -123,6 +123,28 @@ def sequence(seed, nops):
                 value = int(rng.choice(values))
                 eng.set_option(key, value)
                 log.append("%s=%d" % (key, value))
+                continue
+            elif op == "reduce":
+                # the device reductions read rows through the same aliases
+                j = int(rng.integers(0, L))
+                if cpu.engine.valid[j] and (j == 0 or cpu.engine.valid[j - 1]):
+                    kind = rng.choice(["rms", "rms_ref", "rmax", "refocus"])
+                    if kind == "rms":
+                        a, b = dev.rms(j), cpu.rms(j)
+                    elif kind == "rms_ref":
+                        r = int(rng.integers(cpu.nrays))
+                        a, b = dev.rms(j, ref=r), cpu.rms(j, ref=r)
+                    elif kind == "rmax":
+                        a, b = dev.engine.row_rmax(j), cpu.engine.row_rmax(j)
+                    else:
+                        a = dev.engine.refocus_shift(j)
+                        b = cpu.engine.refocus_shift(j)
+                    ok = (np.isnan(a) and np.isnan(b)) or \
+                        abs(a - b) <= 1e-8*max(1., abs(b)) or \
+                        (not np.isfinite(b) and not np.isfinite(a))
+                    assert ok, "%s(%d) %r != %r after: %s" % (
+                        kind, j, a, b, " | ".join(log[-10:]))
+                    log.append("%s(%d)" % (kind, j))
                 continue
             elif op == "upload":
                 # the caller's own data into one row of one array: rows that
