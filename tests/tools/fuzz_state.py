@@ -67,8 +67,10 @@ def sequence(seed, nops):
     try:
         for _ in range(nops):
             op = rng.choice(["given", "fields", "prop", "prop", "prop",
-                             "read", "opt", "mutate", "upload", "reduce"])
-            if not seeded and op not in ("given", "fields"):
+                             "read", "opt", "mutate", "upload", "reduce",
+                             "groups", "variants"])
+            if not seeded and op not in ("given", "fields", "groups",
+                                         "variants"):
                 op = "given"
             if op == "given":
                 n = int(rng.choice(SIZES))
@@ -81,6 +83,29 @@ def sequence(seed, nops):
                     t.rays_given(y, u, w=w)
                 seeded = True
                 log.append("given n=%d w=%s" % (n, w is not None))
+            elif op == "groups":
+                # the same rays at two wavelengths: two ray groups, one
+                # surface table each, one launch
+                m = int(rng.choice((64, 128, 4096)))
+                y, u = random_rays(int(rng.integers(1 << 30)), m, p)
+                l0 = system.wavelengths[0]
+                for t in (dev, cpu):
+                    t.rays_given(y, u, l=[l0, l0*1.07])
+                seeded = True
+                log.append("given groups 2x%d" % m)
+            elif op == "variants":
+                # the same rays through two variants of the system
+                m = int(rng.choice((5, 64, 777)))
+                y, u = random_rays(int(rng.integers(1 << 30)), m, p)
+                other = copy.deepcopy(system)
+                k = int(rng.integers(1, L))
+                if hasattr(other[k], "curvature"):
+                    other[k].curvature *= 1.003
+                other[k].distance = other[k].distance*1.001
+                for t in (dev, cpu):
+                    t.rays_variants(y, u, [system, other])
+                seeded = True
+                log.append("given variants 2x%d" % m)
             elif op == "fields":
                 nf = int(rng.integers(1, 5))
                 m = int(rng.choice((64, 200, 333)))
