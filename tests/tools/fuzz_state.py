@@ -63,7 +63,7 @@ def sequence(seed, nops):
     eng = dev.engine
     for k, v in DEFAULTS.items():
         eng.set_option(k, v)
-    log, seeded = [], False
+    log, seeded, grouped = [], False, False
     try:
         for _ in range(nops):
             op = rng.choice(["given", "fields", "prop", "prop", "prop",
@@ -81,7 +81,7 @@ def sequence(seed, nops):
                     w /= w.sum()
                 for t in (dev, cpu):
                     t.rays_given(y, u, w=w)
-                seeded = True
+                seeded, grouped = True, False
                 log.append("given n=%d w=%s" % (n, w is not None))
             elif op == "groups":
                 # the same rays at two wavelengths: two ray groups, one
@@ -89,9 +89,10 @@ def sequence(seed, nops):
                 m = int(rng.choice((64, 128, 4096)))
                 y, u = random_rays(int(rng.integers(1 << 30)), m, p)
                 l0 = system.wavelengths[0]
+                eng.set_option("rays_per_thread", 1)   # groups of 64 rays
                 for t in (dev, cpu):
                     t.rays_given(y, u, l=[l0, l0*1.07])
-                seeded = True
+                seeded = grouped = True
                 log.append("given groups 2x%d" % m)
             elif op == "variants":
                 # the same rays through two variants of the system
@@ -102,9 +103,10 @@ def sequence(seed, nops):
                 if hasattr(other[k], "curvature"):
                     other[k].curvature *= 1.003
                 other[k].distance = other[k].distance*1.001
+                eng.set_option("rays_per_thread", 1)
                 for t in (dev, cpu):
                     t.rays_variants(y, u, [system, other])
-                seeded = True
+                seeded = grouped = True
                 log.append("given variants 2x%d" % m)
             elif op == "fields":
                 nf = int(rng.integers(1, 5))
@@ -116,7 +118,7 @@ def sequence(seed, nops):
                               if np.isfinite(e.radius))
                     for t in (dev, cpu):
                         t.rays_fields(fields, yp, 40., .5*rad)
-                    seeded = True
+                    seeded, grouped = True, False
                     log.append("fields %dx%d" % (nf, m))
             elif op == "prop":
                 valid = [j for j in range(L - 1) if cpu.engine.valid[j]]
@@ -145,6 +147,8 @@ def sequence(seed, nops):
                 continue
             elif op == "opt":
                 key, values = OPTIONS[int(rng.integers(len(OPTIONS)))]
+                if grouped and key == "rays_per_thread":
+                    continue    # a group must then be a multiple of 64 R rays
                 value = int(rng.choice(values))
                 eng.set_option(key, value)
                 log.append("%s=%d" % (key, value))
