@@ -53,9 +53,29 @@ def compare(dev, cpu, log):
         raise AssertionError("n differs after: " + " | ".join(log[-6:]))
 
 
+def named_prescriptions():
+    """Designs with a field of view (the random ones image an axial point):
+    aiming, generated bundles of several fields, dispersion."""
+    import yaml
+    from rayopt_amd import prescriptions as P
+    texts = [P.COOKE % dict(air=1.0, sk16="1.62041/60.32",
+                            f2="1.62004/36.37"),
+             P.DOUBLE_GAUSS, P.TORTURE,
+             P.ASPHERE_PHONE.replace("pupil: {radius: 0.6}",
+                                     "pupil: {radius: 0.6, aim: True}")]
+    return [yaml.safe_load(t) for t in texts]
+
+
+NAMED = named_prescriptions()
+PATTERNS = ("meridional", "sagittal", "cross", "tee", "square", "triangular",
+            "hexapolar")
+
+
 def sequence(seed, nops):
     rng = np.random.default_rng(seed)
-    p = random_prescription(seed)
+    designed = seed % 3 == 0
+    p = copy.deepcopy(NAMED[(seed//3) % len(NAMED)]) if designed else \
+        random_prescription(seed)
     system = ra.system_from_dict(copy.deepcopy(p))
     L = len(system)
     dev = ra.GeometricTrace(system)
@@ -68,9 +88,10 @@ def sequence(seed, nops):
         for _ in range(nops):
             op = rng.choice(["given", "fields", "prop", "prop", "prop",
                              "read", "opt", "mutate", "upload", "reduce",
-                             "groups", "variants"])
+                             "groups", "variants"] +
+                            (["points", "points"] if designed else []))
             if not seeded and op not in ("given", "fields", "groups",
-                                         "variants"):
+                                         "variants", "points"):
                 op = "given"
             if op == "given":
                 n = int(rng.choice(SIZES))
@@ -83,6 +104,25 @@ def sequence(seed, nops):
                     t.rays_given(y, u, w=w)
                 seeded, grouped = True, False
                 log.append("given n=%d w=%s" % (n, w is not None))
+            elif op == "points":
+                # pattern -> aiming kernel (or first-order pupil) ->
+                # generation -> trace, several fields, maybe all wavelengths
+                nf = int(rng.integers(1, 5))
+                fields = rng.uniform(-1, 1, (nf, 2))*.9
+                ls = system.wavelengths
+                kw = dict(nrays=int(rng.choice((5, 12, 40))),
+                          distribution=str(rng.choice(PATTERNS)),
+                          clip=bool(rng.random() < .5),
+                          aim=[True, False, None][int(rng.integers(3))],
+                          rim=bool(rng.random() < .3),
+                          wavelength=list(ls) if len(ls) > 1 and
+                          rng.random() < .5 else None)
+                if kw["wavelength"]:
+                    eng.set_option("rays_per_thread", 1)
+                for t in (dev, cpu):
+                    t.rays_points(fields, **kw)
+                seeded, grouped = True, bool(kw["wavelength"])
+                log.append("points %d fields %s" % (nf, kw))
             elif op == "groups":
                 # the same rays at two wavelengths: two ray groups, one
                 # surface table each, one launch
