@@ -83,7 +83,7 @@ def sequence(seed, nops):
     eng = dev.engine
     for k, v in DEFAULTS.items():
         eng.set_option(k, v)
-    log, seeded, grouped = [], False, False
+    log, seeded, grouped, last_seed = [], False, False, None
     try:
         for _ in range(nops):
             op = rng.choice(["given", "fields", "prop", "prop", "prop",
@@ -102,7 +102,7 @@ def sequence(seed, nops):
                     w /= w.sum()
                 for t in (dev, cpu):
                     t.rays_given(y, u, w=w)
-                seeded, grouped = True, False
+                seeded, grouped, last_seed = True, False, "given"
                 log.append("given n=%d w=%s" % (n, w is not None))
             elif op == "points":
                 # pattern -> aiming kernel (or first-order pupil) ->
@@ -110,7 +110,7 @@ def sequence(seed, nops):
                 nf = int(rng.integers(1, 5))
                 fields = rng.uniform(-1, 1, (nf, 2))*.9
                 ls = system.wavelengths
-                kw = dict(nrays=int(rng.choice((5, 12, 40))),
+                kw = dict(nrays=int(rng.choice((12, 40, 90))),  # > 1 ray
                           distribution=str(rng.choice(PATTERNS)),
                           clip=bool(rng.random() < .5),
                           aim=[True, False, None][int(rng.integers(3))],
@@ -119,9 +119,22 @@ def sequence(seed, nops):
                           rng.random() < .5 else None)
                 if kw["wavelength"]:
                     eng.set_option("rays_per_thread", 1)
+                failed = []
                 for t in (dev, cpu):
-                    t.rays_points(fields, **kw)
+                    try:
+                        t.rays_points(fields, **kw)
+                        failed.append(None)
+                    except ValueError as err:   # a field that cannot be aimed
+                        failed.append(str(err))
+                assert failed[0] == failed[1], \
+                    "aiming: device %r, double %r" % tuple(failed)
+                if failed[0] is not None:
+                    # both refused in the same words; start over
+                    seeded = False
+                    log.append("points refused")
+                    continue
                 seeded, grouped = True, bool(kw["wavelength"])
+                last_seed = "points"
                 log.append("points %d fields %s" % (nf, kw))
             elif op == "groups":
                 # the same rays at two wavelengths: two ray groups, one
@@ -133,6 +146,7 @@ def sequence(seed, nops):
                 for t in (dev, cpu):
                     t.rays_given(y, u, l=[l0, l0*1.07])
                 seeded = grouped = True
+                last_seed = "groups"
                 log.append("given groups 2x%d" % m)
             elif op == "variants":
                 # the same rays through two variants of the system
@@ -147,6 +161,7 @@ def sequence(seed, nops):
                 for t in (dev, cpu):
                     t.rays_variants(y, u, [system, other])
                 seeded = grouped = True
+                last_seed = "variants"
                 log.append("given variants 2x%d" % m)
             elif op == "fields":
                 nf = int(rng.integers(1, 5))
@@ -158,7 +173,7 @@ def sequence(seed, nops):
                               if np.isfinite(e.radius))
                     for t in (dev, cpu):
                         t.rays_fields(fields, yp, 40., .5*rad)
-                    seeded, grouped = True, False
+                    seeded, grouped, last_seed = True, False, "fields"
                     log.append("fields %dx%d" % (nf, m))
             elif op == "prop":
                 valid = [j for j in range(L - 1) if cpu.engine.valid[j]]
@@ -200,13 +215,8 @@ def sequence(seed, nops):
                     # (refocus is a ratio of two sums that both vanish for
                     # the parallel bundles `fields` makes of these systems'
                     # axial object point: rounding noise over rounding noise)
-                    kind = rng.choice(["rms", "rms_ref", "rmax"] +
-                                      (["refocus"] if log and any(
-                                          e.startswith(("given", "fields"))
-                                          for e in log) and [
-                                          e for e in log if e.startswith(
-                                              ("given", "fields"))][-1]
-                                          .startswith("given") else []))
+                    kind = rng.choice(["rms", "rms_ref", "rmax"] + (
+                        ["refocus"] if last_seed == "given" else []))
                     if kind == "rms":
                         a, b = dev.rms(j), cpu.rms(j)
                     elif kind == "rms_ref":
