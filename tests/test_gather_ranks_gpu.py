@@ -149,17 +149,21 @@ def test_missing_transport_library_is_loud():
     assert res.returncode != 0 and "libnope.so" in res.stderr
 
 
-def test_bench_two_ranks_one_device_real_gather():
+@pytest.mark.parametrize("every_step", [False, True])
+def test_bench_two_ranks_one_device_real_gather(every_step):
     """`python bench.py --gpus 2` end to end on the one device: self-spawned
     ranks, host group, communicator, the job's gather inside the timed
-    region, every gathered shard checked on rank 0; the line says test_mode."""
+    region (or in every step, the snapshot of step k+1 queued behind the
+    transfer of step k), every gathered shard checked on rank 0; the line
+    says test_mode."""
     import json
     env = dict(os.environ, RT_BENCH_SHARE_DEVICE="1",
                RT_TRANSPORT_LIBRARY=build_stub())
     out = subprocess.check_output(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
          "--total-rays", "400001", "--steps", "3", "--warmup", "1",
-         "--settle", "0"], text=True, cwd=ROOT, env=env,
+         "--settle", "0"] + (["--gather-every-step"] if every_step else []),
+        text=True, cwd=ROOT, env=env,
         stderr=subprocess.DEVNULL, timeout=600)
     lines = [ln for ln in out.splitlines() if ln.strip()]
     assert len(lines) == 1
