@@ -67,8 +67,13 @@ class Material(Stamped):
     mirror = False
 
     def _pack_key(self):
-        """What identifies n(lambda) of this medium to the packer's cache."""
-        return (self._stamp,)
+        """What identifies n(lambda) of this medium to the packer's cache:
+        its stamp (attribute assignments) and the VALUES of every array it
+        holds (``GasFormula.b/c``, dispersion coefficients: they can be
+        edited in place, which no stamp sees)."""
+        return (self._stamp,) + tuple(
+            v.tobytes() for v in self.__dict__.values()
+            if type(v) is np.ndarray)
 
     catalog = None
 
@@ -299,8 +304,9 @@ class DispersionGlass(Material):
 
     def _pack_key(self):
         c = self.coefficients
-        return (self._stamp,
-                c.tobytes() if hasattr(c, "tobytes") else tuple(c))
+        if type(c) is np.ndarray:
+            return super()._pack_key()
+        return (self._stamp, tuple(c))
 
     def refractive_index(self, wavelength):
         n = DISPERSION[self.typ](wavelength/1e-6, self.coefficients)

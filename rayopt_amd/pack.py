@@ -53,7 +53,16 @@ def _note(el):
     else:
         return False
     asph = getattr(el, "aspherics", None)
-    return stamp, mkey, None if asph is None else tuple(asph)
+    # the arrays the packer reads are handed out mutable, as the reference
+    # hands them out (``el.offset[1] += .3``, ``set_path((j, "offset", 1),
+    # v)``; rayopt/system.py:461 re-reads e.offset on every call): their
+    # VALUES are part of the note, an in-place edit is a miss
+    off = el.offset
+    rot = el.rot_normal if getattr(el, "rotated", False) else None
+    return (stamp, mkey, None if asph is None else tuple(asph),
+            off.tobytes() if hasattr(off, "tobytes") else tuple(off),
+            None if rot is None else
+            rot.tobytes() if hasattr(rot, "tobytes") else repr(rot))
 
 
 def _notes(system):

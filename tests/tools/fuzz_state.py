@@ -24,6 +24,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rayopt_amd as ra
 from fake_engine import OracleEngine
 from random_systems import random_prescription, random_rays
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuzz_pack
 
 # (not 1: numpy hands a (1,3) @ (3,3) product to another BLAS routine than
 # an (N,3) one, and the double -- like the reference -- then rounds a tilted
@@ -253,13 +255,37 @@ def sequence(seed, nops):
             elif op == "mutate":
                 j = int(rng.integers(1, L))
                 el = system[j]
-                what = rng.choice(["distance", "curvature", "radius"])
+                what = rng.choice(["distance", "curvature", "radius",
+                                   "offset_inplace", "rot_inplace",
+                                   "aspherics_inplace"])
                 if what == "curvature" and hasattr(el, "curvature"):
                     el.curvature *= 1. + 1e-3*rng.normal()
                 elif what == "radius" and np.isfinite(el.radius):
                     el.radius *= 1. + 1e-2*rng.normal()
+                elif what == "offset_inplace":
+                    # arrays are handed out mutable, as the reference hands
+                    # them out (rayopt/system.py:461 re-reads e.offset)
+                    el.offset[int(rng.integers(3))] += 1e-3*rng.normal()
+                elif what == "rot_inplace" and el.rotated:
+                    a = 1e-3*rng.normal()
+                    c, s = np.cos(a), np.sin(a)
+                    el.rot_normal[...] = el.rot_normal @ np.array(
+                        ((c, s, 0.), (-s, c, 0.), (0., 0., 1.)))
+                elif what == "aspherics_inplace" and \
+                        getattr(el, "aspherics", None) is not None:
+                    el.aspherics[0] *= 1. + 1e-3*rng.normal()
                 else:
+                    what = "distance"
                     el.distance = el.distance*(1. + 1e-3*rng.normal())
+                # the table the next trace packs through its caches must be
+                # the one a cache-less copy packs (tests/tools/fuzz_pack.py)
+                l0 = system.wavelengths[0]
+                n00 = system.refractive_index(l0, 0)
+                assert fuzz_pack.packed_bytes(system, l0, n00) == \
+                    fuzz_pack.packed_bytes(fuzz_pack.scratch(system), l0,
+                                           n00), \
+                    "stale packed table after: " + " | ".join(
+                        log[-6:] + ["mutate %d %s" % (j, what)])
                 log.append("mutate %d %s" % (j, what))
                 continue
             compare(dev, cpu, log)
