@@ -272,6 +272,19 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa);
  */
 int rt_trace(rt_ctx *ctx, int start, int stop, int clip);
 /*
+ * The same trace for one CHUNK of the batch's rays: the rays are cut into
+ * `nchunks` pieces of whole 256-ray workgroups (rt_chunk_bounds: [lo, hi) of
+ * chunk k for a batch of n rays; the last pieces may be short or empty) and
+ * chunk `chunk` is traced.  All chunks of a step, in any order, give what
+ * rt_trace gives.  For multi-GPU jobs: rt_gather_chunk of chunk k runs on the
+ * communication stream while chunk k+1 is traced.  Not for batches with
+ * several surface tables (ray groups).
+ */
+int rt_trace_chunk(rt_ctx *ctx, int start, int stop, int clip, int chunk,
+                   int nchunks);
+int rt_chunk_bounds(int64_t n, int chunk, int nchunks, int64_t *lo,
+                    int64_t *hi);
+/*
  * Extension over the reference: choose which surface rows propagate()
  * stores.  keep[j] != 0 keeps row j; NULL restores the reference behaviour
  * (every row).  Rows that are not kept are still traced (the ray state lives
@@ -290,30 +303,25 @@ int rt_kernel_ms(rt_ctx *ctx, double *ms);
 int rt_event_record(rt_ctx *ctx, int slot);
 int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
 /*
- * Kernel variant selection for A/B measurements (defaults are the tuned
- * ones): key "rays_per_thread" (1,2,4), "nontemporal" (0,1), "xcd_remap"
- * (0,1), "block" (64..1024), "alias_i" (1 = do not write I[j] where it is
- * identical to U[j-1], the default; 0 = materialise every row of I),
+ * Engine options (defaults are the measured best): key
+ * "alias_i" (1 = do not write I[j] where it is identical to U[j-1], nor U[j]
+ * where an unclipped trace leaves it identical to I[j], the default; 0 =
+ * materialise every row),
  * "fuse_generate" (1 = the first trace after rt_generate_rays builds the
  * rays in registers and writes row 0 itself, the default; 0 = a separate
  * generation kernel writes row 0 and the trace reads it),
  * "regenerate" (1 = default: later traces of a generated batch from element 1
  * build the launch rays again in registers -- the values row 0 holds, bit for
  * bit -- as long as row 0 is what the generator wrote; 0 = they read row 0),
- * "lds_pad" (bytes of unused dynamic LDS per workgroup: caps the resident
- * workgroups per CU for occupancy experiments; default 0),
- * "fast_asphere" (0 = default: even aspheres reproduce the reference's Newton
- * solve operation for operation; 1 = the same iteration on fused
- * multiply-adds and rcp/rsq + refinement, one reciprocal per iterate:
- * results within the 1e-8 contract for iterated aspheres, ~1e-13 in
- * practice, identical NaN masks up to rays that sit on a decision boundary
- * to 1e-15),
- * "tile_rays" (measurement only: 0 = the documented SoA layout; TR = a power
- * of two: results are written tile-major [tile of TR rays][L][10][TR] so a
- * workgroup's whole output is one contiguous region; nothing can be read
- * back in that layout -- it exists to measure the store pattern),
- * "probe_store" (rt_probe pattern modes only: 0 plain stores, 1 non-temporal,
- * 2 sc1 write-through, 3 sc0 sc1),
+ * "exact_asphere" / "fast_asphere" (one switch, two names: even aspheres run
+ * the reference's Newton iteration -- rayopt/elements.py:333-349: x0 = plane
+ * intercept, |step| <= 1e-7, five iterates, NaN on failure -- by DEFAULT on
+ * fused multiply-adds and rcp/rsq + refinement with one reciprocal per
+ * iterate: results within the 1e-8 contract for iterated aspheres (~1e-13 in
+ * practice), identical NaN masks; "exact_asphere" = 1 reproduces scipy's
+ * iteration operation for operation: the reference's bits, ~20 % slower on
+ * aspheric systems.  The environment variable RT_MI355_EXACT_ASPHERE=1 makes
+ * the exact path the default of every context the process creates),
  * "compact" (clipped-ray compaction: 0 = never, the default; 1 = traces that
  * drop rows (rt_set_keep_rows) run the compacting kernel -- rays whose
  * direction is NaN are retired, their remaining kept rows filled with NaN,
@@ -321,27 +329,11 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * with ballots and an LDS exchange; 2 = every trace.  Results are identical
  * to the plain kernel's, NaN payloads aside), "compact_every" (k: the
  * survivors of a workgroup are counted -- one barrier -- at every k-th element
- * only; default 4, the measured optimum: asking costs ~0.5 us per workgroup),
- * "uniform_fix" (measurement only, results are wrong unless the data happen to
- * be so: 6-bit mask of input components read from the wavefront's first
- * column), "gate_log2" / "gate_window" (measurement only: input reads wait
- * for chip-wide windows of the 100 MHz reference counter).
+ * only; default 4, the measured optimum: asking costs ~0.5 us per workgroup).
+ * Measurement-only variants and the memory-system probes live in a separate
+ * laboratory build (include/rt_mi355_probes.h), not in this library.
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
-/*
- * Memory-system calibration on the context's own result arrays (row 0 is
- * preserved): mode 0 = the trace kernel's 80 B store pattern without
- * arithmetic, 1 = grid-stride 16-byte fill, 2 = 16-byte copy, 3 = fill with one
- * 16-byte store per lane, 4 = same, non-temporal; 5 / 6 = mode 0 with the
- * 48 B/ray input read from an L2-resident window / not at all; 7 / 8 = the
- * default kernel's own pattern (56 B per op, 8-byte stores) with / without
- * the input read; 9 = mode 7 with non-temporal loads; 10 / 11 / 12 = mode 7
- * with 2 / 4 / 8 rays per lane marched one after the other, inputs loaded up
- * front; 13 / 14 = mode 7 with the input rows in an uncached / an ordinary
- * allocation of their own.  Modes 0 and 5-14 honour "tile_rays" and "block".  Returns
- * kernel time and the bytes moved.  Overwrites rows >= 1.
- */
-int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes);
 
 /*
  * Lazy D2H of surface rows [surf_lo, surf_hi) of one array into a caller
@@ -438,6 +430,22 @@ int rt_comm_destroy(rt_ctx *ctx);
  */
 int rt_gather_final(rt_ctx *ctx, int which, int surf, const int64_t *counts,
                     int root, double *d_dst);
+/*
+ * The same for chunk `chunk` of `nchunks` of every rank's rays (the pieces
+ * rt_trace_chunk traces; every rank cuts its own counts[r] rays with
+ * rt_chunk_bounds): the gather of chunk k overlaps the trace of chunk k+1.
+ * All chunks of a step together fill d_dst exactly as rt_gather_final does.
+ * Up to RT_GATHER_SLOTS = 4 gathers may be in flight.
+ */
+int rt_gather_chunk(rt_ctx *ctx, int which, int surf, const int64_t *counts,
+                    int root, double *d_dst, int chunk, int nchunks);
+/*
+ * Timing of the last gather (all its chunks) from HIP events: total_ms =
+ * first to last operation on the communication stream, exposed_ms = what is
+ * left of it after this rank's last trace kernel finished (0 if the exchange
+ * was hidden completely).  Synchronises.
+ */
+int rt_gather_ms(rt_ctx *ctx, double *total_ms, double *exposed_ms);
 int rt_comm_sync(rt_ctx *ctx);
 
 /* device scratch owned by the context (e.g. gather destination on root) */

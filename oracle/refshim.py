@@ -10,23 +10,44 @@ image:
 * PyYAML 6 requires an explicit ``Loader`` (rayopt/formats.py:86).
 * ``np.complex_`` was removed in numpy 2 (rayopt/gaussian_trace.py:39).
 
-It is used ONLY by ``tests/golden/make_golden.py`` (to generate the committed
-golden fixtures) and by the CPU tests that validate ``oracle/trace_numpy.py``
-against the real reference when ``/root/reference`` is present.  It is never
-imported by the product package (``rayopt_amd``), by ``-m gpu`` tests, by
-``bench.py`` or by ``smoke()``: ``/root/reference`` does not exist on the GPU
-box.
+It is used by ``tests/golden/make_golden.py`` (to generate the committed
+golden fixtures), by the tests that compare the oracle and the device with
+the real reference, and by ``bench.py``'s ``cpu_baseline`` leg.  The source is
+``/root/reference`` where that exists (the build container) and otherwise the
+byte-for-byte copy ``oracle/make_ref.py`` made under the git-ignored
+``oracle/_ref/``, which travels to the GPU box like a built ``.so``.  It is
+never imported by the product package (``rayopt_amd``).
 """
 import functools
 import os
 import sys
 import types
 
+# where the unmodified reference lies: the tree itself in the build container,
+# the byte-for-byte copy oracle/make_ref.py put under oracle/_ref/ (git-ignored,
+# travels with the gpurun snapshot) on a GPU box
+_CARRIED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref",
+                        "rayopt_reference.zip")
 REFERENCE_ROOT = os.environ.get("RAYOPT_REFERENCE", "/root/reference")
+if not os.path.isdir(os.path.join(REFERENCE_ROOT, "rayopt")) and \
+        os.path.isfile(_CARRIED):
+    REFERENCE_ROOT = _CARRIED           # a zip on sys.path is importable
+
+
+def carried():
+    """True when the reference in use is the archive under oracle/_ref/."""
+    return REFERENCE_ROOT == _CARRIED
 
 
 def available():
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, "rayopt"))
+    return carried() or os.path.isdir(os.path.join(REFERENCE_ROOT, "rayopt"))
+
+
+def library_db():
+    """Path of the reference's glass database (read-only; copy before use)."""
+    if carried():
+        return os.path.join(os.path.dirname(_CARRIED), "library.sqlite")
+    return os.path.join(REFERENCE_ROOT, "rayopt", "library.sqlite")
 
 
 def load():

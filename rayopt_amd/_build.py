@@ -1,7 +1,15 @@
-"""Build librt_mi355.so (HIP, gfx950) in-tree with hipcc.
+"""Build the HIP engine (gfx950) in-tree with hipcc.
 
-The shared library is kept next to the package (``rayopt_amd/librt_mi355.so``)
-so that it travels with a snapshot of the repository; it is git-ignored.
+``librt_mi355.so`` -- the product: rt_engine.hip (contexts, tables, seeding,
+the trace), rt_consumers.hip (aiming, rms / refocus / spot statistics / opd),
+rt_comm.hip (RCCL gather).  Kept next to the package so that it travels with
+a snapshot of the repository; git-ignored.
+
+``librt_mi355_probes.so`` -- the laboratory (``python -m rayopt_amd._build
+probes``): the same sources compiled with ``-DRT_BUILD_PROBES`` plus
+rt_probes.hip (rejected kernel variants, bandwidth probes, measurement
+options).  Only the measurement scripts load it (``RT_MI355_LIB``).
+
 ``-ffp-contract=off`` is part of the numerical contract (see csrc/rt_math.h):
 numpy never fuses a multiply into an add and parity with the reference is
 judged at 1e-10.
@@ -9,16 +17,25 @@ judged at 1e-10.
 import os
 import shutil
 import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_mi355.so")
-SOURCES = [os.path.join(CSRC, "rt_engine.hip")]
-HEADERS = [os.path.join(CSRC, "rt_math.h"), os.path.join(CSRC, "rt_kernels.h"),
-           os.path.join(CSRC, "rt_aim.h"),
-           os.path.join(HERE, "..", "include", "rt_mi355.h")]
+PROBES_LIB = os.path.join(HERE, "librt_mi355_probes.so")
+UNITS = ["rt_engine.hip", "rt_consumers.hip", "rt_comm.hip"]
+PROBE_UNITS = UNITS + ["rt_probes.hip"]
+SOURCES = [os.path.join(CSRC, u) for u in UNITS]
+HEADERS = [os.path.join(CSRC, h) for h in (
+    "rt_math.h", "rt_lay.h", "rt_ctx.h", "rt_march.h", "rt_trace_kernels.h",
+    "rt_consumer_kernels.h", "rt_aim.h")] + [
+    os.path.join(HERE, "..", "include", "rt_mi355.h")]
+PROBE_HEADERS = HEADERS + [os.path.join(CSRC, "rt_probe_kernels.h"),
+                           os.path.join(HERE, "..", "include",
+                                        "rt_mi355_probes.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-         "-fPIC", "-shared"]
+         "-fPIC"]
 
 
 def hipcc():
@@ -28,27 +45,62 @@ def hipcc():
     return exe
 
 
-def stale():
-    if not os.path.exists(LIB):
+def _stale(lib, files):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(f) > t for f in files)
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP engine for gfx950; returns the path of the .so."""
-    if not force and not stale():
-        return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB + ".tmp"] + SOURCES + ["-ldl"]
+def stale():
+    return _stale(LIB, SOURCES + HEADERS)
+
+
+def _run(cmd, verbose):
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+        raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd),
+                                                      res.stdout))
+    return res.stdout
+
+
+def _build(lib, units, defines, tag, verbose):
+    """One object per translation unit (compiled side by side), one link."""
+    objdir = os.path.join(HERE, "build", tag)
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    objs = [os.path.join(objdir, u[:-4] + ".o") for u in units]
+    cmds = [[cc] + FLAGS + defines + ["-c", os.path.join(CSRC, u), "-o", o]
+            for u, o in zip(units, objs)]
+    with ThreadPoolExecutor(len(cmds)) as pool:
+        list(pool.map(lambda c: _run(c, verbose), cmds))
+    _run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
+          lib + ".tmp"] + objs + ["-ldl"], verbose)
+    os.replace(lib + ".tmp", lib)
+    return lib
+
+
+def build(force=False, verbose=False):
+    """Compile the shipped engine for gfx950; returns the path of the .so."""
+    if not force and not stale():
+        return LIB
+    return _build(LIB, UNITS, [], "product", verbose)
+
+
+def build_probes(force=False, verbose=False):
+    """Compile the laboratory build; returns the path of its .so."""
+    files = [os.path.join(CSRC, u) for u in PROBE_UNITS] + PROBE_HEADERS
+    if not force and not _stale(PROBES_LIB, files):
+        return PROBES_LIB
+    return _build(PROBES_LIB, PROBE_UNITS, ["-DRT_BUILD_PROBES"], "probes",
+                  verbose)
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    if "probes" in sys.argv[1:]:
+        print(build_probes(force=True, verbose=True))
+    else:
+        print(build(force=True, verbose=True))

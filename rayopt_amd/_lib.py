@@ -14,7 +14,7 @@ RT_MAX_SURFACES = 256
 
 F_ROTATED, F_CURVED, F_CONIC, F_ASPH, F_ALT, F_REFRACT, F_MIRROR = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40)
-F_FAST = 0x400          # set by the library: rt_set_option("fast_asphere")
+F_FAST = 0x400          # set by the library (default; "exact_asphere" clears)
 RT_Y, RT_U, RT_I, RT_T = 0, 1, 2, 3
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 
@@ -92,6 +92,11 @@ SIGNATURES = {
                                      ctypes.c_void_p]),
     "rt_trace": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_int]),
+    "rt_trace_chunk": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int]),
+    "rt_chunk_bounds": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int,
+                                       ctypes.c_int, _c_int64_p, _c_int64_p]),
     "rt_set_keep_rows": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_int]),
     "rt_sync": (ctypes.c_int, [_ctx]),
     "rt_kernel_ms": (ctypes.c_int, [_ctx, _c_double_p]),
@@ -99,7 +104,6 @@ SIGNATURES = {
     "rt_event_elapsed": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                         _c_double_p]),
     "rt_set_option": (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int]),
-    "rt_probe": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p, _c_double_p]),
     "rt_download": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_void_p]),
     "rt_download_ray": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,
@@ -126,6 +130,11 @@ SIGNATURES = {
     "rt_gather_final": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                        _c_int64_p, ctypes.c_int,
                                        ctypes.c_void_p]),
+    "rt_gather_chunk": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
+                                       _c_int64_p, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_int]),
+    "rt_gather_ms": (ctypes.c_int, [_ctx, _c_double_p, _c_double_p]),
     "rt_comm_sync": (ctypes.c_int, [_ctx]),
     "rt_scratch": (ctypes.c_int, [_ctx, ctypes.c_int64,
                                   ctypes.POINTER(ctypes.c_void_p)]),
@@ -133,27 +142,41 @@ SIGNATURES = {
                                        ctypes.c_int64]),
 }
 
-_lib = None
+# only in the laboratory build (librt_mi355_probes.so, RT_MI355_LIB):
+# include/rt_mi355_probes.h
+PROBE_SIGNATURES = {
+    "rt_probes_built": (ctypes.c_int, []),
+    "rt_probe": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p, _c_double_p]),
+}
+
+_libs = {}
 
 
 class EngineError(RuntimeError):
     pass
 
 
-def load():
-    """Load librt_mi355.so; raises EngineError when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load librt_mi355.so (or the library at ``path``: the laboratory build
+    next to the shipped one, for A/B measurements in one process); raises
+    EngineError when it has not been built."""
+    path = os.path.abspath(path or LIB_PATH)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise EngineError(
             "%s not found: build it with `python -m rayopt_amd._build` "
-            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "(hipcc, gfx950). There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in PROBE_SIGNATURES.items():
+        fn = getattr(lib, name, None)       # the shipped library has none
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if lib.rt_sizeof_surface() != SURFACE_DTYPE.itemsize:
         raise EngineError("struct rt_surface is %d bytes in the library but "
                           "%d in SURFACE_DTYPE" % (lib.rt_sizeof_surface(),
@@ -165,5 +188,5 @@ def load():
     if lib.rt_sizeof_aim_seed() != AIM_SEED_DTYPE.itemsize or \
             lib.rt_sizeof_aim_args() != AIM_ARGS_DTYPE.itemsize:
         raise EngineError("struct rt_aim_seed / rt_aim_args layout mismatch")
-    _lib = lib
+    _libs[path] = lib
     return lib

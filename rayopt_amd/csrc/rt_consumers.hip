@@ -1,0 +1,351 @@
+/*
+ * rt_consumers.hip -- what runs after (or around) a trace on device-resident
+ * rows: the aiming kernel behind System.pupil,
+ * GeometricTrace.rms / refocus / resize sums, per-bundle spot statistics and
+ * the per-ray part of opd.  Deterministic two-level reductions, scalars (or
+ * 24 B/ray for opd) cross PCIe instead of rows.  Part of librt_mi355.so.
+ */
+#include "rt_ctx.h"
+#include "rt_consumer_kernels.h"
+
+extern "C" {
+
+int rt_sizeof_aim_seed(void) { return (int)sizeof(rt_aim_seed); }
+int rt_sizeof_aim_args(void) { return (int)sizeof(rt_aim_args); }
+
+int rt_aim_pupil(rt_ctx *ctx, const rt_aim_seed *seeds, int nfields,
+                 const rt_aim_args *args, double *z, double *a,
+                 int32_t *status)
+{
+    if (!ctx || !seeds || !args || !z || !a || !status || nfields < 1)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_aim_pupil: bad argument");
+    if (ctx->nsurf < 3)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_aim_pupil: rt_upload_system must come first");
+    if (args->stop < 1 || args->stop > ctx->nsurf - 2 || args->maxiter < 1)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_aim_pupil: stop %d of %d elements",
+                       args->stop, ctx->nsurf);
+    for (int f = 0; f < nfields; ++f)
+        if (seeds[f].group < 0 || seeds[f].group >= ctx->ngroups)
+            return rt_fail(ctx, RT_ERR_ARG,
+                           "rt_aim_pupil: field %d names table %d of %d", f,
+                           seeds[f].group, ctx->ngroups);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    /* scratch: tables | seeds | z | a | status, each 256-byte aligned; the
+     * same layout in one pinned host buffer, so that a call costs one copy
+     * in, the kernel, one copy out */
+    const size_t ntab = (size_t)ctx->nsurf * ctx->ngroups;
+    const size_t tb = (sizeof(rt_surface) * ntab + 255) / 256 * 256;
+    const size_t sb = (sizeof(rt_aim_seed) * nfields + 255) / 256 * 256;
+    const size_t zb = (sizeof(double) * nfields + 255) / 256 * 256;
+    const size_t ab = (sizeof(double) * 4 * nfields + 255) / 256 * 256;
+    const size_t cb = (sizeof(int32_t) * nfields + 255) / 256 * 256;
+    const size_t all = tb + sb + zb + ab + cb;
+    int rc = rt_need_scratch(ctx, all);
+    if (rc != RT_OK)
+        return rc;
+    if (all > ctx->h_aim_bytes) {
+        if (ctx->h_aim)
+            (void)hipHostFree(ctx->h_aim);
+        ctx->h_aim = NULL;
+        ctx->h_aim_bytes = 0;
+        const size_t want = all + all / 2;
+        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_aim, want));
+        ctx->h_aim_bytes = want;
+    }
+    char *base = (char *)ctx->d_scratch, *host = ctx->h_aim;
+    rt_surface *d_tab = (rt_surface *)base;
+    rt_aim_seed *d_seeds = (rt_aim_seed *)(base + tb);
+    double *d_z = (double *)(base + tb + sb);
+    double *d_a = (double *)(base + tb + sb + zb);
+    int32_t *d_status = (int32_t *)(base + tb + sb + zb + ab);
+    memcpy(host, ctx->h_surf, sizeof(rt_surface) * ntab);
+    memcpy(host + tb, seeds, sizeof(rt_aim_seed) * nfields);
+    RT_HIP(ctx, hipMemcpyAsync(base, host, tb + sb, hipMemcpyHostToDevice,
+                               ctx->stream));
+    /* one wavefront per field while they are all resident at once, 16
+     * fields per wavefront beyond that (rt_kernels.h) */
+    if (nfields <= 32768)
+        hipLaunchKernelGGL(rt_aim_kernel<true>, dim3((unsigned)nfields),
+                           dim3(4), 0, ctx->stream, d_tab, ctx->nsurf, d_seeds,
+                           nfields, *args, d_z, d_a, d_status);
+    else
+        hipLaunchKernelGGL(rt_aim_kernel<false>,
+                           dim3((unsigned)(((int64_t)nfields * 4 + 63) / 64)),
+                           dim3(64), 0, ctx->stream, d_tab, ctx->nsurf,
+                           d_seeds, nfields, *args, d_z, d_a, d_status);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(host + tb + sb, base + tb + sb, zb + ab + cb,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(z, host + tb + sb, sizeof(double) * nfields);
+    memcpy(a, host + tb + sb + zb, sizeof(double) * 4 * nfields);
+    memcpy(status, host + tb + sb + zb + ab, sizeof(int32_t) * nfields);
+    return RT_OK;
+}
+
+int rt_set_weights(rt_ctx *ctx, const double *w)
+{
+    if (!ctx)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_set_weights: NULL context");
+    if (ctx->n < 1)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_set_weights: set rays first");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!w) {
+        if (ctx->d_w)
+            RT_HIP(ctx, hipFree(ctx->d_w));
+        ctx->d_w = NULL;
+        ctx->w_cap = 0;
+        ctx->w_n = 0;
+        return RT_OK;
+    }
+    if ((size_t)ctx->n > ctx->w_cap) {
+        if (ctx->d_w)
+            RT_HIP(ctx, hipFree(ctx->d_w));
+        ctx->d_w = NULL;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_w, ctx->n * sizeof(double)));
+        ctx->w_cap = (size_t)ctx->n;
+    }
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_w, w, ctx->n * sizeof(double),
+                               hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->w_n = ctx->n;
+    return RT_OK;
+}
+
+/* fetch and add the per-workgroup partials in index order */
+static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
+{
+    if (!ctx)
+        return rt_fail(ctx, RT_ERR_ARG, "%s: NULL context", who);
+    if (!ctx->d_buf || ctx->n < 1 || surf < 0 || surf >= ctx->buf_nsurf ||
+        !ctx->valid[surf])
+        return rt_fail(ctx, RT_ERR_STATE, "%s: row %d holds no data", who,
+                       surf);
+    if (rt_soa_only(ctx, who) != RT_OK)
+        return RT_ERR_STATE;
+    if (ctx->d_w && ctx->w_n != ctx->n)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "%s: the weights on the device were set for a batch "
+                       "of %lld rays, this one has %lld: call rt_set_weights "
+                       "after seeding (NULL for uniform weights)", who,
+                       (long long)ctx->w_n, (long long)ctx->n);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_partials)
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_partials,
+                              sizeof(double) * (RT_RED_BLOCKS * 8 + 16)));
+    return rt_gen_flush(ctx);
+}
+
+/* workgroups of a reduction over n rays: no more than there is work for */
+static inline unsigned rt_red_blocks(int64_t n)
+{
+    const int64_t b = (n + RT_RED_THREADS - 1) / RT_RED_THREADS;
+    return (unsigned)(b < 1 ? 1 : (b > RT_RED_BLOCKS ? RT_RED_BLOCKS : b));
+}
+
+/* device-side second level of a reduction: k sums -> ctx->d_partials tail */
+static inline double *rt_reduced(rt_ctx *ctx, int slot)
+{
+    return ctx->d_partials + (size_t)RT_RED_BLOCKS * 8 + slot;
+}
+
+int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
+{
+    int rc = rt_consumer_ready(ctx, surf, "rt_rms");
+    if (rc != RT_OK)
+        return rc;
+    if (!rms || ref >= ctx->n)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_rms: bad argument");
+    const double *Yrow = rt_row(ctx, RT_Y, surf);
+    const unsigned blocks = rt_red_blocks(ctx->n);
+    /* both passes and their second levels are queued back to back; the host
+     * waits once, for one double */
+    if (ref < 0) {
+        hipLaunchKernelGGL(rt_sum_xy_kernel, dim3(blocks),
+                           dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, ctx->n,
+                           ctx->ld, ctx->d_partials);
+        hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0,
+                           ctx->stream, ctx->d_partials, (int)blocks, 2,
+                           rt_reduced(ctx, 0));
+    }
+    hipLaunchKernelGGL(rt_rms_kernel, dim3(blocks), dim3(RT_RED_THREADS), 0,
+                       ctx->stream, Yrow, ctx->d_w, 1. / (double)ctx->n,
+                       rt_reduced(ctx, 0), ref, ctx->n, ctx->ld,
+                       ctx->d_partials);
+    hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       ctx->d_partials, (int)blocks, 1, rt_reduced(ctx, 2));
+    RT_HIP(ctx, hipGetLastError());
+    double sum;
+    RT_HIP(ctx, hipMemcpyAsync(&sum, rt_reduced(ctx, 2), sizeof sum,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *rms = sqrt(sum);
+    return RT_OK;
+}
+
+int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax)
+{
+    int rc = rt_consumer_ready(ctx, surf, "rt_row_rmax");
+    if (rc != RT_OK)
+        return rc;
+    if (!rmax)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_row_rmax: NULL");
+    hipLaunchKernelGGL(rt_r2max_kernel, dim3(RT_RED_BLOCKS),
+                       dim3(RT_RED_THREADS), 0, ctx->stream,
+                       rt_row(ctx, RT_Y, surf), ctx->n, ctx->ld,
+                       ctx->d_partials);
+    double host[RT_RED_BLOCKS * 2];
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(host, ctx->d_partials, sizeof host,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double mx = 0., bad = 0.;
+    for (int b = 0; b < RT_RED_BLOCKS; ++b) {
+        mx = host[2 * b] > mx ? host[2 * b] : mx;
+        bad = host[2 * b + 1] > bad ? host[2 * b + 1] : bad;
+    }
+    *rmax = bad ? __builtin_nan("") : sqrt(mx);
+    return RT_OK;
+}
+
+int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
+                  double *out)
+{
+    int rc = rt_consumer_ready(ctx, surf, "rt_spot_stats");
+    if (rc != RT_OK)
+        return rc;
+    if (!out || group_rays < 1 || ngroups < 1 || ngroups > 65535 ||
+        group_rays * (int64_t)ngroups != ctx->n)
+        return rt_fail(ctx, RT_ERR_ARG,
+                       "rt_spot_stats: %d groups of %lld rays do not tile the "
+                       "%lld rays of the batch", ngroups, (long long)group_rays,
+                       (long long)ctx->n);
+    /* enough workgroups per group to fill the chip, no more than it has rays
+     * for */
+    int64_t pb = 2048 / ngroups;
+    const int64_t fit = (group_rays + RT_RED_THREADS - 1) / RT_RED_THREADS;
+    pb = pb > fit ? fit : pb;
+    pb = pb < 1 ? 1 : (pb > 256 ? 256 : pb);
+    const size_t need = (size_t)ngroups * (RT_GRP_STATS + (size_t)pb * 4);
+    if (need > ctx->group_cap) {
+        if (ctx->d_group)
+            (void)hipFree(ctx->d_group);
+        ctx->d_group = nullptr;
+        ctx->group_cap = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_group, need * sizeof(double)));
+        ctx->group_cap = need;
+    }
+    double *stats = ctx->d_group;
+    double *partials = stats + (size_t)ngroups * RT_GRP_STATS;
+    const double *Yrow = rt_row(ctx, RT_Y, surf);
+    const dim3 grid((unsigned)pb, (unsigned)ngroups), block(RT_RED_THREADS);
+    const dim3 fgrid((unsigned)((ngroups + 63) / 64)), fblock(64);
+    hipLaunchKernelGGL(rt_group_sums_kernel, grid, block, 0, ctx->stream, Yrow,
+                       ctx->d_w, group_rays, ctx->ld, partials);
+    hipLaunchKernelGGL(rt_group_centroid_kernel, fgrid, fblock, 0, ctx->stream,
+                       partials, (int)pb, ngroups, stats);
+    hipLaunchKernelGGL(rt_group_spread_kernel, grid, block, 0, ctx->stream,
+                       Yrow, ctx->d_w, group_rays, ctx->ld, stats, partials);
+    hipLaunchKernelGGL(rt_group_finish_kernel, fgrid, fblock, 0, ctx->stream,
+                       partials, (int)pb, ngroups, stats);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(out, stats,
+                               sizeof(double) * RT_GRP_STATS * ngroups,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
+{
+    int rc = rt_consumer_ready(ctx, surf, "rt_refocus_shift");
+    if (rc != RT_OK)
+        return rc;
+    if (!shift)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_refocus_shift: NULL");
+    const double *Yrow = rt_row(ctx, RT_Y, surf);
+    const double *Irow = rt_row(ctx, RT_I, surf);
+    double d[2];
+    const unsigned blocks = rt_red_blocks(ctx->n);
+    hipLaunchKernelGGL(rt_refocus_sums_kernel, dim3(blocks),
+                       dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow, ctx->n,
+                       ctx->ld, ctx->d_partials);
+    hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       ctx->d_partials, (int)blocks, 5, rt_reduced(ctx, 0));
+    hipLaunchKernelGGL(rt_refocus_dots_kernel, dim3(blocks),
+                       dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow,
+                       ctx->d_w, 1. / (double)ctx->n, rt_reduced(ctx, 0),
+                       ctx->n, ctx->ld, ctx->d_partials);
+    hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       ctx->d_partials, (int)blocks, 2, rt_reduced(ctx, 5));
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(d, rt_reduced(ctx, 5), sizeof d,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *shift = -d[0] / d[1];
+    return RT_OK;
+}
+
+int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa)
+{
+    if (!ctx || !args || !out_soa)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_opd_rays: NULL argument");
+    int rc = rt_consumer_ready(ctx, 0, "rt_opd_rays");
+    if (rc != RT_OK)
+        return rc;
+    const int L = ctx->buf_nsurf;
+    if (args->nrows < 0 || args->nrows > L || args->after < 0 ||
+        args->after >= L || args->image < 0 || args->image >= L ||
+        args->ref < 0 || args->ref >= ctx->n)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_opd_rays: index out of range");
+    for (int j = 0; j < L; ++j)
+        if (!ctx->valid[j] &&
+            (j < args->nrows || j == args->after || j == args->image))
+            return rt_fail(ctx, RT_ERR_STATE,
+                           "rt_opd_rays: row %d holds no data", j);
+    /* reference-ray columns: small strided D2H, then one struct upload */
+    rt_opd_ref href;
+    memset(&href, 0, sizeof href);
+    double col[RT_MAX_SURFACES * 3];
+    rc = rt_download_ray(ctx, RT_T, args->ref, col);
+    if (rc != RT_OK)
+        return rc;
+    memcpy(href.t, col, sizeof(double) * L);
+    rc = rt_download_ray(ctx, RT_Y, args->ref, col);
+    if (rc != RT_OK)
+        return rc;
+    memcpy(href.y0, col, sizeof(double) * 3);
+    memcpy(href.ya, col + 3 * args->after, sizeof(double) * 3);
+    memcpy(href.yi, col + 3 * args->image, sizeof(double) * 3);
+    rc = rt_download_ray(ctx, RT_U, args->ref, col);
+    if (rc != RT_OK)
+        return rc;
+    memcpy(href.u0, col, sizeof(double) * 3);
+    memcpy(href.ua, col + 3 * args->after, sizeof(double) * 3);
+    if (!ctx->d_opd_ref)
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_opd_ref, sizeof(rt_opd_ref)));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_opd_ref, &href, sizeof href,
+                               hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t bytes = (size_t)ctx->n * 3 * sizeof(double);
+    rc = rt_need_scratch(ctx, bytes);
+    if (rc != RT_OK)
+        return rc;
+    rc = rt_detach(ctx, RT_U, args->after); /* read at its natural address */
+    if (rc != RT_OK)
+        return rc;
+    const unsigned grid = (unsigned)((ctx->n + 255) / 256);
+    RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
+    hipLaunchKernelGGL(rt_opd_kernel, dim3(grid), dim3(256), 0, ctx->stream,
+                       *args, ctx->d_opd_ref, rt_arr(ctx, RT_Y),
+                       rt_arr(ctx, RT_U), rt_arr(ctx, RT_T), ctx->n, ctx->ld,
+                       (double *)ctx->d_scratch);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
+    ctx->traced = 1;
+    return rt_d2h(ctx, out_soa, ctx->d_scratch, bytes);
+}
+
+} /* extern "C" */

@@ -1,0 +1,271 @@
+/*
+ * rt_ctx.h -- what the translation units of librt_mi355.so share: the
+ * context, error plumbing, row addressing and the few internal helpers that
+ * cross TU borders.  Not installed; the public surface is include/rt_mi355.h.
+ *
+ *   rt_engine.hip     contexts, surface tables, seeding / generation, the
+ *                     trace launch, row bookkeeping (served rows), downloads
+ *   rt_consumers.hip  aiming kernel, rms / refocus / spot statistics / opd
+ *   rt_comm.hip       RCCL communicator and the gather of a result row
+ *   rt_probes.hip     laboratory only (-DRT_BUILD_PROBES ->
+ *                     librt_mi355_probes.so): rejected kernel variants,
+ *                     bandwidth probes, measurement options
+ */
+#ifndef RT_CTX_H
+#define RT_CTX_H
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rt_math.h"
+#include "rt_lay.h"
+
+#define RT_INTERNAL __attribute__((visibility("hidden")))
+
+#define RT_NEVENTS 8
+#define RT_MAX_GROUPS 65535 /* surface tables per launch (wavelengths, or
+                               variants of a system: tolerancing runs) */
+#define RT_GATHER_SLOTS 4   /* staging buffers of rt_gather_final: gathers of
+                               that many steps (or chunks) may be in flight */
+
+struct rt_rccl_api {
+    void *lib;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*GroupStart)(void);
+    ncclResult_t (*GroupEnd)(void);
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t,
+                         hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t,
+                         hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+};
+
+#ifdef RT_BUILD_PROBES
+/* laboratory state (rt_probes.hip) */
+struct rt_lab {
+    int r, nt, xcd;   /* rays per lane, non-temporal stores, XCD dealing */
+    int block;        /* threads per workgroup of the lab kernels */
+    int lds;          /* bytes of unused dynamic LDS per workgroup */
+    int tile;         /* tile-major result layout, rays per tile */
+    int uniform_fix;  /* input components read as if wave-uniform (mask) */
+    int gate_log2, gate_window; /* chip-wide read windows */
+    int probe_store;  /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
+    void *d_probe_in; /* rt_probe modes 13/14: input rows of their own */
+    size_t probe_in_bytes;
+    int probe_in_uc;
+};
+#endif
+
+struct rt_ctx {
+    int device;
+    hipStream_t stream;      /* trace + copies */
+    hipStream_t comm_stream; /* RCCL gather */
+    hipEvent_t k0, k1;       /* around the last trace kernel */
+    hipEvent_t ev[RT_NEVENTS];
+    int traced;
+
+    rt_surface *d_surf;  /* = d_tab[tab_cur]: the table kernels read */
+    rt_surface *d_tab[2]; /* double buffered: a changed table is sent while a
+                             kernel in flight still reads the previous one */
+    hipEvent_t tab_used[2]; /* last DMA into / kernel reading buffer k */
+    int tab_cur;
+    int nsurf;
+    rt_surface *h_surf;                 /* [ngroups][nsurf] as given */
+    size_t tab_cap;                     /* entries h_surf/h_stage/d_surf hold */
+    int ngroups;                        /* surface tables (wavelengths) */
+    rt_surface *h_stage;                /* = h_pinned[tab_cur] */
+    rt_surface *h_pinned[2];            /* pinned: flags finalised */
+    int table_dirty;
+    int table_start;
+    unsigned char keep[RT_MAX_SURFACES];  /* rows propagate() stores */
+    unsigned char valid[RT_MAX_SURFACES]; /* rows that hold data */
+
+    double *d_buf; /* Y | U | I | T */
+    size_t cap_doubles;
+    int64_t n, ld;
+    int buf_nsurf; /* L the buffer is laid out for */
+
+    void *d_scratch;
+    size_t scratch_bytes;
+    void *d_user; /* rt_scratch */
+    size_t user_bytes;
+    void *h_pin[2]; /* pinned staging for large pageable copies */
+    hipEvent_t pin_done[2];
+    int pin_busy[2]; /* a DMA recorded in pin_done[k] may still use h_pin[k] */
+    char *h_aim; /* pinned: rt_aim_pupil's tables | seeds out, z | a | status in */
+    size_t h_aim_bytes;
+    double *d_w;  /* ray weights, NULL = uniform 1/n */
+    size_t w_cap;
+    int64_t w_n;  /* rays the weights were given for (must equal n) */
+    double *d_partials; /* RT_RED_BLOCKS x 8 doubles + 16 reduced values */
+    double *d_group;    /* rt_spot_stats: stats | partials */
+    size_t group_cap;   /* doubles */
+    struct rt_opd_ref *d_opd_ref;
+
+    /* kernel choices */
+    int opt_alias;
+    int opt_fuse; /* build generated rays inside the first trace */
+    int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
+    int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
+    int opt_compact_every; /* survivors are counted at every k-th element */
+    int last_compact; /* the last trace ran the compacting kernel */
+
+    /* rt_generate_rays: field frames | pupil points, and whether row 0 is
+     * still to be built from them */
+    void *d_gen;
+    size_t gen_bytes, gen_fpad;
+    int gen_pending, gen_nf;
+    int gen_live; /* row 0 still holds exactly what d_gen describes: a trace
+                     from element 1 may rebuild the rays instead of reading
+                     them */
+    int opt_regen;
+    int64_t gen_np, gen_n;
+    rt_surface gen_s0;
+    /* per row of I: 0 = materialised, 1 = identical to U[j-1], 2 = to U[j] */
+    unsigned char i_alias[RT_MAX_SURFACES];
+    /* per row of U: 1 = identical to I[j] (RT_F_SKIP_U), not materialised */
+    unsigned char u_alias[RT_MAX_SURFACES];
+    int table_clip; /* clip the device table was finalised for */
+
+    /* multi GPU (rt_comm.hip) */
+    ncclComm_t comm;
+    int nranks, rank;
+    double *d_stage[RT_GATHER_SLOTS];
+    size_t stage_bytes[RT_GATHER_SLOTS];
+    hipEvent_t staged[RT_GATHER_SLOTS], gathered[RT_GATHER_SLOTS];
+    hipEvent_t g0, g1; /* timing: first / last operation of a gather on the
+                          communication stream */
+    int gather_pending[RT_GATHER_SLOTS];
+    int gather_slot;
+
+#ifdef RT_BUILD_PROBES
+    rt_lab lab;
+#endif
+    char err[512];
+};
+
+RT_INTERNAL extern rt_rccl_api g_rccl;
+
+extern "C" RT_INTERNAL int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...);
+
+#define RT_HIP(ctx, call)                                                     \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess)                                                 \
+            return rt_fail(ctx, RT_ERR_HIP, "%s: %s (%s:%d)", #call,          \
+                           hipGetErrorString(e_), __FILE__, __LINE__);        \
+    } while (0)
+
+#define RT_NCCL(ctx, call)                                                    \
+    do {                                                                      \
+        ncclResult_t r_ = (call);                                             \
+        if (r_ != ncclSuccess)                                                \
+            return rt_fail(ctx, RT_ERR_RCCL, "%s: %s (%s:%d)", #call,         \
+                           g_rccl.GetErrorString(r_), __FILE__, __LINE__);    \
+    } while (0)
+
+static inline double *rt_arr(const rt_ctx *c, int which)
+{
+    /* Y,U,I are [L][3][ld]; T is [L][ld] */
+    const size_t plane = (size_t)c->buf_nsurf * 3 * (size_t)c->ld;
+    return c->d_buf + (size_t)which * plane;
+}
+
+static inline int rt_ncomp(int which) { return which == RT_T ? 1 : 3; }
+
+/* addressing of the result arrays as the kernels see it (rt_lay.h) */
+static inline rt_lay rt_layout(const rt_ctx *c)
+{
+    rt_lay a;
+#ifdef RT_BUILD_PROBES
+    if (c->lab.tile) { /* [tile][L][10][TR] */
+        const int64_t tr = c->lab.tile;
+        a.Y = c->d_buf;
+        a.U = c->d_buf + 3 * tr;
+        a.I = c->d_buf + 6 * tr;
+        a.T = c->d_buf + 9 * tr;
+        a.cs = tr;
+        a.ss = a.ssT = 10 * tr;
+        a.ts = (int64_t)c->buf_nsurf * 10 * tr;
+        a.tshift = __builtin_ctzll((unsigned long long)tr);
+        return a;
+    }
+    a.tshift = 8;
+    a.ts = 256;
+#endif
+    a.Y = rt_arr(c, RT_Y);
+    a.U = rt_arr(c, RT_U);
+    a.I = rt_arr(c, RT_I);
+    a.T = rt_arr(c, RT_T);
+    a.cs = c->ld;
+    a.ss = 3 * c->ld;
+    a.ssT = c->ld;
+    return a;
+}
+
+/* everything that reads rows back assumes the documented SoA layout */
+static inline int rt_soa_only(rt_ctx *c, const char *who)
+{
+#ifdef RT_BUILD_PROBES
+    if (c && c->lab.tile)
+        return rt_fail(c, RT_ERR_STATE,
+                       "%s: the tile_rays layout is a measurement option; "
+                       "results can only be read back in the SoA layout", who);
+#endif
+    (void)c;
+    (void)who;
+    return RT_OK;
+}
+
+/* device address of one surface row, resolving the I -> U aliasing */
+static inline double *rt_row(const rt_ctx *c, int which, int surf)
+{
+    if (which == RT_I && c->i_alias[surf])
+        return rt_row(c, RT_U, c->i_alias[surf] == 1 ? surf - 1 : surf);
+    if (which == RT_U && c->u_alias[surf])
+        return rt_row(c, RT_I, surf); /* surf >= 1, and I[surf] never points
+                                         back at U[surf] there */
+    return rt_arr(c, which) + (size_t)surf * rt_ncomp(which) * c->ld;
+}
+
+extern "C" { /* (linkage only: none of these is exported) */
+/* rt_engine.hip */
+RT_INTERNAL int rt_detach(rt_ctx *c, int which, int surf);
+RT_INTERNAL int rt_gen_flush(rt_ctx *c);
+RT_INTERNAL int rt_need_scratch(rt_ctx *ctx, size_t bytes);
+RT_INTERNAL int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes);
+RT_INTERNAL int rt_d2h(rt_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* rt_comm.hip */
+RT_INTERNAL void rt_comm_release(rt_ctx *ctx);
+}
+
+#ifdef RT_BUILD_PROBES
+/* rt_probes.hip: hooks of the laboratory build */
+extern "C" {
+RT_INTERNAL void rt_lab_init(rt_ctx *c);
+RT_INTERNAL void rt_lab_destroy(rt_ctx *c);
+/* 1 = handled, 0 = not a lab key, < 0 = error */
+RT_INTERNAL int rt_lab_set_option(rt_ctx *c, const char *key, int value);
+RT_INTERNAL bool rt_lab_variant(const rt_ctx *c); /* a lab kernel is selected */
+RT_INTERNAL int rt_lab_launch(rt_ctx *c, int start, int stop, int clip);
+}
+static inline int64_t rt_ld_quantum(const rt_ctx *c)
+{
+    return c->lab.tile ? c->lab.tile : 64;
+}
+static inline int rt_group_quantum(const rt_ctx *c) { return 64 * c->lab.r; }
+static inline int rt_gen_block(const rt_ctx *c) { return c->lab.block; }
+static inline size_t rt_gen_lds(const rt_ctx *c) { return (size_t)c->lab.lds; }
+#else
+static inline bool rt_lab_variant(const rt_ctx *) { return false; }
+static inline int64_t rt_ld_quantum(const rt_ctx *) { return 64; }
+static inline int rt_group_quantum(const rt_ctx *) { return 64; }
+#endif
+
+#endif /* RT_CTX_H */

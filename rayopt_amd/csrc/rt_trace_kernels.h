@@ -1,0 +1,301 @@
+/*
+ * rt_trace_kernels.h -- device code of the hot path: the fused trace kernel
+ * (host-seeded, device-generated and compacting forms) and the kernels that
+ * put launch rays into row 0.  Included by rt_engine.hip; the per-ray
+ * arithmetic lives in rt_math.h.
+ */
+#ifndef RT_TRACE_KERNELS_H
+#define RT_TRACE_KERNELS_H
+
+#include "rt_march.h"
+
+/*
+ * THE kernel: one lane owns one ray, state in VGPRs across the whole surface
+ * loop, surface table through scalar loads, 7-10 coalesced 512-byte stores
+ * per wavefront and element.
+ */
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
+                int clip, rt_lay a, int64_t ld, int64_t group_rays, int nsurf)
+{
+    const int64_t j = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (j >= ld)
+        return;
+    if (group_rays) {
+        /* ray groups with their own surface table (one wavelength each):
+         * group boundaries are multiples of 64 rays, so the group -- and
+         * with it every table read -- stays wave-uniform (SGPRs) */
+        const int64_t j0 = j - (int64_t)(threadIdx.x & 63);
+        const int g = __builtin_amdgcn_readfirstlane((int)(j0 / group_rays));
+        surf += (int64_t)g * nsurf;
+    }
+    const int64_t col = rt_col(a, j);
+    double y[1][3], u[1][3];
+    rt_load_state<1>(a, start - 1, col, y, u);
+    rt_march<1, false>(surf, start, stop, clip, a, col, y, u);
+}
+
+/*
+ * The first trace after rt_generate_rays: the launch rays are built in
+ * registers (field f = j / npupil through pupil point j % npupil), row 0 is
+ * written from there and the march goes on -- the generated batch never
+ * makes the round trip through HBM that a separate generation kernel plus
+ * the 48 B/ray input read would cost (the read is the expensive kind:
+ * profiles/r01_probes/ab_store_order.log (9)).  Later traces of the same
+ * batch from element 1 (store0 = 0) build the rays again the same way --
+ * the values row 0 holds, bit for bit -- instead of reading them.
+ */
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
+                    rt_lay a, int64_t ld, int64_t group_rays, int nsurf,
+                    const rt_field *__restrict__ fields,
+                    const double *__restrict__ pupil, int64_t npupil,
+                    int64_t n, int64_t j0, rt_surface S0, int store_i0,
+                    int store0)
+{
+    /* `a` and `ld` describe the window of columns this launch covers (the
+     * whole batch: j0 = 0); j0 + column = index of the ray in the batch */
+    const int64_t w = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (w >= ld)
+        return;
+    const int64_t j = j0 + w;
+    if (group_rays) {
+        const int64_t jw = j - (int64_t)(threadIdx.x & 63);
+        const int g = __builtin_amdgcn_readfirstlane((int)(jw / group_rays));
+        surf += (int64_t)g * nsurf;
+    }
+    double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
+    if (j < n) {
+        const int64_t p = j % npupil;
+        rt_generate_ray(fields + j / npupil, pupil[2 * p], pupil[2 * p + 1],
+                        &S0, y, u);
+    }
+    const int64_t col = rt_col(a, w);
+    if (store0) { /* first trace of the batch; later ones leave row 0 alone */
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.Y[c * a.cs + col] = y[0][c];
+            a.U[c * a.cs + col] = u[0][c];
+            if (store_i0)
+                a.I[c * a.cs + col] = u[0][c];
+        }
+        a.T[col] = 0.;
+    }
+    rt_march<1, false>(surf, 1, stop, clip, a, col, y, u);
+}
+
+/*
+ * Clipped-ray compaction (BASELINE north_star: "wavefront ballots for ...
+ * clipped-ray compaction").  A ray whose direction has become NaN -- clipped
+ * by an aperture (rayopt/elements.py:206-209), missed surface, TIR, Newton
+ * failure -- is NaN in every array of every later element, so there is
+ * nothing left to compute for it; with rows that are all stored the kernel is
+ * bound by those stores and a dead ray costs exactly what a live one does
+ * (measured: profiles/r02_probes, part C), but when rows are NOT stored
+ * (rt_set_keep_rows: merit functions keep the image row) the kernel is bound
+ * by FP64 issue and dead lanes are wasted issue slots.  This variant retires
+ * dead rays -- their remaining kept rows are filled with NaN at once -- and,
+ * whenever that frees a whole wavefront of the 256-ray workgroup, packs the
+ * surviving rays into the low lanes: 64-bit ballots + popcounts give every
+ * survivor its slot, the state (y, u and the ray's column) moves through LDS,
+ * and the emptied wavefronts only keep the barriers company.  A ray keeps
+ * its column, so results land where the plain kernel puts them, bit for bit.
+ */
+#define RT_CB 256
+
+/* NaN into the rows of element s for one column (flags say which exist) */
+__device__ __forceinline__ void rt_store_nan_row(unsigned f, int s,
+                                                 const rt_lay &a, int64_t col)
+{
+    const int64_t row = s * a.ss + col;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.Y[row + c * a.cs] = RT_NAN;
+        if (!(f & RT_F_SKIP_U))
+            a.U[row + c * a.cs] = RT_NAN;
+        if (f & RT_F_STORE_I)
+            a.I[row + c * a.cs] = RT_NAN;
+    }
+    a.T[s * a.ssT + col] = RT_NAN;
+}
+
+__global__ void __launch_bounds__(RT_CB)
+rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
+                        int stop, int clip, rt_lay a, int64_t ld,
+                        int64_t group_rays, int nsurf, int every)
+{
+    __shared__ int cnt[2][RT_CB / 64]; /* by parity of the ROUND (the k-th
+                                          time the question is asked): a
+                                          wavefront may still read round k
+                                          while another already writes round
+                                          k + 1 */
+    __shared__ double sm[6][RT_CB];
+    __shared__ int smi[RT_CB];
+    __shared__ unsigned short gone[RT_CB]; /* column -> first element whose
+                                              rows are NaN (0: alive) */
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t tile0 = (int64_t)blockIdx.x * RT_CB;
+    if (group_rays) /* a tile never straddles two groups (host checks) */
+        surf += (tile0 / group_rays) * nsurf;
+    /* SoA (the only layout this kernel is launched for): the tile's columns
+     * are consecutive */
+    const int64_t col0 = tile0;
+    const bool exists = tile0 + tid < ld;
+    bool has = exists;
+    int idx = tid; /* the ray's column inside the tile */
+    gone[tid] = 0;
+    double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
+    if (has)
+        rt_load_state<1>(a, start - 1, col0 + idx, y, u);
+    {
+        const rt_surface *S0 = surf + (start - 1);
+        rt_leave<1>(S0, S0->flags, y, u);
+    }
+    int nwaves = RT_CB / 64; /* wavefronts that may still hold rays */
+    for (int s = start; s < stop; ++s) {
+        /* retire the rays that died at the previous element: their later
+         * kept rows are NaN, written below when those rows come up */
+        if (has && !(u[0][0] == u[0][0])) {
+            gone[idx] = (unsigned short)s; /* a wavefront that is still at
+                                              the rows of element s-1 reads
+                                              "not yet" */
+            has = false;
+        }
+        /* survivors per wavefront -> can a whole wavefront be freed?  The
+         * question costs a workgroup barrier, so it is asked only at every
+         * `every`-th element (uniform across the workgroup) */
+        const bool ask = (s - start) % every == every - 1 && nwaves > 1;
+        if (ask) {
+            const int par = ((s - start) / every) & 1;
+            const unsigned long long mine = __ballot(has);
+            if (wave < nwaves && lane == 0)
+                cnt[par][wave] = __popcll(mine);
+            __syncthreads();
+            int total = 0, before = 0, used = 0;
+            for (int w = 0; w < nwaves; ++w) {
+                const int c = cnt[par][w];
+                before += w < wave ? c : 0;
+                total += c;
+                used += c > 0;
+            }
+            const int need = (total + 63) >> 6;
+            if (need < used) { /* workgroup-uniform */
+                if (has) {
+                    const int dst =
+                        before + __popcll(mine & ((1ull << lane) - 1ull));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        sm[c][dst] = y[0][c];
+                        sm[3 + c][dst] = u[0][c];
+                    }
+                    smi[dst] = idx;
+                }
+                __syncthreads();
+                has = tid < total;
+                if (has) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        y[0][c] = sm[c][tid];
+                        u[0][c] = sm[3 + c][tid];
+                    }
+                    idx = smi[tid];
+                }
+                nwaves = need;
+                __syncthreads(); /* sm is rewritten by the next compaction */
+            }
+        }
+        const rt_surface *S = surf + s;
+        const unsigned flags = S->flags;
+        if (RT_WAVE_ANY(has)) {
+            double iv[1][3], t[1];
+            rt_step<1>(S, flags, clip, y, u, iv, t);
+            if (has)
+                rt_store_rows<1, false>(flags, s, a, col0 + idx, y, u, iv, t);
+            rt_leave<1>(S, flags, y, u);
+        }
+        if (!(flags & RT_F_NOSTORE)) {
+            /* a kept row: the columns of retired rays get their NaN from the
+             * thread that owns the column, next to the survivors' stores */
+            __syncthreads();
+            const int from = gone[tid];
+            if (exists && from && from <= s)
+                rt_store_nan_row(flags, s, a, col0 + tid);
+        }
+    }
+}
+
+/* rays_given: AoS (n,3) staging -> SoA row 0 of Y,U,I and T[0] = 0 */
+__global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
+                                   const double *__restrict__ u_aos,
+                                   int64_t n, rt_lay a, int64_t ld,
+                                   int store_i, int64_t period)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld)
+        return;
+    const bool in = j < n;
+    const int64_t k = j % period; /* the same rays for every group */
+    const int64_t col = rt_col(a, j);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double p = in ? y_aos[k * 3 + c] : 0.;
+        const double q = in ? u_aos[k * 3 + c] : 0.;
+        a.Y[c * a.cs + col] = p;
+        a.U[c * a.cs + col] = q;
+        if (store_i)
+            a.I[c * a.cs + col] = q;
+    }
+    a.T[col] = 0.;
+}
+
+/* rays_given for SoA (3,n) device/staged input */
+__global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
+                                   const double *__restrict__ u_soa,
+                                   int64_t n, rt_lay a, int64_t ld,
+                                   int store_i, int64_t period)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld)
+        return;
+    const bool in = j < n;
+    const int64_t k = j % period; /* the same rays for every group */
+    const int64_t col = rt_col(a, j);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double p = in ? y_soa[c * period + k] : 0.;
+        const double q = in ? u_soa[c * period + k] : 0.;
+        a.Y[c * a.cs + col] = p;
+        a.U[c * a.cs + col] = q;
+        if (store_i)
+            a.I[c * a.cs + col] = q;
+    }
+    a.T[col] = 0.;
+}
+
+/* rays of field f x pupil point p, see rt_generate_rays in rt_mi355.h */
+__global__ void rt_generate_kernel(const rt_field *__restrict__ fields,
+                                   const double *__restrict__ pupil,
+                                   int64_t npupil, int64_t n, rt_surface S0,
+                                   rt_lay a, int64_t ld, int store_i)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ld)
+        return;
+    double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
+    if (r < n) {
+        const int64_t p = r % npupil;
+        rt_generate_ray(fields + r / npupil, pupil[2 * p], pupil[2 * p + 1],
+                        &S0, y, u);
+    }
+    const int64_t col = rt_col(a, r);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.Y[c * a.cs + col] = y[0][c];
+        a.U[c * a.cs + col] = u[0][c];
+        if (store_i)
+            a.I[c * a.cs + col] = u[0][c];
+    }
+    a.T[col] = 0.;
+}
+
+#endif /* RT_TRACE_KERNELS_H */

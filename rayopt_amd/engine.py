@@ -25,8 +25,8 @@ def _default_device():
 class Engine:
     """Owns one device context (stream, events, result arrays in HBM)."""
 
-    def __init__(self, device=None):
-        self.lib = _lib.load()
+    def __init__(self, device=None, lib_path=None):
+        self.lib = _lib.load(lib_path)
         self.device = _default_device() if device is None else int(device)
         ctx = ctypes.c_void_p()
         rc = self.lib.rt_create(self.device, ctypes.byref(ctx))
@@ -182,8 +182,28 @@ class Engine:
         self._check(self.lib.rt_set_option(self.ctx, key.encode(), int(value)),
                     "rt_set_option(%s)" % key)
 
+    def trace_chunk(self, start, stop, clip, chunk, nchunks):
+        """The trace for chunk ``chunk`` of ``nchunks`` of the rays
+        (rt_trace_chunk); all chunks together = :meth:`trace`."""
+        self._check(self.lib.rt_trace_chunk(
+            self.ctx, int(start), int(stop), 1 if clip else 0, int(chunk),
+            int(nchunks)), "rt_trace_chunk")
+
+    def chunk_bounds(self, n, chunk, nchunks):
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.rt_chunk_bounds(
+            int(n), int(chunk), int(nchunks), ctypes.byref(lo),
+            ctypes.byref(hi)), "rt_chunk_bounds")
+        return lo.value, hi.value
+
     def probe(self, mode):
-        """(ms, bytes) of a bandwidth probe kernel (rt_probe)."""
+        """(ms, bytes) of a bandwidth probe kernel (rt_probe): laboratory
+        build only (librt_mi355_probes.so via RT_MI355_LIB)."""
+        if not hasattr(self.lib, "rt_probe"):
+            raise EngineError(
+                "rt_probe is not part of the shipped library: build the "
+                "laboratory one (python -m rayopt_amd._build probes) and "
+                "point RT_MI355_LIB at it")
         ms, nbytes = ctypes.c_double(), ctypes.c_double()
         self._check(self.lib.rt_probe(self.ctx, mode, ctypes.byref(ms),
                                       ctypes.byref(nbytes)), "rt_probe")
@@ -301,6 +321,25 @@ class Engine:
             self.ctx, which, surf,
             counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), root,
             ctypes.c_void_p(d_dst)), "rt_gather_final")
+
+    def gather_chunk(self, which, surf, counts, root, d_dst, chunk, nchunks):
+        """:meth:`gather_final` for chunk ``chunk`` of ``nchunks`` of every
+        rank's rays: overlaps the trace of the next chunk."""
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        self._check(self.lib.rt_gather_chunk(
+            self.ctx, which, surf,
+            counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), root,
+            ctypes.c_void_p(d_dst), int(chunk), int(nchunks)),
+            "rt_gather_chunk")
+
+    def gather_ms(self):
+        """(total, exposed) ms of the last gather from HIP events: exposed =
+        what is left after this rank's last trace kernel finished."""
+        total, exposed = ctypes.c_double(), ctypes.c_double()
+        self._check(self.lib.rt_gather_ms(self.ctx, ctypes.byref(total),
+                                          ctypes.byref(exposed)),
+                    "rt_gather_ms")
+        return total.value, exposed.value
 
     def comm_destroy(self):
         self._check(self.lib.rt_comm_destroy(self.ctx), "rt_comm_destroy")

@@ -793,14 +793,22 @@ class GeometricTrace(Trace):
 
     # -- the hot path ---------------------------------------------------------
     def propagate(self, start=1, stop=None, clip=False, keep=None,
-                  _fresh=False):
+                  _fresh=False, chunks=1, after_chunk=None):
         """Trace elements ``start .. stop-1`` for all rays on the GPU
         (rayopt/geometric_trace.py:72-80 + rayopt/system.py:459-464).
 
         ``keep`` (extension, default None = every row as in the reference):
         iterable of surface indices whose rows are stored, e.g. ``keep=[-1]``
         for the image-plane intercepts only.  The other rows are traced but
-        not written (no HBM traffic); reading them raises."""
+        not written (no HBM traffic); reading them raises.
+
+        ``chunks, after_chunk`` (extension, multi-GPU jobs): the rays are
+        traced in ``chunks`` pieces (``rt_trace_chunk``) and
+        ``after_chunk(k, chunks)`` is called after piece ``k`` has been
+        queued -- the place to start the gather of that piece
+        (``Engine.gather_chunk``), which then runs on the communication
+        stream while the next piece is traced.  The result is the result of
+        the unchunked call."""
         if not hasattr(self, "y"):
             raise ValueError("propagate: no rays; call rays_given() first")
         self._snapshot_geometry()
@@ -830,7 +838,15 @@ class GeometricTrace(Trace):
             mask[[range(self.length)[k] for k in keep]] = 1
             mask[:a] = 1        # rows before `start` are not touched
             self.engine.set_keep_rows(mask)
-        self.engine.trace(a, b, clip)
+        if chunks <= 1:
+            self.engine.trace(a, b, clip)
+            if after_chunk is not None:
+                after_chunk(0, 1)
+        else:
+            for k in range(chunks):
+                self.engine.trace_chunk(a, b, clip, k, chunks)
+                if after_chunk is not None:
+                    after_chunk(k, chunks)
         if grouped:
             self.n[:, a:b] = ns[:, a:b]
         else:

@@ -71,6 +71,12 @@ class OracleEngine:
         keep = np.ones(self.nsurf, bool) if self.keep is None else self.keep
         self.valid[start:stop] = keep[start:stop]
 
+    def trace_chunk(self, start, stop, clip, chunk, nchunks):
+        """rt_trace_chunk on the double: the whole trace when the last chunk
+        is asked for (rays are independent: the union of the chunks)."""
+        if chunk == nchunks - 1:
+            self.trace(start, stop, clip)
+
     def download(self, which, lo, hi, out=None):
         assert self.valid[lo:hi].all(), "row holds no data"
         a = self.rows[which][lo:hi]

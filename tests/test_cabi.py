@@ -39,6 +39,26 @@ def test_every_declared_symbol_is_exported(dll):
         assert hasattr(raw, name), name
 
 
+def test_shipped_library_carries_no_laboratory(dll):
+    """Probes, rejected kernel variants and measurement options are built
+    only into librt_mi355_probes.so (-DRT_BUILD_PROBES): the shipped library
+    exports none of their symbols and its kernel has none of their
+    parameters."""
+    import subprocess
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _lib.PROBE_SIGNATURES:
+        assert not hasattr(raw, name), name
+    syms = subprocess.check_output(["nm", "-D", "--defined-only",
+                                    _lib.LIB_PATH], text=True)
+    assert "probe" not in syms and "_lab_" not in syms
+    # the trace kernel's signature: table, start, stop, clip, layout, ld,
+    # group_rays, nsurf -- and nothing else
+    assert "_Z15rt_trace_kernelPK10rt_surfaceiii6rt_laylli\n" in syms + "\n"
+    probes = open(os.path.join(ROOT, "include", "rt_mi355_probes.h")).read()
+    for name in _lib.PROBE_SIGNATURES:
+        assert name in probes
+
+
 def test_struct_layout(dll):
     assert dll.rt_abi_version() == 1
     assert dll.rt_sizeof_surface() == _lib.SURFACE_DTYPE.itemsize == 344

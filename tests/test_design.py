@@ -61,7 +61,7 @@ def reference_with_library():
     ro = refshim.load()
     try:
         from rayopt.library import Library as RefLibrary
-        path = os.path.join(refshim.REFERENCE_ROOT, "rayopt", "library.sqlite")
+        path = refshim.library_db()
         RefLibrary._one = RefLibrary("sqlite:///%s" % path)
     except Exception as err:
         pytest.skip("reference library not usable here: %r" % (err,))

@@ -161,7 +161,7 @@ def test_generation_fused_into_the_first_trace():
 
     want = run("trace", 0)
     for first in ("trace", "row0", "rms0", "partial"):
-        for opts in ({}, {"rays_per_thread": 2}, {"alias_i": 0}):
+        for opts in ({}, {"compact": 2}, {"alias_i": 0}):
             got = run(first, 1, **opts)
             for name in "yuit":
                 assert np.array_equal(got[name], want[name], equal_nan=True), \

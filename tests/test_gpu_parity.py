@@ -67,10 +67,8 @@ def test_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("options", [
-    dict(rays_per_thread=1), dict(rays_per_thread=4),
-    dict(nontemporal=1), dict(xcd_remap=1), dict(block=64), dict(block=512),
-    dict(alias_i=0),
-    dict(rays_per_thread=4, nontemporal=1, xcd_remap=1, block=128)])
+    dict(alias_i=0), dict(compact=2), dict(compact=2, compact_every=1),
+    dict(regenerate=0, fuse_generate=0)])
 @pytest.mark.parametrize("key", ["double_gauss", "asphere_phone", "torture"])
 def test_kernel_variants_are_bit_identical(key, options):
     system = ra.system_from_yaml(P.ALL[key])
@@ -688,17 +686,15 @@ def test_repeated_traces_are_identical_and_follow_new_seeds(n):
         for a, b in zip(got, want):
             assert np.array_equal(a[1:], b, equal_nan=True), rep
         first = first or got
-    for variant in (dict(rays_per_thread=2), dict(rays_per_thread=4),
-                    dict(block=64), dict(block=1024, xcd_remap=1),
-                    dict(lds_pad=40960)):
+    for variant in (dict(alias_i=0), dict(compact=2),
+                    dict(compact=2, compact_every=1)):
         for k, v in variant.items():
             g.engine.set_option(k, v)
         for rep in range(3):
             g.propagate(clip=True)
             assert np.array_equal(np.asarray(g.y[-1]), first[0][-1],
                                   equal_nan=True), (variant, rep)
-        for k, v in dict(rays_per_thread=1, block=256, xcd_remap=0,
-                         lds_pad=0).items():
+        for k, v in dict(alias_i=1, compact=0, compact_every=4).items():
             g.engine.set_option(k, v)
     # new rays of the same count
     y2, u2 = ra.bundles.disc_bundle(n, 12., -6., 9,

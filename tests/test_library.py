@@ -86,7 +86,7 @@ def test_same_answers_as_the_reference_library():
     """Every 7th material of the reference's database, by name, through both
     libraries: same n(lambda) where the reference can evaluate it."""
     ro = refshim.load()
-    path = os.path.join(refshim.REFERENCE_ROOT, "rayopt", "library.sqlite")
+    path = refshim.library_db()
     db = sqlite3.connect("file:%s?mode=ro" % path, uri=True)
     rows = db.execute("select m.name, c.name from material m join catalog c "
                       "on c.id = m.catalog_id order by m.id").fetchall()[::7]

@@ -9,6 +9,8 @@ tests/test_gather_ranks_gpu.py over a stand-in transport; RCCL itself with
 several ranks runs in ``bench.py --gpus N`` on a multi-GPU node only."""
 import os
 import socket
+import struct
+import time
 import subprocess
 import sys
 import textwrap
@@ -184,3 +186,73 @@ def test_under_torch_distributed_run(tmp_path):
         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:]
     assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
+
+
+def test_frames_round_trip_and_nothing_is_unpickled():
+    """The host group's wire format is a fixed header + raw bytes: every
+    payload kind a job sends survives, anything else is refused on both
+    ends, and a pickle sent by a stranger is never loaded."""
+    import pickle
+    a, b = socket.socketpair()
+    try:
+        for obj in (None, True, 7, -2.5, "text", bytes(range(128)),
+                    np.arange(12.).reshape(3, 4),
+                    np.arange(5, dtype=np.int64)):
+            D._send(a, obj)
+            got = D._recv(b)
+            if isinstance(obj, np.ndarray):
+                assert got.dtype == obj.dtype and np.array_equal(got, obj)
+            else:
+                assert got == obj and type(got) is type(obj)
+        with pytest.raises(TypeError):
+            D._send(a, {"a": 1})
+        evil = pickle.dumps(os.system)
+        a.sendall(struct.pack("<Q", len(evil)) + evil + b"\0"*64)
+        with pytest.raises(ConnectionError):
+            D._recv(b)
+    finally:
+        a.close()
+        b.close()
+    assert "pickle" not in open(D.__file__).read().replace(
+        "No pickle", "")
+
+
+def test_expired_wait_names_the_missing_rank(tmp_path):
+    """Every host-group wait is bounded; the error says who did not come."""
+    import threading
+    path = str(tmp_path / "private" / "rdzv")
+    os.mkdir(os.path.dirname(path), 0o700)
+    errors = {}
+
+    def rank1():
+        g = D.HostGroup(2, 1, path=path, timeout=20.)
+        time.sleep(3.)          # never takes part in the barrier
+        g.close()
+    t = threading.Thread(target=rank1)
+    t.start()
+    g = D.HostGroup(2, 0, path=path, timeout=1.)
+    with pytest.raises(TimeoutError, match="for rank 1 in my barrier"):
+        g.barrier("my barrier")
+    g.close()
+    t.join()
+    # a rank that never connects is named as well
+    with pytest.raises(TimeoutError, match=r"rank\(s\) \[1, 2\] of 3"):
+        D.HostGroup(3, 0, path=path, timeout=1.)
+
+
+def test_rendezvous_is_private_to_the_user(tmp_path):
+    path = str(tmp_path / "d" / "rdzv")
+    os.mkdir(os.path.dirname(path), 0o700)
+    D._publish(path, "1234 token\n")
+    assert os.stat(path).st_mode & 0o777 == 0o600
+    assert D._read_published(path) == (1234, "token")
+    os.chmod(path, 0o644)
+    with pytest.raises(PermissionError):
+        D._read_published(path)
+    os.chmod(os.path.dirname(path), 0o755)
+    with pytest.raises(PermissionError):
+        D._publish(path, "1 t\n")
+    # the path an external launcher leads to carries the uid and lies in a
+    # directory of its own
+    p = D.rendezvous_path({"MASTER_PORT": "29500"})
+    assert ("_%d_29500_" % os.getuid()) in p and p.endswith("/rdzv")

@@ -73,8 +73,7 @@ def test_same_system_as_reference_importer():
     ro = refshim.load()
     import os, shutil, tempfile
     db = os.path.join(tempfile.mkdtemp(), "library.sqlite")
-    shutil.copy(os.path.join(refshim.REFERENCE_ROOT, "rayopt",
-                             "library.sqlite"), db)
+    shutil.copy(refshim.library_db(), db)
     ro.library.Library.one(db="sqlite:///" + db)
     from rayopt.zemax import zmx_to_system as ref_import
     ref = ref_import(ZMX)

@@ -32,10 +32,11 @@ import fuzz_pack
 # element's rotation differently for that single ray)
 SIZES = (2, 63, 64, 65, 777, 4099)
 OPTIONS = (("alias_i", (0, 1)), ("regenerate", (0, 1)),
-           ("fuse_generate", (0, 1)), ("rays_per_thread", (1, 2, 4)),
-           ("nontemporal", (0, 1)), ("compact", (0, 1, 2)))
-DEFAULTS = dict(alias_i=1, regenerate=1, fuse_generate=1, rays_per_thread=1,
-                nontemporal=0, compact=0)
+           ("fuse_generate", (0, 1)), ("compact", (0, 1, 2)),
+           ("compact_every", (1, 2, 3, 4)))
+# (exact_asphere: the double is the reference's arithmetic, bit for bit)
+DEFAULTS = dict(alias_i=1, regenerate=1, fuse_generate=1, compact=0,
+                compact_every=4, exact_asphere=1)
 
 
 def compare(dev, cpu, log):
@@ -119,8 +120,6 @@ def sequence(seed, nops):
                           rim=bool(rng.random() < .3),
                           wavelength=list(ls) if len(ls) > 1 and
                           rng.random() < .5 else None)
-                if kw["wavelength"]:
-                    eng.set_option("rays_per_thread", 1)
                 failed = []
                 for t in (dev, cpu):
                     try:
@@ -144,7 +143,6 @@ def sequence(seed, nops):
                 m = int(rng.choice((64, 128, 4096)))
                 y, u = random_rays(int(rng.integers(1 << 30)), m, p)
                 l0 = system.wavelengths[0]
-                eng.set_option("rays_per_thread", 1)   # groups of 64 rays
                 for t in (dev, cpu):
                     t.rays_given(y, u, l=[l0, l0*1.07])
                 seeded = grouped = True
@@ -159,7 +157,6 @@ def sequence(seed, nops):
                 if hasattr(other[k], "curvature"):
                     other[k].curvature *= 1.003
                 other[k].distance = other[k].distance*1.001
-                eng.set_option("rays_per_thread", 1)
                 for t in (dev, cpu):
                     t.rays_variants(y, u, [system, other])
                 seeded = grouped = True
@@ -204,8 +201,6 @@ def sequence(seed, nops):
                 continue
             elif op == "opt":
                 key, values = OPTIONS[int(rng.integers(len(OPTIONS)))]
-                if grouped and key == "rays_per_thread":
-                    continue    # a group must then be a multiple of 64 R rays
                 value = int(rng.choice(values))
                 eng.set_option(key, value)
                 log.append("%s=%d" % (key, value))
