@@ -57,13 +57,27 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                 re-trace rebuilds its launch rays in registers instead of
                 reading row 0 -- own timed loop, value / kernel_ms / achieved
   full_i / unclipped / image_row_only   (--extras) other store modes
-  cpu_baseline  the numpy port of the reference path (oracle/trace_numpy.py,
-                same whole-array numpy operations as rayopt) timed on this
-                host, ONE core, on a bounded sample of the same workload;
-                kind "reference" = rayopt itself, when /root/reference is
-                present on the box
-  cpu_baseline_all_cores   the same port on every host core (one forked
-                process per core over contiguous ray shards)
+  cpu_baseline  rayopt's own GeometricTrace.propagate()
+                (rayopt/geometric_trace.py:72-80, imported unmodified from
+                oracle/_ref/, which oracle/make_ref.py packs in the build
+                container and which travels with the snapshot) timed on this
+                host, ONE process, on a bounded sample of the same workload:
+                kind "reference"; the numpy port (oracle/trace_numpy.py) is
+                timed beside it (``port_value``) and stands in (kind "port")
+                only where the reference archive is missing
+  cpu_baseline_all_cores   the same on every host core (one forked process
+                per core over contiguous ray shards)
+  configs       every BASELINE config on this GPU, one record each: C1
+                (singlet 10^4), C2 (Cooke 10^6 rays x 3 wavelengths, ONE
+                launch), C3 (= the headline), C4 (asphere phone lens 10^7
+                rays: default arithmetic and exact_asphere), C5 on one GPU
+                (double-Gauss 10^8 rays built on the device) -- kernel_ms,
+                algorithmic bytes, frac, parity of a 10^5-ray subsample
+                against the C oracle, and the reference's own rate on a
+                small sample of the same config
+  telemetry     gfx clock, HBM clock, socket power, temperatures sampled by
+                a child process (amdsmi) around the timed loop, and ``frac``
+                against the HBM clock actually observed
   cpu_baseline_c the independent plain-C port (oracle/trace_c.c) with OpenMP:
                 the compiled multi-threaded CPU figure, as a range over team
                 sizes (boxes of the pool differ by x1.8)
@@ -79,9 +93,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# seeded, trigonometry-free bundle builders shared with the digest tests
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 HBM_PEAK_GBS = 8000.        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.  # same guide: measured float4 copy
+HBM_NOMINAL_MHZ = 2000.     # uclk at which the 8 TB/s figure holds (amdsmi:
+                            # MEM clock min = max = 2000 MHz on MI355X)
 FIELD_FRACTIONS = (0, .35, .5, .7, 1.)
 BUNDLE_RADIUS = 17.
 
@@ -154,39 +172,50 @@ def host_cpu():
 
 
 def cpu_one_core(table, system, y, u, clip, S, g, L, sample, l):
-    """One propagate() of the numpy port -- or of rayopt itself where
-    /root/reference exists -- on one core; doubles as a parity check of the
-    bench run itself."""
+    """One propagate() of rayopt itself (oracle/_ref) -- and of the numpy
+    port beside it -- on one core of this host; doubles as a parity check of
+    the bench run itself: the image row the GPU computed in the timed loop
+    against the reference's, bit for bit."""
     from oracle import trace_numpy as tn
+    from oracle import refshim
+    from rayopt_amd import prescriptions as P
     m = min(sample, y.shape[0])
+    mp = min(m, 2_000_000)          # the port: a bounded slice of the sample
     ys, us = y[:m], u[:m]
     tn.propagate(table, ys[:100000], us[:100000], clip=clip)   # warm
     t0 = time.perf_counter()
-    Y, U, I, T = tn.propagate(table, ys, us, clip=clip)
+    Y, U, I, T = tn.propagate(table, ys[:mp], us[:mp], clip=clip)
     dt = time.perf_counter() - t0
     got = np.asarray(g.y[L - 1])[:m]
     ref = Y[-1]
-    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(np.isnan(got[:mp]), np.isnan(ref))
     fin = np.isfinite(ref)
-    assert (np.abs(got[fin] - ref[fin]) <=
+    assert (np.abs(got[:mp][fin] - ref[fin]) <=
             1e-10*np.maximum(np.abs(ref[fin]), 1.)).all()
-    out = {
-        "value": m*S/dt, "unit": "ray-surface-ops/s", "cores": 1,
+    port = {
+        "value": mp*S/dt, "unit": "ray-surface-ops/s", "cores": 1,
         "kind": "port",
         "sample": "first %d rays of the same workload, one propagate() of "
                   "the numpy port (%.1f s); host has %d cores" % (
-                      m, dt, os.cpu_count()),
+                      mp, dt, os.cpu_count()),
         "host": host_cpu(),
-        # the port is the reference's arithmetic bit for bit (tests/): so is
-        # what the GPU just computed in the timed loop
         "image_row_bit_identical_to_gpu": bool(
-            np.array_equal(got, ref, equal_nan=True)),
+            np.array_equal(got[:mp], ref, equal_nan=True)),
     }
-    from oracle import ref_timing
-    ref = ref_timing.time_reference(ys, us, l, clip, want_image_row=Y[-1])
-    if ref is not None:         # rayopt itself, where the box has it
-        ref["port_value"] = m*S/dt
-        out = ref
+    del Y, U, I, T
+    if not refshim.available():     # no archive travelled: the port stands in
+        port["note"] = ("oracle/_ref is missing (python -m oracle.make_ref "
+                        "in the build container): the numpy port stands in "
+                        "for the reference")
+        return port
+    out, t = reference_one_process(P.DOUBLE_GAUSS, ys, us, l, clip, m)
+    image = t.y[-1]
+    assert np.array_equal(np.isnan(got), np.isnan(image))
+    out["host"] = host_cpu()
+    out["image_row_bit_identical_to_gpu"] = bool(
+        np.array_equal(got, image, equal_nan=True))
+    out["port_value"] = port["value"]
+    out["port_sample"] = port["sample"]
     return out
 
 
@@ -234,6 +263,203 @@ def cpu_c_oracle(table, y, u, clip, S, g, L, sample=2_000_000):
                   "figure -- read it as a range" % (m, os.cpu_count()),
         "image_row_bit_identical_to_gpu": bool(same),
     }
+
+
+# --------------------------------------------------------------------------
+# telemetry: clocks / power / temperature around the timed loop
+# --------------------------------------------------------------------------
+
+def telemetry_child(device, period):
+    """Body of the sampling child (``bench.py --telemetry-child``): amdsmi
+    metrics every ``period`` s until "stop" arrives on stdin; "mark <label>"
+    lines stamp the sample stream.  A process of its own, so that sampling
+    never competes with the launch loop for the interpreter."""
+    import select
+    out = {"samples": [], "marks": [], "error": None}
+    try:
+        import amdsmi
+        amdsmi.amdsmi_init()
+        handles = amdsmi.amdsmi_get_processor_handles()
+        h = handles[device if device < len(handles) else 0]
+        out["handles"] = len(handles)
+    except Exception as err:
+        out["error"] = repr(err)[:200]
+        h = None
+    sys.stdout.write("ready\n")
+    sys.stdout.flush()
+
+    def num(v):
+        return float(v) if isinstance(v, (int, float)) else None
+    running = True
+    while running:
+        r, _, _ = select.select([sys.stdin], [], [], period)
+        if r:
+            line = sys.stdin.readline()
+            if not line or line.strip() == "stop":
+                running = False
+            elif line.startswith("mark "):
+                out["marks"].append((line[5:].strip(), time.time()))
+        if h is None:
+            continue
+        try:
+            m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+            gfx = [num(v) for v in (m.get("current_gfxclks") or [])]
+            gfx = [v for v in gfx if v]
+            out["samples"].append((
+                time.time(),
+                sum(gfx)/len(gfx) if gfx else num(m.get("current_gfxclk")),
+                num(m.get("current_uclk")),
+                num(m.get("current_socket_power")),
+                num(m.get("temperature_hotspot")),
+                num(m.get("temperature_mem")),
+                num(m.get("average_gfx_activity"))))
+        except Exception as err:
+            out["error"] = repr(err)[:200]
+            h = None
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+
+
+class Telemetry:
+    """Parent side of the sampling child."""
+    FIELDS = ("gfxclk_mhz", "hbm_uclk_mhz", "socket_power_w", "hotspot_c",
+              "hbm_c", "gfx_activity_pct")
+
+    def __init__(self, device=0, period=0.004):
+        import subprocess
+        self.proc = None
+        try:
+            self.proc = subprocess.Popen(
+                [sys.executable, os.path.abspath(__file__),
+                 "--telemetry-child", str(device), str(period)],
+                stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                stderr=subprocess.DEVNULL, text=True)
+            if self.proc.stdout.readline().strip() != "ready":
+                raise RuntimeError("telemetry child did not start")
+        except Exception as err:
+            log("[bench] telemetry unavailable: %r" % (err,))
+            self.proc = None
+
+    def mark(self, label):
+        if self.proc is not None:
+            try:
+                self.proc.stdin.write("mark %s\n" % label)
+                self.proc.stdin.flush()
+            except OSError:
+                self.proc = None
+
+    def stop(self):
+        """{window: {field: [min, mean, max]}} for the windows between marks
+        "<name>:begin" and "<name>:end", plus the first and last sample."""
+        if self.proc is None:
+            return None
+        try:
+            self.proc.stdin.write("stop\n")
+            self.proc.stdin.flush()
+            data = json.loads(self.proc.stdout.readline())
+            self.proc.wait(timeout=10)
+        except Exception as err:
+            return {"error": repr(err)[:200]}
+        samples, marks = data["samples"], dict(
+            (k, t) for k, t in data["marks"])
+
+        def window(t0, t1):
+            rows = [r for r in samples if t0 <= r[0] <= t1]
+            out = {"samples": len(rows)}
+            for k, name in enumerate(self.FIELDS, 1):
+                v = [r[k] for r in rows if r[k] is not None]
+                if v:
+                    out[name] = [min(v), sum(v)/len(v), max(v)]
+            return out
+        out = {"source": "amdsmi_get_gpu_metrics_info in a child process",
+               "error": data.get("error"),
+               "samples": len(samples)}
+        if samples:
+            out["first_sample_idle"] = dict(zip(self.FIELDS, samples[0][1:]))
+            out["last_sample"] = dict(zip(self.FIELDS, samples[-1][1:]))
+        for name in sorted({k.split(":")[0] for k in marks}):
+            if name + ":begin" in marks and name + ":end" in marks:
+                out[name] = window(marks[name + ":begin"],
+                                   marks[name + ":end"])
+        return out
+
+
+# --------------------------------------------------------------------------
+# the reference itself on this host (oracle/_ref, test infrastructure)
+# --------------------------------------------------------------------------
+
+_REF = {}
+
+
+def _ref_shard_worker(k):
+    ro, text, y, u, l, clip, bounds = (_REF[key] for key in (
+        "ro", "text", "y", "u", "l", "clip", "bounds"))
+    lo, hi = bounds[k]
+    system = ro.system_from_yaml(text)
+    t = ro.GeometricTrace(system)
+    t.rays_given(y[lo:hi], u[lo:hi], l)
+    with np.errstate(all="ignore"):
+        t.propagate(clip=clip)
+    return float(np.nansum(t.y[-1]))
+
+
+def reference_on_processes(text, y, u, l, clip, procs):
+    """rayopt's own propagate() on ``procs`` forked processes over contiguous
+    shards of the batch (forks: before this process opens the GPU)."""
+    import multiprocessing as mp
+    import warnings
+    from oracle import refshim
+    from rayopt_amd.distributed import shard_bounds
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ro = refshim.load()
+    _REF.update(ro=ro, text=text, y=y, u=u, l=l, clip=clip,
+                bounds=shard_bounds(len(y), procs))
+    ctx = mp.get_context("fork")
+    with ctx.Pool(procs) as pool:
+        pool.map(_ref_shard_worker, range(procs))          # warm
+        t0 = time.perf_counter()
+        pool.map(_ref_shard_worker, range(procs))
+        dt = time.perf_counter() - t0
+    S = len(ro.system_from_yaml(text)) - 1
+    _REF.clear()
+    return {"value": len(y)*S/dt, "unit": "ray-surface-ops/s",
+            "cores": procs, "kind": "reference",
+            "sample": "the whole %d-ray batch on %d forked processes (one "
+                      "per host core), contiguous shards, one rayopt."
+                      "GeometricTrace.propagate() each (%.2f s)" % (
+                          len(y), procs, dt)}
+
+
+def reference_one_process(text, y, u, l, clip, sample):
+    """One rayopt.GeometricTrace.propagate() of the first ``sample`` rays,
+    one process.  Returns (record, trace) -- the trace for parity checks."""
+    import warnings
+    from oracle import refshim
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ro = refshim.load()
+        system = ro.system_from_yaml(text)
+    m = min(sample, len(y))
+    warm = ro.GeometricTrace(system)
+    warm.rays_given(y[:max(1, m//20)], u[:max(1, m//20)], l)
+    with np.errstate(all="ignore"):
+        warm.propagate(clip=clip)
+    t = ro.GeometricTrace(system)
+    t.rays_given(y[:m], u[:m], l)
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        t.propagate(clip=clip)
+    dt = time.perf_counter() - t0
+    S = len(system) - 1
+    return {"value": m*S/dt, "unit": "ray-surface-ops/s", "cores": 1,
+            "kind": "reference", "rays": m, "seconds": dt,
+            "sample": "first %d rays of the workload, one rayopt."
+                      "GeometricTrace.propagate() (rayopt/geometric_trace.py"
+                      ":72-80, unmodified, imported from %s), one process "
+                      "(%.1f s); host has %d cores" % (
+                          m, "oracle/_ref" if refshim.carried() else
+                          refshim.REFERENCE_ROOT, dt, os.cpu_count())}, t
 
 
 def traffic_from_profile():
@@ -347,12 +573,19 @@ class Job:
         self.L = len(g.system)
 
     exchange = True
+    chunks = 1
 
     def gather(self):
         from rayopt_amd._lib import RT_Y
         if self.exchange:
             self.eng.gather_final(RT_Y, self.L - 1, self.counts, 0,
                                   self.d_dst)
+
+    def gather_chunk(self, k, chunks):
+        from rayopt_amd._lib import RT_Y
+        if self.exchange:
+            self.eng.gather_chunk(RT_Y, self.L - 1, self.counts, 0,
+                                  self.d_dst, k, chunks)
 
     def fence(self):
         self.eng.sync()
@@ -361,20 +594,26 @@ class Job:
                 self.eng.comm_sync()
             self.group.barrier()
 
-    def timed(self, step, steps, warmup, final_gather):
+    def timed(self, step, steps, warmup, final_gather, last_step=None):
         """W untimed + exactly K timed calls of `step`, bracketed by device
         sync + barrier on both sides.  Returns (wall s, HIP-event ms over the
-        K steps on the trace stream, ms of the last kernel)."""
+        K steps on the trace stream, ms of the last kernel).  With
+        ``final_gather`` the job's one exchange follows the last step inside
+        the timed region; ``last_step`` (if given) IS the K-th step, traced
+        in chunks whose gathers overlap the following chunks."""
         eng = self.eng
         for _ in range(warmup):
             step()
         self.fence()
         t0 = time.perf_counter()
         eng.event_record(0)
-        for _ in range(steps):
+        chunked = final_gather and last_step is not None
+        for _ in range(steps - 1 if chunked else steps):
             step()
+        if chunked:
+            last_step()         # K-th step + the exchange, pipelined
         eng.event_record(1)
-        if final_gather:
+        if final_gather and not chunked:
             self.gather()       # the job's one exchange
         self.fence()
         return (time.perf_counter() - t0, eng.event_elapsed(0, 1),
@@ -396,10 +635,10 @@ def main():
                          "(overrides --rays; 100000000 at --gpus 8 is "
                          "BASELINE configs[4])")
     ap.add_argument("--no-clip", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
-                    help="rays of the workload timed on the host (0: skip "
-                         "every CPU leg); the default is the whole batch, "
-                         "~10 s on one core")
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000,
+                    help="rays of the workload the reference is timed on, "
+                         "one process (0: skip every CPU leg); the default "
+                         "is ~8 s of rayopt on one core")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the all-cores leg of the numpy port "
                          "(forked before the GPU is touched); -1 = one per "
@@ -428,6 +667,18 @@ def main():
     ap.add_argument("--no-configs4", action="store_true",
                     help="N>1: skip the BASELINE configs[4] leg (10^8 rays "
                          "in total)")
+    ap.add_argument("--gather-chunks", type=int, default=4,
+                    help="N>1: the last step is traced in this many pieces "
+                         "and the gather of piece k overlaps the trace of "
+                         "piece k+1 (1: trace, then gather)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the per-config records (C1, C2, C4, C5 on one "
+                         "GPU)")
+    ap.add_argument("--no-configs5", action="store_true",
+                    help="skip the 10^8-ray one-GPU batch (104 GB) of the "
+                         "configs leg")
+    ap.add_argument("--configs5-rays", type=int, default=0,
+                    help="rays of that batch (default 10^8)")
     ap.add_argument("--option", action="append", default=[],
                     help="kernel variant key=value (rt_set_option)")
     args = ap.parse_args()
@@ -506,7 +757,14 @@ def main():
     procs = os.cpu_count() if args.cpu_procs < 0 else args.cpu_procs
     if procs > 1 and args.cpu_sample > 0 and rank == 0 and not dist_mode:
         try:            # forks: before this process opens the GPU
-            cpu_all = cpu_port_on_processes(system, y, u, clip, procs)
+            from oracle import refshim
+            if refshim.available():
+                cpu_all = reference_on_processes(
+                    P.DOUBLE_GAUSS, y, u, system.wavelengths[0], clip, procs)
+                cpu_all["port_value"] = cpu_port_on_processes(
+                    system, y, u, clip, procs)["value"]
+            else:
+                cpu_all = cpu_port_on_processes(system, y, u, clip, procs)
         except Exception as err:      # a reported extra, never fatal
             cpu_all = {"error": repr(err)[:200]}
     if world == 1:
@@ -574,11 +832,38 @@ def main():
                                      False)
         engine_leg = (e_eng, ev_eng/args.steps)
 
-    elapsed, ev_ms, last_kernel_ms = job.timed(step, args.steps, args.warmup,
-                                               final_gather)
-    gather_ms = None
+    job.chunks = max(1, args.gather_chunks)
+
+    def last_step():            # the K-th step, its gather pipelined with it
+        g.propagate(clip=mode["clip"], chunks=job.chunks,
+                    after_chunk=job.gather_chunk)
+
+    plain_loop = None
+    if dist_mode and final_gather:
+        # the same K steps WITHOUT the exchange, same process: what the
+        # one exposed gather costs the job, and how this multi-process line
+        # relates to the plain N = 1 one
+        e_plain, _, _ = job.timed(step, args.steps, args.warmup, False)
+        plain_loop = group.allreduce_max(e_plain)
+    tele = Telemetry(local_rank) if (rank == 0 and not os.environ.get(
+        "RT_BENCH_CHILD")) else None
+    if tele is not None:
+        tele.mark("loop:begin")
+    elapsed, ev_ms, last_kernel_ms = job.timed(
+        step, args.steps, args.warmup, final_gather,
+        last_step if (final_gather and job.chunks > 1 and job.exchange)
+        else None)
+    if tele is not None:
+        tele.mark("loop:end")
+    gather_ms = gather_exposed = None
     if dist_mode:
-        # the exchange alone (not part of `value`'s timed region)
+        if final_gather and job.exchange:
+            # HIP events: the whole exchange, and what was left of it after
+            # this rank's last trace kernel had finished
+            tot, exp = eng.gather_ms()
+            gather_exposed = [group.allreduce_max(tot),
+                              group.allreduce_max(exp)]
+        # the exchange alone, unpipelined (not part of the timed region)
         job.fence()
         t0 = time.perf_counter()
         job.gather()
@@ -740,6 +1025,22 @@ def main():
     if dist_mode:
         out["gather_ms"] = gather_ms
         out["kernel_ms_per_rank"] = per_rank_kernel_ms
+        if gather_exposed is not None:
+            out["gather_pipelined_ms"] = gather_exposed[0]
+            out["gather_exposed_ms"] = gather_exposed[1]
+            out["gather_chunks"] = job.chunks
+        if plain_loop is not None:
+            out["plain_loop_ms_per_step"] = plain_loop*1e3/args.steps
+            out["exchange_cost_ratio"] = elapsed/plain_loop
+            out["note"] = (
+                "`value` includes the job's one exchange (RCCL gather of "
+                "y[L-1] to rank 0, the last step traced in %d chunks so that "
+                "all but the last chunk's gather overlaps tracing): "
+                "ms_per_step x steps = plain_loop_ms_per_step x steps + the "
+                "exposed part of the gather.  The plain N = 1 line (no host "
+                "group, no exchange) is the plain loop of this line; "
+                "processes of one box differ by up to +-4 %% "
+                "(profiles/README.md)" % job.chunks)
         if share:
             out["test_mode"] = ("RT_BENCH_SHARE_DEVICE: all ranks on device "
                                 "0, %s -- not a measurement" % (
@@ -798,6 +1099,30 @@ def main():
                     "the image row stored (80 B/ray); FP64-VALU bound" % S,
         }
 
+    if tele is not None:
+        t = tele.stop()
+        if t:
+            loop = t.get("loop") or {}
+            uclk = (loop.get("hbm_uclk_mhz") or [None, None, None])[1]
+            if uclk:
+                out["roofline"]["hbm_uclk_mhz_observed"] = uclk
+                out["roofline"]["frac_at_observed_hbm_clock"] = \
+                    achieved/(HBM_PEAK_GBS*uclk/HBM_NOMINAL_MHZ)
+            out["telemetry"] = t
+    if world == 1 and not dist_mode and plain and not args.no_configs and \
+            not os.environ.get("RT_BENCH_CHILD"):
+        try:
+            del ylast, ulast
+            out["configs"] = [{
+                "config": "C3 double-Gauss, %d rays in 5 field bundles "
+                          "(the headline line above)" % n,
+                "rays": n, "surfaces": S, "clip": clip,
+                "kernel_ms": kernel_ms, "value": n*S/(kernel_ms*1e-3),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "achieved": achieved, "frac": achieved/HBM_PEAK_GBS}] + \
+                run_configs(ra, local_rank, args)
+        except Exception as err:      # reported extras, never fatal
+            out["configs"] = {"error": repr(err)[:300]}
     if world == 1 and not dist_mode and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_one_core(table, system, y, u, clip, S, g, L,
                                            args.cpu_sample, g.l)
@@ -811,6 +1136,181 @@ def main():
     if dist_mode:
         group.barrier()
         group.close()
+
+
+# --------------------------------------------------------------------------
+# every BASELINE config on this GPU
+# --------------------------------------------------------------------------
+
+def algorithmic_bytes(tables, n, clip, generated=False, alias=True,
+                      pupil_reuse=1):
+    """HBM bytes one launch has to move for ``n`` rays through the packed
+    table(s): per ray-surface op 56 written (y 24, u 24, t 8), + 24 where i
+    must be materialised (element j or j-1 tilted), - 24 where an unclipped
+    trace leaves u[j] = i[j] (no bend); per ray 48 read (host-seeded rows) or
+    16 (pupil coordinates of a device-generated batch)."""
+    from rayopt_amd._lib import F_ROTATED, F_REFRACT
+    flags = np.atleast_2d(tables["flags"])
+    rot = ((flags & F_ROTATED) != 0).any(0)
+    bends = ((flags & F_REFRACT) != 0).any(0)
+    L = flags.shape[1]
+    stored_i = sum(1 for j in range(1, L) if not alias or rot[j] or rot[j - 1])
+    skipped_u = sum(1 for j in range(1, L) if alias and not clip
+                    and not bends[j])
+    per_op = 56*(L - 1) + 24*stored_i - 24*skipped_u
+    return n*(per_op + (16 if generated else 48)), per_op/(L - 1)
+
+
+def kernel_ms_of(g, clip, warm=10, reps=12):
+    """Median HIP-event duration of one propagate() of the resident batch."""
+    for _ in range(warm):
+        g.propagate(clip=clip)
+    t = []
+    for _ in range(reps):
+        g.propagate(clip=clip)
+        t.append(g.kernel_ms())
+    return float(np.median(t))
+
+
+def subsample_parity(ra, device, system, y, u, l, clip, options, m=100_000):
+    """The first ``m`` rays traced on their own with the same options against
+    the plain-C oracle (a ray's result does not depend on its batch): every
+    value of y, u, i, t of every row.  Exact arithmetic: bit identity;
+    default asphere arithmetic: worst error relative to the row scale and
+    whether the NaN masks are the same."""
+    from oracle import build_c
+    from rayopt_amd.pack import pack_system
+    y, u = np.ascontiguousarray(y[:m]), np.ascontiguousarray(u[:m])
+    g = ra.GeometricTrace(system, device=device, **options)
+    g.rays_given(y, u, l)
+    g.propagate(clip=clip)
+    ls = list(np.atleast_1d(l if l is not None else system.wavelengths[0]))
+    same, masks, worst = True, True, 0.
+    per = len(y)
+    for k, lk in enumerate(ls):
+        table, _ = pack_system(system, lk, system.refractive_index(lk, 0))
+        want = build_c.propagate(table, y, u, clip=clip)
+        for rows, ref in zip((g.y, g.u, g.i, g.t), want):
+            got = np.asarray(rows[1:])[:, k*per:(k + 1)*per]
+            same = same and np.array_equal(got, ref, equal_nan=True)
+            masks = masks and np.array_equal(np.isnan(got), np.isnan(ref))
+            with np.errstate(all="ignore"):
+                for a, b in zip(got, ref):
+                    fin = np.isfinite(a) & np.isfinite(b)
+                    if fin.any():
+                        scale = np.abs(b[fin]).max()
+                        worst = max(worst, float(
+                            (np.abs(a[fin] - b[fin]) /
+                             np.maximum(np.abs(b[fin]), scale)).max()))
+    return {"rays": per, "bit_identical_to_c_oracle": bool(same),
+            "nan_masks_equal": bool(masks), "max_rel_err": worst}
+
+
+def run_configs(ra, device, args):
+    """One record per BASELINE config (C3 is the headline itself)."""
+    from rayopt_amd import prescriptions as P
+    from rayopt_amd.pack import pack_system
+    from oracle import refshim
+    import digest_cases as dc
+    out = []
+
+    def reference_rate(text, y, u, l, clip, m):
+        if not refshim.available():
+            return None
+        rec, _ = reference_one_process(text, y, u, l, clip, m)
+        return {k: rec[k] for k in ("value", "rays", "seconds", "kind")}
+
+    def record(name, system, g, n, l, clip, generated, parity, ref, note=""):
+        ls = np.atleast_1d(l)
+        tables = np.stack([pack_system(system, lk,
+                                       system.refractive_index(lk, 0))[0]
+                           for lk in ls])
+        ms = kernel_ms_of(g, clip)
+        alg, per_op = algorithmic_bytes(tables, n, clip, generated)
+        S = len(system) - 1
+        rec = {"config": name, "rays": n, "surfaces": S, "clip": clip,
+               "kernel_ms": ms, "value": n*S/(ms*1e-3),
+               "algorithmic_bytes_per_launch": alg,
+               "bytes_per_ray_surface_op": per_op,
+               "achieved": alg/(ms*1e-3)/1e9,
+               "frac": alg/(ms*1e-3)/1e9/HBM_PEAK_GBS,
+               "parity_subsample": parity,
+               "cpu_reference": ref}
+        if note:
+            rec["note"] = note
+        out.append(rec)
+        log("[configs] %s: %.4f ms, frac %.3f" % (name, ms, rec["frac"]))
+
+    # C1: singlet, 10^4 rays, one wavelength (launch-latency bound: 40 waves)
+    s1 = ra.system_from_yaml(P.SINGLET)
+    y, u = dc.bundle(10**4, 8., 0., 0)
+    l1 = s1.wavelengths[0]
+    g = ra.GeometricTrace(s1, device=device)
+    g.rays_given(y, u, l1)
+    record("C1 singlet, 10^4 rays", s1, g, len(y), l1, True, False,
+           subsample_parity(ra, device, s1, y, u, l1, True, {}),
+           reference_rate(P.SINGLET, y, u, l1, True, 10**4),
+           "160 wavefronts on 256 CUs: bound by launch latency, not HBM")
+    # C2: Cooke triplet, 10^6 rays x 3 wavelengths as ONE launch (ray groups)
+    s2 = ra.system_from_yaml(P.COOKE % dict(
+        air="air", sk16="SCHOTT-SK|N-SK16", f2="SCHOTT-F|N-F2"))
+    ls = [587.56e-9, 656.27e-9, 486.13e-9]
+    y, u = dc.bundle(10**6, 5.5, 5., 0)
+    g = ra.GeometricTrace(s2, device=device)
+    g.rays_given(y, u, l=ls)
+    ref = None
+    if refshim.available():
+        rates = [reference_rate(P.cooke(lk), y, u, lk, True, 100_000)
+                 for lk in ls]
+        ref = {"value": sum(r["rays"] for r in rates)*(len(s2) - 1) /
+               sum(r["seconds"] for r in rates), "kind": "reference",
+               "rays": rates[0]["rays"], "note": "three traces, one per "
+               "wavelength, as the reference has to run them"}
+    record("C2 Cooke triplet, 10^6 rays x 3 wavelengths, one launch", s2, g,
+           3*len(y), ls, True, False,
+           subsample_parity(ra, device, s2, y, u, ls, True, {}, 64*1500),
+           ref)
+    del g
+    # C4: aspheric phone lens, 10^7 rays: default and exact arithmetic
+    s4 = ra.system_from_yaml(P.ASPHERE_PHONE)
+    n4 = 10_000_000 if not args.rays or args.rays >= 10**6 else args.rays
+    y, u = dc.bundle(n4, .6, 10., 4)
+    y[:, 1] -= .5*np.tan(np.radians(10.))
+    l4 = s4.wavelengths[0]
+    ref4 = reference_rate(P.ASPHERE_PHONE, y, u, l4, True, 10**4)
+    if ref4 is not None:
+        ref4["note"] = ("per-ray scipy.optimize.newton in a Python loop "
+                        "(rayopt/elements.py:333-349): timed on 10^4 rays "
+                        "and extrapolated, BASELINE.md 3.4")
+    for label, opts in (("default (FMA / rcp / rsq Newton, 1e-8 contract)",
+                         {}), ("exact_asphere=True (the reference's bits)",
+                               {"exact_asphere": 1})):
+        g = ra.GeometricTrace(s4, device=device, **opts)
+        g.rays_given(y, u, l4)
+        record("C4 aspheric phone lens, %d rays, %s" % (n4, label), s4, g,
+               n4, l4, True, False,
+               subsample_parity(ra, device, s4, y, u, l4, True, opts), ref4)
+        del g
+    del y, u
+    # C5 on ONE GPU: double-Gauss, 10^8 rays built on the device (104 GB)
+    if not args.no_configs5:
+        s5 = ra.system_from_yaml(P.DOUBLE_GAUSS)
+        nf = len(FIELD_FRACTIONS)
+        m = (args.configs5_rays or 100_000_000)//nf//64*64
+        pts = dc.disc_points(m, 91)
+        g = ra.GeometricTrace(s5, device=device)
+        g.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS], pts,
+                      P.DOUBLE_GAUSS_PUPIL_Z, BUNDLE_RADIUS)
+        g.propagate(clip=True)
+        record("C5 on one GPU: double-Gauss, %d rays built on the device"
+               % (m*nf), s5, g, m*nf, s5.wavelengths[0], True, True, None,
+               None, "the 8-GPU form shards these rays and gathers y[L-1] "
+               "over RCCL (bench.py --gpus 8 --total-rays 100000000)")
+        ulast = np.asarray(g.u[-1])[::997, 0]
+        out[-1]["finite_fraction_at_image_sampled"] = float(
+            np.isfinite(ulast).mean())
+        del g
+    return out
 
 
 def small_batch_latency(ra, system, device, n=10_000, reps=300):
@@ -922,8 +1422,18 @@ def run_configs4(ra, system, g, job, group, world, rank, args, clip,
 
     def step():
         g.propagate(clip=clip)
+
+    def last_step():
+        g.propagate(clip=clip, chunks=job.chunks,
+                    after_chunk=job.gather_chunk)
     settle(g, args.settle, clip)
-    elapsed, ev_ms, _ = job.timed(step, args.steps, args.warmup, True)
+    elapsed, ev_ms, _ = job.timed(
+        step, args.steps, args.warmup, True,
+        last_step if (job.chunks > 1 and job.exchange) else None)
+    exposed = None
+    if job.exchange:
+        tot_ms, exp_ms = eng.gather_ms()
+        exposed = [group.allreduce_max(tot_ms), group.allreduce_max(exp_ms)]
     job.fence()
     t0 = time.perf_counter()
     job.gather()
@@ -935,6 +1445,9 @@ def run_configs4(ra, system, g, job, group, world, rank, args, clip,
         return None
     tot = int(counts.sum())
     return {
+        "gather_pipelined_ms": exposed[0] if exposed else None,
+        "gather_exposed_ms": exposed[1] if exposed else None,
+        "gather_chunks": job.chunks,
         "workload": "BASELINE configs[4]: double-Gauss, %d rays in total "
                     "over %d GPUs (%d per GPU), built on the device, RCCL "
                     "gather of y[L-1] to rank 0 after the last step inside "
@@ -949,4 +1462,7 @@ def run_configs4(ra, system, g, job, group, world, rank, args, clip,
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 4 and sys.argv[1] == "--telemetry-child":
+        telemetry_child(int(sys.argv[2]), float(sys.argv[3]))
+    else:
+        main()

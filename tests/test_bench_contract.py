@@ -38,14 +38,34 @@ def test_single_process_line():
     out = subprocess.check_output(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--rays", "200000",
          "--steps", "4", "--warmup", "1", "--cpu-sample", "50000",
-         "--cpu-procs", "4", "--settle", "0.05", "--extras"], text=True,
-        cwd=ROOT)
+         "--cpu-procs", "4", "--settle", "0.05", "--extras",
+         "--configs5-rays", "2000000"], text=True, cwd=ROOT)
     d = check_line(out, 4, 1)
+    from oracle import refshim
+    kind = "reference" if refshim.available() else "port"
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert c["kind"] == kind and c["cores"] == 1 and c["value"] > 0
     assert c["image_row_bit_identical_to_gpu"] is True and "cores" in c["host"]
     a = d["cpu_baseline_all_cores"]
-    assert a["kind"] == "port" and a["cores"] == 4 and a["value"] > 0
+    assert a["kind"] == kind and a["cores"] == 4 and a["value"] > 0
+    if kind == "reference":
+        assert c["port_value"] > 0 and "rayopt" in c["sample"]
+    # clocks / power around the timed loop (amdsmi in a child process)
+    t = d["telemetry"]
+    assert t["samples"] > 0 and t["loop"]["hbm_uclk_mhz"][1] > 0
+    assert d["roofline"]["frac_at_observed_hbm_clock"] > 0
+    # one record per BASELINE config
+    names = [r["config"] for r in d["configs"]]
+    assert [n[:2] for n in names] == ["C3", "C1", "C2", "C4", "C4", "C5"]
+    for r in d["configs"][1:]:
+        assert r["kernel_ms"] > 0 and r["algorithmic_bytes_per_launch"] > 0
+        par = r["parity_subsample"]
+        if par is not None:
+            assert par["nan_masks_equal"] is True
+            if "default" in r["config"]:
+                assert par["max_rel_err"] <= 1e-8
+            else:
+                assert par["bit_identical_to_c_oracle"] is True
     cc = d["cpu_baseline_c"]
     assert cc["range"][0] <= cc["value"] <= cc["range"][1]
     assert cc["image_row_bit_identical_to_gpu"] is True

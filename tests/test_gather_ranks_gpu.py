@@ -93,6 +93,36 @@ WORKER = textwrap.dedent("""
         for r, part in enumerate(D.split_gathered(have[root], counts, 3)):
             if not np.array_equal(part, want[r], equal_nan=True):
                 bad.append(("snapshot", r))
+    # the chunked form: the step is traced in pieces and the gather of piece
+    # k is issued before piece k+1 is traced (rt_trace_chunk /
+    # rt_gather_chunk); all pieces together = the unchunked trace + gather,
+    # also where a rank's shard is smaller than one piece
+    for chunks in (1, 3, 4, 7):
+        y, u = disc_bundle(n, 12., 5., 4000 + 10*chunks + rank)
+        g.rays_given(y, u)
+        g.propagate(clip=True)
+        want_rows = [np.array(np.asarray(r[:])) for r in (g.y, g.u, g.i, g.t)]
+        g.rays_given(y, u)
+        g.propagate(clip=True, chunks=chunks,
+                    after_chunk=lambda k, q: eng.gather_chunk(
+                        RT_Y, L - 1, counts, root, d3, k, q))
+        eng.comm_sync()
+        for a, rows in zip(want_rows, (g.y, g.u, g.i, g.t)):
+            if not np.array_equal(a, np.asarray(rows[:]), equal_nan=True):
+                bad.append(("chunked trace differs", chunks, rank))
+        total_ms, exposed_ms = eng.gather_ms()
+        if not (total_ms >= 0. and exposed_ms >= 0.):
+            bad.append(("gather_ms", total_ms, exposed_ms))
+        box = group.gather(want_rows[0][L - 1])
+        have = group.gather(
+            eng.copy_to_host(d3, total*3*8) if rank == root else None)
+        flags = group.gather(len(bad))
+        if rank == 0:
+            for r, part in enumerate(D.split_gathered(have[root], counts, 3)):
+                if not np.array_equal(part, box[r], equal_nan=True):
+                    bad.append(("chunked gather", chunks, r))
+            if any(flags[1:]):
+                bad.append(("a worker saw a difference", flags))
     group.barrier()
     if rank == 0:
         assert not bad, bad
@@ -138,6 +168,30 @@ def test_three_ranks_gather_root_in_the_middle():
     run(3, [4097, 65, 20_000], root_rank=1)
 
 
+def test_eight_ranks_uneven_shards_root_not_zero():
+    """BASELINE configs[4]'s shape -- eight ranks -- at a reduced ray count:
+    uneven shards (one smaller than a 256-ray workgroup, one smaller than a
+    wavefront), the root in the middle of the node."""
+    run(8, [30_001, 255, 12_800, 63, 20_000, 4097, 1, 9_999], root_rank=5,
+        timeout=900)
+
+
+def test_chunk_bounds_tile_the_batch():
+    """rt_chunk_bounds: whole 256-ray workgroups, contiguous, covering
+    [0, n) exactly once for every n and chunk count."""
+    from rayopt_amd.engine import Engine
+    eng = Engine(0)
+    for n in (1, 63, 256, 257, 4097, 10**7, 12_500_000):
+        for q in (1, 2, 3, 4, 7, 8, 64):
+            edge = 0
+            for k in range(q):
+                lo, hi = eng.chunk_bounds(n, k, q)
+                assert lo == edge and lo <= hi <= n and lo % 256 == 0 or \
+                    lo == n
+                edge = hi
+            assert edge == n
+
+
 def test_missing_transport_library_is_loud():
     env = dict(os.environ, RT_TRANSPORT_LIBRARY="/nonexistent/libnope.so")
     res = subprocess.run(
@@ -171,3 +225,27 @@ def test_bench_two_ranks_one_device_real_gather(every_step):
     assert d["n_gpus"] == 2 and "stand-in" in d["test_mode"]
     assert d["config"]["total_rays"] == 400001
     assert d["gather_ms"] > 0 and len(d["kernel_ms_per_rank"]) == 2
+    if not every_step:
+        assert d["gather_chunks"] == 4 and d["gather_exposed_ms"] >= 0.
+        assert d["plain_loop_ms_per_step"] > 0 and "exchange" in d["note"]
+
+
+def test_bench_eight_ranks_one_device_configs4_shape():
+    """`python bench.py --gpus 8 --total-rays N` -- the literal configs[4]
+    command at a reduced N -- over the stand-in transport: eight self-spawned
+    ranks, uneven shards, the chunked last step with its pipelined gather,
+    every gathered shard checked on rank 0."""
+    import json
+    env = dict(os.environ, RT_BENCH_SHARE_DEVICE="1",
+               RT_TRANSPORT_LIBRARY=build_stub())
+    out = subprocess.check_output(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8",
+         "--total-rays", "800003", "--steps", "3", "--warmup", "1",
+         "--settle", "0"], text=True, cwd=ROOT, env=env,
+        stderr=subprocess.DEVNULL, timeout=900)
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and "stand-in" in d["test_mode"]
+    assert d["config"]["total_rays"] == 800003
+    assert len(d["kernel_ms_per_rank"]) == 8 and d["gather_chunks"] == 4
