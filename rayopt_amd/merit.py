@@ -98,14 +98,22 @@ class Variable(_Described):
 
 class PathVariable(Variable):
     """The attribute or item ``system.get_path(path)`` reaches, e.g.
-    ``(1, "curvature")`` (rayopt/optimize.py:46)."""
+    ``(1, "curvature")`` (rayopt/optimize.py:46).  ``get`` / ``set`` are
+    ordinary methods resolved at call time against ``self.system`` and
+    ``self.path``: a subclass may override them (clamp, transform), and a
+    variable whose ``system`` is rebound -- or deep-copied together with its
+    system -- follows."""
     def __init__(self, system, path, bounds=(-np.inf, np.inf), scale=None,
                  init=None):
         self.path = tuple(path) if isinstance(path, list) else path
-        Variable.__init__(
-            self, system, bounds, scale, init,
-            getter=lambda: system.get_path(path),
-            setter=lambda value: system.set_path(path, value))
+        self.system = system        # get() below reads it
+        Variable.__init__(self, system, bounds, scale, init)
+
+    def get(self):
+        return self.system.get_path(self.path)
+
+    def set(self, value):
+        self.system.set_path(self.path, value)
 
 
 class Operand(_Described):

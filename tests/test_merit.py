@@ -308,3 +308,29 @@ def test_batched_gradient_host_logic():
 @pytest.mark.gpu
 def test_batched_gradient_gpu():
     _batched_gradient_checks(lambda s: ra.GeometricTrace(s))
+
+
+def test_path_variable_methods_resolve_at_call_time():
+    """Round-2 advisor finding: get/set of a PathVariable are methods, not
+    closures over the constructor's arguments -- a subclass that overrides
+    them is honoured, and a variable deep-copied with its system (or whose
+    system is rebound) reads and writes THAT system
+    (rayopt/optimize.py:46-56 resolves self.system at call time)."""
+    import copy
+    from rayopt_amd.merit import PathVariable
+    s = ra.system_from_yaml(ra.prescriptions.SINGLET)
+
+    class Clamped(PathVariable):
+        def set(self, value):
+            PathVariable.set(self, min(value, .05))
+
+    v = Clamped(s, (1, "curvature"), bounds=(-1, 1))
+    v.set(.5)
+    assert s[1].curvature == .05 and v.get() == .05
+    s2, v2 = copy.deepcopy((s, v))
+    v2.set(.01)
+    assert s2[1].curvature == .01 and s[1].curvature == .05
+    other = ra.system_from_yaml(ra.prescriptions.SINGLET)
+    v.system = other
+    v.set(.02)
+    assert other[1].curvature == .02 and s[1].curvature == .05
