@@ -104,7 +104,15 @@ elements:
     # 1e-10 -- 3x3 products summed in index order there, by BLAS here)
     import yaml
     from random_systems import random_prescription, random_rays
-    for seed in (7075, 4200, 4307, 7284, 1361):
+    # ... and seed 3791 (round-2 soak): a tilted surface in front of a
+    # near-parabolic one (conic -1.0052).  The reference's small-root formula
+    # -(d+g)/e amplifies a last-bit difference of the rotated direction by
+    # ~1e5 there: on a host whose BLAS does NOT sum a 3-vector with the FMA
+    # chain the reference differs from this golden (i.e. from itself on
+    # another machine) by 5.2e-10 -- outside the 1e-10 contract, and nobody's
+    # bug.  Where BLAS follows the chain (this golden's host: OpenBLAS,
+    # x86-64 FMA3) the device reproduces it bit for bit.
+    for seed in (7075, 4200, 4307, 7284, 1361, 3791):
         p = random_prescription(seed)
         add("tilted_seed_%d" % seed, yaml.safe_dump(p),
             *random_rays(seed, 300, p))
