@@ -290,15 +290,23 @@ def telemetry_child(device, period):
 
     def num(v):
         return float(v) if isinstance(v, (int, float)) else None
-    running = True
+    running, pending = True, b""
     while running:
-        r, _, _ = select.select([sys.stdin], [], [], period)
+        r, _, _ = select.select([0], [], [], period)
         if r:
-            line = sys.stdin.readline()
-            if not line or line.strip() == "stop":
+            # raw reads: lines that arrive together must not hide in a
+            # buffered reader where select() cannot see them
+            chunk = os.read(0, 65536)
+            if not chunk:
                 running = False
-            elif line.startswith("mark "):
-                out["marks"].append((line[5:].strip(), time.time()))
+            pending += chunk
+            while b"\n" in pending:
+                line, pending = pending.split(b"\n", 1)
+                line = line.decode().strip()
+                if line == "stop":
+                    running = False
+                elif line.startswith("mark "):
+                    out["marks"].append((line[5:].strip(), time.time()))
         if h is None:
             continue
         try:
@@ -312,7 +320,12 @@ def telemetry_child(device, period):
                 num(m.get("current_socket_power")),
                 num(m.get("temperature_hotspot")),
                 num(m.get("temperature_mem")),
-                num(m.get("average_gfx_activity"))))
+                num(m.get("average_gfx_activity")),
+                num(m.get("ppt_residency_acc")),
+                num(m.get("socket_thm_residency_acc")),
+                num(m.get("hbm_thm_residency_acc")),
+                num(m.get("prochot_residency_acc")),
+                num(m.get("accumulation_counter"))))
         except Exception as err:
             out["error"] = repr(err)[:200]
             h = None
@@ -323,7 +336,10 @@ def telemetry_child(device, period):
 class Telemetry:
     """Parent side of the sampling child."""
     FIELDS = ("gfxclk_mhz", "hbm_uclk_mhz", "socket_power_w", "hotspot_c",
-              "hbm_c", "gfx_activity_pct")
+              "hbm_c", "gfx_activity_pct", "ppt_residency_acc",
+              "socket_thm_residency_acc", "hbm_thm_residency_acc",
+              "prochot_residency_acc", "accumulation_counter")
+    COUNTERS = FIELDS[6:]   # running totals: reported as the window's gain
 
     def __init__(self, device=0, period=0.004):
         import subprocess
@@ -348,9 +364,10 @@ class Telemetry:
             except OSError:
                 self.proc = None
 
-    def stop(self):
+    def stop(self, raw=False):
         """{window: {field: [min, mean, max]}} for the windows between marks
-        "<name>:begin" and "<name>:end", plus the first and last sample."""
+        "<name>:begin" and "<name>:end", plus the first and last sample
+        (``raw``: also the sample rows themselves)."""
         if self.proc is None:
             return None
         try:
@@ -368,14 +385,27 @@ class Telemetry:
             out = {"samples": len(rows)}
             for k, name in enumerate(self.FIELDS, 1):
                 v = [r[k] for r in rows if r[k] is not None]
-                if v:
+                if not v:
+                    continue
+                if name in self.COUNTERS:
+                    out[name + "_gain"] = v[-1] - v[0]
+                else:
                     out[name] = [min(v), sum(v)/len(v), max(v)]
+            if "ppt_residency_acc_gain" in out and \
+                    out.get("accumulation_counter_gain"):
+                # share of the window the power limiter was active
+                out["power_limited_fraction"] = \
+                    out["ppt_residency_acc_gain"] / \
+                    out["accumulation_counter_gain"]
             return out
         out = {"source": "amdsmi_get_gpu_metrics_info in a child process",
                "error": data.get("error"),
                "samples": len(samples)}
+        if raw:
+            out["rows"] = samples
+            out["fields"] = ("t",) + self.FIELDS
         if samples:
-            out["first_sample_idle"] = dict(zip(self.FIELDS, samples[0][1:]))
+            out["first_sample"] = dict(zip(self.FIELDS, samples[0][1:]))
             out["last_sample"] = dict(zip(self.FIELDS, samples[-1][1:]))
         for name in sorted({k.split(":")[0] for k in marks}):
             if name + ":begin" in marks and name + ":end" in marks:
@@ -1407,7 +1437,9 @@ def run_configs4(ra, system, g, job, group, world, rank, args, clip,
     counts = D.shard_counts(total, world)
     nf = len(FIELD_FRACTIONS)
     m = int(counts[rank])//nf//64*64       # pupil points per field bundle
-    counts = np.array(group.broadcast(group.gather(m*nf)), dtype=np.int64)
+    box = group.gather(m*nf)
+    counts = group.broadcast(np.array(box, dtype=np.int64)
+                             if rank == 0 else None)
     rng = np.random.default_rng(7000 + rank)
     r, phi = np.sqrt(rng.random(m)), 2*np.pi*rng.random(m)
     yp = np.c_[r*np.cos(phi), r*np.sin(phi)]

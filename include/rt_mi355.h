@@ -330,6 +330,11 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * to the plain kernel's, NaN payloads aside), "compact_every" (k: the
  * survivors of a workgroup are counted -- one barrier -- at every k-th element
  * only; default 4, the measured optimum: asking costs ~0.5 us per workgroup).
+ * "resident_lds" (-1 = default: chosen per trace; 0..65536 = bytes of unused
+ * dynamic LDS per workgroup of the trace kernels, i.e. a cap of 160 KB / bytes
+ * on the workgroups resident per CU: traces that store their rows run with two
+ * workgroups per CU, which the memory side likes better than the seven the
+ * registers allow; FP64-bound traces are not capped).
  * Measurement-only variants and the memory-system probes live in a separate
  * laboratory build (include/rt_mi355_probes.h), not in this library.
  */

@@ -112,6 +112,9 @@ struct rt_ctx {
     int opt_alias;
     int opt_fuse; /* build generated rays inside the first trace */
     int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
+    int opt_resident; /* bytes of unused dynamic LDS per workgroup of the
+                         trace kernels: caps the workgroups resident per CU
+                         (160 KB / bytes); -1 = chosen per trace */
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
     int opt_compact_every; /* survivors are counted at every k-th element */
     int last_compact; /* the last trace ran the compacting kernel */

@@ -86,6 +86,35 @@ int rt_gen_flush(rt_ctx *c)
     return RT_OK;
 }
 
+/*
+ * Unused dynamic LDS per workgroup of the trace kernels = a cap on the
+ * workgroups resident per CU (160 KB / bytes; the registers allow seven).
+ * A trace that stores its rows is bound by the memory side, and with TWO
+ * workgroups per CU the chip writes a more compact window of every row stream
+ * at any moment: measured never slower and 0.2-6 % faster depending on the
+ * kind of trace and on the box (host-seeded C3 +0.2 % on slow boxes, +5 % on
+ * a fast one; unclipped +3 %; device-generated +6 %; C2 +3 %).  Traces that
+ * keep few rows live on FP64 issue and want every wavefront (image row only:
+ * 0.60 -> 0.81 ms with two workgroups); the Newton solves of aspheric
+ * elements sit in between: four workgroups per CU on the default arithmetic
+ * (+1.4 %), no cap on the exact one.  profiles/r03_probes/README.md.
+ */
+static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
+{
+    if (c->opt_resident >= 0)
+        return (size_t)c->opt_resident;
+    int stored = 0, newton = 0;
+    for (int s = start; s < stop; ++s) {
+        stored += !(c->h_stage[s].flags & RT_F_NOSTORE);
+        newton += (c->h_stage[s].flags & RT_F_ASPH) != 0;
+    }
+    if (2 * stored < stop - start)
+        return 0;
+    if (newton)
+        return c->opt_fast ? 32768 : 0;
+    return 65536;
+}
+
 /* the compacting variant pays (one barrier per element) only where dead rays
  * are wasted FP64 issue, i.e. where rows are traced but not stored */
 static bool rt_use_compact(const rt_ctx *c, int start, int stop)
@@ -153,6 +182,7 @@ int rt_create(int device, rt_ctx **out)
         const char *e = getenv("RT_MI355_EXACT_ASPHERE");
         c->opt_fast = (e && atoi(e)) ? 0 : 1;
     }
+    c->opt_resident = -1;
     c->opt_compact_every = 4; /* measured best, profiles/r02_probes */
 #define RT_HIP_C(call)                                                        \
     do {                                                                      \
@@ -869,12 +899,13 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
     const int64_t cols = (hi == ctx->n ? ctx->ld : hi) - lo;
     const int64_t group_rays = ctx->ngroups > 1 ? ctx->n / ctx->ngroups : 0;
     const unsigned grid = (unsigned)((cols + RT_BLOCK - 1) / RT_BLOCK);
+    const size_t lds = rt_resident_lds(ctx, start, stop);
     if (cols <= 0 || start >= stop) {
         /* an empty window, or nothing to trace */
     } else if (fused || regen) {
         ctx->gen_pending = 0;
-        hipLaunchKernelGGL(rt_trace_gen_kernel, dim3(grid), dim3(RT_BLOCK), 0,
-                           ctx->stream, ctx->d_surf, stop, clip, lay, cols,
+        hipLaunchKernelGGL(rt_trace_gen_kernel, dim3(grid), dim3(RT_BLOCK),
+                           lds, ctx->stream, ctx->d_surf, stop, clip, lay, cols,
                            group_rays, ctx->nsurf,
                            (const rt_field *)ctx->d_gen,
                            (const double *)((char *)ctx->d_gen + ctx->gen_fpad),
@@ -896,7 +927,7 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
             return rc;
 #endif
     } else {
-        hipLaunchKernelGGL(rt_trace_kernel, dim3(grid), dim3(RT_BLOCK), 0,
+        hipLaunchKernelGGL(rt_trace_kernel, dim3(grid), dim3(RT_BLOCK), lds,
                            ctx->stream, ctx->d_surf, start, stop, clip, lay,
                            cols, group_rays, ctx->nsurf);
         RT_HIP(ctx, hipGetLastError());
@@ -1002,6 +1033,11 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         if (fast != ctx->opt_fast)
             ctx->table_dirty = 1;
         ctx->opt_fast = fast;
+    } else if (!strcmp(key, "resident_lds")) {
+        if (value < -1 || value > 65536)
+            return rt_fail(ctx, RT_ERR_ARG,
+                           "resident_lds must be -1 (auto) or 0..65536 bytes");
+        ctx->opt_resident = value;
     } else if (!strcmp(key, "compact")) {
         if (value < 0 || value > 2)
             return rt_fail(ctx, RT_ERR_ARG, "compact must be 0, 1 or 2");
