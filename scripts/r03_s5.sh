@@ -5,6 +5,6 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 OUT=gpurun_out/r03_s5
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 800 python scripts/r03_resident.py > $OUT/resident.jsonl 2> $OUT/resident.err
-tail -3 $OUT/resident.err
-wc -l $OUT/resident.jsonl
+RT_MI355_LIB=$PWD/rayopt_amd/librt_mi355_probes.so timeout 800 python scripts/r03_lowocc_variants.py > $OUT/lowocc.jsonl 2> $OUT/lowocc.err
+tail -3 $OUT/lowocc.err
+wc -l $OUT/lowocc.jsonl
