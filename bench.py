@@ -829,7 +829,16 @@ def main():
     def step_engine():          # the bare C-ABI call, table already there
         eng.trace(1, 0, mode["clip"])
 
+    # clocks / power / limiter residency: a child process that samples amdsmi
+    # from before the settle phase on (its start-up and first queries are
+    # over long before the timed loop)
+    tele = Telemetry(local_rank, period=0.01) if (
+        rank == 0 and not os.environ.get("RT_BENCH_CHILD")) else None
+    if tele is not None:
+        tele.mark("settle:begin")
     settle(g, args.settle, clip)    # setup, not part of W or K
+    if tele is not None:
+        tele.mark("settle:end")
 
     final_gather = dist_mode and not args.gather_every_step
     plain = not dist_mode and not args.option
@@ -875,8 +884,6 @@ def main():
         # relates to the plain N = 1 one
         e_plain, _, _ = job.timed(step, args.steps, args.warmup, False)
         plain_loop = group.allreduce_max(e_plain)
-    tele = Telemetry(local_rank) if (rank == 0 and not os.environ.get(
-        "RT_BENCH_CHILD")) else None
     if tele is not None:
         tele.mark("loop:begin")
     elapsed, ev_ms, last_kernel_ms = job.timed(

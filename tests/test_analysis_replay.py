@@ -196,9 +196,20 @@ def test_analysis_replay_on_the_engine_double(name):
                                                   engine=OracleEngine()))
 
 
+def _installed_rayopt():
+    """aiming="reference" binds the INSTALLED rayopt's own solver methods to
+    device traces (rayopt_amd/aiming_reference.py): the package has to be
+    importable -- here the unmodified reference (oracle/_ref on a GPU box)."""
+    from oracle import refshim
+    if not refshim.available():
+        pytest.skip("no importable rayopt (oracle/_ref not built)")
+    refshim.load()
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_analysis_replay_with_the_reference_aiming(name):
     from fake_engine import OracleEngine
+    _installed_rayopt()
     replay(name, lambda system: ra.GeometricTrace(
         system, engine=OracleEngine(), aiming="reference"), EXACT)
 
@@ -212,5 +223,6 @@ def test_analysis_replay_on_the_device(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_analysis_replay_on_the_device_with_the_reference_aiming(name):
+    _installed_rayopt()
     replay(name, lambda system: ra.GeometricTrace(system, aiming="reference"),
            EXACT_DEVICE)
