@@ -382,7 +382,13 @@ class Telemetry:
 
         def window(t0, t1):
             rows = [r for r in samples if t0 <= r[0] <= t1]
-            out = {"samples": len(rows)}
+            out = {"samples": len(rows), "seconds": t1 - t0}
+            # the window's neighbours bracket it: counters are differenced
+            # across them, and a window shorter than the sampling period
+            # still gets the state it ran in
+            before = [r for r in samples if r[0] < t0][-1:]
+            after = [r for r in samples if r[0] > t1][:1]
+            rows = before + rows + after
             for k, name in enumerate(self.FIELDS, 1):
                 v = [r[k] for r in rows if r[k] is not None]
                 if not v:

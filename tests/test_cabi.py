@@ -102,3 +102,24 @@ def test_product_does_not_import_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", text,
                                      flags=re.M), f
                 assert "trace_numpy" not in text, f
+
+
+def test_chunk_bounds_tile_any_batch(dll):
+    """rt_chunk_bounds (host arithmetic, no GPU): pieces of whole 256-ray
+    workgroups, contiguous, covering [0, n) once -- what rt_trace_chunk traces
+    and what every rank computes for every other rank in rt_gather_chunk."""
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    for n in (0, 1, 63, 256, 257, 4097, 10**7, 12_500_000, 2**33 + 5):
+        for q in (1, 2, 3, 4, 7, 8, 64):
+            edge = 0
+            for k in range(q):
+                assert dll.rt_chunk_bounds(n, k, q, ctypes.byref(lo),
+                                           ctypes.byref(hi)) == 0
+                assert lo.value == edge and lo.value <= hi.value <= n
+                assert lo.value % 256 == 0 or lo.value == n
+                edge = hi.value
+            assert edge == n
+    assert dll.rt_chunk_bounds(10, 3, 3, ctypes.byref(lo),
+                               ctypes.byref(hi)) != 0
+    assert dll.rt_chunk_bounds(10, 0, 0, ctypes.byref(lo),
+                               ctypes.byref(hi)) != 0
