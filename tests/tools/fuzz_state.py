@@ -184,10 +184,14 @@ def sequence(seed, nops):
                 if rng.random() < .3:
                     keep = sorted(set(int(x) for x in rng.integers(
                         0, L, int(rng.integers(1, L)))))
+                # a step traced in pieces (rt_trace_chunk: what a multi-GPU
+                # job overlaps its gather with) is the same step
+                chunks = 1 if grouped else int(rng.choice((1, 1, 2, 3, 5)))
                 for t in (dev, cpu):
-                    t.propagate(start=start, stop=stop, clip=clip, keep=keep)
-                log.append("prop %d:%s clip=%s keep=%s" % (start, stop, clip,
-                                                           keep))
+                    t.propagate(start=start, stop=stop, clip=clip, keep=keep,
+                                chunks=chunks)
+                log.append("prop %d:%s clip=%s keep=%s chunks=%d" % (
+                    start, stop, clip, keep, chunks))
             elif op == "read":
                 j = int(rng.integers(0, L))
                 name = "yuit"[int(rng.integers(4))]
