@@ -984,7 +984,11 @@ def main():
     # the ray (u[j] is i[j] bit for bit: stop, image)
     skipped_u = sum(1 for j in range(1, L)
                     if alias_on and not clip and not bends[j])
-    alg_bytes = n*(56*S + 24*stored_i - 24*skipped_u + 48)  # one GPU's shard
+    # what the launch rows cost: 48 B per ray, less where the seed kernel
+    # found components uniform across 64-ray tiles (this workload: five
+    # collimated bundles starting on a plane -> y2, u0, u1, u2)
+    read_bytes, uniform_share = input_bytes(eng, n)
+    alg_bytes = n*(56*S + 24*stored_i - 24*skipped_u) + read_bytes  # one shard
     achieved = alg_bytes/(kernel_ms*1e-3)/1e9
     traffic = traffic_source = traffic_detail = None
     plain_kernel = alias_on and not args.option
@@ -1062,6 +1066,8 @@ def main():
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
             "bytes_per_ray_surface_op": (56*S + 24*stored_i - 24*skipped_u)/S,
+            "input_bytes_per_ray": read_bytes/n,
+            "input_uniform_share_y0y1y2u0u1u2": uniform_share,
             "frac_of_achievable_6290": achieved/HBM_ACHIEVABLE_GBS,
         },
     }
@@ -1110,7 +1116,7 @@ def main():
 
     if full_i is not None:
         e_full, k_full = full_i
-        b_full = n*(80*S + 48)
+        b_full = n*80*S + read_bytes
         out["full_i"] = {
             "value": total_rays*S*args.steps/e_full,
             "kernel_ms": k_full,
@@ -1121,7 +1127,7 @@ def main():
         }
     if unclipped is not None:
         e_nc, k_nc = unclipped
-        b_nc = n*(56*S + 24*stored_i + 48 - 24*sum(
+        b_nc = read_bytes + n*(56*S + 24*stored_i - 24*sum(
             1 for j in range(1, L) if alias_on and not bends[j]))
         out["unclipped"] = {
             "value": total_rays*S*args.steps/e_nc,
@@ -1189,8 +1195,21 @@ def main():
 # every BASELINE config on this GPU
 # --------------------------------------------------------------------------
 
+def input_bytes(eng, n):
+    """Bytes of the launch rows (row 0 of Y and U) a trace from element 1 has
+    to read: 8 per ray and component, except where a component is one bit
+    pattern across a 64-ray tile -- the direction of a collimated bundle, z = 0
+    of rays starting on a plane: noted by the seed kernel, fetched once per
+    tile (8 B) -- plus the 4-byte note per tile."""
+    uniform, tiles = eng.input_uniform()
+    if not any(uniform):
+        return 48*n, [0]*6
+    return (sum(8*(n - 64*u) + 8*u for u in uniform) + 4*tiles,
+            [u/tiles for u in uniform])
+
+
 def algorithmic_bytes(tables, n, clip, generated=False, alias=True,
-                      pupil_reuse=1):
+                      pupil_reuse=1, read_bytes=None):
     """HBM bytes one launch has to move for ``n`` rays through the packed
     table(s): per ray-surface op 56 written (y 24, u 24, t 8), + 24 where i
     must be materialised (element j or j-1 tilted), - 24 where an unclipped
@@ -1205,7 +1224,9 @@ def algorithmic_bytes(tables, n, clip, generated=False, alias=True,
     skipped_u = sum(1 for j in range(1, L) if alias and not clip
                     and not bends[j])
     per_op = 56*(L - 1) + 24*stored_i - 24*skipped_u
-    return n*(per_op + (16 if generated else 48)), per_op/(L - 1)
+    if read_bytes is None:
+        read_bytes = n*(16 if generated else 48)
+    return n*per_op + read_bytes, per_op/(L - 1)
 
 
 def kernel_ms_of(g, clip, warm=10, reps=12):
@@ -1273,12 +1294,15 @@ def run_configs(ra, device, args):
                                        system.refractive_index(lk, 0))[0]
                            for lk in ls])
         ms = kernel_ms_of(g, clip)
-        alg, per_op = algorithmic_bytes(tables, n, clip, generated)
+        rb, uni = (None, None) if generated else input_bytes(g.engine, n)
+        alg, per_op = algorithmic_bytes(tables, n, clip, generated,
+                                        read_bytes=rb)
         S = len(system) - 1
         rec = {"config": name, "rays": n, "surfaces": S, "clip": clip,
                "kernel_ms": ms, "value": n*S/(ms*1e-3),
                "algorithmic_bytes_per_launch": alg,
                "bytes_per_ray_surface_op": per_op,
+               "input_bytes_per_ray": (rb if rb is not None else 16*n)/n,
                "achieved": alg/(ms*1e-3)/1e9,
                "frac": alg/(ms*1e-3)/1e9/HBM_PEAK_GBS,
                "parity_subsample": parity,

@@ -330,6 +330,12 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * to the plain kernel's, NaN payloads aside), "compact_every" (k: the
  * survivors of a workgroup are counted -- one barrier -- at every k-th element
  * only; default 4, the measured optimum: asking costs ~0.5 us per workgroup).
+ * "uniform_input" (1 = default: launch components that are ONE bit pattern
+ * across a 64-ray tile of row 0 -- the direction of a collimated bundle, the
+ * origin of a bundle from an object point, z = 0 of rays starting on a plane --
+ * are fetched once per wavefront instead of once per ray: the seeding kernels
+ * note them per tile, anything that rewrites row 0 voids the notes; same
+ * values, same results; 0 = every component of every ray is read),
  * "resident_lds" (-1 = default: chosen per trace; 0..65536 = bytes of unused
  * dynamic LDS per workgroup of the trace kernels, i.e. a cap of 160 KB / bytes
  * on the workgroups resident per CU: traces that store their rows run with two
@@ -452,6 +458,14 @@ int rt_gather_chunk(rt_ctx *ctx, int which, int surf, const int64_t *counts,
  */
 int rt_gather_ms(rt_ctx *ctx, double *total_ms, double *exposed_ms);
 int rt_comm_sync(rt_ctx *ctx);
+
+/*
+ * How much of the launch rows a trace from element 1 has to read: tiles7[c],
+ * c = 0..5 (y0 y1 y2 u0 u1 u2) = number of 64-ray tiles of row 0 in which
+ * that component is uniform (fetched once per tile), tiles7[6] = number of
+ * tiles.  All zero but tiles7[6] when the notes are void or switched off.
+ */
+int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
 
 /* device scratch owned by the context (e.g. gather destination on root) */
 int rt_scratch(rt_ctx *ctx, int64_t bytes, void **out);

@@ -86,6 +86,11 @@ struct rt_ctx {
     unsigned char keep[RT_MAX_SURFACES];  /* rows propagate() stores */
     unsigned char valid[RT_MAX_SURFACES]; /* rows that hold data */
 
+    unsigned *d_uni; /* per 64-ray tile of row 0: which launch components
+                        are one bit pattern across the tile (seed kernels) */
+    size_t uni_cap;  /* tiles d_uni holds */
+    int uni_valid;   /* d_uni describes what row 0 holds now */
+    int opt_uniform; /* the trace uses it (default on) */
     double *d_buf; /* Y | U | I | T */
     size_t cap_doubles;
     int64_t n, ld;

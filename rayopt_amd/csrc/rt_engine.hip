@@ -75,6 +75,7 @@ int rt_gen_flush(rt_ctx *c)
     if (!c || !c->gen_pending)
         return RT_OK;
     c->gen_pending = 0;
+    c->uni_valid = 0; /* row 0 is rewritten */
     RT_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(rt_generate_kernel,
                        dim3((unsigned)((c->ld + 255) / 256)), dim3(256), 0,
@@ -183,6 +184,7 @@ int rt_create(int device, rt_ctx **out)
         c->opt_fast = (e && atoi(e)) ? 0 : 1;
     }
     c->opt_resident = -1;
+    c->opt_uniform = 1;
     c->opt_compact_every = 4; /* measured best, profiles/r02_probes */
 #define RT_HIP_C(call)                                                        \
     do {                                                                      \
@@ -243,6 +245,8 @@ int rt_destroy(rt_ctx *ctx)
     rt_comm_destroy(ctx);
     if (ctx->d_buf)
         (void)hipFree(ctx->d_buf);
+    if (ctx->d_uni)
+        (void)hipFree(ctx->d_uni);
     if (ctx->d_scratch)
         (void)hipFree(ctx->d_scratch);
     if (ctx->d_user)
@@ -373,8 +377,10 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     const int64_t quantum = rt_ld_quantum(ctx);
     const int64_t ld = (nrays + quantum - 1) / quantum * quantum;
     if (ld == ctx->ld && ctx->buf_nsurf == ctx->nsurf && ctx->d_buf) {
-        if (nrays != ctx->n)
+        if (nrays != ctx->n) {
             ctx->gen_live = 0;
+            ctx->uni_valid = 0;
+        }
         ctx->n = nrays;
         return RT_OK;
     }
@@ -396,6 +402,16 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
         }
         ctx->cap_doubles = need;
     }
+    const size_t tiles = (size_t)(ld / 64);
+    if (tiles > ctx->uni_cap) {
+        if (ctx->d_uni)
+            (void)hipFree(ctx->d_uni);
+        ctx->d_uni = NULL;
+        ctx->uni_cap = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_uni, tiles * sizeof(unsigned)));
+        ctx->uni_cap = tiles;
+    }
+    ctx->uni_valid = 0;
     ctx->n = nrays;
     ctx->ld = ld;
     ctx->buf_nsurf = ctx->nsurf;
@@ -434,15 +450,17 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
 {
     const int block = 256;
     const unsigned grid = (unsigned)((ctx->ld + block - 1) / block);
+    ctx->uni_valid = 0;
     if (layout == RT_LAYOUT_AOS)
         hipLaunchKernelGGL(rt_seed_aos_kernel, dim3(grid), dim3(block), 0,
                            ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
-                           !ctx->opt_alias, period);
+                           !ctx->opt_alias, period, ctx->d_uni);
     else
         hipLaunchKernelGGL(rt_seed_soa_kernel, dim3(grid), dim3(block), 0,
                            ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
-                           !ctx->opt_alias, period);
+                           !ctx->opt_alias, period, ctx->d_uni);
     RT_HIP(ctx, hipGetLastError());
+    ctx->uni_valid = !rt_lab_variant(ctx); /* the notes describe row 0 */
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
     ctx->u_alias[0] = 0;
     ctx->valid[0] = 1;
@@ -651,6 +669,7 @@ int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
      * describe: set again once both copies are on their way */
     ctx->gen_live = 0;
     ctx->gen_pending = 0;
+    ctx->uni_valid = 0;
     int rc = rt_reserve(ctx, n);
     if (rc != RT_OK)
         return rc;
@@ -730,8 +749,10 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
         if (rc != RT_OK)
             return rc;
     }
-    if (surf == 0 && which != RT_I && which != RT_T)
+    if (surf == 0 && which != RT_I && which != RT_T) {
         ctx->gen_live = 0; /* the launch rays are the caller's from here on */
+        ctx->uni_valid = 0;
+    }
     if (which == RT_I)
         ctx->i_alias[surf] = 0; /* now holds its own data */
     if (which == RT_U)
@@ -904,6 +925,8 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
         /* an empty window, or nothing to trace */
     } else if (fused || regen) {
         ctx->gen_pending = 0;
+        if (fused)
+            ctx->uni_valid = 0; /* this launch writes row 0 */
         hipLaunchKernelGGL(rt_trace_gen_kernel, dim3(grid), dim3(RT_BLOCK),
                            lds, ctx->stream, ctx->d_surf, stop, clip, lay, cols,
                            group_rays, ctx->nsurf,
@@ -927,9 +950,14 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
             return rc;
 #endif
     } else {
+        /* launch components that are uniform across a 64-ray tile are
+         * fetched once per wavefront (the seed kernels' notes on row 0) */
+        const unsigned *uni = start == 1 && ctx->uni_valid && ctx->opt_uniform
+                                  ? ctx->d_uni + lo / 64
+                                  : NULL;
         hipLaunchKernelGGL(rt_trace_kernel, dim3(grid), dim3(RT_BLOCK), lds,
                            ctx->stream, ctx->d_surf, start, stop, clip, lay,
-                           cols, group_rays, ctx->nsurf);
+                           cols, group_rays, ctx->nsurf, uni);
         RT_HIP(ctx, hipGetLastError());
     }
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
@@ -1033,6 +1061,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         if (fast != ctx->opt_fast)
             ctx->table_dirty = 1;
         ctx->opt_fast = fast;
+    } else if (!strcmp(key, "uniform_input")) {
+        ctx->opt_uniform = value ? 1 : 0;
     } else if (!strcmp(key, "resident_lds")) {
         if (value < -1 || value > 65536)
             return rt_fail(ctx, RT_ERR_ARG,
@@ -1139,9 +1169,43 @@ int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
     int rc = rt_gen_flush(ctx);
     if (rc != RT_OK)
         return rc;
-    if (surf == 0)
+    if (surf == 0) {
         ctx->gen_live = 0; /* the caller may write through the pointer */
+        ctx->uni_valid = 0;
+    }
     *out = rt_row(ctx, which, surf);
+    return RT_OK;
+}
+
+int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7)
+{
+    if (!ctx || !tiles7)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_input_uniform: NULL argument");
+    for (int c = 0; c < 7; ++c)
+        tiles7[c] = 0;
+    if (!ctx->d_buf || ctx->ld < 64)
+        return RT_OK;
+    tiles7[6] = ctx->ld / 64;
+    if (!ctx->uni_valid || !ctx->opt_uniform)
+        return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned *host = (unsigned *)malloc((size_t)tiles7[6] * sizeof(unsigned));
+    if (!host)
+        return rt_fail(ctx, RT_ERR_NOMEM, "rt_input_uniform: host allocation");
+    hipError_t e = hipMemcpyAsync(host, ctx->d_uni,
+                                  (size_t)tiles7[6] * sizeof(unsigned),
+                                  hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        free(host);
+        return rt_fail(ctx, RT_ERR_HIP, "rt_input_uniform: %s",
+                       hipGetErrorString(e));
+    }
+    for (int64_t t = 0; t < tiles7[6]; ++t)
+        for (int c = 0; c < 6; ++c)
+            tiles7[c] += (host[t] >> c) & 1u;
+    free(host);
     return RT_OK;
 }
 

@@ -14,9 +14,34 @@
  * loop, surface table through scalar loads, 7-10 coalesced 512-byte stores
  * per wavefront and element.
  */
+/*
+ * Launch rays whose components are the SAME bit pattern across the 64 rays of
+ * a wavefront are not read 64 times: the seed kernels note per 64-ray tile
+ * which of y0 y1 y2 u0 u1 u2 are uniform (bit c of uni[tile]), and the trace
+ * fetches such a component from the tile's first column -- one request per
+ * wavefront instead of a 512-byte segment.  Collimated bundles (a field point
+ * at infinity: one direction, rays starting on a plane) read 16 instead of
+ * 48 B per ray, bundles from an object point 24; the values, hence the
+ * results, are the same bits.  The mask is wave-uniform (SGPR): the choice
+ * of the column is scalar, nothing diverges.
+ */
+__device__ __forceinline__ void rt_load_state_tiles(
+    const rt_lay &a, int srow, int64_t col, int64_t col0, unsigned m,
+    double (&y)[1][3], double (&u)[1][3])
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double *py = a.Y + srow * a.ss + c * a.cs;
+        const double *pu = a.U + srow * a.ss + c * a.cs;
+        y[0][c] = py[(m >> c) & 1 ? col0 : col];
+        u[0][c] = pu[(m >> (3 + c)) & 1 ? col0 : col];
+    }
+}
+
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
-                int clip, rt_lay a, int64_t ld, int64_t group_rays, int nsurf)
+                int clip, rt_lay a, int64_t ld, int64_t group_rays, int nsurf,
+                const unsigned *__restrict__ uni)
 {
     const int64_t j = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (j >= ld)
@@ -31,7 +56,13 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
     }
     const int64_t col = rt_col(a, j);
     double y[1][3], u[1][3];
-    rt_load_state<1>(a, start - 1, col, y, u);
+    if (uni) {
+        const int lane = threadIdx.x & 63;
+        const int tile = __builtin_amdgcn_readfirstlane((int)((j - lane) >> 6));
+        rt_load_state_tiles(a, start - 1, col, col - lane, uni[tile], y, u);
+    } else {
+        rt_load_state<1>(a, start - 1, col, y, u);
+    }
     rt_march<1, false>(surf, start, stop, clip, a, col, y, u);
 }
 
@@ -224,11 +255,23 @@ rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
     }
 }
 
+/* bit c (Y) / 3+c (U) of the tile's note: all 64 rays of the wavefront hold
+ * the same bit pattern in that component */
+__device__ __forceinline__ unsigned rt_uniform_bit(double v, int bit)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)b);
+    const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    const long long first = ((long long)hi << 32) | (unsigned)lo;
+    return __ballot(b != first) == 0ull ? 1u << bit : 0u;
+}
+
 /* rays_given: AoS (n,3) staging -> SoA row 0 of Y,U,I and T[0] = 0 */
 __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
                                    const double *__restrict__ u_aos,
                                    int64_t n, rt_lay a, int64_t ld,
-                                   int store_i, int64_t period)
+                                   int store_i, int64_t period,
+                                   unsigned *__restrict__ uni)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
@@ -236,6 +279,7 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
     const bool in = j < n;
     const int64_t k = j % period; /* the same rays for every group */
     const int64_t col = rt_col(a, j);
+    unsigned note = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const double p = in ? y_aos[k * 3 + c] : 0.;
@@ -244,15 +288,23 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
         a.U[c * a.cs + col] = q;
         if (store_i)
             a.I[c * a.cs + col] = q;
+        note |= rt_uniform_bit(p, c) | rt_uniform_bit(q, 3 + c);
     }
     a.T[col] = 0.;
+    if (uni && (threadIdx.x & 63) == 0) {
+        /* (ld is a multiple of 64: a wavefront is one tile; a tile with
+         * padding columns beyond n is read the ordinary way) */
+        const int64_t tile0 = j;
+        uni[tile0 >> 6] = tile0 + 64 <= n ? note : 0u;
+    }
 }
 
 /* rays_given for SoA (3,n) device/staged input */
 __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
                                    const double *__restrict__ u_soa,
                                    int64_t n, rt_lay a, int64_t ld,
-                                   int store_i, int64_t period)
+                                   int store_i, int64_t period,
+                                   unsigned *__restrict__ uni)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
@@ -260,6 +312,7 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
     const bool in = j < n;
     const int64_t k = j % period; /* the same rays for every group */
     const int64_t col = rt_col(a, j);
+    unsigned note = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const double p = in ? y_soa[c * period + k] : 0.;
@@ -268,8 +321,15 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
         a.U[c * a.cs + col] = q;
         if (store_i)
             a.I[c * a.cs + col] = q;
+        note |= rt_uniform_bit(p, c) | rt_uniform_bit(q, 3 + c);
     }
     a.T[col] = 0.;
+    if (uni && (threadIdx.x & 63) == 0) {
+        /* (ld is a multiple of 64: a wavefront is one tile; a tile with
+         * padding columns beyond n is read the ordinary way) */
+        const int64_t tile0 = j;
+        uni[tile0 >> 6] = tile0 + 64 <= n ? note : 0u;
+    }
 }
 
 /* rays of field f x pupil point p, see rt_generate_rays in rt_mi355.h */

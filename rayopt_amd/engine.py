@@ -288,6 +288,13 @@ class Engine:
                                            ctypes.byref(p)), "rt_device_ptr")
         return p.value
 
+    def input_uniform(self):
+        """(tiles uniform per launch component y0 y1 y2 u0 u1 u2, tiles): how
+        much of row 0 a trace from element 1 reads (rt_input_uniform)."""
+        t = (ctypes.c_int64*7)()
+        self._check(self.lib.rt_input_uniform(self.ctx, t), "rt_input_uniform")
+        return list(t[:6]), int(t[6])
+
     def scratch(self, nbytes):
         p = ctypes.c_void_p()
         self._check(self.lib.rt_scratch(self.ctx, int(nbytes),

@@ -33,10 +33,12 @@ import fuzz_pack
 SIZES = (2, 63, 64, 65, 777, 4099)
 OPTIONS = (("alias_i", (0, 1)), ("regenerate", (0, 1)),
            ("fuse_generate", (0, 1)), ("compact", (0, 1, 2)),
-           ("compact_every", (1, 2, 3, 4)))
+           ("compact_every", (1, 2, 3, 4)), ("uniform_input", (0, 1)),
+           ("resident_lds", (-1, 0, 65536)))
 # (exact_asphere: the double is the reference's arithmetic, bit for bit)
 DEFAULTS = dict(alias_i=1, regenerate=1, fuse_generate=1, compact=0,
-                compact_every=4, exact_asphere=1)
+                compact_every=4, exact_asphere=1, uniform_input=1,
+                resident_lds=-1)
 
 
 def compare(dev, cpu, log):
@@ -99,6 +101,15 @@ def sequence(seed, nops):
             if op == "given":
                 n = int(rng.choice(SIZES))
                 y, u = random_rays(int(rng.integers(1 << 30)), n, p)
+                if rng.random() < .4:
+                    # a collimated bundle, or one from a point: components
+                    # uniform across 64-ray tiles are fetched once per tile
+                    if rng.random() < .5:
+                        u[:] = u[0]
+                    else:
+                        y[:] = y[0]
+                    k = int(rng.integers(n))    # ... but for one ray
+                    u[k], y[k] = u[(k + 1) % n]*1., y[(k + 1) % n] + 1e-3
                 w = None
                 if rng.random() < .3:
                     w = rng.random(n)
