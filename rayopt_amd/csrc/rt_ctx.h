@@ -86,8 +86,9 @@ struct rt_ctx {
     unsigned char keep[RT_MAX_SURFACES];  /* rows propagate() stores */
     unsigned char valid[RT_MAX_SURFACES]; /* rows that hold data */
 
-    unsigned *d_uni; /* per 64-ray tile of row 0: which launch components
-                        are one bit pattern across the tile (seed kernels) */
+    unsigned *d_uni; /* per 64-ray tile of row 0 (seed kernels): note[cap]
+                        -- which launch components are one bit pattern across
+                        the tile -- then first[6][cap], the tile's first ray */
     size_t uni_cap;  /* tiles d_uni holds */
     int uni_valid;   /* d_uni describes what row 0 holds now */
     int opt_uniform; /* the trace uses it (default on) */

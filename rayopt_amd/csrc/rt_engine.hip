@@ -69,6 +69,26 @@ int rt_detach(rt_ctx *c, int which, int surf)
     return RT_OK;
 }
 
+/* the notes on row 0's tiles as the kernels take them (rt_trace_kernels.h),
+ * starting at tile `t0` */
+static inline size_t rt_tiles_bytes(size_t tiles)
+{
+    return ((tiles + 1) / 2 * 2) * sizeof(unsigned) +
+           6 * tiles * sizeof(double);
+}
+
+static inline rt_tiles rt_tiles_of(const rt_ctx *c, int64_t t0, bool on)
+{
+    rt_tiles t = {NULL, NULL, 0};
+    if (on && c->d_uni) {
+        const size_t cap = c->uni_cap;
+        t.note = c->d_uni + t0;
+        t.first = (double *)(c->d_uni + (cap + 1) / 2 * 2) + t0;
+        t.stride = (int64_t)cap;
+    }
+    return t;
+}
+
 /* row 0 of a generated batch, if no trace has built it yet */
 int rt_gen_flush(rt_ctx *c)
 {
@@ -408,7 +428,9 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
             (void)hipFree(ctx->d_uni);
         ctx->d_uni = NULL;
         ctx->uni_cap = 0;
-        RT_HIP(ctx, hipMalloc((void **)&ctx->d_uni, tiles * sizeof(unsigned)));
+        /* note[tiles] (padded to 8 bytes) | first[6][tiles] */
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_uni,
+                              rt_tiles_bytes(tiles)));
         ctx->uni_cap = tiles;
     }
     ctx->uni_valid = 0;
@@ -454,11 +476,13 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
     if (layout == RT_LAYOUT_AOS)
         hipLaunchKernelGGL(rt_seed_aos_kernel, dim3(grid), dim3(block), 0,
                            ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
-                           !ctx->opt_alias, period, ctx->d_uni);
+                           !ctx->opt_alias, period,
+                           rt_tiles_of(ctx, 0, !rt_lab_variant(ctx)));
     else
         hipLaunchKernelGGL(rt_seed_soa_kernel, dim3(grid), dim3(block), 0,
                            ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
-                           !ctx->opt_alias, period, ctx->d_uni);
+                           !ctx->opt_alias, period,
+                           rt_tiles_of(ctx, 0, !rt_lab_variant(ctx)));
     RT_HIP(ctx, hipGetLastError());
     ctx->uni_valid = !rt_lab_variant(ctx); /* the notes describe row 0 */
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
@@ -952,12 +976,11 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
     } else {
         /* launch components that are uniform across a 64-ray tile are
          * fetched once per wavefront (the seed kernels' notes on row 0) */
-        const unsigned *uni = start == 1 && ctx->uni_valid && ctx->opt_uniform
-                                  ? ctx->d_uni + lo / 64
-                                  : NULL;
+        const rt_tiles tiles = rt_tiles_of(
+            ctx, lo / 64, start == 1 && ctx->uni_valid && ctx->opt_uniform);
         hipLaunchKernelGGL(rt_trace_kernel, dim3(grid), dim3(RT_BLOCK), lds,
                            ctx->stream, ctx->d_surf, start, stop, clip, lay,
-                           cols, group_rays, ctx->nsurf, uni);
+                           cols, group_rays, ctx->nsurf, tiles);
         RT_HIP(ctx, hipGetLastError());
     }
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));

@@ -16,32 +16,44 @@
  */
 /*
  * Launch rays whose components are the SAME bit pattern across the 64 rays of
- * a wavefront are not read 64 times: the seed kernels note per 64-ray tile
- * which of y0 y1 y2 u0 u1 u2 are uniform (bit c of uni[tile]), and the trace
- * fetches such a component from the tile's first column -- one request per
- * wavefront instead of a 512-byte segment.  Collimated bundles (a field point
- * at infinity: one direction, rays starting on a plane) read 16 instead of
- * 48 B per ray, bundles from an object point 24; the values, hence the
- * results, are the same bits.  The mask is wave-uniform (SGPR): the choice
- * of the column is scalar, nothing diverges.
+ * a wavefront are not read 64 times.  The seed kernels keep, per 64-ray tile
+ * of row 0, a note -- bit c: component c of y0 y1 y2 u0 u1 u2 is uniform --
+ * and the tile's first ray, packed: rt_tiles { note[tiles], first[6][tiles] }.
+ * The trace takes a uniform component from `first` (8 B per tile, sixteen
+ * tiles to a cache line, read through the scalar path) instead of a 512-byte
+ * segment of the row.  Collimated bundles (a field point at infinity: one
+ * direction, rays starting on a plane) read 16 instead of 48 B per ray,
+ * bundles from an object point 24; the values, hence the results, are the
+ * same bits.  Note and index are wave-uniform (SGPRs): nothing diverges.
  */
+struct rt_tiles {
+    unsigned *note;   /* [tiles], already offset to the launch's first tile */
+    double *first;    /* [6][stride], likewise */
+    int64_t stride;   /* tiles of the whole batch */
+};
+
 __device__ __forceinline__ void rt_load_state_tiles(
-    const rt_lay &a, int srow, int64_t col, int64_t col0, unsigned m,
+    const rt_lay &a, int srow, int64_t col, const rt_tiles &tl, int tile,
     double (&y)[1][3], double (&u)[1][3])
 {
+    const unsigned m = tl.note[tile];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double *py = a.Y + srow * a.ss + c * a.cs;
-        const double *pu = a.U + srow * a.ss + c * a.cs;
-        y[0][c] = py[(m >> c) & 1 ? col0 : col];
-        u[0][c] = pu[(m >> (3 + c)) & 1 ? col0 : col];
+        if ((m >> c) & 1)
+            y[0][c] = tl.first[c * tl.stride + tile];
+        else
+            y[0][c] = a.Y[srow * a.ss + c * a.cs + col];
+        if ((m >> (3 + c)) & 1)
+            u[0][c] = tl.first[(3 + c) * tl.stride + tile];
+        else
+            u[0][c] = a.U[srow * a.ss + c * a.cs + col];
     }
 }
 
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
                 int clip, rt_lay a, int64_t ld, int64_t group_rays, int nsurf,
-                const unsigned *__restrict__ uni)
+                rt_tiles tiles)
 {
     const int64_t j = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (j >= ld)
@@ -56,10 +68,10 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
     }
     const int64_t col = rt_col(a, j);
     double y[1][3], u[1][3];
-    if (uni) {
-        const int lane = threadIdx.x & 63;
-        const int tile = __builtin_amdgcn_readfirstlane((int)((j - lane) >> 6));
-        rt_load_state_tiles(a, start - 1, col, col - lane, uni[tile], y, u);
+    if (tiles.note) {
+        const int tile = __builtin_amdgcn_readfirstlane(
+            (int)((j - (threadIdx.x & 63)) >> 6));
+        rt_load_state_tiles(a, start - 1, col, tiles, tile, y, u);
     } else {
         rt_load_state<1>(a, start - 1, col, y, u);
     }
@@ -271,7 +283,7 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
                                    const double *__restrict__ u_aos,
                                    int64_t n, rt_lay a, int64_t ld,
                                    int store_i, int64_t period,
-                                   unsigned *__restrict__ uni)
+                                   rt_tiles tiles)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
@@ -280,10 +292,13 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
     const int64_t k = j % period; /* the same rays for every group */
     const int64_t col = rt_col(a, j);
     unsigned note = 0;
+    double first[6];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const double p = in ? y_aos[k * 3 + c] : 0.;
         const double q = in ? u_aos[k * 3 + c] : 0.;
+        first[c] = p;
+        first[3 + c] = q;
         a.Y[c * a.cs + col] = p;
         a.U[c * a.cs + col] = q;
         if (store_i)
@@ -291,11 +306,16 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
         note |= rt_uniform_bit(p, c) | rt_uniform_bit(q, 3 + c);
     }
     a.T[col] = 0.;
-    if (uni && (threadIdx.x & 63) == 0) {
+    if (tiles.note && (threadIdx.x & 63) == 0) {
         /* (ld is a multiple of 64: a wavefront is one tile; a tile with
          * padding columns beyond n is read the ordinary way) */
-        const int64_t tile0 = j;
-        uni[tile0 >> 6] = tile0 + 64 <= n ? note : 0u;
+        const int64_t t = j >> 6;
+        tiles.note[t] = j + 64 <= n ? note : 0u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            tiles.first[c * tiles.stride + t] = first[c];
+            tiles.first[(3 + c) * tiles.stride + t] = first[3 + c];
+        }
     }
 }
 
@@ -304,7 +324,7 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
                                    const double *__restrict__ u_soa,
                                    int64_t n, rt_lay a, int64_t ld,
                                    int store_i, int64_t period,
-                                   unsigned *__restrict__ uni)
+                                   rt_tiles tiles)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld)
@@ -313,10 +333,13 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
     const int64_t k = j % period; /* the same rays for every group */
     const int64_t col = rt_col(a, j);
     unsigned note = 0;
+    double first[6];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const double p = in ? y_soa[c * period + k] : 0.;
         const double q = in ? u_soa[c * period + k] : 0.;
+        first[c] = p;
+        first[3 + c] = q;
         a.Y[c * a.cs + col] = p;
         a.U[c * a.cs + col] = q;
         if (store_i)
@@ -324,11 +347,16 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
         note |= rt_uniform_bit(p, c) | rt_uniform_bit(q, 3 + c);
     }
     a.T[col] = 0.;
-    if (uni && (threadIdx.x & 63) == 0) {
+    if (tiles.note && (threadIdx.x & 63) == 0) {
         /* (ld is a multiple of 64: a wavefront is one tile; a tile with
          * padding columns beyond n is read the ordinary way) */
-        const int64_t tile0 = j;
-        uni[tile0 >> 6] = tile0 + 64 <= n ? note : 0u;
+        const int64_t t = j >> 6;
+        tiles.note[t] = j + 64 <= n ? note : 0u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            tiles.first[c * tiles.stride + t] = first[c];
+            tiles.first[(3 + c) * tiles.stride + t] = first[3 + c];
+        }
     }
 }
 

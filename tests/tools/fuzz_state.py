@@ -101,7 +101,8 @@ def sequence(seed, nops):
             if op == "given":
                 n = int(rng.choice(SIZES))
                 y, u = random_rays(int(rng.integers(1 << 30)), n, p)
-                if rng.random() < .4:
+                special = rng.random() < .4
+                if special:
                     # a collimated bundle, or one from a point: components
                     # uniform across 64-ray tiles are fetched once per tile
                     if rng.random() < .5:
@@ -116,8 +117,11 @@ def sequence(seed, nops):
                     w /= w.sum()
                 for t in (dev, cpu):
                     t.rays_given(y, u, w=w)
-                seeded, grouped, last_seed = True, False, "given"
-                log.append("given n=%d w=%s" % (n, w is not None))
+                # (refocus of a parallel bundle is 0/0: not compared)
+                seeded, grouped = True, False
+                last_seed = "given, parallel or point" if special else "given"
+                log.append("given n=%d w=%s special=%s" % (n, w is not None,
+                                                           special))
             elif op == "points":
                 # pattern -> aiming kernel (or first-order pupil) ->
                 # generation -> trace, several fields, maybe all wavelengths
