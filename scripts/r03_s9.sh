@@ -1,0 +1,7 @@
+#!/bin/bash
+set -u
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+OUT=gpurun_out/r03_s9
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 300 python scripts/r03_uniform_ab.py 2> $OUT/uniform_ab.err | tee $OUT/uniform_ab_$(date +%H%M%S).jsonl
