@@ -4,4 +4,4 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 OUT=gpurun_out/r03_s9
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 300 python scripts/r03_uniform_ab.py 2> $OUT/uniform_ab.err | tee $OUT/uniform_ab_$(date +%H%M%S).jsonl
+timeout 300 python scripts/r03_resident2.py 2> $OUT/resident2.err | tee $OUT/resident2_$(date +%H%M%S).jsonl
