@@ -1068,6 +1068,11 @@ def main():
             "bytes_per_ray_surface_op": (56*S + 24*stored_i - 24*skipped_u)/S,
             "input_bytes_per_ray": read_bytes/n,
             "input_uniform_share_y0y1y2u0u1u2": uniform_share,
+            # for comparison with lines written before the tile notes
+            # (rounds 1-2 counted 48 B per ray read): NOT what is moved
+            "frac_if_48B_per_ray_were_read":
+                (alg_bytes - read_bytes + 48*n)/(kernel_ms*1e-3)/1e9 /
+                HBM_PEAK_GBS,
             "frac_of_achievable_6290": achieved/HBM_ACHIEVABLE_GBS,
         },
     }
@@ -1303,6 +1308,9 @@ def run_configs(ra, device, args):
                "algorithmic_bytes_per_launch": alg,
                "bytes_per_ray_surface_op": per_op,
                "input_bytes_per_ray": (rb if rb is not None else 16*n)/n,
+               "frac_if_48B_per_ray_were_read":
+                   (alg - (rb if rb is not None else 16*n) + 48*n) /
+                   (ms*1e-3)/1e9/HBM_PEAK_GBS,
                "achieved": alg/(ms*1e-3)/1e9,
                "frac": alg/(ms*1e-3)/1e9/HBM_PEAK_GBS,
                "parity_subsample": parity,
