@@ -60,7 +60,7 @@ extern "C" {
  * clip (Element.clip is what would poison u, :206-209) -- and is served
  * from I[j] (which may in turn be U[j-1]) */
 #define RT_F_SKIP_U 0x200u
-/* set by the library (rt_set_option "fast_asphere"): this aspheric element
+/* set by the library (default; rt_set_option "exact_asphere" clears it): this aspheric element
  * runs its Newton intercept and refraction on FMA / rcp / rsq arithmetic
  * (csrc/rt_math.h) -- same iteration, results inside the 1e-8 contract for
  * iterated aspheres instead of bit-identical to the reference */

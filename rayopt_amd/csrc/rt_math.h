@@ -215,13 +215,14 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
 }
 
 /* ------------------------------------------------------------------ */
-/* opt-in fast arithmetic for even aspheres (RT_F_FAST)               */
+/* default arithmetic for even aspheres (RT_F_FAST)                   */
 /* ------------------------------------------------------------------ */
 /*
  * The contract for iterated aspheres is 1e-8 relative (BASELINE north_star),
  * not bit identity, and the exact Newton solve above is FP64-issue bound:
  * three IEEE divisions and a square root per iterate, each a 10-20
- * instruction sequence.  With RT_F_FAST (rt_set_option "fast_asphere") an
+ * instruction sequence.  With RT_F_FAST (the default since round 3;
+ * rt_set_option "exact_asphere" clears it) an
  * aspheric element runs the same iteration -- same start, same |step| <= 1e-7
  * test, same five-iterate limit, same NaN on failure
  * (rayopt/elements.py:333-349 + scipy newton) -- on

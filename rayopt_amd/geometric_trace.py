@@ -194,10 +194,11 @@ class GeometricTrace(Trace):
     """
     def __init__(self, system, engine=None, device=None, **options):
         """``options`` (extension): engine options applied to this trace's
-        context (``rt_set_option``), e.g. ``fast_asphere=True`` -- even
-        aspheres on the FMA / rcp / rsq arithmetic, results within the 1e-8
-        contract for iterated aspheres instead of bit-identical to the
-        reference -- or ``compact=1``, the clipped-ray compacting kernel for
+        context (``rt_set_option``), e.g. ``exact_asphere=True`` -- even
+        aspheres on the bit-for-bit restatement of scipy's Newton iteration
+        (the reference's bits) instead of the default FMA / rcp / rsq
+        arithmetic, whose results are within the 1e-8 contract for iterated
+        aspheres -- or ``compact=1``, the clipped-ray compacting kernel for
         traces that do not store every row."""
         super().__init__(system)
         self._engine = engine
