@@ -52,8 +52,11 @@ def test_single_process_line():
         assert c["port_value"] > 0 and "rayopt" in c["sample"]
     # clocks / power around the timed loop (amdsmi in a child process)
     t = d["telemetry"]
-    assert t["samples"] > 0 and t["loop"]["hbm_uclk_mhz"][1] > 0
-    assert d["roofline"]["frac_at_observed_hbm_clock"] > 0
+    if t.get("samples"):        # (a box without a working amdsmi says so)
+        assert t["loop"]["hbm_uclk_mhz"][1] > 0
+        assert d["roofline"]["frac_at_observed_hbm_clock"] > 0
+    else:
+        assert t.get("error")
     # one record per BASELINE config
     names = [r["config"] for r in d["configs"]]
     assert [n[:2] for n in names] == ["C3", "C1", "C2", "C4", "C4", "C5"]
