@@ -1154,7 +1154,8 @@ def main():
         }
 
     if tele is not None:
-        t = tele.stop()
+        t = tele.stop() or {"samples": 0,
+                            "error": "the telemetry child did not start"}
         if t:
             loop = t.get("loop") or {}
             uclk = (loop.get("hbm_uclk_mhz") or [None, None, None])[1]
