@@ -217,8 +217,12 @@ static int rt_gather_window(rt_ctx *ctx, int which, int surf,
                                                                     : end));
     }
     RT_HIP(ctx, hipEventRecord(ctx->gathered[p], ctx->comm_stream));
-    if (chunk == nchunks - 1)
+    if (chunk == 0)
+        ctx->gather_timed = 0;
+    if (chunk == nchunks - 1) {
         RT_HIP(ctx, hipEventRecord(ctx->g1, ctx->comm_stream));
+        ctx->gather_timed = 1;
+    }
     ctx->gather_pending[p] = 1;
     return RT_OK;
 }
@@ -288,8 +292,10 @@ int rt_gather_ms(rt_ctx *ctx, double *total_ms, double *exposed_ms)
 {
     if (!ctx || !total_ms || !exposed_ms)
         return rt_fail(ctx, RT_ERR_ARG, "rt_gather_ms: NULL argument");
-    if (!ctx->comm || !ctx->traced)
-        return rt_fail(ctx, RT_ERR_STATE, "rt_gather_ms: nothing gathered yet");
+    if (!ctx->comm || !ctx->traced || !ctx->gather_timed)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_gather_ms: no complete gather yet (the last chunk "
+                       "closes it)");
     RT_HIP(ctx, hipEventSynchronize(ctx->g1));
     RT_HIP(ctx, hipEventSynchronize(ctx->k1));
     float f = 0.f;

@@ -103,7 +103,9 @@ int rt_set_weights(rt_ctx *ctx, const double *w)
     if ((size_t)ctx->n > ctx->w_cap) {
         if (ctx->d_w)
             RT_HIP(ctx, hipFree(ctx->d_w));
-        ctx->d_w = NULL;
+        ctx->d_w = NULL; /* uniform weights if the allocation fails */
+        ctx->w_cap = 0;
+        ctx->w_n = 0;
         RT_HIP(ctx, hipMalloc((void **)&ctx->d_w, ctx->n * sizeof(double)));
         ctx->w_cap = (size_t)ctx->n;
     }

@@ -152,6 +152,7 @@ struct rt_ctx {
                           communication stream */
     int gather_pending[RT_GATHER_SLOTS];
     int gather_slot;
+    int gather_timed; /* g0 and g1 have both been recorded */
 
 #ifdef RT_BUILD_PROBES
     rt_lab lab;

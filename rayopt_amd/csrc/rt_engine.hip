@@ -152,6 +152,12 @@ static bool rt_use_compact(const rt_ctx *c, int start, int stop)
     return false;
 }
 
+static inline void rt_event_free(hipEvent_t e)
+{
+    if (e)
+        (void)hipEventDestroy(e);
+}
+
 extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
@@ -211,7 +217,7 @@ int rt_create(int device, rt_ctx **out)
         hipError_t e_ = (call);                                               \
         if (e_ != hipSuccess) {                                               \
             rt_fail(NULL, RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
-            free(c);                                                          \
+            rt_destroy(c); /* whatever exists so far */                       \
             return RT_ERR_HIP;                                                \
         }                                                                     \
     } while (0)
@@ -233,7 +239,7 @@ int rt_create(int device, rt_ctx **out)
     c->tab_cap = (size_t)4 * RT_MAX_SURFACES; /* grows in rt_upload_system */
     c->h_surf = (rt_surface *)calloc(c->tab_cap, sizeof(rt_surface));
     if (!c->h_surf) {
-        free(c);
+        rt_destroy(c);
         return rt_fail(NULL, RT_ERR_NOMEM, "rt_create: host allocation");
     }
     for (int k = 0; k < 2; ++k) {
@@ -259,9 +265,13 @@ int rt_destroy(rt_ctx *ctx)
 {
     if (!ctx)
         return RT_OK;
+    /* also the way out of a failed rt_create: every member is either what
+     * calloc left (NULL) or a live resource */
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->comm_stream);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream)
+        (void)hipStreamSynchronize(ctx->comm_stream);
     rt_comm_destroy(ctx);
     if (ctx->d_buf)
         (void)hipFree(ctx->d_buf);
@@ -296,22 +306,24 @@ int rt_destroy(rt_ctx *ctx)
             (void)hipFree(ctx->d_tab[k]);
         if (ctx->h_pinned[k])
             (void)hipHostFree(ctx->h_pinned[k]);
-        (void)hipEventDestroy(ctx->tab_used[k]);
+        rt_event_free(ctx->tab_used[k]);
     }
     free(ctx->h_surf);
     rt_comm_release(ctx);
     for (int i = 0; i < RT_GATHER_SLOTS; ++i) {
-        (void)hipEventDestroy(ctx->staged[i]);
-        (void)hipEventDestroy(ctx->gathered[i]);
+        rt_event_free(ctx->staged[i]);
+        rt_event_free(ctx->gathered[i]);
     }
-    (void)hipEventDestroy(ctx->g0);
-    (void)hipEventDestroy(ctx->g1);
+    rt_event_free(ctx->g0);
+    rt_event_free(ctx->g1);
     for (int i = 0; i < RT_NEVENTS; ++i)
-        (void)hipEventDestroy(ctx->ev[i]);
-    (void)hipEventDestroy(ctx->k0);
-    (void)hipEventDestroy(ctx->k1);
-    (void)hipStreamDestroy(ctx->stream);
-    (void)hipStreamDestroy(ctx->comm_stream);
+        rt_event_free(ctx->ev[i]);
+    rt_event_free(ctx->k0);
+    rt_event_free(ctx->k1);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    if (ctx->comm_stream)
+        (void)hipStreamDestroy(ctx->comm_stream);
     free(ctx);
     return RT_OK;
 }
@@ -405,10 +417,17 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
         return RT_OK;
     }
     ctx->gen_live = 0;
+    ctx->uni_valid = 0;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld;
     if (need > ctx->cap_doubles) {
+        /* from here until the new buffer exists the context holds no rays:
+         * a failed allocation must not leave the old sizes without a buffer */
+        ctx->n = 0;
+        ctx->ld = 0;
+        ctx->traced = 0;
+        memset(ctx->valid, 0, sizeof ctx->valid);
         if (ctx->d_buf)
             RT_HIP(ctx, hipFree(ctx->d_buf));
         ctx->d_buf = NULL;
@@ -433,7 +452,6 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
                               rt_tiles_bytes(tiles)));
         ctx->uni_cap = tiles;
     }
-    ctx->uni_valid = 0;
     ctx->n = nrays;
     ctx->ld = ld;
     ctx->buf_nsurf = ctx->nsurf;
