@@ -86,3 +86,42 @@ def test_c_example(tmp_path):
     mid = n//2 + n//20
     assert float(fields[fields.index("y_image[mid]") + 1]) == \
         pytest.approx(Y[-1][mid, 1], rel=1e-9)
+
+
+def test_failed_allocation_leaves_an_empty_context():
+    """A batch that cannot be allocated (10^12 rays: 80 TB) is an error with
+    the size in the message; the context holds no rays afterwards -- every
+    entry that needs rows says so instead of touching a freed buffer -- and
+    takes a new batch as if nothing had happened."""
+    dll = _lib.load()
+    ctx = ctypes.c_void_p()
+    assert dll.rt_create(0, ctypes.byref(ctx)) == 0
+    system = ra.system_from_yaml(ra.prescriptions.COOKE %
+                                 ra.prescriptions.COOKE_INDICES[587.56e-9])
+    table, ns = pack_system(system, 587.56e-9, 1.0002771748755976)
+    assert dll.rt_upload_system(ctx, table.ctypes.data, len(table)) == 0
+    y, u = ra.bundles.disc_bundle(3000, 5.5, 5., 2)
+    ys, us = np.ascontiguousarray(y.T), np.ascontiguousarray(u.T)
+    assert dll.rt_set_rays(ctx, ys.ctypes.data, us.ctypes.data, 3000,
+                           _lib.LAYOUT_SOA) == 0
+    assert dll.rt_trace(ctx, 1, 0, 1) == 0
+    first = np.empty((3, 3000))
+    assert dll.rt_download(ctx, _lib.RT_Y, 8, 9, first.ctypes.data) == 0
+
+    assert dll.rt_reserve(ctx, 10**12) == -5            # RT_ERR_NOMEM
+    assert b"GB failed" in dll.rt_last_error(ctx)
+    assert dll.rt_nrays(ctx) == 0 and dll.rt_ld(ctx) == 0
+    out = np.empty((3, 3000))
+    assert dll.rt_trace(ctx, 1, 0, 1) == -2
+    assert dll.rt_download(ctx, _lib.RT_Y, 8, 9, out.ctypes.data) == -2
+    rms = ctypes.c_double()
+    assert dll.rt_rms(ctx, 8, -1, ctypes.byref(rms)) == -2
+    tiles = (ctypes.c_int64*7)()
+    assert dll.rt_input_uniform(ctx, tiles) == 0 and not any(tiles)
+
+    assert dll.rt_set_rays(ctx, ys.ctypes.data, us.ctypes.data, 3000,
+                           _lib.LAYOUT_SOA) == 0
+    assert dll.rt_trace(ctx, 1, 0, 1) == 0
+    assert dll.rt_download(ctx, _lib.RT_Y, 8, 9, out.ctypes.data) == 0
+    assert np.array_equal(out, first, equal_nan=True)
+    assert dll.rt_destroy(ctx) == 0
