@@ -898,6 +898,18 @@ def main():
         else None)
     if tele is not None:
         tele.mark("loop:end")
+    # two or four workgroups per CU: what the engine measured on this
+    # allocation during the settle phase, and which the timed loop ran with
+    t_state, t_lds, t_ms = eng.tuning()
+    tuning = {"state": ("off", "sampling", "waiting", "decided")[t_state],
+              "resident_lds": t_lds if t_state == 3 else None,
+              "workgroups_per_cu": ({65536: 2, 32768: 4}.get(t_lds)
+                                    if t_state == 3 else None),
+              "ms_at_two_per_cu": t_ms[0] if t_state == 3 else None,
+              "ms_at_four_per_cu": t_ms[1] if t_state == 3 else None,
+              "note": "which is faster is a property of the allocation the "
+                      "arrays live in: the first 8 launches alternate, the "
+                      "medians decide (rt_tuning); results do not depend on it"}
     gather_ms = gather_exposed = None
     if dist_mode:
         if final_gather and job.exchange:
@@ -1074,6 +1086,7 @@ def main():
                 (alg_bytes - read_bytes + 48*n)/(kernel_ms*1e-3)/1e9 /
                 HBM_PEAK_GBS,
             "frac_of_achievable_6290": achieved/HBM_ACHIEVABLE_GBS,
+            "resident_workgroups": tuning,
         },
     }
     if dist_mode:

@@ -340,7 +340,9 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * dynamic LDS per workgroup of the trace kernels, i.e. a cap of 160 KB / bytes
  * on the workgroups resident per CU: traces that store their rows run with two
  * workgroups per CU, which the memory side likes better than the seven the
- * registers allow; FP64-bound traces are not capped).
+ * registers allow; FP64-bound traces are not capped), "tune_resident" (1 =
+ * default: large store-bound traces measure two against four workgroups per
+ * CU on the allocation they live in and keep the faster, rt_tuning; 0 = two).
  * Measurement-only variants and the memory-system probes live in a separate
  * laboratory build (include/rt_mi355_probes.h), not in this library.
  */
@@ -466,6 +468,19 @@ int rt_comm_sync(rt_ctx *ctx);
  * tiles.  All zero but tiles7[6] when the notes are void or switched off.
  */
 int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
+
+/*
+ * Two or four workgroups per CU: which of the two a large store-bound trace
+ * runs faster with is a property of the allocation its arrays live in, so the
+ * engine measures it -- the first 8 launches of a trace of >= 2^20 rays
+ * alternate, then the medians decide (option "tune_resident", default 1;
+ * results never depend on it).  state: 0 = not measuring (switched off, a cap
+ * set by hand, small batches), 1 = sampling, 2 = waiting for the samples,
+ * 3 = decided: *resident_lds = the cap chosen (bytes of unused LDS per
+ * workgroup: 65536 = two per CU, 32768 = four), ms2[0] / ms2[1] = median
+ * launch time at two / at four per CU.
+ */
+int rt_tuning(rt_ctx *ctx, int *state, int *resident_lds, double *ms2);
 
 /* device scratch owned by the context (e.g. gather destination on root) */
 int rt_scratch(rt_ctx *ctx, int64_t bytes, void **out);

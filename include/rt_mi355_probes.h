@@ -14,7 +14,15 @@
  * 2 sc1 write-through, 3 sc0 sc1), "uniform_fix" (results are wrong unless
  * the data happen to be so: 6-bit mask of input components read from the
  * wavefront's first column), "gate_log2" / "gate_window" (input reads wait
- * for chip-wide windows of the 100 MHz reference counter).
+ * for chip-wide windows of the 100 MHz reference counter), "base_offset_kb"
+ * (the result arrays start this far into their allocation, which is 1 GiB
+ * larger in this build: placement experiments, scripts/r03_offset_sweep.py),
+ * "alloc_round" (the allocation behind the arrays is rounded up to a multiple
+ * of 2^k bytes, 99 = to a power of two), "alloc_vmm_mb" / "alloc_vmm_align_mb"
+ * / "alloc_vmm_shuffle" / "alloc_vmm_seed" (the arrays live in a virtual
+ * address range backed by hipMemCreate chunks of that many MiB, mapped in
+ * order or in a pseudo-random order; a new seed re-maps the same chunks at
+ * once).  What they showed: profiles/r03_probes/README.md, "Placement".
  */
 #ifndef RT_MI355_PROBES_H
 #define RT_MI355_PROBES_H

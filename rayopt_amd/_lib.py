@@ -137,6 +137,9 @@ SIGNATURES = {
     "rt_gather_ms": (ctypes.c_int, [_ctx, _c_double_p, _c_double_p]),
     "rt_comm_sync": (ctypes.c_int, [_ctx]),
     "rt_input_uniform": (ctypes.c_int, [_ctx, _c_int64_p]),
+    "rt_tuning": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_int),
+                                 ctypes.POINTER(ctypes.c_int),
+                                 ctypes.POINTER(ctypes.c_double)]),
     "rt_scratch": (ctypes.c_int, [_ctx, ctypes.c_int64,
                                   ctypes.POINTER(ctypes.c_void_p)]),
     "rt_copy_to_host": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p,

@@ -59,8 +59,50 @@ struct rt_lab {
     void *d_probe_in; /* rt_probe modes 13/14: input rows of their own */
     size_t probe_in_bytes;
     int probe_in_uc;
+    int vmm_mb;       /* > 0: the arrays live in virtual memory backed by
+                         physical chunks of this many MiB (hipMemCreate /
+                         hipMemMap), mapped in shuffled order if vmm_shuffle */
+    int vmm_shuffle;
+    unsigned vmm_seed;
+    int vmm_align_mb;
+    void *vmm_base;   /* the reservation d_buf points at, if any */
+    size_t vmm_bytes, vmm_chunk;
+    void *vmm_handles; /* hipMemGenericAllocationHandle_t[vmm_n] */
+    size_t vmm_n;
+    int alloc_round;  /* the allocation is rounded up: 0 no, 1..40 to a
+                         multiple of 2^k bytes, 99 to a power of two */
+    size_t base_off;  /* doubles: the arrays start this far into d_buf (the
+                         laboratory build allocates RT_LAB_SLACK more) */
 };
+#define RT_LAB_SLACK ((size_t)1 << 27) /* doubles = 1 GiB */
 #endif
+
+/*
+ * Two or four workgroups per CU for a store-bound trace?  Which is faster is a
+ * property of the ALLOCATION the result arrays live in (the physical memory
+ * behind it), stable for its life and different from one allocation to the
+ * next: at four per CU the same launch takes 1.18-1.20 ms in one allocation
+ * and 1.31-1.36 ms in another, at two per CU 1.215-1.24 ms in all of them
+ * (profiles/r03_probes/README.md, "placement").  So it is measured: the first
+ * RT_TUNE_SAMPLES launches of a large trace of one shape alternate between the
+ * two, timed with events nobody waits for; when the last has completed the
+ * medians decide.  Results do not depend on the choice.
+ */
+#define RT_TUNE_SAMPLES 8
+#define RT_TUNE_RESETS 6       /* shapes tried per allocation before giving up */
+#define RT_TUNE_MIN_RAYS ((int64_t)1 << 20)
+#define RT_TUNE_GAIN 0.985     /* the alternative must be 1.5 % faster */
+struct rt_tune {
+    const void *buf;           /* allocation the measurements belong to */
+    int kind, start, stop, clip;
+    int64_t n;                 /* shape of the launches being measured */
+    int state;                 /* 0 idle, 1 sampling, 2 waiting, 3 decided */
+    int nsample, resets;
+    int choice;                /* bytes of unused LDS per workgroup */
+    float ms[2];               /* median launch time: default, alternative */
+    int have_events;
+    hipEvent_t e0[RT_TUNE_SAMPLES], e1[RT_TUNE_SAMPLES];
+};
 
 struct rt_ctx {
     int device;
@@ -121,6 +163,9 @@ struct rt_ctx {
     int opt_resident; /* bytes of unused dynamic LDS per workgroup of the
                          trace kernels: caps the workgroups resident per CU
                          (160 KB / bytes); -1 = chosen per trace */
+    int opt_tune;     /* measure two against four workgroups per CU on this
+                         allocation (rt_tune below); default on */
+    struct rt_tune tune;
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
     int opt_compact_every; /* survivors are counted at every k-th element */
     int last_compact; /* the last trace ran the compacting kernel */
@@ -184,7 +229,11 @@ static inline double *rt_arr(const rt_ctx *c, int which)
 {
     /* Y,U,I are [L][3][ld]; T is [L][ld] */
     const size_t plane = (size_t)c->buf_nsurf * 3 * (size_t)c->ld;
+#ifdef RT_BUILD_PROBES
+    return c->d_buf + c->lab.base_off + (size_t)which * plane;
+#else
     return c->d_buf + (size_t)which * plane;
+#endif
 }
 
 static inline int rt_ncomp(int which) { return which == RT_T ? 1 : 3; }
@@ -264,6 +313,9 @@ RT_INTERNAL void rt_lab_destroy(rt_ctx *c);
 RT_INTERNAL int rt_lab_set_option(rt_ctx *c, const char *key, int value);
 RT_INTERNAL bool rt_lab_variant(const rt_ctx *c); /* a lab kernel is selected */
 RT_INTERNAL int rt_lab_launch(rt_ctx *c, int start, int stop, int clip);
+/* allocation experiments: hipMalloc, or chunked virtual memory */
+RT_INTERNAL hipError_t rt_lab_alloc(rt_ctx *c, void **out, size_t bytes);
+RT_INTERNAL hipError_t rt_lab_free(rt_ctx *c, void *p);
 }
 static inline int64_t rt_ld_quantum(const rt_ctx *c)
 {

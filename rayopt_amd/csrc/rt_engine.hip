@@ -136,6 +136,95 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
     return 65536;
 }
 
+static void rt_tune_forget(rt_ctx *c)
+{
+    c->tune.buf = NULL;
+    c->tune.state = 0;
+    c->tune.resets = 0;
+}
+
+static int rt_cmp_float(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return x < y ? -1 : x > y;
+}
+
+/*
+ * The cap for this launch (rt_tune in rt_ctx.h): `lds` is what
+ * rt_resident_lds chose; *slot >= 0 = the launch is a sample, bracket it with
+ * e0[*slot] / e1[*slot].
+ */
+static size_t rt_tune_pick(rt_ctx *c, size_t lds, int kind, int start,
+                           int stop, int clip, int *slot)
+{
+    rt_tune &t = c->tune;
+    *slot = -1;
+    if (!c->opt_tune || c->opt_resident >= 0 || lds != 65536 ||
+        c->n < RT_TUNE_MIN_RAYS)
+        return lds;
+    if (t.buf != c->d_buf) { /* a new allocation: measure again */
+        t.buf = c->d_buf;
+        t.resets = 0;
+        t.state = 0;
+    }
+    const bool same = t.state && t.kind == kind && t.start == start &&
+                      t.stop == stop && t.clip == clip && t.n == c->n;
+    if (!same) {
+        if (t.resets >= RT_TUNE_RESETS)
+            return lds; /* a caller that changes shape with every launch */
+        if (!t.have_events) {
+            for (int k = 0; k < RT_TUNE_SAMPLES; ++k)
+                if (hipEventCreate(&t.e0[k]) != hipSuccess ||
+                    hipEventCreate(&t.e1[k]) != hipSuccess) {
+                    (void)hipGetLastError();
+                    c->opt_tune = 0;
+                    return lds;
+                }
+            t.have_events = 1;
+        }
+        ++t.resets;
+        t.kind = kind;
+        t.start = start;
+        t.stop = stop;
+        t.clip = clip;
+        t.n = c->n;
+        t.state = 1;
+        t.nsample = 0;
+    }
+    if (t.state == 1) {
+        *slot = t.nsample;
+        const size_t pick = (t.nsample & 1) ? 32768 : 65536;
+        if (++t.nsample == RT_TUNE_SAMPLES)
+            t.state = 2;
+        return pick;
+    }
+    if (t.state == 2) {
+        if (hipEventQuery(t.e1[RT_TUNE_SAMPLES - 1]) != hipSuccess) {
+            (void)hipGetLastError(); /* not ready is not an error */
+            return lds;
+        }
+        /* the first pair warms up; medians of the other three per candidate */
+        float ms[2][RT_TUNE_SAMPLES / 2];
+        int cnt[2] = {0, 0};
+        bool ok = true;
+        for (int k = 2; k < RT_TUNE_SAMPLES && ok; ++k)
+            ok = hipEventElapsedTime(&ms[k & 1][cnt[k & 1]++], t.e0[k],
+                                     t.e1[k]) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            t.choice = (int)lds;
+        } else {
+            for (int q = 0; q < 2; ++q) {
+                qsort(ms[q], cnt[q], sizeof(float), rt_cmp_float);
+                t.ms[q] = ms[q][cnt[q] / 2];
+            }
+            t.choice = t.ms[1] < RT_TUNE_GAIN * t.ms[0] ? 32768 : 65536;
+        }
+        t.state = 3;
+    }
+    return (size_t)t.choice;
+}
+
 /* the compacting variant pays (one barrier per element) only where dead rays
  * are wasted FP64 issue, i.e. where rows are traced but not stored */
 static bool rt_use_compact(const rt_ctx *c, int start, int stop)
@@ -210,6 +299,7 @@ int rt_create(int device, rt_ctx **out)
         c->opt_fast = (e && atoi(e)) ? 0 : 1;
     }
     c->opt_resident = -1;
+    c->opt_tune = 1;
     c->opt_uniform = 1;
     c->opt_compact_every = 4; /* measured best, profiles/r02_probes */
 #define RT_HIP_C(call)                                                        \
@@ -273,8 +363,13 @@ int rt_destroy(rt_ctx *ctx)
     if (ctx->comm_stream)
         (void)hipStreamSynchronize(ctx->comm_stream);
     rt_comm_destroy(ctx);
+#ifdef RT_BUILD_PROBES
+    if (ctx->d_buf)
+        (void)rt_lab_free(ctx, ctx->d_buf);
+#else
     if (ctx->d_buf)
         (void)hipFree(ctx->d_buf);
+#endif
     if (ctx->d_uni)
         (void)hipFree(ctx->d_uni);
     if (ctx->d_scratch)
@@ -314,6 +409,11 @@ int rt_destroy(rt_ctx *ctx)
         rt_event_free(ctx->staged[i]);
         rt_event_free(ctx->gathered[i]);
     }
+    if (ctx->tune.have_events)
+        for (int k = 0; k < RT_TUNE_SAMPLES; ++k) {
+            rt_event_free(ctx->tune.e0[k]);
+            rt_event_free(ctx->tune.e1[k]);
+        }
     rt_event_free(ctx->g0);
     rt_event_free(ctx->g1);
     for (int i = 0; i < RT_NEVENTS; ++i)
@@ -420,7 +520,20 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     ctx->uni_valid = 0;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef RT_BUILD_PROBES
+    size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld + RT_LAB_SLACK;
+    if (ctx->lab.alloc_round == 99) {
+        size_t p2 = 1;
+        while (p2 < need)
+            p2 <<= 1;
+        need = p2;
+    } else if (ctx->lab.alloc_round > 3) {
+        const size_t q = ((size_t)1 << ctx->lab.alloc_round) / 8;
+        need = (need + q - 1) / q * q;
+    }
+#else
     const size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld;
+#endif
     if (need > ctx->cap_doubles) {
         /* from here until the new buffer exists the context holds no rays:
          * a failed allocation must not leave the old sizes without a buffer */
@@ -428,11 +541,22 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
         ctx->ld = 0;
         ctx->traced = 0;
         memset(ctx->valid, 0, sizeof ctx->valid);
+#ifdef RT_BUILD_PROBES
+        if (ctx->d_buf)
+            RT_HIP(ctx, rt_lab_free(ctx, ctx->d_buf));
+#else
         if (ctx->d_buf)
             RT_HIP(ctx, hipFree(ctx->d_buf));
+#endif
         ctx->d_buf = NULL;
         ctx->cap_doubles = 0;
+        rt_tune_forget(ctx); /* what was measured belonged to that memory */
+#ifdef RT_BUILD_PROBES
+        hipError_t e = rt_lab_alloc(ctx, (void **)&ctx->d_buf,
+                                    need * sizeof(double));
+#else
         hipError_t e = hipMalloc((void **)&ctx->d_buf, need * sizeof(double));
+#endif
         if (e != hipSuccess) {
             (void)hipGetLastError();
             return rt_fail(ctx, RT_ERR_NOMEM,
@@ -962,7 +1086,15 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
     const int64_t cols = (hi == ctx->n ? ctx->ld : hi) - lo;
     const int64_t group_rays = ctx->ngroups > 1 ? ctx->n / ctx->ngroups : 0;
     const unsigned grid = (unsigned)((cols + RT_BLOCK - 1) / RT_BLOCK);
-    const size_t lds = rt_resident_lds(ctx, start, stop);
+    size_t lds = rt_resident_lds(ctx, start, stop);
+    int sample = -1;
+    if (cols > 0 && start < stop && !windowed && !fused &&
+        !rt_lab_variant(ctx) && !rt_use_compact(ctx, start, stop))
+        lds = rt_tune_pick(ctx, lds, (regen ? 1 : 0) | (ctx->opt_alias ? 2 : 0),
+                           start, stop, clip != 0,
+                           &sample);
+    if (sample >= 0)
+        RT_HIP(ctx, hipEventRecord(ctx->tune.e0[sample], ctx->stream));
     if (cols <= 0 || start >= stop) {
         /* an empty window, or nothing to trace */
     } else if (fused || regen) {
@@ -1001,6 +1133,8 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
                            cols, group_rays, ctx->nsurf, tiles);
         RT_HIP(ctx, hipGetLastError());
     }
+    if (sample >= 0)
+        RT_HIP(ctx, hipEventRecord(ctx->tune.e1[sample], ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
     for (int sidx = start; sidx < stop; ++sidx) {
         const unsigned f = ctx->h_stage[sidx].flags;
@@ -1104,6 +1238,9 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         ctx->opt_fast = fast;
     } else if (!strcmp(key, "uniform_input")) {
         ctx->opt_uniform = value ? 1 : 0;
+    } else if (!strcmp(key, "tune_resident")) {
+        ctx->opt_tune = value ? 1 : 0;
+        rt_tune_forget(ctx);
     } else if (!strcmp(key, "resident_lds")) {
         if (value < -1 || value > 65536)
             return rt_fail(ctx, RT_ERR_ARG,
@@ -1247,6 +1384,19 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7)
         for (int c = 0; c < 6; ++c)
             tiles7[c] += (host[t] >> c) & 1u;
     free(host);
+    return RT_OK;
+}
+
+int rt_tuning(rt_ctx *ctx, int *state, int *resident_lds, double *ms2)
+{
+    if (!ctx || !state || !resident_lds || !ms2)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_tuning: NULL argument");
+    const rt_tune &t = ctx->tune;
+    *state = (!ctx->opt_tune || ctx->opt_resident >= 0 ||
+              t.buf != ctx->d_buf) ? 0 : t.state;
+    *resident_lds = *state == 3 ? t.choice : -1;
+    ms2[0] = *state == 3 ? t.ms[0] : 0.;
+    ms2[1] = *state == 3 ? t.ms[1] : 0.;
     return RT_OK;
 }
 

@@ -32,6 +32,107 @@ void rt_lab_destroy(rt_ctx *c)
     c->lab.d_probe_in = NULL;
 }
 
+hipError_t rt_lab_free(rt_ctx *c, void *p)
+{
+    rt_lab &l = c->lab;
+    if (!p || p != l.vmm_base)
+        return p ? hipFree(p) : hipSuccess;
+    hipMemGenericAllocationHandle_t *h =
+        (hipMemGenericAllocationHandle_t *)l.vmm_handles;
+    (void)hipMemUnmap(l.vmm_base, l.vmm_bytes);
+    for (size_t k = 0; k < l.vmm_n; ++k)
+        (void)hipMemRelease(h[k]);
+    (void)hipMemAddressFree(l.vmm_base, l.vmm_bytes);
+    free(h);
+    l.vmm_base = NULL;
+    l.vmm_handles = NULL;
+    l.vmm_n = 0;
+    return hipSuccess;
+}
+
+/* chunk k of the address range <- physical chunk order[k]: the identity, or
+ * a pseudo-random permutation drawn from vmm_seed */
+static hipError_t rt_lab_vmm_map(rt_ctx *c)
+{
+    rt_lab &l = c->lab;
+    const size_t n = l.vmm_n, chunk = l.vmm_chunk;
+    hipMemGenericAllocationHandle_t *h =
+        (hipMemGenericAllocationHandle_t *)l.vmm_handles;
+    size_t *order = (size_t *)malloc(n * sizeof(size_t));
+    for (size_t k = 0; k < n; ++k)
+        order[k] = k;
+    if (l.vmm_shuffle) {
+        unsigned long long x = 0x9E3779B97F4A7C15ull * (l.vmm_seed + 1);
+        for (size_t k = n - 1; k > 0; --k) {
+            x ^= x << 13;
+            x ^= x >> 7;
+            x ^= x << 17;
+            const size_t j = (size_t)(x % (k + 1));
+            const size_t tmp = order[k];
+            order[k] = order[j];
+            order[j] = tmp;
+        }
+    }
+    hipError_t e = hipSuccess;
+    for (size_t k = 0; k < n && e == hipSuccess; ++k)
+        e = hipMemMap((char *)l.vmm_base + k * chunk, chunk, 0, h[order[k]],
+                      0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = c->device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(l.vmm_base, l.vmm_bytes, &acc, 1);
+    }
+    free(order);
+    return e;
+}
+
+hipError_t rt_lab_alloc(rt_ctx *c, void **out, size_t bytes)
+{
+    rt_lab &l = c->lab;
+    if (l.vmm_mb <= 0)
+        return hipMalloc(out, bytes);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(
+        &gran, &prop, hipMemAllocationGranularityRecommended);
+    if (e != hipSuccess)
+        return e;
+    size_t chunk = (size_t)l.vmm_mb << 20;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = (bytes + chunk - 1) / chunk;
+    const size_t total = n * chunk;
+    void *base = NULL;
+    e = hipMemAddressReserve(&base, total,
+                             (size_t)(l.vmm_align_mb > 0 ? l.vmm_align_mb : 2)
+                                 << 20,
+                             NULL, 0);
+    if (e != hipSuccess)
+        return e;
+    hipMemGenericAllocationHandle_t *h =
+        (hipMemGenericAllocationHandle_t *)calloc(
+            n, sizeof(hipMemGenericAllocationHandle_t));
+    for (size_t k = 0; k < n && e == hipSuccess; ++k)
+        e = hipMemCreate(&h[k], chunk, &prop, 0);
+    l.vmm_base = base;
+    l.vmm_bytes = total;
+    l.vmm_chunk = chunk;
+    l.vmm_handles = h;
+    l.vmm_n = n;
+    if (e == hipSuccess)
+        e = rt_lab_vmm_map(c);
+    if (e != hipSuccess) {
+        (void)rt_lab_free(c, base);
+        return e;
+    }
+    *out = base;
+    return hipSuccess;
+}
+
 bool rt_lab_variant(const rt_ctx *c)
 {
     const rt_lab &l = c->lab;
@@ -76,6 +177,46 @@ int rt_lab_set_option(rt_ctx *ctx, const char *key, int value)
             ctx->n = 0;
             memset(ctx->valid, 0, sizeof ctx->valid);
         }
+    } else if (!strcmp(key, "alloc_vmm_mb")) {
+        /* takes effect with the next allocation */
+        if (value < 0 || value > 65536)
+            return rt_fail(ctx, RT_ERR_ARG, "alloc_vmm_mb: 0..65536");
+        l.vmm_mb = value;
+    } else if (!strcmp(key, "alloc_vmm_align_mb")) {
+        l.vmm_align_mb = value; /* alignment of the address range */
+    } else if (!strcmp(key, "alloc_vmm_shuffle")) {
+        l.vmm_shuffle = value ? 1 : 0;
+    } else if (!strcmp(key, "alloc_vmm_seed")) {
+        /* another permutation of the physical chunks behind the SAME
+         * addresses, at once; what the rows held is gone */
+        l.vmm_seed = (unsigned)value;
+        if (l.vmm_base) {
+            RT_HIP(ctx, hipDeviceSynchronize());
+            RT_HIP(ctx, hipMemUnmap(l.vmm_base, l.vmm_bytes));
+            RT_HIP(ctx, rt_lab_vmm_map(ctx));
+            ctx->n = 0;
+            ctx->ld = 0;
+            memset(ctx->valid, 0, sizeof ctx->valid);
+            ctx->tune.buf = NULL;
+        }
+    } else if (!strcmp(key, "alloc_round")) {
+        /* size of the allocation behind the arrays: rounded up to a multiple
+         * of 2^value bytes (4..40), or to a power of two (99); takes effect
+         * with the next allocation */
+        if (value && value != 99 && (value < 4 || value > 40))
+            return rt_fail(ctx, RT_ERR_ARG, "alloc_round: 0, 4..40 or 99");
+        l.alloc_round = value;
+    } else if (!strcmp(key, "base_offset_kb")) {
+        /* where in its allocation the result arrays start (placement
+         * experiments); takes effect with the next rt_reserve / rt_set_rays */
+        if (value < 0 || (size_t)value * 128 >= RT_LAB_SLACK)
+            return rt_fail(ctx, RT_ERR_ARG, "base_offset_kb must be in "
+                           "[0, %zu)", RT_LAB_SLACK / 128);
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        l.base_off = (size_t)value * 128;
+        ctx->ld = 0;
+        ctx->n = 0;
+        memset(ctx->valid, 0, sizeof ctx->valid);
     } else if (!strcmp(key, "lds_pad")) {
         /* dynamic LDS the kernel never touches, to cap the workgroups
          * resident per CU (160 KB / lds_pad) */

@@ -295,6 +295,16 @@ class Engine:
         self._check(self.lib.rt_input_uniform(self.ctx, t), "rt_input_uniform")
         return list(t[:6]), int(t[6])
 
+    def tuning(self):
+        """(state, resident_lds, (ms at two, ms at four workgroups per CU)):
+        what the engine measured on this allocation (rt_tuning); state 3 =
+        decided."""
+        st, lds = ctypes.c_int(), ctypes.c_int()
+        ms = (ctypes.c_double*2)()
+        self._check(self.lib.rt_tuning(self.ctx, ctypes.byref(st),
+                                       ctypes.byref(lds), ms), "rt_tuning")
+        return st.value, lds.value, (ms[0], ms[1])
+
     def scratch(self, nbytes):
         p = ctypes.c_void_p()
         self._check(self.lib.rt_scratch(self.ctx, int(nbytes),

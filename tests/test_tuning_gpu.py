@@ -1,0 +1,87 @@
+"""Two or four workgroups per CU, measured per allocation (rt_tuning): the
+choice never changes a result, small batches and hand-set caps are left
+alone, a new allocation is measured again."""
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd import prescriptions as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _trace(n, seed=3):
+    system = ra.system_from_yaml(P.COOKE % P.COOKE_INDICES[587.56e-9])
+    y, u = ra.bundles.disc_bundle(n, 5.5, 5., seed)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    return g
+
+
+def test_choice_is_made_and_results_do_not_depend_on_it():
+    n = (1 << 20) + 4096
+    g = _trace(n)
+    eng = g.engine
+    assert eng.tuning()[0] == 0         # nothing launched yet
+    rows = []
+    for k in range(14):
+        g.propagate(clip=True)
+        if k in (0, 1, 2, 7, 13):       # sampled at both caps, then decided
+            rows.append([np.array(getattr(g, a)[-1]) for a in "yuit"])
+    eng.sync()
+    g.propagate(clip=True)
+    state, lds, ms = eng.tuning()
+    assert state == 3 and lds in (65536, 32768)
+    assert ms[0] > 0 and ms[1] > 0
+    # the alternative is taken only if it was at least 1.5 % faster
+    assert (lds == 32768) == (ms[1] < .985*ms[0])
+    for other in rows[1:]:
+        for a, b in zip(rows[0], other):
+            assert np.array_equal(a, b, equal_nan=True)
+    # switched off: two per CU, the same bits
+    eng.set_option("tune_resident", 0)
+    g.propagate(clip=True)
+    assert eng.tuning()[0] == 0
+    for a, b in zip(rows[0], [np.array(getattr(g, x)[-1]) for x in "yuit"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    # on again: measured again from scratch
+    eng.set_option("tune_resident", 1)
+    g.propagate(clip=True)
+    assert eng.tuning()[0] == 1
+    # a cap set by hand is not overruled
+    eng.set_option("resident_lds", 0)
+    g.propagate(clip=True)
+    assert eng.tuning()[0] == 0
+    eng.set_option("resident_lds", -1)
+
+
+def test_small_batches_and_changing_shapes_are_left_alone():
+    g = _trace(50_000)
+    for _ in range(10):
+        g.propagate(clip=True)
+    assert g.engine.tuning()[0] == 0
+    # a caller that changes shape with every launch: after a few shapes no
+    # new one is sampled (the last one still is, whenever it recurs);
+    # results stay right
+    g = _trace((1 << 20) + 64)
+    g.propagate(clip=True)
+    want = [np.array(g.y[-1]), np.array(g.y[4])]
+    for k in range(40):
+        g.propagate(clip=bool(k & 1))
+    g.propagate(clip=True)
+    assert np.array_equal(want[0], np.array(g.y[-1]), equal_nan=True)
+    assert np.array_equal(want[1], np.array(g.y[4]), equal_nan=True)
+
+
+def test_a_new_allocation_is_measured_again():
+    n = (1 << 20) + 4096
+    g = _trace(n)
+    for _ in range(12):
+        g.propagate(clip=True)
+    g.engine.sync()
+    g.propagate(clip=True)
+    assert g.engine.tuning()[0] == 3
+    y, u = ra.bundles.disc_bundle(4*n, 5.5, 5., 5)
+    g.rays_given(y, u)                  # four times the rays: new arrays
+    g.propagate(clip=True)
+    assert g.engine.tuning()[0] == 1
