@@ -901,15 +901,17 @@ def main():
     # two or four workgroups per CU: what the engine measured on this
     # allocation during the settle phase, and which the timed loop ran with
     t_state, t_lds, t_ms = eng.tuning()
-    tuning = {"state": ("off", "sampling", "waiting", "decided")[t_state],
+    tuning = {"state": ("off", "sampling", "waiting", "decided",
+                        "counting launches")[t_state],
               "resident_lds": t_lds if t_state == 3 else None,
               "workgroups_per_cu": ({65536: 2, 32768: 4}.get(t_lds)
                                     if t_state == 3 else None),
               "ms_at_two_per_cu": t_ms[0] if t_state == 3 else None,
               "ms_at_four_per_cu": t_ms[1] if t_state == 3 else None,
               "note": "which is faster is a property of the allocation the "
-                      "arrays live in: the first 8 launches alternate, the "
-                      "medians decide (rt_tuning); results do not depend on it"}
+                      "arrays live in: after 48 launches 8 alternate, the "
+                      "medians decide if they are steady (rt_tuning); results "
+                      "do not depend on it"}
     gather_ms = gather_exposed = None
     if dist_mode:
         if final_gather and job.exchange:

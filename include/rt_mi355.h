@@ -472,13 +472,18 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
 /*
  * Two or four workgroups per CU: which of the two a large store-bound trace
  * runs faster with is a property of the allocation its arrays live in, so the
- * engine measures it -- the first 8 launches of a trace of >= 2^20 rays
- * alternate, then the medians decide (option "tune_resident", default 1;
- * results never depend on it).  state: 0 = not measuring (switched off, a cap
- * set by hand, small batches), 1 = sampling, 2 = waiting for the samples,
- * 3 = decided: *resident_lds = the cap chosen (bytes of unused LDS per
- * workgroup: 65536 = two per CU, 32768 = four), ms2[0] / ms2[1] = median
- * launch time at two / at four per CU.
+ * engine measures it: once a trace of >= 2^20 rays has been launched 48 times
+ * in one shape (a device coming out of idle ranks the two differently), 8
+ * launches alternate and the medians decide -- provided the launches were back
+ * to back and the samples of each setting agree to 4 %; otherwise the
+ * measurement is repeated later, up to 6 times (option "tune_resident",
+ * default 1; results never depend on it).  state: 0 = not measuring (switched
+ * off, a cap set by hand, small batches, nothing launched yet), 4 = counting
+ * launches, 1 = sampling, 2 = waiting for the samples, 3 = decided:
+ * *resident_lds = the cap chosen (bytes of unused LDS per workgroup: 65536 =
+ * two per CU, 32768 = four), ms2[0] / ms2[1] = median launch time at two / at
+ * four per CU (both 0 if no steady measurement was ever had and the default
+ * stayed).
  */
 int rt_tuning(rt_ctx *ctx, int *state, int *resident_lds, double *ms2);
 

@@ -83,21 +83,30 @@ struct rt_lab {
  * behind it), stable for its life and different from one allocation to the
  * next: at four per CU the same launch takes 1.18-1.20 ms in one allocation
  * and 1.31-1.36 ms in another, at two per CU 1.215-1.24 ms in all of them
- * (profiles/r03_probes/README.md, "placement").  So it is measured: the first
- * RT_TUNE_SAMPLES launches of a large trace of one shape alternate between the
- * two, timed with events nobody waits for; when the last has completed the
- * medians decide.  Results do not depend on the choice.
+ * (profiles/r03_probes/README.md, "placement").  So it is measured: once a
+ * large trace of one shape has been launched RT_TUNE_WARM times (a device
+ * coming out of idle ranks the two differently for its first ~50 launches),
+ * RT_TUNE_SAMPLES launches alternate between the two, timed with events
+ * nobody waits for; when the last has completed the medians decide -- if the
+ * samples of each setting agree among themselves and the launches were back
+ * to back; otherwise the measurement is repeated later, a few times.  Results
+ * do not depend on the choice.
  */
 #define RT_TUNE_SAMPLES 8
+#define RT_TUNE_WARM 48        /* launches of the shape before sampling */
+#define RT_TUNE_RETRIES 6      /* measurements that may be thrown away */
 #define RT_TUNE_RESETS 6       /* shapes tried per allocation before giving up */
 #define RT_TUNE_MIN_RAYS ((int64_t)1 << 20)
 #define RT_TUNE_GAIN 0.985     /* the alternative must be 1.5 % faster */
+#define RT_TUNE_SPREAD 0.04    /* samples of one setting agree to 4 % */
+#define RT_TUNE_GAP_MS 0.3f    /* idle time between sampled launches */
 struct rt_tune {
     const void *buf;           /* allocation the measurements belong to */
     int kind, start, stop, clip;
     int64_t n;                 /* shape of the launches being measured */
-    int state;                 /* 0 idle, 1 sampling, 2 waiting, 3 decided */
-    int nsample, resets;
+    int state;                 /* 0 idle, 1 sampling, 2 waiting, 3 decided,
+                                  4 warming up (counting launches) */
+    int nsample, resets, seen, retries;
     int choice;                /* bytes of unused LDS per workgroup */
     float ms[2];               /* median launch time: default, alternative */
     int have_events;

@@ -188,6 +188,13 @@ static size_t rt_tune_pick(rt_ctx *c, size_t lds, int kind, int start,
         t.stop = stop;
         t.clip = clip;
         t.n = c->n;
+        t.state = 4;
+        t.seen = 0;
+        t.retries = 0;
+    }
+    if (t.state == 4) { /* not before the device has warmed up on this shape */
+        if (++t.seen < RT_TUNE_WARM)
+            return lds;
         t.state = 1;
         t.nsample = 0;
     }
@@ -203,23 +210,44 @@ static size_t rt_tune_pick(rt_ctx *c, size_t lds, int kind, int start,
             (void)hipGetLastError(); /* not ready is not an error */
             return lds;
         }
-        /* the first pair warms up; medians of the other three per candidate */
+        /* the first pair is dropped; three samples per setting.  The
+         * measurement counts only if the launches were back to back and the
+         * samples of each setting agree: a device that is still ramping its
+         * clocks, or a caller that waits between launches, is measured
+         * again later */
         float ms[2][RT_TUNE_SAMPLES / 2];
         int cnt[2] = {0, 0};
-        bool ok = true;
-        for (int k = 2; k < RT_TUNE_SAMPLES && ok; ++k)
+        bool ok = true, steady = true;
+        for (int k = 2; k < RT_TUNE_SAMPLES && ok; ++k) {
+            float gap = 0.f;
             ok = hipEventElapsedTime(&ms[k & 1][cnt[k & 1]++], t.e0[k],
-                                     t.e1[k]) == hipSuccess;
+                                     t.e1[k]) == hipSuccess &&
+                 hipEventElapsedTime(&gap, t.e1[k - 1], t.e0[k]) == hipSuccess;
+            steady = steady && gap < RT_TUNE_GAP_MS;
+        }
         if (!ok) {
             (void)hipGetLastError();
-            t.choice = (int)lds;
-        } else {
-            for (int q = 0; q < 2; ++q) {
-                qsort(ms[q], cnt[q], sizeof(float), rt_cmp_float);
-                t.ms[q] = ms[q][cnt[q] / 2];
-            }
-            t.choice = t.ms[1] < RT_TUNE_GAIN * t.ms[0] ? 32768 : 65536;
+            c->opt_tune = 0; /* events that cannot be read: no measuring */
+            return lds;
         }
+        for (int q = 0; q < 2; ++q) {
+            qsort(ms[q], cnt[q], sizeof(float), rt_cmp_float);
+            t.ms[q] = ms[q][cnt[q] / 2];
+            steady = steady && ms[q][cnt[q] - 1] - ms[q][0] <=
+                                   RT_TUNE_SPREAD * ms[q][0];
+        }
+        if (!steady) {
+            if (++t.retries > RT_TUNE_RETRIES) {
+                t.choice = (int)lds; /* never steady: the default stays */
+                t.ms[0] = t.ms[1] = 0.f;
+                t.state = 3;
+                return lds;
+            }
+            t.state = 4;
+            t.seen = 0;
+            return lds;
+        }
+        t.choice = t.ms[1] < RT_TUNE_GAIN * t.ms[0] ? 32768 : 65536;
         t.state = 3;
     }
     return (size_t)t.choice;
@@ -1093,6 +1121,11 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
         lds = rt_tune_pick(ctx, lds, (regen ? 1 : 0) | (ctx->opt_alias ? 2 : 0),
                            start, stop, clip != 0,
                            &sample);
+    else if (windowed && lds == 65536 && ctx->opt_tune &&
+             ctx->opt_resident < 0 && ctx->tune.state == 3 &&
+             ctx->tune.buf == ctx->d_buf)
+        lds = (size_t)ctx->tune.choice; /* pieces of a trace run with what
+                                           the whole one was measured to like */
     if (sample >= 0)
         RT_HIP(ctx, hipEventRecord(ctx->tune.e0[sample], ctx->stream));
     if (cols <= 0 || start >= stop) {

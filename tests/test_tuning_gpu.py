@@ -24,17 +24,23 @@ def test_choice_is_made_and_results_do_not_depend_on_it():
     eng = g.engine
     assert eng.tuning()[0] == 0         # nothing launched yet
     rows = []
-    for k in range(14):
+    state = 0
+    for k in range(48*8):               # counting, sampling, perhaps again
         g.propagate(clip=True)
-        if k in (0, 1, 2, 7, 13):       # sampled at both caps, then decided
+        if k in (0, 1, 47, 48, 49, 50, 55, 56, 60):
             rows.append([np.array(getattr(g, a)[-1]) for a in "yuit"])
-    eng.sync()
-    g.propagate(clip=True)
+        if k > 56 and k % 8 == 0:
+            eng.sync()
+            state = eng.tuning()[0]
+            if state == 3:
+                break
     state, lds, ms = eng.tuning()
     assert state == 3 and lds in (65536, 32768)
-    assert ms[0] > 0 and ms[1] > 0
-    # the alternative is taken only if it was at least 1.5 % faster
-    assert (lds == 32768) == (ms[1] < .985*ms[0])
+    if ms[0] > 0:       # a steady measurement was had
+        # the alternative is taken only if it was at least 1.5 % faster
+        assert (lds == 32768) == (ms[1] < .985*ms[0])
+    else:
+        assert lds == 65536
     for other in rows[1:]:
         for a, b in zip(rows[0], other):
             assert np.array_equal(a, b, equal_nan=True)
@@ -47,7 +53,7 @@ def test_choice_is_made_and_results_do_not_depend_on_it():
     # on again: measured again from scratch
     eng.set_option("tune_resident", 1)
     g.propagate(clip=True)
-    assert eng.tuning()[0] == 1
+    assert eng.tuning()[0] == 4
     # a cap set by hand is not overruled
     eng.set_option("resident_lds", 0)
     g.propagate(clip=True)
@@ -66,7 +72,7 @@ def test_small_batches_and_changing_shapes_are_left_alone():
     g = _trace((1 << 20) + 64)
     g.propagate(clip=True)
     want = [np.array(g.y[-1]), np.array(g.y[4])]
-    for k in range(40):
+    for k in range(140):
         g.propagate(clip=bool(k & 1))
     g.propagate(clip=True)
     assert np.array_equal(want[0], np.array(g.y[-1]), equal_nan=True)
@@ -76,12 +82,12 @@ def test_small_batches_and_changing_shapes_are_left_alone():
 def test_a_new_allocation_is_measured_again():
     n = (1 << 20) + 4096
     g = _trace(n)
-    for _ in range(12):
+    for _ in range(20):
         g.propagate(clip=True)
-    g.engine.sync()
-    g.propagate(clip=True)
-    assert g.engine.tuning()[0] == 3
+    assert g.engine.tuning()[0] == 4    # counting launches on these arrays
     y, u = ra.bundles.disc_bundle(4*n, 5.5, 5., 5)
     g.rays_given(y, u)                  # four times the rays: new arrays
-    g.propagate(clip=True)
-    assert g.engine.tuning()[0] == 1
+    for _ in range(3):
+        g.propagate(clip=True)
+    st, lds, ms = g.engine.tuning()
+    assert st == 4 and lds == -1        # counted from zero again
