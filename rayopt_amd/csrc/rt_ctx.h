@@ -69,6 +69,8 @@ struct rt_lab {
     size_t vmm_bytes, vmm_chunk;
     void *vmm_handles; /* hipMemGenericAllocationHandle_t[vmm_n] */
     size_t vmm_n;
+    int tune_min_rays, tune_warm; /* > 0: thresholds of the occupancy tuner
+                         (rt_tune) for the state fuzz, which runs small */
     int alloc_round;  /* the allocation is rounded up: 0 no, 1..40 to a
                          multiple of 2^k bytes, 99 to a power of two */
     size_t base_off;  /* doubles: the arrays start this far into d_buf (the
@@ -330,11 +332,21 @@ static inline int64_t rt_ld_quantum(const rt_ctx *c)
 {
     return c->lab.tile ? c->lab.tile : 64;
 }
+static inline int64_t rt_tune_min_rays(const rt_ctx *c)
+{
+    return c->lab.tune_min_rays > 0 ? c->lab.tune_min_rays : RT_TUNE_MIN_RAYS;
+}
+static inline int rt_tune_warm(const rt_ctx *c)
+{
+    return c->lab.tune_warm > 0 ? c->lab.tune_warm : RT_TUNE_WARM;
+}
 static inline int rt_group_quantum(const rt_ctx *c) { return 64 * c->lab.r; }
 static inline int rt_gen_block(const rt_ctx *c) { return c->lab.block; }
 static inline size_t rt_gen_lds(const rt_ctx *c) { return (size_t)c->lab.lds; }
 #else
 static inline bool rt_lab_variant(const rt_ctx *) { return false; }
+static inline int64_t rt_tune_min_rays(const rt_ctx *) { return RT_TUNE_MIN_RAYS; }
+static inline int rt_tune_warm(const rt_ctx *) { return RT_TUNE_WARM; }
 static inline int64_t rt_ld_quantum(const rt_ctx *) { return 64; }
 static inline int rt_group_quantum(const rt_ctx *) { return 64; }
 #endif

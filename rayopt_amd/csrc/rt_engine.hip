@@ -160,7 +160,7 @@ static size_t rt_tune_pick(rt_ctx *c, size_t lds, int kind, int start,
     rt_tune &t = c->tune;
     *slot = -1;
     if (!c->opt_tune || c->opt_resident >= 0 || lds != 65536 ||
-        c->n < RT_TUNE_MIN_RAYS)
+        c->n < rt_tune_min_rays(c))
         return lds;
     if (t.buf != c->d_buf) { /* a new allocation: measure again */
         t.buf = c->d_buf;
@@ -193,7 +193,7 @@ static size_t rt_tune_pick(rt_ctx *c, size_t lds, int kind, int start,
         t.retries = 0;
     }
     if (t.state == 4) { /* not before the device has warmed up on this shape */
-        if (++t.seen < RT_TUNE_WARM)
+        if (++t.seen < rt_tune_warm(c))
             return lds;
         t.state = 1;
         t.nsample = 0;

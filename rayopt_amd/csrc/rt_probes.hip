@@ -199,6 +199,10 @@ int rt_lab_set_option(rt_ctx *ctx, const char *key, int value)
             memset(ctx->valid, 0, sizeof ctx->valid);
             ctx->tune.buf = NULL;
         }
+    } else if (!strcmp(key, "tune_min_rays")) {
+        l.tune_min_rays = value; /* 0 = the shipped threshold */
+    } else if (!strcmp(key, "tune_warm")) {
+        l.tune_warm = value;
     } else if (!strcmp(key, "alloc_round")) {
         /* size of the allocation behind the arrays: rounded up to a multiple
          * of 2^value bytes (4..40), or to a power of two (99); takes effect
