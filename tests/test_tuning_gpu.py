@@ -25,7 +25,7 @@ def test_choice_is_made_and_results_do_not_depend_on_it():
     assert eng.tuning()[0] == 0         # nothing launched yet
     rows = []
     state = 0
-    for k in range(48*8):               # counting, sampling, perhaps again
+    for k in range(56*12):              # counting, sampling, perhaps again
         g.propagate(clip=True)
         if k in (0, 1, 47, 48, 49, 50, 55, 56, 60):
             rows.append([np.array(getattr(g, a)[-1]) for a in "yuit"])
