@@ -898,20 +898,17 @@ def main():
         else None)
     if tele is not None:
         tele.mark("loop:end")
-    # two or four workgroups per CU: what the engine measured on this
-    # allocation during the settle phase, and which the timed loop ran with
-    t_state, t_lds, t_ms = eng.tuning()
-    tuning = {"state": ("off", "sampling", "waiting", "decided",
-                        "counting launches")[t_state],
-              "resident_lds": t_lds if t_state == 3 else None,
-              "workgroups_per_cu": ({65536: 2, 32768: 4}.get(t_lds)
-                                    if t_state == 3 else None),
-              "ms_at_two_per_cu": t_ms[0] if t_state == 3 else None,
-              "ms_at_four_per_cu": t_ms[1] if t_state == 3 else None,
-              "note": "which is faster is a property of the allocation the "
-                      "arrays live in: after 48 launches 8 alternate, the "
-                      "medians decide if they are steady (rt_tuning); results "
-                      "do not depend on it"}
+    # where the result arrays live: pieces of device memory in a measured mix
+    # of memory classes (rt_placement); store-bound traces then run four
+    # workgroups per CU from the first launch on, two otherwise
+    placement = eng.placement()
+    placement["workgroups_per_cu_cap"] = 4 if placement["mixed"] else 2
+    placement["note"] = (
+        "the speed of the trace's simultaneous row streams is a property of "
+        "the physical memory behind the arrays (bare store pattern: 7.0 / "
+        "6.3 / 5.65 TB/s); arrays >= 1.5 GiB are built from pieces whose "
+        "class is measured at allocation (~1 ms each) and mixed "
+        "(csrc/rt_place.h); results do not depend on it")
     gather_ms = gather_exposed = None
     if dist_mode:
         if final_gather and job.exchange:
@@ -1088,7 +1085,7 @@ def main():
                 (alg_bytes - read_bytes + 48*n)/(kernel_ms*1e-3)/1e9 /
                 HBM_PEAK_GBS,
             "frac_of_achievable_6290": achieved/HBM_ACHIEVABLE_GBS,
-            "resident_workgroups": tuning,
+            "placement": placement,
         },
     }
     if dist_mode:

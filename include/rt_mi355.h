@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2 /* 2: rt_surface.rc, rt_selftest_arith, rt_comm_info;
+                           the default asphere arithmetic; no rt_probe */
 #define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
 #define RT_MAX_SURFACES 256 /* elements per System */
 
@@ -65,6 +66,13 @@ extern "C" {
  * (csrc/rt_math.h) -- same iteration, results inside the 1e-8 contract for
  * iterated aspheres instead of bit-identical to the reference */
 #define RT_F_FAST 0x400u
+/* set by the library (rt_set_option "range_shortcuts" = 0 clears it): the
+ * element's wave-uniform operands (c of a sphere, mu^2 - 1 of a refracting
+ * surface) have magnitudes in [2^-100, 2^100], so its IEEE quotients and
+ * square roots may run without the compiler's range scaffolding wherever the
+ * per-ray operands are in that range too -- the same bits from fewer
+ * instructions (csrc/rt_math.h, "IEEE quotients and square roots ...") */
+#define RT_F_RANGE 0x800u
 
 /* which array (rt_download / rt_upload_row / rt_device_ptr) */
 #define RT_Y 0 /* intercepts, element-normal frame, relative to vertex */
@@ -102,6 +110,7 @@ typedef enum rt_status {
  *   rot[9]         element.rot_normal row-major; identity if not rotated
  *   asph[i]        aspherics[i], coefficient of r^(2(i+1))      (:448-454)
  *   dasph[i]       2*(i + 1)*aspherics[i]                       (:469-473)
+ *   rc             not the caller's: filled in by the library
  */
 typedef struct rt_surface {
     double c, k, kw, kc2;
@@ -114,11 +123,25 @@ typedef struct rt_surface {
     double dasph[RT_MAX_ASPH];
     int32_t nasph;
     uint32_t flags;
+    double rc; /* set by the library ON THE DEVICE: 1/c as the device's
+                  division sequence refines it (csrc/rt_math.h); callers
+                  leave it 0 */
 } rt_surface;
 
 typedef struct rt_ctx rt_ctx;
 
 int rt_abi_version(void);
+/*
+ * Self-test of the arithmetic the trace kernels rely on (csrc/rt_math.h):
+ * n operand triples drawn on the device from `seed`, magnitudes 2^-span ..
+ * 2^span plus edge values; every IEEE quotient and square root that runs
+ * without the compiler's range scaffolding is compared with the compiler's
+ * own sequence, bit for bit.  mismatches[0..2] (refraction quotient, table
+ * quotient, square root) must be 0 for any span; mismatches[3] counts how
+ * often the unguarded core alone would differ (0 for span <= 100).
+ */
+int rt_selftest_arith(rt_ctx *ctx, uint64_t seed, int64_t n, int span,
+                      uint64_t mismatches[4]);
 int rt_sizeof_surface(void); /* sizeof(rt_surface), layout check for FFI */
 /* number of visible HIP devices (0 and RT_ERR_HIP text when there is none) */
 int rt_device_count(int *count);
@@ -340,9 +363,12 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * dynamic LDS per workgroup of the trace kernels, i.e. a cap of 160 KB / bytes
  * on the workgroups resident per CU: traces that store their rows run with two
  * workgroups per CU, which the memory side likes better than the seven the
- * registers allow; FP64-bound traces are not capped), "tune_resident" (1 =
- * default: large store-bound traces measure two against four workgroups per
- * CU on the allocation they live in and keep the faster, rt_tuning; 0 = two).
+ * registers allow, four where the arrays lie in a measured mix of memory
+ * classes, rt_placement; FP64-bound traces are not capped), "placement"
+ * (rt_placement), "range_shortcuts" (1 = default: IEEE quotients and square
+ * roots run without the compiler's range scaffolding where the operands are
+ * checked to be inside [2^-100, 2^100] -- the same bits from a third fewer
+ * instructions, RT_F_RANGE; 0 = the compiler's sequences everywhere).
  * Measurement-only variants and the memory-system probes live in a separate
  * laboratory build (include/rt_mi355_probes.h), not in this library.
  */
@@ -470,22 +496,25 @@ int rt_comm_sync(rt_ctx *ctx);
 int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
 
 /*
- * Two or four workgroups per CU: which of the two a large store-bound trace
- * runs faster with is a property of the allocation its arrays live in, so the
- * engine measures it: once a trace of >= 2^20 rays has been launched 48 times
- * in one shape (a device coming out of idle ranks the two differently), 8
- * launches alternate and the medians decide -- provided the launches were back
- * to back and the samples of each setting agree to 4 %; otherwise the
- * measurement is repeated later, up to 6 times (option "tune_resident",
- * default 1; results never depend on it).  state: 0 = not measuring (switched
- * off, a cap set by hand, small batches, nothing launched yet), 4 = counting
- * launches, 1 = sampling, 2 = waiting for the samples, 3 = decided:
- * *resident_lds = the cap chosen (bytes of unused LDS per workgroup: 65536 =
- * two per CU, 32768 = four), ms2[0] / ms2[1] = median launch time at two / at
- * four per CU (both 0 if no steady measurement was ever had and the default
- * stayed).
+ * Where the result arrays live.  The speed of a trace's 7-10 simultaneous row
+ * streams depends on the physical memory behind the arrays (measured: 7.0 /
+ * 6.3 / 5.65 TB/s for the bare store pattern of C3; pieces of device memory
+ * fall into classes, and streams dealt over pieces of two or three classes
+ * run at the fast level, streams inside one class -- every plain hipMalloc of
+ * 10 GB seen -- at the slow one: csrc/rt_place.h).  Arrays of >= 1.5 GiB are
+ * therefore built from pieces (hipMemCreate, 1 GiB; three pieces for smaller
+ * arrays) whose class the library measures at rt_reserve with a ~1 ms pair
+ * test each, an even mix of classes mapped behind one address range, the
+ * surplus released (option "placement", default 1; RT_MI355_PLACEMENT=0 for
+ * the whole process; plain hipMalloc if anything on the way fails; results
+ * never depend on it).  info[0] = pieces behind the arrays (0: hipMalloc),
+ * [1] = MiB per piece, [2] = pieces created on the way, [3] = classes seen,
+ * [4..6] = pieces of class 0 / 1 / 2 kept, [7] = 1 if no class holds more
+ * than 60 % (store-bound traces then run four workgroups per CU instead of
+ * two); ms[0] / ms[1] = the pair test's launch time inside one piece /
+ * across two classes.
  */
-int rt_tuning(rt_ctx *ctx, int *state, int *resident_lds, double *ms2);
+int rt_placement(rt_ctx *ctx, int info[8], double ms[2]);
 
 /* device scratch owned by the context (e.g. gather destination on root) */
 int rt_scratch(rt_ctx *ctx, int64_t bytes, void **out);

@@ -22,9 +22,7 @@
  * / "alloc_vmm_shuffle" / "alloc_vmm_seed" (the arrays live in a virtual
  * address range backed by hipMemCreate chunks of that many MiB, mapped in
  * order or in a pseudo-random order; a new seed re-maps the same chunks at
- * once), "tune_min_rays" / "tune_warm" (thresholds of the occupancy tuner,
- * rt_tuning, so that tests/tools/fuzz_state.py can run it on small batches:
- * RT_FUZZ_TUNE=1).  What they showed: profiles/r03_probes/README.md, "Placement".
+ * once).  What they showed: profiles/r03_probes/README.md, "Placement".
  */
 #ifndef RT_MI355_PROBES_H
 #define RT_MI355_PROBES_H

@@ -16,6 +16,7 @@ F_ROTATED, F_CURVED, F_CONIC, F_ASPH, F_ALT, F_REFRACT, F_MIRROR = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40)
 F_FAST = 0x400          # set by the library (default; "exact_asphere" clears)
 RT_Y, RT_U, RT_I, RT_T = 0, 1, 2, 3
+RT_ABI_VERSION = 2      # include/rt_mi355.h
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 
 SURFACE_DTYPE = np.dtype([
@@ -28,6 +29,7 @@ SURFACE_DTYPE = np.dtype([
     ("asph", "f8", (RT_MAX_ASPH,)),
     ("dasph", "f8", (RT_MAX_ASPH,)),
     ("nasph", "i4"), ("flags", "u4"),
+    ("rc", "f8"),           # the library's (device-side 1/c), callers leave 0
 ], align=True)
 
 OPD_ARGS_DTYPE = np.dtype([
@@ -137,9 +139,11 @@ SIGNATURES = {
     "rt_gather_ms": (ctypes.c_int, [_ctx, _c_double_p, _c_double_p]),
     "rt_comm_sync": (ctypes.c_int, [_ctx]),
     "rt_input_uniform": (ctypes.c_int, [_ctx, _c_int64_p]),
-    "rt_tuning": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_int),
-                                 ctypes.POINTER(ctypes.c_int),
-                                 ctypes.POINTER(ctypes.c_double)]),
+    "rt_placement": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_int),
+                                    ctypes.POINTER(ctypes.c_double)]),
+    "rt_selftest_arith": (ctypes.c_int, [_ctx, ctypes.c_uint64,
+                                         ctypes.c_int64, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_uint64)]),
     "rt_scratch": (ctypes.c_int, [_ctx, ctypes.c_int64,
                                   ctypes.POINTER(ctypes.c_void_p)]),
     "rt_copy_to_host": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p,
@@ -181,6 +185,11 @@ def load(path=None):
         if fn is not None:
             fn.restype = res
             fn.argtypes = args
+    if lib.rt_abi_version() != RT_ABI_VERSION:
+        raise EngineError(
+            "%s speaks ABI version %d, this package %d: rebuild it "
+            "(python -m rayopt_amd._build)" % (path, lib.rt_abi_version(),
+                                               RT_ABI_VERSION))
     if lib.rt_sizeof_surface() != SURFACE_DTYPE.itemsize:
         raise EngineError("struct rt_surface is %d bytes in the library but "
                           "%d in SURFACE_DTYPE" % (lib.rt_sizeof_surface(),

@@ -69,8 +69,6 @@ struct rt_lab {
     size_t vmm_bytes, vmm_chunk;
     void *vmm_handles; /* hipMemGenericAllocationHandle_t[vmm_n] */
     size_t vmm_n;
-    int tune_min_rays, tune_warm; /* > 0: thresholds of the occupancy tuner
-                         (rt_tune) for the state fuzz, which runs small */
     int alloc_round;  /* the allocation is rounded up: 0 no, 1..40 to a
                          multiple of 2^k bytes, 99 to a power of two */
     size_t base_off;  /* doubles: the arrays start this far into d_buf (the
@@ -80,39 +78,20 @@ struct rt_lab {
 #endif
 
 /*
- * Two or four workgroups per CU for a store-bound trace?  Which is faster is a
- * property of the ALLOCATION the result arrays live in (the physical memory
- * behind it), stable for its life and different from one allocation to the
- * next: at four per CU the same launch takes 1.18-1.20 ms in one allocation
- * and 1.31-1.36 ms in another, at two per CU 1.215-1.24 ms in all of them
- * (profiles/r03_probes/README.md, "placement").  So it is measured: once a
- * large trace of one shape has been launched RT_TUNE_WARM times (a device
- * coming out of idle ranks the two differently for its first ~50 launches),
- * RT_TUNE_SAMPLES launches alternate between the two, timed with events
- * nobody waits for; when the last has completed the medians decide -- if the
- * samples of each setting agree among themselves and the launches were back
- * to back; otherwise the measurement is repeated later, a few times.  Results
- * do not depend on the choice.
+ * Where the result arrays live (rt_place.h): pieces of device memory whose
+ * "class" was measured, mapped behind one address range in an even mix.
  */
-#define RT_TUNE_SAMPLES 8
-#define RT_TUNE_WARM 48        /* launches of the shape before sampling */
-#define RT_TUNE_RETRIES 6      /* measurements that may be thrown away */
-#define RT_TUNE_RESETS 6       /* shapes tried per allocation before giving up */
-#define RT_TUNE_MIN_RAYS ((int64_t)1 << 20)
-#define RT_TUNE_GAIN 0.985     /* the alternative must be 1.5 % faster */
-#define RT_TUNE_SPREAD 0.04    /* samples of one setting agree to 4 % */
-#define RT_TUNE_GAP_MS 0.3f    /* idle time between sampled launches */
-struct rt_tune {
-    const void *buf;           /* allocation the measurements belong to */
-    int kind, start, stop, clip;
-    int64_t n;                 /* shape of the launches being measured */
-    int state;                 /* 0 idle, 1 sampling, 2 waiting, 3 decided,
-                                  4 warming up (counting launches) */
-    int nsample, resets, seen, retries;
-    int choice;                /* bytes of unused LDS per workgroup */
-    float ms[2];               /* median launch time: default, alternative */
-    int have_events;
-    hipEvent_t e0[RT_TUNE_SAMPLES], e1[RT_TUNE_SAMPLES];
+#define RT_PLACE_CLASSES 4
+struct rt_place {
+    void *base;      /* the mapped range (= d_buf), NULL: plain hipMalloc */
+    size_t bytes, piece;
+    int n;           /* pieces mapped */
+    void *handles;   /* hipMemGenericAllocationHandle_t[n] */
+    int created;     /* pieces created on the way (the surplus was released) */
+    int nclass;      /* classes seen */
+    int count[RT_PLACE_CLASSES]; /* pieces of each class among the n */
+    int mixed;       /* no class holds more than 60 % of the pieces */
+    float self_ms, cross_ms; /* pair test: same piece / another class */
 };
 
 struct rt_ctx {
@@ -171,12 +150,12 @@ struct rt_ctx {
     int opt_alias;
     int opt_fuse; /* build generated rays inside the first trace */
     int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
+    int opt_range; /* quotients / roots without range scaffolding (RT_F_RANGE) */
     int opt_resident; /* bytes of unused dynamic LDS per workgroup of the
                          trace kernels: caps the workgroups resident per CU
                          (160 KB / bytes); -1 = chosen per trace */
-    int opt_tune;     /* measure two against four workgroups per CU on this
-                         allocation (rt_tune below); default on */
-    struct rt_tune tune;
+    int opt_place;    /* large arrays in class-mixed pieces (rt_place.h) */
+    struct rt_place place;
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
     int opt_compact_every; /* survivors are counted at every k-th element */
     int last_compact; /* the last trace ran the compacting kernel */
@@ -332,21 +311,11 @@ static inline int64_t rt_ld_quantum(const rt_ctx *c)
 {
     return c->lab.tile ? c->lab.tile : 64;
 }
-static inline int64_t rt_tune_min_rays(const rt_ctx *c)
-{
-    return c->lab.tune_min_rays > 0 ? c->lab.tune_min_rays : RT_TUNE_MIN_RAYS;
-}
-static inline int rt_tune_warm(const rt_ctx *c)
-{
-    return c->lab.tune_warm > 0 ? c->lab.tune_warm : RT_TUNE_WARM;
-}
 static inline int rt_group_quantum(const rt_ctx *c) { return 64 * c->lab.r; }
 static inline int rt_gen_block(const rt_ctx *c) { return c->lab.block; }
 static inline size_t rt_gen_lds(const rt_ctx *c) { return (size_t)c->lab.lds; }
 #else
 static inline bool rt_lab_variant(const rt_ctx *) { return false; }
-static inline int64_t rt_tune_min_rays(const rt_ctx *) { return RT_TUNE_MIN_RAYS; }
-static inline int rt_tune_warm(const rt_ctx *) { return RT_TUNE_WARM; }
 static inline int64_t rt_ld_quantum(const rt_ctx *) { return 64; }
 static inline int rt_group_quantum(const rt_ctx *) { return 64; }
 #endif

@@ -38,6 +38,7 @@
 
 #include "rt_ctx.h"
 #include "rt_trace_kernels.h"
+#include "rt_place.h"
 
 static char g_err[512] = "";
 
@@ -133,124 +134,39 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
         return 0;
     if (newton)
         return c->opt_fast ? 32768 : 0;
-    return 65536;
+    /* store bound: four workgroups per CU where the arrays lie in a mix of
+     * memory classes (rt_place.h: 1.12 ms against 1.25 with two), two where
+     * they do not -- two per CU is the setting that does not care where it
+     * writes (1.22-1.25 ms in any allocation; four: 1.35 in a bad one) */
+    return c->place.mixed ? 32768 : 65536;
 }
 
-static void rt_tune_forget(rt_ctx *c)
+/* the result arrays: class-mixed pieces (rt_place.h); the laboratory build
+ * can ask for other kinds of allocation instead */
+static hipError_t rt_buf_alloc(rt_ctx *c, void **out, size_t bytes)
 {
-    c->tune.buf = NULL;
-    c->tune.state = 0;
-    c->tune.resets = 0;
+#ifdef RT_BUILD_PROBES
+    if (c->lab.vmm_mb > 0) {
+        memset(&c->place, 0, sizeof c->place);
+        return rt_lab_alloc(c, out, bytes);
+    }
+#endif
+    return rt_place_alloc(c, out, bytes);
 }
 
-static int rt_cmp_float(const void *a, const void *b)
+static hipError_t rt_buf_free(rt_ctx *c, void *p)
 {
-    const float x = *(const float *)a, y = *(const float *)b;
-    return x < y ? -1 : x > y;
+#ifdef RT_BUILD_PROBES
+    if (p && p != c->place.base)
+        return rt_lab_free(c, p);
+#endif
+    return rt_place_free(c, p);
 }
 
-/*
- * The cap for this launch (rt_tune in rt_ctx.h): `lds` is what
- * rt_resident_lds chose; *slot >= 0 = the launch is a sample, bracket it with
- * e0[*slot] / e1[*slot].
- */
-static size_t rt_tune_pick(rt_ctx *c, size_t lds, int kind, int start,
-                           int stop, int clip, int *slot)
+static bool rt_in_range(double x)
 {
-    rt_tune &t = c->tune;
-    *slot = -1;
-    if (!c->opt_tune || c->opt_resident >= 0 || lds != 65536 ||
-        c->n < rt_tune_min_rays(c))
-        return lds;
-    if (t.buf != c->d_buf) { /* a new allocation: measure again */
-        t.buf = c->d_buf;
-        t.resets = 0;
-        t.state = 0;
-    }
-    const bool same = t.state && t.kind == kind && t.start == start &&
-                      t.stop == stop && t.clip == clip && t.n == c->n;
-    if (!same) {
-        if (t.resets >= RT_TUNE_RESETS)
-            return lds; /* a caller that changes shape with every launch */
-        if (!t.have_events) {
-            for (int k = 0; k < RT_TUNE_SAMPLES; ++k)
-                if (hipEventCreate(&t.e0[k]) != hipSuccess ||
-                    hipEventCreate(&t.e1[k]) != hipSuccess) {
-                    (void)hipGetLastError();
-                    c->opt_tune = 0;
-                    return lds;
-                }
-            t.have_events = 1;
-        }
-        ++t.resets;
-        t.kind = kind;
-        t.start = start;
-        t.stop = stop;
-        t.clip = clip;
-        t.n = c->n;
-        t.state = 4;
-        t.seen = 0;
-        t.retries = 0;
-    }
-    if (t.state == 4) { /* not before the device has warmed up on this shape */
-        if (++t.seen < rt_tune_warm(c))
-            return lds;
-        t.state = 1;
-        t.nsample = 0;
-    }
-    if (t.state == 1) {
-        *slot = t.nsample;
-        const size_t pick = (t.nsample & 1) ? 32768 : 65536;
-        if (++t.nsample == RT_TUNE_SAMPLES)
-            t.state = 2;
-        return pick;
-    }
-    if (t.state == 2) {
-        if (hipEventQuery(t.e1[RT_TUNE_SAMPLES - 1]) != hipSuccess) {
-            (void)hipGetLastError(); /* not ready is not an error */
-            return lds;
-        }
-        /* the first pair is dropped; three samples per setting.  The
-         * measurement counts only if the launches were back to back and the
-         * samples of each setting agree: a device that is still ramping its
-         * clocks, or a caller that waits between launches, is measured
-         * again later */
-        float ms[2][RT_TUNE_SAMPLES / 2];
-        int cnt[2] = {0, 0};
-        bool ok = true, steady = true;
-        for (int k = 2; k < RT_TUNE_SAMPLES && ok; ++k) {
-            float gap = 0.f;
-            ok = hipEventElapsedTime(&ms[k & 1][cnt[k & 1]++], t.e0[k],
-                                     t.e1[k]) == hipSuccess &&
-                 hipEventElapsedTime(&gap, t.e1[k - 1], t.e0[k]) == hipSuccess;
-            steady = steady && gap < RT_TUNE_GAP_MS;
-        }
-        if (!ok) {
-            (void)hipGetLastError();
-            c->opt_tune = 0; /* events that cannot be read: no measuring */
-            return lds;
-        }
-        for (int q = 0; q < 2; ++q) {
-            qsort(ms[q], cnt[q], sizeof(float), rt_cmp_float);
-            t.ms[q] = ms[q][cnt[q] / 2];
-            steady = steady && ms[q][cnt[q] - 1] - ms[q][0] <=
-                                   RT_TUNE_SPREAD * ms[q][0];
-        }
-        if (!steady) {
-            if (++t.retries > RT_TUNE_RETRIES) {
-                t.choice = (int)lds; /* never steady: the default stays */
-                t.ms[0] = t.ms[1] = 0.f;
-                t.state = 3;
-                return lds;
-            }
-            t.state = 4;
-            t.seen = 0;
-            return lds;
-        }
-        t.choice = t.ms[1] < RT_TUNE_GAIN * t.ms[0] ? 32768 : 65536;
-        t.state = 3;
-    }
-    return (size_t)t.choice;
+    const double a = fabs(x);
+    return a >= RT_RANGE_TINY && a <= 0x1p99; /* strictly inside the guard */
 }
 
 /* the compacting variant pays (one barrier per element) only where dead rays
@@ -327,7 +243,11 @@ int rt_create(int device, rt_ctx **out)
         c->opt_fast = (e && atoi(e)) ? 0 : 1;
     }
     c->opt_resident = -1;
-    c->opt_tune = 1;
+    c->opt_range = 1;
+    {
+        const char *e = getenv("RT_MI355_PLACEMENT");
+        c->opt_place = (e && !atoi(e)) ? 0 : 1;
+    }
     c->opt_uniform = 1;
     c->opt_compact_every = 4; /* measured best, profiles/r02_probes */
 #define RT_HIP_C(call)                                                        \
@@ -391,13 +311,8 @@ int rt_destroy(rt_ctx *ctx)
     if (ctx->comm_stream)
         (void)hipStreamSynchronize(ctx->comm_stream);
     rt_comm_destroy(ctx);
-#ifdef RT_BUILD_PROBES
     if (ctx->d_buf)
-        (void)rt_lab_free(ctx, ctx->d_buf);
-#else
-    if (ctx->d_buf)
-        (void)hipFree(ctx->d_buf);
-#endif
+        (void)rt_buf_free(ctx, ctx->d_buf);
     if (ctx->d_uni)
         (void)hipFree(ctx->d_uni);
     if (ctx->d_scratch)
@@ -437,11 +352,6 @@ int rt_destroy(rt_ctx *ctx)
         rt_event_free(ctx->staged[i]);
         rt_event_free(ctx->gathered[i]);
     }
-    if (ctx->tune.have_events)
-        for (int k = 0; k < RT_TUNE_SAMPLES; ++k) {
-            rt_event_free(ctx->tune.e0[k]);
-            rt_event_free(ctx->tune.e1[k]);
-        }
     rt_event_free(ctx->g0);
     rt_event_free(ctx->g1);
     for (int i = 0; i < RT_NEVENTS; ++i)
@@ -569,22 +479,12 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
         ctx->ld = 0;
         ctx->traced = 0;
         memset(ctx->valid, 0, sizeof ctx->valid);
-#ifdef RT_BUILD_PROBES
         if (ctx->d_buf)
-            RT_HIP(ctx, rt_lab_free(ctx, ctx->d_buf));
-#else
-        if (ctx->d_buf)
-            RT_HIP(ctx, hipFree(ctx->d_buf));
-#endif
+            RT_HIP(ctx, rt_buf_free(ctx, ctx->d_buf));
         ctx->d_buf = NULL;
         ctx->cap_doubles = 0;
-        rt_tune_forget(ctx); /* what was measured belonged to that memory */
-#ifdef RT_BUILD_PROBES
-        hipError_t e = rt_lab_alloc(ctx, (void **)&ctx->d_buf,
+        hipError_t e = rt_buf_alloc(ctx, (void **)&ctx->d_buf,
                                     need * sizeof(double));
-#else
-        hipError_t e = hipMalloc((void **)&ctx->d_buf, need * sizeof(double));
-#endif
         if (e != hipSuccess) {
             (void)hipGetLastError();
             return rt_fail(ctx, RT_ERR_NOMEM,
@@ -1072,11 +972,30 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
                 for (int q = S->nasph; q < RT_MAX_ASPH; ++q)
                     S->asph[q] = S->dasph[q] = 0.;
             }
+            /* IEEE quotients / square roots without their range
+             * scaffolding (rt_math.h): the element's own operands must be
+             * inside the range the per-ray checks assume */
+            f &= ~RT_F_RANGE;
+            if (ctx->opt_range) {
+                const rt_surface *S = ctx->h_stage + jj;
+                const bool sphere = (f & RT_F_CURVED) &&
+                                    !(f & (RT_F_CONIC | RT_F_ASPH));
+                const bool snell = (f & RT_F_REFRACT) && !(f & RT_F_MIRROR);
+                if ((!sphere || rt_in_range(S->c)) &&
+                    (!snell || rt_in_range(S->mu2m1)) &&
+                    (!(f & RT_F_REFRACT) || rt_in_range(S->muf)))
+                    f |= RT_F_RANGE;
+            }
             ctx->h_stage[jj].flags = f;
+            ctx->h_stage[jj].rc = 0.;
         }
         RT_HIP(ctx, hipMemcpyAsync(ctx->d_surf, ctx->h_stage,
                                    sizeof(rt_surface) * ntab,
                                    hipMemcpyHostToDevice, ctx->stream));
+        /* rt_surface.rc: 1/c as the device's division refines it */
+        hipLaunchKernelGGL(rt_table_finish_kernel, dim3((ntab + 63) / 64),
+                           dim3(64), 0, ctx->stream, ctx->d_surf, ntab);
+        RT_HIP(ctx, hipGetLastError());
         ctx->table_dirty = 0;
         ctx->table_start = start;
         ctx->table_clip = clip != 0;
@@ -1114,20 +1033,7 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
     const int64_t cols = (hi == ctx->n ? ctx->ld : hi) - lo;
     const int64_t group_rays = ctx->ngroups > 1 ? ctx->n / ctx->ngroups : 0;
     const unsigned grid = (unsigned)((cols + RT_BLOCK - 1) / RT_BLOCK);
-    size_t lds = rt_resident_lds(ctx, start, stop);
-    int sample = -1;
-    if (cols > 0 && start < stop && !windowed && !fused &&
-        !rt_lab_variant(ctx) && !rt_use_compact(ctx, start, stop))
-        lds = rt_tune_pick(ctx, lds, (regen ? 1 : 0) | (ctx->opt_alias ? 2 : 0),
-                           start, stop, clip != 0,
-                           &sample);
-    else if (windowed && lds == 65536 && ctx->opt_tune &&
-             ctx->opt_resident < 0 && ctx->tune.state == 3 &&
-             ctx->tune.buf == ctx->d_buf)
-        lds = (size_t)ctx->tune.choice; /* pieces of a trace run with what
-                                           the whole one was measured to like */
-    if (sample >= 0)
-        RT_HIP(ctx, hipEventRecord(ctx->tune.e0[sample], ctx->stream));
+    const size_t lds = rt_resident_lds(ctx, start, stop);
     if (cols <= 0 || start >= stop) {
         /* an empty window, or nothing to trace */
     } else if (fused || regen) {
@@ -1166,8 +1072,6 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
                            cols, group_rays, ctx->nsurf, tiles);
         RT_HIP(ctx, hipGetLastError());
     }
-    if (sample >= 0)
-        RT_HIP(ctx, hipEventRecord(ctx->tune.e1[sample], ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
     for (int sidx = start; sidx < stop; ++sidx) {
         const unsigned f = ctx->h_stage[sidx].flags;
@@ -1269,11 +1173,15 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         if (fast != ctx->opt_fast)
             ctx->table_dirty = 1;
         ctx->opt_fast = fast;
+    } else if (!strcmp(key, "range_shortcuts")) {
+        if ((value != 0) != ctx->opt_range)
+            ctx->table_dirty = 1;
+        ctx->opt_range = value ? 1 : 0;
     } else if (!strcmp(key, "uniform_input")) {
         ctx->opt_uniform = value ? 1 : 0;
-    } else if (!strcmp(key, "tune_resident")) {
-        ctx->opt_tune = value ? 1 : 0;
-        rt_tune_forget(ctx);
+    } else if (!strcmp(key, "placement")) {
+        /* takes effect with the next allocation of the result arrays */
+        ctx->opt_place = value ? 1 : 0;
     } else if (!strcmp(key, "resident_lds")) {
         if (value < -1 || value > 65536)
             return rt_fail(ctx, RT_ERR_ARG,
@@ -1420,16 +1328,50 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7)
     return RT_OK;
 }
 
-int rt_tuning(rt_ctx *ctx, int *state, int *resident_lds, double *ms2)
+int rt_selftest_arith(rt_ctx *ctx, uint64_t seed, int64_t n, int span,
+                      uint64_t mismatches[4])
 {
-    if (!ctx || !state || !resident_lds || !ms2)
-        return rt_fail(ctx, RT_ERR_ARG, "rt_tuning: NULL argument");
-    const rt_tune &t = ctx->tune;
-    *state = (!ctx->opt_tune || ctx->opt_resident >= 0 ||
-              t.buf != ctx->d_buf) ? 0 : t.state;
-    *resident_lds = *state == 3 ? t.choice : -1;
-    ms2[0] = *state == 3 ? t.ms[0] : 0.;
-    ms2[1] = *state == 3 ? t.ms[1] : 0.;
+    if (!ctx || !mismatches || n < 1 || span < 1 || span > 1000)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_selftest_arith: bad argument");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long *d = NULL;
+    RT_HIP(ctx, hipMalloc((void **)&d, 4 * sizeof *d));
+    hipError_t e = hipMemsetAsync(d, 0, 4 * sizeof *d, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rt_selftest_kernel,
+                           dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           ctx->stream, (unsigned long long)seed,
+                           (long long)n, span, d);
+        e = hipGetLastError();
+    }
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+        return rt_fail(ctx, RT_ERR_HIP, "rt_selftest_arith: %s",
+                       hipGetErrorString(e));
+    for (int k = 0; k < 4; ++k)
+        mismatches[k] = h[k];
+    return RT_OK;
+}
+
+int rt_placement(rt_ctx *ctx, int info[8], double ms[2])
+{
+    if (!ctx || !info || !ms)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_placement: NULL argument");
+    const rt_place &p = ctx->place;
+    info[0] = p.base ? p.n : 0;
+    info[1] = (int)(p.piece >> 20);
+    info[2] = p.created;
+    info[3] = p.nclass;
+    for (int k = 0; k < 3; ++k)
+        info[4 + k] = p.count[k];
+    info[7] = p.mixed;
+    ms[0] = p.self_ms;
+    ms[1] = p.cross_ms;
     return RT_OK;
 }
 

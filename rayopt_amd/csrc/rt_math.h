@@ -89,6 +89,92 @@ RT_HD void rt_rot_from(const double *__restrict__ r, double (&v)[3])
     v[2] = rt_dot3(a, b, c, r[2], r[5], r[8]);
 }
 
+/* ------------------------------------------------------------------ */
+/* IEEE quotients and square roots without the range scaffolding      */
+/* ------------------------------------------------------------------ */
+/*
+ * `a / b` and `sqrt(x)` in FP64 are not instructions on gfx950 but sequences
+ * the compiler expands (checked in the ISA of this file's kernels):
+ *
+ *   a / b   v_div_scale x2, v_rcp, 4 FMA (two Newton steps on the reciprocal),
+ *           v_mul, v_fma (residual), v_div_fmas, v_div_fixup      11 VALU
+ *   sqrt    v_cmp + v_cndmask + v_ldexp (scale up below 2^-767), v_rsq,
+ *           2 v_mul, 7 FMA, v_cndmask + v_ldexp (scale back),
+ *           v_cmp_class + 2 v_cndmask (0 and inf pass through)    18 VALU
+ *
+ * The scaffolding -- div_scale / div_fmas / div_fixup, the ldexp pair --
+ * only ACTS at the ends of the exponent range: v_div_scale returns its
+ * operand unchanged and clears VCC unless an operand is zero / denormal /
+ * infinite / NaN, the exponents differ by >= 768, or the quotient or the
+ * reciprocal would be denormal; v_div_fmas with VCC clear IS v_fma;
+ * v_div_fixup returns the quotient it is handed unless an operand is zero,
+ * infinite or NaN.  So for operands with magnitudes in [2^-100, 2^100] the
+ * eleven instructions compute exactly what the seven in rt_rcp_refined +
+ * rt_quot compute -- the same instructions on the same operands -- and the
+ * results are the same bits.  What that buys: (i) two quotients by the same
+ * denominator share the reciprocal (refraction: a = mu (u.r) / r^2 and
+ * b = (mu^2 - 1) / r^2, elements.py:358-366), (ii) a quotient by a
+ * wave-uniform denominator (the sphere's -(d + g) / e with e = c,
+ * elements.py:492-500) takes its refined reciprocal from the surface table
+ * (rt_surface.rc, filled by the device when the table is uploaded).
+ *
+ * The range is CHECKED, per wavefront, with two or three compares: a
+ * wavefront in which any lane holds a finite operand outside the range takes
+ * the compiler's own sequence for all its lanes (scalar branch).  NaN lanes
+ * (dead rays) do not count: both forms give NaN.  Zeros and infinities do
+ * count (the fix-up cases).  RT_F_RANGE on the element says its wave-uniform
+ * operands (c, mu^2 - 1) are inside the range; without it the plain form
+ * runs.  rt_selftest_arith() (include/rt_mi355.h) compares both forms on the
+ * device bit for bit, operands drawn across and beyond the range.
+ *
+ * The host build (tests/hostemu) has IEEE `/` and sqrt() and uses them.
+ */
+#define RT_RANGE_BIG 0x1p100
+#define RT_RANGE_TINY 0x1p-100
+#define RT_SQRT_SCALED_BELOW 0x1p-767
+
+#if defined(__HIP_DEVICE_COMPILE__)
+/* the reciprocal as the division sequence refines it: v_rcp + two steps */
+RT_HD double rt_rcp_refined(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.), r);
+    return r;
+}
+
+/* n / d given r = rt_rcp_refined(d): v_mul, residual, v_div_fmas (VCC = 0) */
+RT_HD double rt_quot(double n, double d, double r)
+{
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+
+/* sqrt(x) for x outside (0, 2^-767): the sequence without its ldexp pair */
+RT_HD double rt_sqrt_unscaled(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * .5;
+    const double r = __builtin_fma(-h, g, .5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    /* +-0 and +inf pass through (v_cmp_class 0x260) */
+    return __builtin_isfpclass(x, 0x260) ? x : g;
+}
+#else
+/* host build: IEEE division and sqrt as they are */
+RT_HD double rt_rcp_refined(double d) { return 1. / d; }
+RT_HD double rt_quot(double n, double d, double r) { (void)r; return n / d; }
+RT_HD double rt_sqrt_unscaled(double x) { return sqrt(x); }
+#endif
+/* a finite magnitude outside [2^-100, 2^100] (zero and inf included)? */
+#define RT_ODD_MAG(x)                                                         \
+    (__builtin_fabs(x) >= RT_RANGE_BIG || __builtin_fabs(x) < RT_RANGE_TINY)
+
 /*
  * sqrt(1 - (1+k) c^2 r^2): the one square root surface_sag (:451) and
  * surface_normal (:468) both evaluate at the same point; computed once per
@@ -97,7 +183,9 @@ RT_HD void rt_rot_from(const double *__restrict__ r, double (&v)[3])
 RT_HD double rt_conic_root(const rt_surface *__restrict__ S, unsigned flags,
                            double r2)
 {
-    return (flags & RT_F_CURVED) ? sqrt(1. - S->kc2 * r2) : 1.;
+    /* 1 - p is exact for p in [1/2, 2] (Sterbenz) and > 1/2 below: the
+     * argument is <= 0, NaN, or >= 2^-53 -- never in (0, 2^-767) */
+    return (flags & RT_F_CURVED) ? rt_sqrt_unscaled(1. - S->kc2 * r2) : 1.;
 }
 
 /* Spheroid.surface_sag(p) residual, elements.py:440-455 */
@@ -491,10 +579,22 @@ RT_HD void rt_intercept(const rt_surface *__restrict__ S, unsigned flags,
             const double d = c * uy - iv[r][2];
             const double e = c * uu;
             const double f = c * yy - 2. * y[r][2];
-            double g = sqrt(d * d - e * f);
+            const double w = d * d - e * f;
+            double g;
+            if (RT_WAVE_ANY(w > 0. && w < RT_SQRT_SCALED_BELOW))
+                g = sqrt(w);
+            else
+                g = rt_sqrt_unscaled(w);
             if (flags & RT_F_ALT)
                 g *= -1.;
-            s[r] = -(d + g) / e;
+            const double num = -(d + g);
+            /* e = c * 1. = c on a sphere: wave-uniform, its refined
+             * reciprocal comes with the table */
+            if ((flags & (RT_F_RANGE | RT_F_CONIC)) != RT_F_RANGE ||
+                RT_WAVE_ANY(RT_ODD_MAG(num)))
+                s[r] = num / e;
+            else
+                s[r] = rt_quot(num, c, S->rc);
         }
     }
 }
@@ -618,15 +718,33 @@ RT_HD void rt_step_bend(const rt_surface *__restrict__ S, unsigned flags,
             }
             const double r2 = (qx * qx + qy * qy) + 1.;
             const double dot = (u[r][0] * qx + u[r][1] * qy) + u[r][2] * 1.;
-            const double a = S->muf * dot / r2;
+            const double num = S->muf * dot;
+            double a, g = 0.;
+            /* r2 >= 1 or NaN: only its upper end needs the check */
+            if ((flags & RT_F_RANGE) &&
+                !RT_WAVE_ANY(r2 >= RT_RANGE_BIG || RT_ODD_MAG(num))) {
+                const double rr = rt_rcp_refined(r2);
+                a = rt_quot(num, r2, rr);
+                if (!(flags & RT_F_MIRROR)) {
+                    /* in range a*a and b are both >= 2^-400 in magnitude:
+                     * their difference is 0 or >= 2^-453, never inside
+                     * (0, 2^-767) */
+                    const double b = rt_quot(S->mu2m1, r2, rr);
+                    g = -a + S->smu * rt_sqrt_unscaled(a * a - b);
+                }
+            } else {
+                a = num / r2;
+                if (!(flags & RT_F_MIRROR)) {
+                    const double b = S->mu2m1 / r2;
+                    g = -a + S->smu * sqrt(a * a - b);
+                }
+            }
             if (flags & RT_F_MIRROR) {
                 const double a2 = 2. * a;
                 u[r][0] = u[r][0] - a2 * qx;
                 u[r][1] = u[r][1] - a2 * qy;
                 u[r][2] = u[r][2] - a2 * 1.;
             } else {
-                const double b = S->mu2m1 / r2;
-                const double g = -a + S->smu * sqrt(a * a - b);
                 u[r][0] = S->muf * u[r][0] + g * qx;
                 u[r][1] = S->muf * u[r][1] + g * qy;
                 u[r][2] = S->muf * u[r][2] + g * 1.;

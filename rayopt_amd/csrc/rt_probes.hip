@@ -197,12 +197,7 @@ int rt_lab_set_option(rt_ctx *ctx, const char *key, int value)
             ctx->n = 0;
             ctx->ld = 0;
             memset(ctx->valid, 0, sizeof ctx->valid);
-            ctx->tune.buf = NULL;
         }
-    } else if (!strcmp(key, "tune_min_rays")) {
-        l.tune_min_rays = value; /* 0 = the shipped threshold */
-    } else if (!strcmp(key, "tune_warm")) {
-        l.tune_warm = value;
     } else if (!strcmp(key, "alloc_round")) {
         /* size of the allocation behind the arrays: rounded up to a multiple
          * of 2^value bytes (4..40), or to a power of two (99); takes effect
@@ -338,7 +333,8 @@ int rt_probe(rt_ctx *ctx, int mode, double *ms, double *bytes)
     } while (0)
 #define RT_PROBE_FL(IN, RP, SI, FL)                                           \
     hipLaunchKernelGGL((rt_probe_pattern_kernel<IN, RP, FL>), dim3(grid),     \
-                       dim3(block), 0, ctx->stream, 1, L, win, lay, ld, SI)
+                       dim3(block), (size_t)ctx->lab.lds, ctx->stream, 1, L, win, lay, \
+                       ld, SI)
         switch (mode) {
         case 0: RT_PROBE(0, 2, 1); break;
         case 5: RT_PROBE(1, 2, 1); break;

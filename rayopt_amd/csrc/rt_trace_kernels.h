@@ -386,4 +386,111 @@ __global__ void rt_generate_kernel(const rt_field *__restrict__ fields,
     a.T[col] = 0.;
 }
 
+/*
+ * After a surface table has been copied to the device: the refined
+ * reciprocal of every curved element's c, formed by the device's own
+ * division sequence (rt_rcp_refined, rt_math.h).  One thread per element.
+ */
+__global__ void rt_table_finish_kernel(rt_surface *__restrict__ tab, int ntab)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < ntab)
+        tab[j].rc = (tab[j].flags & RT_F_CURVED) ? rt_rcp_refined(tab[j].c) : 0.;
+}
+
+/*
+ * rt_selftest_arith: the quotient and the square root without the range
+ * scaffolding against the compiler's sequences, bit for bit, on operands
+ * drawn from a counter-based generator: magnitudes 2^e with e uniform in
+ * [-span, span], random mantissas and signs, plus the edge values (0, inf,
+ * NaN, denormals, the guard limits and their neighbours) every 64th draw.
+ * The guarded forms are exactly the ones rt_math.h uses: outside the range
+ * they fall back, so they must agree EVERYWHERE; `raw` counts how often the
+ * unguarded core differs (expected > 0 only when span > 100).
+ */
+__device__ __forceinline__ unsigned long long rt_mix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ double rt_draw(unsigned long long key, int span)
+{
+    const unsigned long long h = rt_mix64(key);
+    if ((h & 63ull) == 0ull) {
+        const double edge[16] = {0., -0., __builtin_inf(), -__builtin_inf(),
+                                 __builtin_nan(""), 0x1p-1074, 0x1p-1022,
+                                 RT_RANGE_BIG, RT_RANGE_TINY, 0x1p-767,
+                                 0x1.fffffffffffffp99, 0x1.fffffffffffffp-101,
+                                 1., 0x1.fffffffffffffp-1, 0x1p1023, 0x1p-969};
+        return edge[(h >> 6) & 15ull];
+    }
+    const int e = (int)((h >> 12) % (unsigned long long)(2 * span + 1)) - span;
+    const unsigned long long bits =
+        ((h >> 63) << 63) | ((unsigned long long)(1023 + e) << 52) |
+        (rt_mix64(h) >> 12);
+    return __longlong_as_double((long long)bits);
+}
+
+__device__ __forceinline__ bool rt_same_bits(double a, double b)
+{
+    return __double_as_longlong(a) == __double_as_longlong(b) ||
+           (a != a && b != b);
+}
+
+__global__ void rt_selftest_kernel(unsigned long long seed, long long n,
+                                   int span, unsigned long long *counts)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad_q = 0, bad_c = 0, bad_s = 0, raw = 0;
+    if (i < n) {
+        const unsigned long long k = seed * 0x100000001B3ull + 3ull * i;
+        const double num = rt_draw(k, span);
+        double den = rt_draw(k + 1, span);
+        const double x = rt_draw(k + 2, span);
+        /* (1) two quotients sharing r2-like denominators >= 1 (refraction) */
+        const double r2 = __builtin_fabs(den) + 1.;
+        {
+            const double want = num / r2;
+            double got;
+            if (RT_WAVE_ANY(r2 >= RT_RANGE_BIG || RT_ODD_MAG(num)))
+                got = num / r2;
+            else
+                got = rt_quot(num, r2, rt_rcp_refined(r2));
+            bad_q += !rt_same_bits(want, got);
+            raw += !rt_same_bits(want, rt_quot(num, r2, rt_rcp_refined(r2)));
+        }
+        /* (2) a quotient by a table constant (the sphere's c) */
+        {
+            const double want = num / den;
+            double got;
+            if (RT_ODD_MAG(den) || RT_WAVE_ANY(RT_ODD_MAG(num)))
+                got = num / den;
+            else
+                got = rt_quot(num, den, rt_rcp_refined(den));
+            bad_c += !rt_same_bits(want, got);
+        }
+        /* (3) the square root */
+        {
+            const double want = sqrt(x);
+            double got;
+            if (RT_WAVE_ANY(x > 0. && x < RT_SQRT_SCALED_BELOW))
+                got = sqrt(x);
+            else
+                got = rt_sqrt_unscaled(x);
+            bad_s += !rt_same_bits(want, got);
+        }
+    }
+    if (bad_q)
+        atomicAdd(&counts[0], bad_q);
+    if (bad_c)
+        atomicAdd(&counts[1], bad_c);
+    if (bad_s)
+        atomicAdd(&counts[2], bad_s);
+    if (raw)
+        atomicAdd(&counts[3], raw);
+}
+
 #endif /* RT_TRACE_KERNELS_H */

@@ -295,15 +295,27 @@ class Engine:
         self._check(self.lib.rt_input_uniform(self.ctx, t), "rt_input_uniform")
         return list(t[:6]), int(t[6])
 
-    def tuning(self):
-        """(state, resident_lds, (ms at two, ms at four workgroups per CU)):
-        what the engine measured on this allocation (rt_tuning); state 3 =
-        decided."""
-        st, lds = ctypes.c_int(), ctypes.c_int()
+    def placement(self):
+        """Where the result arrays live (rt_placement): dict with the pieces
+        behind them (0 = plain hipMalloc), MiB per piece, pieces created on
+        the way, classes seen, pieces kept per class, ``mixed`` and the pair
+        test's two launch times."""
+        info = (ctypes.c_int*8)()
         ms = (ctypes.c_double*2)()
-        self._check(self.lib.rt_tuning(self.ctx, ctypes.byref(st),
-                                       ctypes.byref(lds), ms), "rt_tuning")
-        return st.value, lds.value, (ms[0], ms[1])
+        self._check(self.lib.rt_placement(self.ctx, info, ms), "rt_placement")
+        return {"pieces": info[0], "piece_mib": info[1], "created": info[2],
+                "classes": info[3], "per_class": [info[4], info[5], info[6]],
+                "mixed": bool(info[7]),
+                "pair_test_ms": {"same_piece": ms[0], "other_class": ms[1]}}
+
+    def selftest_arith(self, seed, n, span=100):
+        """rt_selftest_arith: mismatch counts (refraction quotient, table
+        quotient, square root, unguarded core)."""
+        bad = (ctypes.c_uint64*4)()
+        self._check(self.lib.rt_selftest_arith(self.ctx, int(seed), int(n),
+                                               int(span), bad),
+                    "rt_selftest_arith")
+        return [int(b) for b in bad]
 
     def scratch(self, nbytes):
         p = ctypes.c_void_p()

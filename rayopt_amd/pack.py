@@ -22,8 +22,9 @@ from ._lib import (SURFACE_DTYPE, RT_MAX_ASPH, RT_MAX_SURFACES, F_ROTATED,
 _IDENTITY = (1., 0., 0., 0., 1., 0., 0., 0., 1.)
 _NO_ASPH = (0.,)*(2*RT_MAX_ASPH)
 # rt_surface is 22 + 2*RT_MAX_ASPH doubles (c k kw kc2 radius2 mu muf smu
-# mu2m1 n0 offset[3] rot[9] asph[] dasph[]) followed by nasph, flags
-_ROW_FMT = "%ddiI" % (22 + 2*RT_MAX_ASPH)
+# mu2m1 n0 offset[3] rot[9] asph[] dasph[]) followed by nasph, flags and rc
+# (the library's: the device fills it in, the caller hands over 0)
+_ROW_FMT = "%ddiId" % (22 + 2*RT_MAX_ASPH)
 assert struct.calcsize("<" + _ROW_FMT) == SURFACE_DTYPE.itemsize
 assert [SURFACE_DTYPE.fields[f][1] for f in ("offset", "rot", "asph", "nasph",
                                              "flags")] == \
@@ -203,7 +204,7 @@ def pack_system(system, wavelength, n_init, start=1, stop=None):
             extend(pad)
             extend([2*(q + 1)*x for q, x in enumerate(a)])          # :471-472
             extend(pad)
-        extend((nasph, flags))
+        extend((nasph, flags, 0.))
         if slot is not None:
             rows = el.__dict__.get("_pack_rows")
             if rows is None or len(rows) > 16:

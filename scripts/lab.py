@@ -1,0 +1,301 @@
+"""scripts/lab.py -- the measurement laboratory (round 4 on): one parameterised
+driver instead of one file per session.  Every sub-command prints JSON lines;
+the records that are kept live under profiles/.
+
+    python scripts/lab.py placement [--contexts 5] [--vmm 3] [--launches 24]
+        N contexts (N hipMalloc'ed sets of result arrays, then --vmm sets in
+        1 GiB hipMemCreate chunks), each timed at two and at four resident
+        workgroups per CU with a FIXED launch schedule, so that the dispatch
+        order of a `rocprofv3 --pmc` pass of the same command can be mapped
+        back to (context, setting): `pmc-summary`.
+    python scripts/lab.py pmc-summary <dir with pass*/...counter_collection.csv + pass*.jsonl>
+    python scripts/lab.py nsweep      [--shape c3|c2] (launch time / frac over N)
+    python scripts/lab.py divab       same-process A/B of two builds of the library
+
+Laboratory options (alloc_vmm_mb, lds_pad ...) need the laboratory build:
+python -m rayopt_amd._build probes.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _imports():
+    import rayopt_amd as ra
+    from rayopt_amd import prescriptions as P, _build
+    from rayopt_amd.engine import Engine
+    return ra, P, _build, Engine
+
+
+def lab_lib():
+    from rayopt_amd import _build
+    return os.path.join(os.path.dirname(_build.LIB), "librt_mi355_probes.so")
+
+
+def out(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def block_ms(eng, launches, clip=True, start=1, stop=0):
+    """`launches` back-to-back traces bracketed by events: ms per launch."""
+    eng.event_record(0)
+    for _ in range(launches):
+        eng.trace(start, stop, clip)
+    eng.event_record(1)
+    return eng.event_elapsed(0, 1)/launches
+
+
+def steady(eng, seconds=.8, per=10, **kw):
+    t_end = time.time() + seconds
+    ms = []
+    while time.time() < t_end:
+        ms.append(block_ms(eng, per, **kw))
+    return float(np.median(ms[len(ms)//3:]))
+
+
+# ---------------------------------------------------------------------------
+def cmd_placement(a):
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    n = a.rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = workload_rays(n, 0)
+    lib = lab_lib()
+    keep, count = [], 0          # count = rt_trace_kernel launches so far
+    plan = [("hipMalloc", {})]*a.contexts + [
+        ("vmm_%dMiB" % a.vmm_mb, {"alloc_vmm_mb": a.vmm_mb,
+                                  "alloc_vmm_align_mb": min(a.vmm_mb, 1024)})
+    ]*a.vmm
+    for k, (kind, opts) in enumerate(plan):
+        eng = Engine(0, lib_path=lib)
+        for key, v in opts.items():
+            eng.set_option(key, v)
+        g = ra.GeometricTrace(system, engine=eng)
+        keep.append(g)
+        g.rays_given(y, u)
+        g.propagate(clip=True)
+        count += 1
+        rec = {"context": k, "kind": kind, "blocks": []}
+        eng.set_option("resident_lds", 65536)
+        for _ in range(a.warm):
+            eng.trace(1, 0, True)
+        count += a.warm
+        for lds in (65536, 32768, 65536, 32768):
+            eng.set_option("resident_lds", lds)
+            ms = []
+            first = count
+            for _ in range(a.launches//4):
+                ms.append(block_ms(eng, 4))
+                count += 4
+            ser = []
+            if a.serial:
+                for _ in range(a.serial):   # one launch at a time, like --pmc
+                    ser.append(block_ms(eng, 1))
+                count += a.serial
+            rec["blocks"].append({"resident_lds": lds, "first": first,
+                                  "count": count - first,
+                                  "ms": float(np.median(ms)),
+                                  "single_launch_ms":
+                                  float(np.median(ser)) if ser else None})
+        if a.probe:
+            for lds in (65536, 32768):
+                eng.set_option("lds_pad", lds)
+                pm = [eng.probe(8)[0] for _ in range(8)]
+                rec["store_pattern_ms_lds_%d" % lds] = float(np.median(pm[2:]))
+            eng.set_option("lds_pad", 0)
+        eng.set_option("resident_lds", -1)
+        out(**rec)
+
+
+def cmd_layouts(a):
+    """SoA against the tile-major layouts (laboratory option tile_rays) in the
+    SAME allocations, each classified by the pure store pattern first."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    n = a.rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = workload_rays(n, 0)
+    lib = lab_lib()
+    keep = []
+    plan = [("hipMalloc", {})]*a.contexts + [
+        ("vmm_1GiB", {"alloc_vmm_mb": 1024, "alloc_vmm_align_mb": 1024})]*a.vmm
+    for k, (kind, opts) in enumerate(plan):
+        eng = Engine(0, lib_path=lib)
+        for key, v in opts.items():
+            eng.set_option(key, v)
+        g = ra.GeometricTrace(system, engine=eng)
+        keep.append(g)
+        rec = {"context": k, "kind": kind}
+        for tile in [0] + a.tiles:
+            eng.set_option("tile_rays", tile)
+            g.rays_given(y, u)
+            g.propagate(clip=True)
+            res = {}
+            # lds_pad (not resident_lds): every layout, SoA included, runs
+            # the SAME laboratory kernel (48 B per ray read, no tile notes)
+            for lds in (65536, 32768, 16384):
+                eng.set_option("lds_pad", lds)
+                for _ in range(6):
+                    eng.trace(1, 0, True)
+                res["trace_%d" % lds] = float(np.median(
+                    [block_ms(eng, 4) for _ in range(6)]))
+                pm = [eng.probe(8)[0] for _ in range(8)]
+                res["store_%d" % lds] = float(np.median(pm[2:]))
+            eng.set_option("lds_pad", 0)
+            rec["tile_%d" % tile] = res
+        out(**rec)
+
+
+def cmd_placed(a):
+    """The shipped library: arithmetic self-test, then contexts with and
+    without the measured placement, each timed per resident setting and with
+    the range shortcuts off / on (same process, alternating blocks); the
+    image rows of both arithmetics are compared bit for bit."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    from rayopt_amd._lib import RT_Y, RT_U, RT_T
+    eng0 = Engine(0)
+    for span in (100, 300, 1000):
+        t0 = time.time()
+        bad = [eng0.selftest_arith(seed, 1 << 26, span) for seed in range(4)]
+        out(selftest_span=span, draws=4 << 26, mismatches=bad,
+            seconds=round(time.time() - t0, 2))
+    eng0.close()
+    n = a.rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = workload_rays(n, 0)
+    keep = []
+    for k in range(a.contexts):
+        placed = k % 2 == 0 or a.all_placed
+        eng = Engine(0)
+        eng.set_option("placement", 1 if placed else 0)
+        t0 = time.time()
+        eng.upload_system(ra.pack.pack_system(
+            system, system.wavelengths[0],
+            system.refractive_index(system.wavelengths[0], 0))[0])
+        eng.reserve(n)
+        eng.sync()
+        t_reserve = time.time() - t0
+        g = ra.GeometricTrace(system, engine=eng)
+        keep.append(g)
+        g.rays_given(y, u)
+        g.propagate(clip=True)
+        eng.sync()
+        rec = {"context": k, "placement": eng.placement(),
+               "reserve_seconds": round(t_reserve, 4)}
+        rec["first_block_ms"] = block_ms(eng, 4)
+        for _ in range(3):
+            block_ms(eng, 10)
+        res = {}
+        for lds in (-1, 65536, 32768, 0):
+            eng.set_option("resident_lds", lds)
+            res[str(lds)] = steady(eng, .5)
+        eng.set_option("resident_lds", -1)
+        rec["ms_by_resident_lds"] = res
+        ab = {"0": [], "1": []}
+        rows = {}
+        for rep in range(3):
+            for v in (0, 1):
+                eng.set_option("range_shortcuts", v)
+                ab[str(v)].append(steady(eng, .6))
+                if rep == 0:
+                    L = len(system)
+                    rows[v] = [eng.download(w, L - 1, L) for w in (RT_Y, RT_U)]
+                    rows[v].append(eng.download(RT_T, 1, L))
+        rec["ms_range_shortcuts_off_on"] = [float(np.median(ab["0"])),
+                                            float(np.median(ab["1"]))]
+        rec["bit_identical"] = all(
+            np.array_equal(p.view(np.uint64), q.view(np.uint64)) or
+            np.array_equal(np.where(np.isnan(p), 0, p).view(np.uint64),
+                           np.where(np.isnan(q), 0, q).view(np.uint64))
+            for p, q in zip(rows[0], rows[1]))
+        out(**rec)
+    # allocation churn: contexts created and destroyed
+    for k in range(3):
+        eng = Engine(0)
+        g = ra.GeometricTrace(system, engine=eng)
+        g.rays_given(y[:4_000_000], u[:4_000_000])
+        g.propagate(clip=True)
+        pl = eng.placement()
+        ms = steady(eng, .3)
+        eng.close()
+        out(churn=k, placement=pl, ms_4e6_rays=ms)
+
+
+def cmd_pmc_summary(a):
+    """For each pass directory: per (context, setting) mean of every counter
+    over the trace-kernel dispatches of that block."""
+    table = collections.OrderedDict()
+    for sched in sorted(glob.glob(os.path.join(a.dir, "pass*.jsonl"))):
+        tag = os.path.basename(sched)[:-6]
+        recs = [json.loads(l) for l in open(sched) if l.startswith("{")]
+        files = glob.glob(os.path.join(a.dir, tag, "**",
+                                       "*counter_collection.csv"),
+                          recursive=True)
+        if not files or not recs:
+            continue
+        rows = [r for f in files for r in csv.DictReader(open(f))
+                if "rt_trace_kernel" in r["Kernel_Name"]]
+        by_counter = collections.defaultdict(dict)
+        for r in rows:
+            by_counter[r["Counter_Name"]][int(r["Dispatch_Id"])] = \
+                float(r["Counter_Value"])
+        for name, d in by_counter.items():
+            ids = sorted(d)
+            for rec in recs:
+                for b in rec["blocks"]:
+                    sel = ids[b["first"]:b["first"] + b["count"]]
+                    if not sel:
+                        continue
+                    key = (tag, rec["context"], rec["kind"],
+                           b["resident_lds"], b["first"])
+                    table.setdefault(key, {"ms_under_pmc": b["ms"]})[name] = \
+                        float(np.mean([d[i] for i in sel]))
+    for key, vals in table.items():
+        out(**{"pass": key[0], "context": key[1], "kind": key[2],
+               "resident_lds": key[3], **vals})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    p = sub.add_parser("placement")
+    p.add_argument("--contexts", type=int, default=5)
+    p.add_argument("--vmm", type=int, default=3)
+    p.add_argument("--launches", type=int, default=24)
+    p.add_argument("--warm", type=int, default=12)
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.add_argument("--probe", type=int, default=1)
+    p.add_argument("--serial", type=int, default=0)
+    p.add_argument("--vmm-mb", type=int, default=1024)
+    p.set_defaults(fn=cmd_placement)
+    p = sub.add_parser("layouts")
+    p.add_argument("--contexts", type=int, default=6)
+    p.add_argument("--vmm", type=int, default=3)
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.add_argument("--tiles", type=int, nargs="*", default=[64, 256, 2048])
+    p.set_defaults(fn=cmd_layouts)
+    p = sub.add_parser("placed")
+    p.add_argument("--contexts", type=int, default=6)
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.add_argument("--all-placed", type=int, default=0)
+    p.set_defaults(fn=cmd_placed)
+    p = sub.add_parser("pmc-summary")
+    p.add_argument("dir")
+    p.set_defaults(fn=cmd_pmc_summary)
+    a = ap.parse_args()
+    a.fn(a)
+
+
+if __name__ == "__main__":
+    main()

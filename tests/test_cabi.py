@@ -61,8 +61,10 @@ def test_shipped_library_carries_no_laboratory(dll):
 
 
 def test_struct_layout(dll):
-    assert dll.rt_abi_version() == 1
-    assert dll.rt_sizeof_surface() == _lib.SURFACE_DTYPE.itemsize == 344
+    assert dll.rt_abi_version() == _lib.RT_ABI_VERSION == 2
+    assert int(re.search(r"#define RT_ABI_VERSION (\d+)", open(HEADER).read()
+                         ).group(1)) == 2
+    assert dll.rt_sizeof_surface() == _lib.SURFACE_DTYPE.itemsize == 352
     text = open(HEADER).read()
     assert int(re.search(r"#define RT_MAX_ASPH (\d+)", text).group(1)) == \
         _lib.RT_MAX_ASPH
@@ -73,6 +75,15 @@ def test_struct_layout(dll):
         val = int(re.search(r"#define RT_F_%s\s+0x([0-9a-f]+)u" % flag,
                             text).group(1), 16)
         assert val == getattr(_lib, "F_" + flag)
+
+
+def test_stale_library_is_refused(dll, monkeypatch):
+    """A library built from other sources (another ABI version) is refused at
+    load instead of being called with the wrong struct layouts."""
+    monkeypatch.setattr(_lib, "RT_ABI_VERSION", _lib.RT_ABI_VERSION + 1)
+    monkeypatch.setattr(_lib, "_libs", {})
+    with pytest.raises(_lib.EngineError, match="ABI version"):
+        _lib.load()
 
 
 def test_no_cpu_fallback_without_gpu(dll):

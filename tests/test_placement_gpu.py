@@ -1,0 +1,140 @@
+"""Where the result arrays live (rt_placement, csrc/rt_place.h) and the
+quotients / square roots without range scaffolding (RT_F_RANGE): both are
+matters of speed -- the results are the same bits with and without."""
+import numpy as np
+import pytest
+
+import rayopt_amd as ra
+from rayopt_amd import prescriptions as P
+from rayopt_amd._lib import RT_Y, RT_U, RT_I, RT_T
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(eng, L):
+    return [eng.download(w, 0, L) for w in (RT_Y, RT_U, RT_I, RT_T)]
+
+
+def _same(a, b):
+    return all(np.array_equal(p, q, equal_nan=True) for p, q in zip(a, b))
+
+
+def test_arithmetic_selftest():
+    """rt_selftest_arith: the guarded short forms agree with the compiler's
+    sequences for operands across and far beyond the checked range; inside
+    the range even the unguarded core does."""
+    eng = ra.Engine()
+    for span in (60, 100, 400, 1000):
+        bad = eng.selftest_arith(17 + span, 1 << 24, span)
+        assert bad[:3] == [0, 0, 0], (span, bad)
+    # operands drawn well inside the range: the core alone is exact (the
+    # edge values every 64th draw excepted -- those are what the guards are
+    # for, and at span 60 they are the only mismatches there can be)
+    inside = eng.selftest_arith(5, 1 << 24, 60)
+    beyond = eng.selftest_arith(5, 1 << 24, 1000)
+    assert beyond[3] > inside[3]
+
+
+def test_large_arrays_are_placed_and_results_do_not_depend_on_it():
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    L = len(system)
+    n = 2_000_000                       # 13 x 10 x 2e6 x 8 B = 2.08 GB
+    from bench import workload_rays
+    y, u = workload_rays(n, 0)
+    got = {}
+    for placed in (1, 0):
+        eng = ra.Engine()
+        eng.set_option("placement", placed)
+        g = ra.GeometricTrace(system, engine=eng)
+        g.rays_given(y, u)
+        g.propagate(clip=True)
+        info = eng.placement()
+        if placed:
+            # pieces behind the arrays (or, if the device could not supply
+            # them, the documented fallback: pieces == 0)
+            assert info["pieces"] == 0 or (
+                info["pieces"]*info["piece_mib"]*2**20 >= L*10*eng.ld*8 and
+                sum(info["per_class"]) <= info["pieces"] and
+                info["created"] >= info["pieces"])
+        else:
+            assert info["pieces"] == 0 and not info["mixed"]
+        got[placed] = _rows(eng, L)
+        # every resident setting, the same bits
+        for lds in (65536, 32768, 0):
+            eng.set_option("resident_lds", lds)
+            g.propagate(clip=True)
+            assert _same(got[placed], _rows(eng, L))
+        eng.close()
+    assert _same(got[0], got[1])
+
+
+def test_small_arrays_are_left_alone_and_growth_places_anew():
+    system = ra.system_from_yaml(P.COOKE % P.COOKE_INDICES[587.56e-9])
+    eng = ra.Engine()
+    g = ra.GeometricTrace(system, engine=eng)
+    y, u = ra.bundles.disc_bundle(50_000, 5.5, 5., 3)
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    assert eng.placement()["pieces"] == 0
+    small = np.array(g.y[-1])
+    y2, u2 = ra.bundles.disc_bundle(3_000_000, 5.5, 5., 3)   # 2.2 GB
+    g.rays_given(y2, u2)
+    g.propagate(clip=True)
+    big = eng.placement()
+    assert big["pieces"] == 0 or big["pieces"] >= 3
+    np.testing.assert_array_equal(np.array(g.y[-1])[:50_000], small)
+    # and back: the arrays only grow, the placement stays
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    assert eng.placement() == big
+    np.testing.assert_array_equal(np.array(g.y[-1]), small)
+
+
+def test_contexts_come_and_go():
+    """Pieces are mapped, unmapped and released with their contexts."""
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    from bench import workload_rays
+    y, u = workload_rays(1_600_000, 0)              # 1.66 GB
+    want = None
+    for _ in range(6):
+        eng = ra.Engine()
+        g = ra.GeometricTrace(system, engine=eng)
+        g.rays_given(y, u)
+        g.propagate(clip=True)
+        row = np.array(g.y[-1])
+        if want is None:
+            want = row
+        assert np.array_equal(row, want, equal_nan=True)
+        eng.close()
+
+
+@pytest.mark.parametrize("seed", range(3100, 3112))
+def test_range_shortcuts_are_the_same_bits(seed):
+    """Random systems (tilts, conics, mirrors, aspheres on the exact
+    arithmetic), huge and tiny coordinates among the rays: the trace with the
+    shortcuts is the trace without, bit for bit."""
+    from random_systems import random_prescription, random_rays
+    import copy
+    p = random_prescription(seed)
+    system = ra.system_from_dict(copy.deepcopy(p))
+    L = len(system)
+    y, u = random_rays(seed, 4099, p)
+    rng = np.random.default_rng(seed)
+    # rays far outside the checked range, NaNs and zeros
+    y[7] *= 1e150
+    y[300] *= 1e-150
+    y[1000] = 0.
+    u[2000] = np.nan
+    y[64*5:64*6] *= 10.**rng.uniform(-180, 180, (64, 1))
+    rows = {}
+    for v in (0, 1):
+        eng = ra.Engine()
+        eng.set_option("exact_asphere", 1)
+        eng.set_option("range_shortcuts", v)
+        g = ra.GeometricTrace(system, engine=eng)
+        with np.errstate(all="ignore"):
+            g.rays_given(y, u)
+            g.propagate(clip=bool(seed & 1))
+        rows[v] = _rows(eng, L)
+        eng.close()
+    assert _same(rows[0], rows[1])

@@ -25,25 +25,3 @@ def test_random_call_sequences_against_the_engine_double(block):
         with np.errstate(all="ignore"):
             steps += fuzz_state.sequence(seed, 30)
     assert steps > 200
-
-
-def test_sequences_with_the_occupancy_tuner_sampling():
-    """The same fuzz with the tuner (rt_tuning) awake on these small batches:
-    the laboratory library lets its thresholds be lowered to 2 rays / 2
-    launches, so launches are sampled at either cap -- and decisions made,
-    thrown away, made again -- between all the other changes of state."""
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lab = os.path.join(root, "rayopt_amd", "librt_mi355_probes.so")
-    if not os.path.exists(lab):
-        pytest.skip("laboratory library not built")
-    env = dict(os.environ, RT_MI355_LIB=lab, RT_FUZZ_TUNE="1",
-               RT_MI355_EXACT_ASPHERE="1")
-    out = subprocess.run(
-        [sys.executable, os.path.join(root, "tests", "tools", "fuzz_state.py"),
-         "7000", "7030"], env=env, capture_output=True, text=True,
-        timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    last = out.stdout.strip().splitlines()[-1]
-    assert last.startswith("state fuzz") and last.endswith(
-        " 0 failing sequences"), out.stdout[-2000:]

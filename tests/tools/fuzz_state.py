@@ -34,19 +34,11 @@ SIZES = (2, 63, 64, 65, 777, 4099)
 OPTIONS = (("alias_i", (0, 1)), ("regenerate", (0, 1)),
            ("fuse_generate", (0, 1)), ("compact", (0, 1, 2)),
            ("compact_every", (1, 2, 3, 4)), ("uniform_input", (0, 1)),
-           ("resident_lds", (-1, 0, 65536)))
+           ("resident_lds", (-1, 0, 65536)), ("range_shortcuts", (0, 1)))
 # (exact_asphere: the double is the reference's arithmetic, bit for bit)
-# RT_FUZZ_TUNE=1 with the laboratory library (RT_MI355_LIB=...probes.so): the
-# occupancy tuner (rt_tuning) runs on these small batches too -- sampling
-# launches at either cap in the middle of every other change of state
-TUNE = bool(os.environ.get("RT_FUZZ_TUNE"))
-if TUNE:
-    OPTIONS = OPTIONS + (("tune_resident", (0, 1)),)
 DEFAULTS = dict(alias_i=1, regenerate=1, fuse_generate=1, compact=0,
                 compact_every=4, exact_asphere=1, uniform_input=1,
-                resident_lds=-1)
-if TUNE:
-    DEFAULTS["tune_resident"] = 1
+                resident_lds=-1, range_shortcuts=1)
 
 
 def compare(dev, cpu, log):
@@ -96,9 +88,6 @@ def sequence(seed, nops):
     eng = dev.engine
     for k, v in DEFAULTS.items():
         eng.set_option(k, v)
-    if TUNE:
-        eng.set_option("tune_min_rays", 2)
-        eng.set_option("tune_warm", 2)
     log, seeded, grouped, last_seed = [], False, False, None
     try:
         for _ in range(nops):
