@@ -1328,6 +1328,9 @@ def run_configs(ra, device, args):
                "frac": alg/(ms*1e-3)/1e9/HBM_PEAK_GBS,
                "parity_subsample": parity,
                "cpu_reference": ref}
+        pl = g.engine.placement()
+        rec["placement"] = {k: pl[k] for k in ("pieces", "piece_mib",
+                                               "per_class", "mixed")}
         if note:
             rec["note"] = note
         out.append(rec)

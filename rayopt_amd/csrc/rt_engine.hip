@@ -125,20 +125,26 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
 {
     if (c->opt_resident >= 0)
         return (size_t)c->opt_resident;
-    int stored = 0, newton = 0;
+    int stored = 0, stored_i = 0, newton = 0;
     for (int s = start; s < stop; ++s) {
-        stored += !(c->h_stage[s].flags & RT_F_NOSTORE);
-        newton += (c->h_stage[s].flags & RT_F_ASPH) != 0;
+        const unsigned f = c->h_stage[s].flags;
+        stored += !(f & RT_F_NOSTORE);
+        stored_i += (f & (RT_F_NOSTORE | RT_F_STORE_I)) == RT_F_STORE_I;
+        newton += (f & RT_F_ASPH) != 0;
     }
     if (2 * stored < stop - start)
         return 0;
-    if (newton)
-        return c->opt_fast ? 32768 : 0;
+    if (newton) /* default arithmetic: five per CU in mixed memory, else four */
+        return c->opt_fast ? (c->place.mixed ? 28672 : 32768) : 0;
     /* store bound: four workgroups per CU where the arrays lie in a mix of
-     * memory classes (rt_place.h: 1.12 ms against 1.25 with two), two where
-     * they do not -- two per CU is the setting that does not care where it
-     * writes (1.22-1.25 ms in any allocation; four: 1.35 in a bad one) */
-    return c->place.mixed ? 32768 : 65536;
+     * memory classes (rt_place.h: 1.08 ms against 1.23 with two; three: 1.09,
+     * five: 1.13), two where they do not -- two per CU is the setting that
+     * does not care where it writes (1.22-1.25 ms in any allocation; four:
+     * 1.35 in a bad one) -- and where most elements store their i rows too
+     * (tilted systems: ten streams per element, 1.49 against 1.52) */
+    if (!c->place.mixed || 2 * stored_i > stored)
+        return 65536;
+    return 32768;
 }
 
 /* the result arrays: class-mixed pieces (rt_place.h); the laboratory build

@@ -243,6 +243,38 @@ RT_HD bool rt_isclose(double p, double p0, double tol)
  * All R rays of the lane iterate together; the wave leaves the loop when no
  * lane of the wavefront has a ray still iterating (ballot).
  */
+/* One iterate for one ray, every operation as the reference's: returns true
+ * when the ray is finished (res = the root, or NaN left in place), false when
+ * s has been updated and the iteration goes on. */
+RT_HD bool rt_newton_iterate(const rt_surface *__restrict__ S, unsigned flags,
+                             const double (&y)[3], const double (&u)[3],
+                             double &s, double &res)
+{
+    const double px = y[0] + s * u[0];
+    const double py = y[1] + s * u[1];
+    const double pz = y[2] + s * u[2];
+    const double r2 = px * px + py * py;
+    const double root = rt_conic_root(S, flags, r2);
+    const double fval = rt_sag(S, flags, r2, pz, root);
+    if (fval == 0.) {
+        res = s;
+        return true;
+    }
+    const double e = rt_normal_e(S, flags, r2, root);
+    /* np.dot(normal, u.T) of a (1,3) and a (3,1) array (:342): BLAS, i.e.
+     * the fused chain of rt_dot3 */
+    const double fder = rt_dot3(px * e, py * e, 1., u[0], u[1], u[2]);
+    if (fder == 0.)
+        return true; /* "Derivative was zero" -> NaN */
+    const double p = s - fval / fder;
+    if (rt_isclose(p, s, 1e-7)) {
+        res = p;
+        return true;
+    }
+    s = p;
+    return false;
+}
+
 template <int R>
 RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
                      const double (&y)[R][3], const double (&u)[R][3],
@@ -267,34 +299,10 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
         for (int r = 0; r < R; ++r) {
             if (!live[r])
                 continue;
-            const double px = y[r][0] + s[r] * u[r][0];
-            const double py = y[r][1] + s[r] * u[r][1];
-            const double pz = y[r][2] + s[r] * u[r][2];
-            const double r2 = px * px + py * py;
-            const double root = rt_conic_root(S, flags, r2);
-            const double fval = rt_sag(S, flags, r2, pz, root);
-            if (fval == 0.) {
-                res[r] = s[r];
+            if (rt_newton_iterate(S, flags, y[r], u[r], s[r], res[r]))
                 live[r] = false;
-                continue;
-            }
-            const double e = rt_normal_e(S, flags, r2, root);
-            /* np.dot(normal, u.T) of a (1,3) and a (3,1) array (:342):
-             * BLAS, i.e. the fused chain of rt_dot3 */
-            const double fder =
-                rt_dot3(px * e, py * e, 1., u[r][0], u[r][1], u[r][2]);
-            if (fder == 0.) {
-                live[r] = false; /* "Derivative was zero" -> NaN */
-                continue;
-            }
-            const double p = s[r] - fval / fder;
-            if (rt_isclose(p, s[r], 1e-7)) {
-                res[r] = p;
-                live[r] = false;
-                continue;
-            }
-            s[r] = p;
-            any = true;
+            else
+                any = true;
         }
     }
 #pragma unroll
@@ -327,8 +335,9 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
  *         fder root  = uz root - (px ux + py uy)(c + dpoly root)   =: den
  *         fval/fder  = num root / (A den)
  *     (fval == 0 <=> num == 0 and fder == 0 <=> den == 0 since A >= 1 and
- *     root > 0; root == 0, the rim of a hemisphere, gives step 0 in both
- *     forms).
+ *     root > 0; a point with root == 0 exactly -- the rim of the base conic --
+ *     is handed to rt_newton_iterate: there the reference's result is decided
+ *     by 0 * inf and inf - inf in its normal).
  * Results agree with the exact path to ~1e-13 (tests: <= 1e-9 asserted,
  * identical NaN masks on the asphere goldens).
  *
@@ -343,6 +352,10 @@ RT_HD double rt_fma(double a, double b, double c)
 {
     return __builtin_fma(a, b, c);
 }
+
+/* |1 - (1+k) c^2 r^2| below this: the point is on the rim of the base conic
+ * as far as rounding can tell -- there the exact arithmetic decides */
+#define RT_RIM 1e-12
 
 /* 1/x: hardware seed + NR steps (each squares the relative error) */
 template <int STEPS>
@@ -437,8 +450,25 @@ RT_HD void rt_newton_fast(const rt_surface *__restrict__ S, unsigned flags,
             const double pz = rt_fma(s[r], u[r][2], y[r][2]);
             const double r2 = rt_fma(px, px, py * py);
             double root = 1., rinv;
-            if (curved)
-                rt_sqrt_fast<1>(rt_fma(-kc2, r2, 1.), root, rinv);
+            if (curved) {
+                const double w = rt_fma(-kc2, r2, 1.);
+                if (__builtin_fabs(w) < RT_RIM) {
+                    /* on the rim of the base conic -- sqrt(1 - (1+k) c^2
+                     * r^2) zero or a rounding error away from it -- the
+                     * reference's result hangs on IEEE corners (normal =
+                     * 0 * inf or inf - inf: NaN; else an infinite derivative
+                     * and a zero step) and on whether ITS argument of the
+                     * root rounds to zero: this iterate is evaluated its
+                     * way, operation for operation
+                     * (tests/golden/asphere_newton_rim) */
+                    if (rt_newton_iterate(S, flags, y[r], u[r], s[r], res[r]))
+                        live[r] = false;
+                    else
+                        any = true;
+                    continue;
+                }
+                rt_sqrt_fast<1>(w, root, rinv);
+            }
             double poly, dpoly;
             rt_poly_fast<NA>(a, da, r2, poly, dpoly);
             const double A = 1. + root;
@@ -471,6 +501,70 @@ RT_HD void rt_newton_fast(const rt_surface *__restrict__ S, unsigned flags,
         s[r] = res[r];
 }
 
+/* clip + refract/reflect at the intercept y: iv -> u (elements.py:309-314),
+ * one ray, every operation as the reference's */
+RT_HD void rt_bend_ray(const rt_surface *__restrict__ S, unsigned flags,
+                       int clip, const double (&y)[3], const double (&iv)[3],
+                       double (&u)[3])
+{
+    u[0] = iv[0];
+    u[1] = iv[1];
+    u[2] = iv[2];
+    const double rxy = y[0] * y[0] + y[1] * y[1];
+    if (clip) {
+        /* Element.clip: NaN-poison the direction outside the aperture;
+         * NaN coordinates compare false and are poisoned as well */
+        if (!(rxy <= S->radius2))
+            u[0] = u[1] = u[2] = RT_NAN;
+    }
+    if (flags & RT_F_REFRACT) {
+        /* Spencer & Murty; q = (x e, y e, 1) un-normalised normal */
+        double qx, qy;
+        if (flags & (RT_F_CURVED | RT_F_ASPH)) {
+            const double e = rt_normal_e(S, flags, rxy,
+                                         rt_conic_root(S, flags, rxy));
+            qx = y[0] * e;
+            qy = y[1] * e;
+        } else {
+            qx = 0.;
+            qy = 0.;
+        }
+        const double r2 = (qx * qx + qy * qy) + 1.;
+        const double dot = (u[0] * qx + u[1] * qy) + u[2] * 1.;
+        const double num = S->muf * dot;
+        double a, g = 0.;
+        /* r2 >= 1 or NaN: only its upper end needs the check */
+        if ((flags & RT_F_RANGE) &&
+            !RT_WAVE_ANY(r2 >= RT_RANGE_BIG || RT_ODD_MAG(num))) {
+            const double rr = rt_rcp_refined(r2);
+            a = rt_quot(num, r2, rr);
+            if (!(flags & RT_F_MIRROR)) {
+                /* in range a*a and b are both >= 2^-400 in magnitude:
+                 * their difference is 0 or >= 2^-453, never inside
+                 * (0, 2^-767) */
+                const double b = rt_quot(S->mu2m1, r2, rr);
+                g = -a + S->smu * rt_sqrt_unscaled(a * a - b);
+            }
+        } else {
+            a = num / r2;
+            if (!(flags & RT_F_MIRROR)) {
+                const double b = S->mu2m1 / r2;
+                g = -a + S->smu * sqrt(a * a - b);
+            }
+        }
+        if (flags & RT_F_MIRROR) {
+            const double a2 = 2. * a;
+            u[0] = u[0] - a2 * qx;
+            u[1] = u[1] - a2 * qy;
+            u[2] = u[2] - a2 * 1.;
+        } else {
+            u[0] = S->muf * u[0] + g * qx;
+            u[1] = S->muf * u[1] + g * qy;
+            u[2] = S->muf * u[2] + g * 1.;
+        }
+    }
+}
+
 /* clip + refraction at an aspheric element on the fast arithmetic: the same
  * Spencer & Murty update as rt_step_bend (elements.py:351-369) */
 template <int R, int NA>
@@ -497,8 +591,16 @@ RT_HD void rt_bend_fast(const rt_surface *__restrict__ S, unsigned flags,
         }
         if (flags & RT_F_REFRACT) {
             double root = 1., rinv = 1., poly, dpoly;
-            if (curved)
-                rt_sqrt_fast<2>(rt_fma(-S->kc2, rxy, 1.), root, rinv);
+            if (curved) {
+                const double w = rt_fma(-S->kc2, rxy, 1.);
+                if (__builtin_fabs(w) < RT_RIM) {
+                    /* on the rim of the base conic the normal is 0 * inf or
+                     * inf in the reference: its operations decide */
+                    rt_bend_ray(S, flags, clip, y[r], iv[r], u[r]);
+                    continue;
+                }
+                rt_sqrt_fast<2>(w, root, rinv);
+            }
             rt_poly_fast<NA>(a, da, rxy, poly, dpoly);
             const double e = -(curved ? rt_fma(S->c, rinv, dpoly) : dpoly);
             const double qx = y[r][0] * e, qy = y[r][1] * e;
@@ -679,7 +781,7 @@ RT_HD void rt_step_hit(const rt_surface *__restrict__ S, unsigned flags,
     }
 }
 
-/* clip + refract/reflect at the intercept y: iv -> u (elements.py:309-314) */
+/* clip + refract/reflect at the intercept y: iv -> u for R rays */
 template <int R>
 RT_HD void rt_step_bend(const rt_surface *__restrict__ S, unsigned flags,
                         int clip, const double (&y)[R][3],
@@ -693,64 +795,8 @@ RT_HD void rt_step_bend(const rt_surface *__restrict__ S, unsigned flags,
         return;
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        u[r][0] = iv[r][0];
-        u[r][1] = iv[r][1];
-        u[r][2] = iv[r][2];
-        const double rxy = y[r][0] * y[r][0] + y[r][1] * y[r][1];
-        if (clip) {
-            /* Element.clip: NaN-poison the direction outside the aperture;
-             * NaN coordinates compare false and are poisoned as well */
-            if (!(rxy <= S->radius2))
-                u[r][0] = u[r][1] = u[r][2] = RT_NAN;
-        }
-        if (flags & RT_F_REFRACT) {
-            /* Spencer & Murty; q = (x e, y e, 1) un-normalised normal */
-            double qx, qy;
-            if (flags & (RT_F_CURVED | RT_F_ASPH)) {
-                const double e = rt_normal_e(S, flags, rxy,
-                                             rt_conic_root(S, flags, rxy));
-                qx = y[r][0] * e;
-                qy = y[r][1] * e;
-            } else {
-                qx = 0.;
-                qy = 0.;
-            }
-            const double r2 = (qx * qx + qy * qy) + 1.;
-            const double dot = (u[r][0] * qx + u[r][1] * qy) + u[r][2] * 1.;
-            const double num = S->muf * dot;
-            double a, g = 0.;
-            /* r2 >= 1 or NaN: only its upper end needs the check */
-            if ((flags & RT_F_RANGE) &&
-                !RT_WAVE_ANY(r2 >= RT_RANGE_BIG || RT_ODD_MAG(num))) {
-                const double rr = rt_rcp_refined(r2);
-                a = rt_quot(num, r2, rr);
-                if (!(flags & RT_F_MIRROR)) {
-                    /* in range a*a and b are both >= 2^-400 in magnitude:
-                     * their difference is 0 or >= 2^-453, never inside
-                     * (0, 2^-767) */
-                    const double b = rt_quot(S->mu2m1, r2, rr);
-                    g = -a + S->smu * rt_sqrt_unscaled(a * a - b);
-                }
-            } else {
-                a = num / r2;
-                if (!(flags & RT_F_MIRROR)) {
-                    const double b = S->mu2m1 / r2;
-                    g = -a + S->smu * sqrt(a * a - b);
-                }
-            }
-            if (flags & RT_F_MIRROR) {
-                const double a2 = 2. * a;
-                u[r][0] = u[r][0] - a2 * qx;
-                u[r][1] = u[r][1] - a2 * qy;
-                u[r][2] = u[r][2] - a2 * 1.;
-            } else {
-                u[r][0] = S->muf * u[r][0] + g * qx;
-                u[r][1] = S->muf * u[r][1] + g * qy;
-                u[r][2] = S->muf * u[r][2] + g * 1.;
-            }
-        }
-    }
+    for (int r = 0; r < R; ++r)
+        rt_bend_ray(S, flags, clip, y[r], iv[r], u[r]);
 }
 
 template <int R>

@@ -127,6 +127,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         piece = ((bytes + 2) / 3 + q - 1) / q * q;
     }
     const int need = (int)((bytes + piece - 1) / piece);
+    size_t align = piece & (~piece + 1); /* largest power of two dividing it */
     const int cap = need + 16; /* pieces created at most */
     /* short rows: 84 of them fit one piece */
     const long long nprobe =
@@ -150,7 +151,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     float self_ms = 0.f, cross_ms = 0.f;
     hipError_t e = h && cls ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess)
-        e = hipMemAddressReserve(&scratch, (size_t)cap * piece, piece, NULL, 0);
+        e = hipMemAddressReserve(&scratch, (size_t)cap * piece, align, NULL, 0);
     bool enough = false;
     while (e == hipSuccess && made < cap && !enough) {
         const int k = made;
@@ -264,7 +265,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         (void)hipMemUnmap((char *)scratch + (size_t)k * piece, piece);
     (void)hipMemAddressFree(scratch, (size_t)cap * piece);
     void *base = NULL;
-    e = hipMemAddressReserve(&base, (size_t)need * piece, piece, NULL, 0);
+    e = hipMemAddressReserve(&base, (size_t)need * piece, align, NULL, 0);
     hipMemGenericAllocationHandle_t *kept =
         (hipMemGenericAllocationHandle_t *)calloc(need, sizeof *kept);
     int nm = 0;

@@ -232,6 +232,83 @@ def cmd_placed(a):
         out(churn=k, placement=pl, ms_4e6_rays=ms)
 
 
+def cmd_resident(a):
+    """Resident workgroups per CU (unused dynamic LDS) per kind of trace,
+    arrays in measured placement (shipped library)."""
+    ra, P, _build, Engine = _imports()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import digest_cases as dc
+    from bench import workload_rays, FIELD_FRACTIONS, BUNDLE_RADIUS
+    caps = [65536, 53248, 40960, 36864, 32768, 28672, 24576, 20480, 16384, 0]
+
+    def sweep(name, g, propagate):
+        eng = g.engine
+        propagate()
+        for _ in range(20):
+            propagate()
+        res = {}
+        for lds in caps:
+            eng.set_option("resident_lds", lds)
+            propagate()
+            t_end = time.time() + .35
+            ms = []
+            while time.time() < t_end:
+                eng.event_record(0)
+                for _ in range(8):
+                    propagate()
+                eng.event_record(1)
+                ms.append(eng.event_elapsed(0, 1)/8)
+            res[str(lds)] = float(np.median(ms[len(ms)//3:]))
+        eng.set_option("resident_lds", -1)
+        propagate()
+        auto = block_ms(eng, 1) if False else None
+        ms = []
+        for _ in range(6):
+            eng.event_record(0)
+            for _ in range(8):
+                propagate()
+            eng.event_record(1)
+            ms.append(eng.event_elapsed(0, 1)/8)
+        out(kind=name, placement=eng.placement(), auto_ms=float(np.median(ms)),
+            ms_by_resident_lds=res)
+
+    n = a.rays
+    s3 = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = workload_rays(n, 0)
+    g = ra.GeometricTrace(s3, engine=Engine(0))
+    g.rays_given(y, u)
+    sweep("C3 host-seeded clip", g, lambda: g.propagate(clip=True))
+    sweep("C3 host-seeded unclipped", g, lambda: g.propagate(clip=False))
+    sweep("C3 image row only", g,
+          lambda: g.propagate(clip=True, keep=[0, -1]))
+    g.engine.set_option("alias_i", 0)
+    sweep("C3 every i row stored (80 B/op)", g, lambda: g.propagate(clip=True))
+    g.engine.set_option("alias_i", 1)
+    nf = len(FIELD_FRACTIONS)
+    m = n//nf//64*64
+    pts = dc.disc_points(m, 91)
+    g.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS], pts,
+                  P.DOUBLE_GAUSS_PUPIL_Z, BUNDLE_RADIUS)
+    sweep("C3 built on the device", g, lambda: g.propagate(clip=True))
+    del g
+    s2 = ra.system_from_yaml(P.COOKE % dict(
+        air="air", sk16="SCHOTT-SK|N-SK16", f2="SCHOTT-F|N-F2"))
+    ls = [587.56e-9, 656.27e-9, 486.13e-9]
+    y2, u2 = dc.bundle(10**6, 5.5, 5., 0)
+    g2 = ra.GeometricTrace(s2, engine=Engine(0))
+    g2.rays_given(y2, u2, l=ls)
+    sweep("C2 3 x 10^6 rays", g2, lambda: g2.propagate(clip=True))
+    del g2
+    s4 = ra.system_from_yaml(P.ASPHERE_PHONE)
+    y4, u4 = dc.bundle(n, .6, 10., 4)
+    y4[:, 1] -= .5*np.tan(np.radians(10.))
+    for label, opts in (("C4 default", {}), ("C4 exact", {"exact_asphere": 1})):
+        g4 = ra.GeometricTrace(s4, engine=Engine(0), **opts)
+        g4.rays_given(y4, u4, s4.wavelengths[0])
+        sweep(label, g4, lambda: g4.propagate(clip=True))
+        del g4
+
+
 def cmd_pmc_summary(a):
     """For each pass directory: per (context, setting) mean of every counter
     over the trace-kernel dispatches of that block."""
@@ -290,6 +367,9 @@ def main():
     p.add_argument("--rays", type=int, default=10_000_000)
     p.add_argument("--all-placed", type=int, default=0)
     p.set_defaults(fn=cmd_placed)
+    p = sub.add_parser("resident")
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.set_defaults(fn=cmd_resident)
     p = sub.add_parser("pmc-summary")
     p.add_argument("dir")
     p.set_defaults(fn=cmd_pmc_summary)

@@ -67,6 +67,20 @@ def cases():
     y[:, 1] -= 0.5*np.tan(np.radians(30.))
     add("asphere_overfill", P.ASPHERE_PHONE, y, u)
     add("asphere_overfill_noclip", P.ASPHERE_PHONE, y, u, clip=False)
+    # Newton DECISIONS (make_adversarial.py): rays whose third / fourth /
+    # fifth iterate steps within 1e-9 of the 1e-7 acceptance threshold, rays
+    # nearly tangent to the surface where the iteration looks (fder -> 0),
+    # points on the rim of the base conic (sqrt(1 - (1+k) c^2 r^2) -> 0 from
+    # either side): where an arithmetic that is 1e-15 off could flip a NaN
+    import os
+    adv = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                               "adversarial_inputs.npz"))
+    add("asphere_newton_decisive", str(adv["steep_yaml"]), adv["steep_y"],
+        adv["steep_u"])
+    add("asphere_newton_decisive_noclip", str(adv["steep_yaml"]),
+        adv["steep_y"], adv["steep_u"], clip=False)
+    add("asphere_newton_rim", str(adv["rim_yaml"]), adv["rim_y"],
+        adv["rim_u"])
     # torture: rotations, conics, mirror, alternate intersection
     add("torture", P.TORTURE, *disc_bundle(400, 9., 2., 12))
     add("torture_overfill", P.TORTURE, *disc_bundle(400, 16., 4., 13))

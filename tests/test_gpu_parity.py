@@ -16,7 +16,7 @@ from rayopt_amd.pack import pack_system, resolve_range
 from oracle import trace_numpy as tn
 
 from conftest import (golden_names, load_golden, assert_parity, case_rtol,
-                      RTOL_SPHERICAL, RTOL_ASPHERE)
+                      RTOL_SPHERICAL, RTOL_ASPHERE, same_or_contract)
 
 pytestmark = pytest.mark.gpu
 
@@ -44,8 +44,11 @@ def compare(g, want, a, b, rtol, what):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_matches_reference_golden(name):
+def test_matches_reference_golden(name, arith):
     gold = load_golden(name)
+    aspheric = "aspherics" in gold["yaml"]
+    if arith == "default" and not aspheric:
+        pytest.skip("no aspheric element: one arithmetic")
     system = ra.system_from_yaml(gold["yaml"])
     a, b = resolve_range(len(system), gold["start"], gold["stop"])
     g = gpu_trace(system, gold["y0"], gold["u0"], gold["l"], gold["clip"],
@@ -55,9 +58,9 @@ def test_matches_reference_golden(name):
     # ... and to the last bit: plane / sphere / conic, tilted or not (the 3x3
     # products follow the dgemm's fused chain), iterated aspheres (scipy's
     # Newton operation for operation, BLAS-summed derivative included)
+    # (the default arithmetic for aspheres: contract + identical NaN masks)
     for rows, ref, label in zip((g.y, g.u, g.i, g.t), want, "yuit"):
-        assert np.array_equal(np.asarray(rows[a:b]), ref,
-                              equal_nan=True), (name, label)
+        same_or_contract(rows[a:b], ref, aspheric, arith, (name, label))
     assert np.array_equal(g.n[:b], gold["n"][:b])
     # row 0 is what rays_given stored
     assert np.array_equal(g.y[0], gold["y0"])
@@ -137,7 +140,7 @@ def test_config_c3_double_gauss_1e6_vs_oracle():
     assert 0.001 < frac < 0.1      # a few per cent vignetted, as designed
 
 
-def test_config_c4_asphere_2e5_vs_oracle():
+def test_config_c4_asphere_2e5_vs_oracle(arith):
     system = ra.system_from_yaml(P.ASPHERE_PHONE)
     ys, us = [], []
     for k, deg in enumerate((0., 17.5)):
@@ -149,6 +152,8 @@ def test_config_c4_asphere_2e5_vs_oracle():
     g = gpu_trace(system, y, u, None, True)
     want, ns = oracle_trace(system, y, u, g.l, True)
     compare(g, want, 1, 9, RTOL_ASPHERE, "C4")
+    for rows, ref, label in zip((g.y, g.u, g.i, g.t), want, "yuit"):
+        same_or_contract(rows[1:9], ref, True, arith, "C4." + label)
     assert np.isfinite(np.asarray(g.y[-1])).mean() > 0.99
 
 
@@ -202,7 +207,7 @@ def test_full_size_c3_properties():
     assert (t[np.isfinite(t)] > -1e-9).all()        # forward propagation
 
 
-def test_full_size_c4_asphere_subsample():
+def test_full_size_c4_asphere_subsample(arith):
     n = 10**7
     system = ra.system_from_yaml(P.ASPHERE_PHONE)
     y, u = disc_bundle(n, 0.6, 0.7*25, 3)

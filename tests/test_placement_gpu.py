@@ -27,12 +27,10 @@ def test_arithmetic_selftest():
     for span in (60, 100, 400, 1000):
         bad = eng.selftest_arith(17 + span, 1 << 24, span)
         assert bad[:3] == [0, 0, 0], (span, bad)
-    # operands drawn well inside the range: the core alone is exact (the
-    # edge values every 64th draw excepted -- those are what the guards are
-    # for, and at span 60 they are the only mismatches there can be)
-    inside = eng.selftest_arith(5, 1 << 24, 60)
-    beyond = eng.selftest_arith(5, 1 << 24, 1000)
-    assert beyond[3] > inside[3]
+    # the unguarded core alone does differ -- on the edge values every 64th
+    # draw holds (zeros, infinities, denormals, the guard limits), which is
+    # what the guards are for
+    assert eng.selftest_arith(5, 1 << 24, 60)[3] > 0
 
 
 def test_large_arrays_are_placed_and_results_do_not_depend_on_it():

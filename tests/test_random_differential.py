@@ -73,8 +73,10 @@ def test_oracle_and_kernel_math_vs_live_reference(seed, hostemu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", SEEDS)
-def test_gpu_vs_oracle_random_systems(seed):
+def test_gpu_vs_oracle_random_systems(seed, arith):
     p = random_prescription(seed)
+    if arith == "default" and not has_asphere(p):
+        pytest.skip("no aspheric element: one arithmetic")
     system = ra.system_from_dict(copy.deepcopy(p))
     n = 20011
     y, u = random_rays(seed, n, p)
@@ -87,13 +89,23 @@ def test_gpu_vs_oracle_random_systems(seed):
         rtol = RTOL_ASPHERE if has_asphere(p) else RTOL_SPHERICAL
         for rows, b in zip((g.y, g.u, g.i, g.t), want):
             assert_parity(np.asarray(rows[1:]), b, rtol, "seed %d" % seed)
-            if EXACT_TILTS or not tilted(p):
+            if (EXACT_TILTS or not tilted(p)) and arith == "exact":
                 assert np.array_equal(np.asarray(rows[1:]), b,
                                       equal_nan=True), seed
         assert np.array_equal(g.n[1:], ns[1:])
 
 
 ASPHERIC_SEEDS = [s for s in range(200) if has_asphere(random_prescription(s))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [s for s in ASPHERIC_SEEDS if s >= len(SEEDS)])
+def test_gpu_vs_oracle_every_aspheric_system(seed, arith):
+    """The aspheric systems among seeds 60..199 as well, on both arithmetics:
+    the exact one == the oracle, the shipped default within 1e-8 of it with
+    identical NaN masks (a flipped convergence decision of the five-iterate
+    Newton solve would show as a mask difference)."""
+    test_gpu_vs_oracle_random_systems(seed, arith)
 
 
 @pytest.mark.parametrize("seed", ASPHERIC_SEEDS[:30])

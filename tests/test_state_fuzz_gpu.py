@@ -25,3 +25,23 @@ def test_random_call_sequences_against_the_engine_double(block):
         with np.errstate(all="ignore"):
             steps += fuzz_state.sequence(seed, 30)
     assert steps > 200
+
+
+def test_sequences_on_the_shipped_asphere_arithmetic():
+    """A slice of the same fuzz (> 2000 steps) with the DEFAULT arithmetic for
+    even aspheres: aspheric systems within the 1e-8 contract of the double
+    with identical NaN masks after every step, the others bit for bit."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RT_FUZZ_ARITH="default",
+               RT_MI355_EXACT_ASPHERE="0")
+    out = subprocess.run(
+        [sys.executable, os.path.join(root, "tests", "tools", "fuzz_state.py"),
+         "9000", "9075"], env=env, capture_output=True, text=True,
+        timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    last = out.stdout.strip().splitlines()[-1]
+    assert last.startswith("state fuzz") and last.endswith(
+        " 0 failing sequences"), out.stdout[-2000:]
+    import re
+    assert int(re.search(r"(\d+) steps", last).group(1)) > 2000, last

@@ -35,10 +35,31 @@ OPTIONS = (("alias_i", (0, 1)), ("regenerate", (0, 1)),
            ("fuse_generate", (0, 1)), ("compact", (0, 1, 2)),
            ("compact_every", (1, 2, 3, 4)), ("uniform_input", (0, 1)),
            ("resident_lds", (-1, 0, 65536)), ("range_shortcuts", (0, 1)))
-# (exact_asphere: the double is the reference's arithmetic, bit for bit)
+# The double is the reference's arithmetic: with exact_asphere=1 the device
+# holds its bits.  RT_FUZZ_ARITH=default runs the SHIPPED arithmetic for even
+# aspheres instead: aspheric systems are then compared at the 1e-8 contract
+# with identical NaN masks, everything else still bit for bit.
+ARITH = os.environ.get("RT_FUZZ_ARITH", "exact")
 DEFAULTS = dict(alias_i=1, regenerate=1, fuse_generate=1, compact=0,
-                compact_every=4, exact_asphere=1, uniform_input=1,
-                resident_lds=-1, range_shortcuts=1)
+                compact_every=4, exact_asphere=int(ARITH == "exact"),
+                uniform_input=1, resident_lds=-1, range_shortcuts=1)
+LOOSE = [False]     # this sequence's system is aspheric, default arithmetic
+
+
+def same(x, w):
+    if not LOOSE[0]:
+        return np.array_equal(x, w, equal_nan=True)
+    x, w = np.asarray(x, dtype=float), np.asarray(w, dtype=float)
+    if x.shape != w.shape or not np.array_equal(np.isnan(x), np.isnan(w)):
+        return False
+    fin = np.isfinite(w)
+    if not np.array_equal(x[~fin & ~np.isnan(w)], w[~fin & ~np.isnan(w)]):
+        return False
+    if not fin.any():
+        return True
+    scale = np.abs(w[fin]).max()
+    return bool((np.abs(x[fin] - w[fin]) <=
+                 1e-8*np.maximum(np.abs(w[fin]), scale)).all())
 
 
 def compare(dev, cpu, log):
@@ -49,7 +70,7 @@ def compare(dev, cpu, log):
             if not cpu.engine.valid[j]:
                 continue
             x, w = np.asarray(a[j]), np.asarray(b[j])
-            if not np.array_equal(x, w, equal_nan=True):
+            if not same(x, w):
                 raise AssertionError("%s[%d] differs after: %s" % (
                     name, j, " | ".join(log[-10:])))
     held = np.asarray(cpu.engine.valid, dtype=bool)
@@ -82,6 +103,8 @@ def sequence(seed, nops):
     p = copy.deepcopy(NAMED[(seed//3) % len(NAMED)]) if designed else \
         random_prescription(seed)
     system = ra.system_from_dict(copy.deepcopy(p))
+    LOOSE[0] = ARITH != "exact" and any(
+        getattr(e, "aspherics", None) is not None for e in system)
     L = len(system)
     dev = ra.GeometricTrace(system)
     cpu = ra.GeometricTrace(system, engine=OracleEngine())
@@ -213,7 +236,7 @@ def sequence(seed, nops):
                 if cpu.engine.valid[j]:
                     x = np.asarray(getattr(dev, name)[j])
                     w = np.asarray(getattr(cpu, name)[j])
-                    assert np.array_equal(x, w, equal_nan=True), \
+                    assert same(x, w), \
                         "read %s[%d] after: %s" % (name, j,
                                                    " | ".join(log[-6:]))
                 log.append("read %s[%d]" % (name, j))
