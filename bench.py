@@ -210,6 +210,13 @@ def cpu_one_core(table, system, y, u, clip, S, g, L, sample, l):
         return port
     out, t = reference_one_process(P.DOUBLE_GAUSS, ys, us, l, clip, m)
     image = t.y[-1]
+    # the reference's own reduction on its result (rayopt/geometric_trace.py:
+    # 171-183), for the `consumers` record
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        ref_rms = float(t.rms())
+    out["reference_rms_seconds"] = time.perf_counter() - t0
+    out["reference_rms"] = ref_rms
     assert np.array_equal(np.isnan(got), np.isnan(image))
     out["host"] = host_cpu()
     out["image_row_bit_identical_to_gpu"] = bool(
@@ -824,6 +831,16 @@ def main():
             d_dst = eng.scratch(int(counts.sum())*3*8)
     job = Job(args, group, g, counts, d_dst)
     job.exchange = not share or bool(stand_in)
+    # what the transport itself says it is (not what the launcher claimed):
+    # ranks in the communicator, RCCL version, link type to every peer device
+    comm_info = None
+    if dist_mode and job.exchange:
+        mine = eng.comm_info()
+        assert mine["nranks_seen"] == world and mine["rank_seen"] == rank, mine
+        every = group.gather(np.array([mine["nranks_seen"],
+                                       mine["rank_seen"]], dtype=np.int64))
+        if rank == 0:
+            comm_info = dict(mine, every_rank_saw=[e.tolist() for e in every])
 
     mode = {"clip": clip}
 
@@ -1090,6 +1107,7 @@ def main():
     }
     if dist_mode:
         out["gather_ms"] = gather_ms
+        out["transport"] = comm_info
         out["kernel_ms_per_rank"] = per_rank_kernel_ms
         if gather_exposed is not None:
             out["gather_pipelined_ms"] = gather_exposed[0]
@@ -1203,6 +1221,15 @@ def main():
             out["cpu_baseline_c"] = cpu_c_oracle(table, y, u, clip, S, g, L)
         except Exception as err:      # a reported extra, never fatal
             out["cpu_baseline_c"] = {"error": repr(err)[:200]}
+    if world == 1 and not dist_mode and plain and not args.no_configs and \
+            not os.environ.get("RT_BENCH_CHILD") and \
+            not _profiled_from_outside(os.environ):
+        try:
+            out["consumers"] = run_consumers(
+                ra, g, system, n, len(FIELD_FRACTIONS),
+                out.get("cpu_baseline"))
+        except Exception as err:      # reported extras, never fatal
+            out["consumers"] = {"error": repr(err)[:300]}
     emit(json.dumps(out))
     if dist_mode:
         group.barrier()
@@ -1247,14 +1274,34 @@ def algorithmic_bytes(tables, n, clip, generated=False, alias=True,
     return n*per_op + read_bytes, per_op/(L - 1)
 
 
-def kernel_ms_of(g, clip, warm=10, reps=12):
-    """Median HIP-event duration of one propagate() of the resident batch."""
-    for _ in range(warm):
-        g.propagate(clip=clip)
+def kernel_ms_of(g, clip, settle_s=.25, per_block=10, blocks=5):
+    """Launch time of one propagate() of the resident batch, measured like
+    the headline's: after a settle phase of back-to-back launches (clocks and
+    power filter in their loaded state), HIP events around blocks of
+    back-to-back launches; the median block / launches per block."""
+    eng = g.engine
+    g.propagate(clip=clip)
+    eng.sync()
+    if g.kernel_ms() < .1:
+        # launch bound (C1): the kernel's own events, one launch at a time
+        t = []
+        for _ in range(40):
+            g.propagate(clip=clip)
+            t.append(g.kernel_ms())
+        return float(np.median(t[10:]))
+    per = max(1, min(per_block, int(40./max(g.kernel_ms(), 1e-3))))
+    t_end = time.perf_counter() + settle_s
+    while time.perf_counter() < t_end:
+        for _ in range(per):
+            g.propagate(clip=clip)
+        eng.sync()
     t = []
-    for _ in range(reps):
-        g.propagate(clip=clip)
-        t.append(g.kernel_ms())
+    for _ in range(blocks):
+        eng.event_record(0)
+        for _ in range(per):
+            g.propagate(clip=clip)
+        eng.event_record(1)
+        t.append(eng.event_elapsed(0, 1)/per)
     return float(np.median(t))
 
 
@@ -1405,6 +1452,82 @@ def run_configs(ra, device, args):
         out[-1]["finite_fraction_at_image_sampled"] = float(
             np.isfinite(ulast).mean())
         del g
+    return out
+
+
+def run_consumers(ra, g, system, n, nf, cpu):
+    """The device-side consumers on the resident headline
+    batch: streaming reductions over one or two rows.  Wall time per call
+    (each returns a scalar or a small array to the host, i.e. includes its own
+    synchronisation), algorithmic bytes read, fraction of the 8 TB/s spec."""
+    eng, L = g.engine, len(system)
+    g.propagate(clip=True)
+    eng.sync()
+
+    def timed(fn, reps=20):
+        fn()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0)/reps*1e3
+
+    def rec(name, ms, nbytes, replaces, note=""):
+        r = {"call": name, "ms": ms, "bytes_read": nbytes,
+             "GBps": nbytes/(ms*1e-3)/1e9,
+             "frac": nbytes/(ms*1e-3)/1e9/HBM_PEAK_GBS,
+             "replaces": replaces}
+        if note:
+            r["note"] = note
+        return r
+    out = []
+    out.append(rec("rms (centroid + spread: two passes over y0, y1)",
+                   timed(lambda: g.rms()), 32*n,
+                   "rayopt/geometric_trace.py:171-183"))
+    out.append(rec("refocus_shift (two passes over y0 y1 i0 i1 i2)",
+                   timed(lambda: eng.refocus_shift(L - 1)), 80*n,
+                   "rayopt/geometric_trace.py:82-97 (the sums; the "
+                   "re-propagate of :98-99 is one more trace)"))
+    out.append(rec("spot_stats, %d field bundles (two passes over y0, y1)"
+                   % nf, timed(lambda: eng.spot_stats(L - 1, n//nf, nf)),
+                   32*n, "per-field rms of rayopt/analysis.py spot diagrams"))
+    out.append(rec("row_rmax (one pass over y0, y1)",
+                   timed(lambda: eng.row_rmax(L - 1)), 16*n,
+                   "rayopt/geometric_trace.py:185-193 resize()"))
+    try:
+        nrows = L - 1
+        ms = timed(lambda: g.opd_rays(radius=100.), reps=4)
+        out.append(rec(
+            "opd_rays (t rows 0..%d, y/u of the last element, y[0]; x y t "
+            "per ray written AND copied to the host)" % (nrows - 1), ms,
+            (8*nrows + 72)*n, "rayopt/geometric_trace.py:101-131",
+            "the call returns three host arrays: 24 B/ray cross PCIe inside "
+            "the timed region, which is what bounds it"))
+    except Exception as err:                  # a reported extra, never fatal
+        out.append({"call": "opd_rays", "error": repr(err)[:200]})
+    try:
+        from rayopt_amd.aiming import FieldAimer
+        from rayopt_amd import prescriptions as P
+        s2 = ra.system_from_yaml(P.cooke().replace("radius: 20.",
+                                                   "radius: 0.364"))
+        s2.update()
+        fields = np.c_[np.zeros(2000), np.linspace(0., 1., 2000)]
+        aimer = FieldAimer(s2, s2.wavelengths[0], eng, aim=None)
+        ms = timed(lambda: aimer.pupil(fields), reps=5)
+        out.append({"call": "aim_pupil, 2000 fields of the Cooke triplet "
+                            "(chief + four marginal root finds each)",
+                    "ms": ms, "fields_per_s": 2000/(ms*1e-3),
+                    "replaces": "rayopt/system.py:507-593 (~130 serial "
+                                "one-ray traces per field)",
+                    "bound": "latency: 8000 lanes, one per root find"})
+        g.rays_given  # (the aimer used its own small batch on this engine)
+    except Exception as err:
+        out.append({"call": "aim_pupil", "error": repr(err)[:200]})
+    if cpu and cpu.get("reference_rms_seconds"):
+        out[0]["cpu_reference"] = {
+            "seconds": cpu["reference_rms_seconds"], "rays": cpu["rays"],
+            "rays_per_s": cpu["rays"]/cpu["reference_rms_seconds"],
+            "device_rays_per_s": n/(out[0]["ms"]*1e-3)}
     return out
 
 

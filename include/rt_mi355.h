@@ -299,7 +299,10 @@ int rt_trace(rt_ctx *ctx, int start, int stop, int clip);
  * `nchunks` pieces of whole 256-ray workgroups (rt_chunk_bounds: [lo, hi) of
  * chunk k for a batch of n rays; the last pieces may be short or empty) and
  * chunk `chunk` is traced.  All chunks of a step, in any order, give what
- * rt_trace gives.  For multi-GPU jobs: rt_gather_chunk of chunk k runs on the
+ * rt_trace gives; until the last of them has been traced the rows hold new
+ * and old columns side by side, and every entry point that reads WHOLE rows
+ * (rt_download, rt_device_ptr, the reductions, rt_gather_final) returns
+ * RT_ERR_STATE (rt_gather_chunk reads only its own chunk's columns).  For multi-GPU jobs: rt_gather_chunk of chunk k runs on the
  * communication stream while chunk k+1 is traced.  Not for batches with
  * several surface tables (ray groups).
  */
@@ -461,6 +464,19 @@ int rt_comm_unique_id(void *id128);
 int rt_comm_init(rt_ctx *ctx, const void *id128, int nranks, int rank);
 int rt_comm_destroy(rt_ctx *ctx);
 /*
+ * What the communicator says about itself, so that a multi-GPU line can be
+ * checked against the transport rather than against what the launcher
+ * claimed: info[0] = ncclCommCount (rt_comm_init already refuses a
+ * communicator whose count or rank differ from what it was asked for),
+ * info[1] = ncclCommUserRank, info[2] = ncclGetVersion's code (e.g. 22707),
+ * info[3] = HIP devices visible to this process.  link_type[d] / hops[d] for
+ * d < min(info[3], max_devices): hipExtGetLinkTypeAndHopCount from this
+ * context's device to device d (HSA_AMD_LINK_INFO_TYPE_*: 4 = xGMI, 2 =
+ * PCIe; -1 for the device itself or no answer).  max_devices may be 0.
+ */
+int rt_comm_info(rt_ctx *ctx, int info[4], int *link_type, int *hops,
+                 int max_devices);
+/*
  * Gather row `surf` of array `which` from every rank to `root`.  counts[r] =
  * rays held by rank r.  On root, d_dst is a device buffer of
  * ncomp*sum(counts) doubles laid out [component][global ray]; ignored
@@ -509,12 +525,14 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * the whole process; plain hipMalloc if anything on the way fails; results
  * never depend on it).  info[0] = pieces behind the arrays (0: hipMalloc),
  * [1] = MiB per piece, [2] = pieces created on the way, [3] = classes seen,
- * [4..6] = pieces of class 0 / 1 / 2 kept, [7] = 1 if no class holds more
- * than 60 % (store-bound traces then run four workgroups per CU instead of
- * two); ms[0] / ms[1] = the pair test's launch time inside one piece /
+ * [4..6] = pieces of class 0 / 1 / 2 kept, [7] = 1 if at least a third of
+ * the pieces lie outside the largest class (store-bound traces then run four
+ * workgroups per CU instead of two), [8] = blocks of ballast (4-8 GiB each)
+ * held during the search so that it moved on through the device memory
+ * (pieces come in runs of one class), [9] = 0; ms[0] / ms[1] = the pair test's launch time inside one piece /
  * across two classes.
  */
-int rt_placement(rt_ctx *ctx, int info[8], double ms[2]);
+int rt_placement(rt_ctx *ctx, int info[10], double ms[2]);
 
 /* device scratch owned by the context (e.g. gather destination on root) */
 int rt_scratch(rt_ctx *ctx, int64_t bytes, void **out);

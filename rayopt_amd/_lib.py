@@ -139,6 +139,10 @@ SIGNATURES = {
     "rt_gather_ms": (ctypes.c_int, [_ctx, _c_double_p, _c_double_p]),
     "rt_comm_sync": (ctypes.c_int, [_ctx]),
     "rt_input_uniform": (ctypes.c_int, [_ctx, _c_int64_p]),
+    "rt_comm_info": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_int),
+                                    ctypes.POINTER(ctypes.c_int),
+                                    ctypes.POINTER(ctypes.c_int),
+                                    ctypes.c_int]),
     "rt_placement": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_int),
                                     ctypes.POINTER(ctypes.c_double)]),
     "rt_selftest_arith": (ctypes.c_int, [_ctx, ctypes.c_uint64,

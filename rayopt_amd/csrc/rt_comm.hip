@@ -58,6 +58,9 @@ static int rt_rccl_load(rt_ctx *ctx)
     RT_SYM(Send, "ncclSend");
     RT_SYM(Recv, "ncclRecv");
     RT_SYM(GetErrorString, "ncclGetErrorString");
+    RT_SYM(CommCount, "ncclCommCount");
+    RT_SYM(CommUserRank, "ncclCommUserRank");
+    RT_SYM(GetVersion, "ncclGetVersion");
 #undef RT_SYM
     api.lib = lib;
     g_rccl = api;
@@ -131,6 +134,8 @@ static int rt_gather_window(rt_ctx *ctx, int which, int surf,
         return rt_fail(ctx, RT_ERR_ARG, "%s: root needs d_dst", who);
     if (rt_soa_only(ctx, who) != RT_OK)
         return RT_ERR_STATE;
+    if (nchunks == 1) /* a whole row: not in the middle of a step in pieces */
+        RT_ROWS_WHOLE(ctx, who);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     {
         int rc = rt_gen_flush(ctx);
@@ -166,8 +171,14 @@ static int rt_gather_window(rt_ctx *ctx, int which, int surf,
                                      hipMemcpyDeviceToDevice, ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->staged[p], ctx->stream));
     RT_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->staged[p], 0));
-    if (chunk == 0)
+    /* the gather's clock runs from the first piece ISSUED to the last one
+     * issued, whatever their order */
+    if (ctx->gather_seen == 0 || ctx->gather_nchunks != nchunks) {
+        ctx->gather_seen = 0;
+        ctx->gather_nchunks = nchunks;
+        ctx->gather_timed = 0;
         RT_HIP(ctx, hipEventRecord(ctx->g0, ctx->comm_stream));
+    }
 
     int64_t total = 0;
     for (int r = 0; r < ctx->nranks; ++r)
@@ -217,11 +228,10 @@ static int rt_gather_window(rt_ctx *ctx, int which, int surf,
                                                                     : end));
     }
     RT_HIP(ctx, hipEventRecord(ctx->gathered[p], ctx->comm_stream));
-    if (chunk == 0)
-        ctx->gather_timed = 0;
-    if (chunk == nchunks - 1) {
+    if (++ctx->gather_seen >= nchunks) {
         RT_HIP(ctx, hipEventRecord(ctx->g1, ctx->comm_stream));
         ctx->gather_timed = 1;
+        ctx->gather_seen = 0;
     }
     ctx->gather_pending[p] = 1;
     return RT_OK;
@@ -255,8 +265,51 @@ int rt_comm_init(rt_ctx *ctx, const void *id128, int nranks, int rank)
     ncclUniqueId id;
     memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
     RT_NCCL(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, id, rank));
+    /* what the communicator itself says it is */
+    int seen = -1, me = -1;
+    ncclResult_t r1 = g_rccl.CommCount(ctx->comm, &seen);
+    ncclResult_t r2 = g_rccl.CommUserRank(ctx->comm, &me);
+    if (r1 != ncclSuccess || r2 != ncclSuccess || seen != nranks ||
+        me != rank) {
+        g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = NULL;
+        return rt_fail(ctx, RT_ERR_RCCL,
+                       "rt_comm_init: asked for rank %d of %d, the "
+                       "communicator says rank %d of %d", rank, nranks, me,
+                       seen);
+    }
     ctx->nranks = nranks;
     ctx->rank = rank;
+    ctx->gather_seen = 0;
+    return RT_OK;
+}
+
+int rt_comm_info(rt_ctx *ctx, int info[4], int *link_type, int *hops,
+                 int max_devices)
+{
+    if (!ctx || !info || max_devices < 0 ||
+        (max_devices > 0 && (!link_type || !hops)))
+        return rt_fail(ctx, RT_ERR_ARG, "rt_comm_info: bad argument");
+    if (!ctx->comm)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_comm_info: rt_comm_init first");
+    info[0] = info[1] = info[2] = -1;
+    RT_NCCL(ctx, g_rccl.CommCount(ctx->comm, &info[0]));
+    RT_NCCL(ctx, g_rccl.CommUserRank(ctx->comm, &info[1]));
+    RT_NCCL(ctx, g_rccl.GetVersion(&info[2]));
+    int ndev = 0;
+    RT_HIP(ctx, hipGetDeviceCount(&ndev));
+    info[3] = ndev;
+    for (int d = 0; d < ndev && d < max_devices; ++d) {
+        uint32_t type = 0, hop = 0;
+        link_type[d] = hops[d] = -1; /* this device itself, or no answer */
+        if (d != ctx->device &&
+            hipExtGetLinkTypeAndHopCount(ctx->device, d, &type, &hop) ==
+                hipSuccess) {
+            link_type[d] = (int)type;
+            hops[d] = (int)hop;
+        }
+        (void)hipGetLastError();
+    }
     return RT_OK;
 }
 

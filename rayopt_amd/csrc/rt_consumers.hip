@@ -127,6 +127,7 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
                        surf);
     if (rt_soa_only(ctx, who) != RT_OK)
         return RT_ERR_STATE;
+    RT_ROWS_WHOLE(ctx, who);
     if (ctx->d_w && ctx->w_n != ctx->n)
         return rt_fail(ctx, RT_ERR_STATE,
                        "%s: the weights on the device were set for a batch "

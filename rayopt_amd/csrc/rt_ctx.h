@@ -44,6 +44,9 @@ struct rt_rccl_api {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t,
                          hipStream_t);
     const char *(*GetErrorString)(ncclResult_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
+    ncclResult_t (*GetVersion)(int *);
 };
 
 #ifdef RT_BUILD_PROBES
@@ -88,9 +91,10 @@ struct rt_place {
     int n;           /* pieces mapped */
     void *handles;   /* hipMemGenericAllocationHandle_t[n] */
     int created;     /* pieces created on the way (the surplus was released) */
+    int ballast;     /* blocks of ballast held while searching */
     int nclass;      /* classes seen */
     int count[RT_PLACE_CLASSES]; /* pieces of each class among the n */
-    int mixed;       /* no class holds more than 60 % of the pieces */
+    int mixed;       /* >= a third of the pieces outside the largest class */
     float self_ms, cross_ms; /* pair test: same piece / another class */
 };
 
@@ -154,6 +158,12 @@ struct rt_ctx {
     int opt_resident; /* bytes of unused dynamic LDS per workgroup of the
                          trace kernels: caps the workgroups resident per CU
                          (160 KB / bytes); -1 = chosen per trace */
+    /* a step traced in pieces (rt_trace_chunk): until every piece has been
+     * traced the rows hold new and old columns side by side, and whatever
+     * reads whole rows must wait (rt_rows_whole) */
+    int pieces_total, pieces_seen, pieces_start, pieces_stop, pieces_clip;
+    uint64_t pieces_mask[4];
+    int gather_seen, gather_nchunks; /* chunks of the gather in progress */
     int opt_place;    /* large arrays in class-mixed pieces (rt_place.h) */
     struct rt_place place;
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
@@ -198,6 +208,17 @@ struct rt_ctx {
 RT_INTERNAL extern rt_rccl_api g_rccl;
 
 extern "C" RT_INTERNAL int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...);
+
+/* refuse to read whole rows in the middle of a step traced in pieces */
+#define RT_ROWS_WHOLE(ctx, who)                                               \
+    do {                                                                      \
+        if ((ctx)->pieces_seen > 0)                                           \
+            return rt_fail(ctx, RT_ERR_STATE,                                 \
+                           "%s: %d of %d pieces of the current step have "    \
+                           "been traced (rt_trace_chunk): the rows are not "  \
+                           "whole yet", who, (ctx)->pieces_seen,              \
+                           (ctx)->pieces_total);                              \
+    } while (0)
 
 #define RT_HIP(ctx, call)                                                     \
     do {                                                                      \

@@ -1036,7 +1036,9 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
     lay.U += lo;
     lay.I += lo;
     lay.T += lo;
-    const int64_t cols = (hi == ctx->n ? ctx->ld : hi) - lo;
+    /* an empty trailing piece (lo == hi == n) launches nothing: the padding
+     * columns belong to the last NON-empty piece */
+    const int64_t cols = lo < hi ? (hi == ctx->n ? ctx->ld : hi) - lo : 0;
     const int64_t group_rays = ctx->ngroups > 1 ? ctx->n / ctx->ngroups : 0;
     const unsigned grid = (unsigned)((cols + RT_BLOCK - 1) / RT_BLOCK);
     const size_t lds = rt_resident_lds(ctx, start, stop);
@@ -1091,7 +1093,10 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
 
 int rt_trace(rt_ctx *ctx, int start, int stop, int clip)
 {
-    return rt_trace_window(ctx, start, stop, clip, 0, ctx ? ctx->n : 0);
+    const int rc = rt_trace_window(ctx, start, stop, clip, 0, ctx ? ctx->n : 0);
+    if (ctx && rc == RT_OK)
+        ctx->pieces_seen = ctx->pieces_total = 0; /* whole rows again */
+    return rc;
 }
 
 int rt_trace_chunk(rt_ctx *ctx, int start, int stop, int clip, int chunk,
@@ -1104,7 +1109,32 @@ int rt_trace_chunk(rt_ctx *ctx, int start, int stop, int clip, int chunk,
     if (rc != RT_OK)
         return rt_fail(ctx, rc, "rt_trace_chunk: chunk %d of %d", chunk,
                        nchunks);
-    return rt_trace_window(ctx, start, stop, clip, lo, hi);
+    rc = rt_trace_window(ctx, start, stop, clip, lo, hi);
+    if (rc != RT_OK || nchunks == 1 || nchunks > 256) {
+        if (rc == RT_OK)
+            ctx->pieces_seen = ctx->pieces_total = 0;
+        return rc;
+    }
+    /* which pieces of this step exist by now (any order) */
+    if (ctx->pieces_seen == 0 || ctx->pieces_total != nchunks ||
+        ctx->pieces_start != start || ctx->pieces_stop != stop ||
+        ctx->pieces_clip != clip) {
+        memset(ctx->pieces_mask, 0, sizeof ctx->pieces_mask);
+        ctx->pieces_seen = 0;
+        ctx->pieces_total = nchunks;
+        ctx->pieces_start = start;
+        ctx->pieces_stop = stop;
+        ctx->pieces_clip = clip;
+    }
+    uint64_t &word = ctx->pieces_mask[chunk >> 6];
+    const uint64_t bit = (uint64_t)1 << (chunk & 63);
+    if (!(word & bit)) {
+        word |= bit;
+        ++ctx->pieces_seen;
+    }
+    if (ctx->pieces_seen == ctx->pieces_total)
+        ctx->pieces_seen = ctx->pieces_total = 0; /* the step is complete */
+    return RT_OK;
 }
 
 int rt_set_keep_rows(rt_ctx *ctx, const unsigned char *keep, int n)
@@ -1215,6 +1245,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
 
 int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
 {
+    if (ctx)
+        RT_ROWS_WHOLE(ctx, "rt_download");
     if (!ctx || !dst || which < RT_Y || which > RT_T)
         return rt_fail(ctx, RT_ERR_ARG, "rt_download: bad argument");
     if (!ctx->d_buf || surf_lo < 0 || surf_hi > ctx->buf_nsurf ||
@@ -1251,6 +1283,8 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
 
 int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
 {
+    if (ctx)
+        RT_ROWS_WHOLE(ctx, "rt_download_ray");
     if (!ctx || !dst || which < RT_Y || which > RT_T)
         return rt_fail(ctx, RT_ERR_ARG, "rt_download_ray: bad argument");
     if (!ctx->d_buf || ray < 0 || ray >= ctx->n)
@@ -1282,6 +1316,8 @@ int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
 
 int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
 {
+    if (ctx)
+        RT_ROWS_WHOLE(ctx, "rt_device_ptr");
     if (!ctx || !out || which < RT_Y || which > RT_T)
         return rt_fail(ctx, RT_ERR_ARG, "rt_device_ptr: bad argument");
     if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
@@ -1364,7 +1400,7 @@ int rt_selftest_arith(rt_ctx *ctx, uint64_t seed, int64_t n, int span,
     return RT_OK;
 }
 
-int rt_placement(rt_ctx *ctx, int info[8], double ms[2])
+int rt_placement(rt_ctx *ctx, int info[10], double ms[2])
 {
     if (!ctx || !info || !ms)
         return rt_fail(ctx, RT_ERR_ARG, "rt_placement: NULL argument");
@@ -1376,6 +1412,8 @@ int rt_placement(rt_ctx *ctx, int info[8], double ms[2])
     for (int k = 0; k < 3; ++k)
         info[4 + k] = p.count[k];
     info[7] = p.mixed;
+    info[8] = p.ballast;
+    info[9] = 0;
     ms[0] = p.self_ms;
     ms[1] = p.cross_ms;
     return RT_OK;

@@ -128,7 +128,15 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     }
     const int need = (int)((bytes + piece - 1) / piece);
     size_t align = piece & (~piece + 1); /* largest power of two dividing it */
-    const int cap = need + 16; /* pieces created at most */
+    const int cap = need + 24; /* pieces created and classified at most */
+    /* Pieces come in runs of one class (2-14 seen, 26+ on one box): once a
+     * class is oversupplied the search HOPS -- a block of ballast is created
+     * and held, unclassified, so that the next piece lies further on in the
+     * device memory -- until another class turns up.  Ballast and surplus
+     * pieces go back to the device before rt_place_alloc returns. */
+    const int max_ballast = 24;
+    hipMemGenericAllocationHandle_t ballast[24];
+    int nballast = 0, hops_in_a_row = 0;
     /* short rows: 84 of them fit one piece */
     const long long nprobe =
         (long long)(piece / sizeof(double) / RT_PLACE_ROWS) / 256 * 256;
@@ -218,6 +226,17 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
             cls[k] = (unsigned char)found;
             ++count[found];
         }
+        if (count[cls[k]] > (need + 1) / 2 && made >= (need + 1) / 2 + 1 &&
+            nballast < max_ballast) {
+            const size_t hop = (size_t)(hops_in_a_row < 3 ? 4 : 8) << 30;
+            if (hipMemCreate(&ballast[nballast], hop, &prop, 0) == hipSuccess)
+                ++nballast;
+            else
+                (void)hipGetLastError(); /* the device is full: no hopping */
+            ++hops_in_a_row;
+        } else {
+            hops_in_a_row = 0;
+        }
         /* enough when `need` pieces can be picked with no class holding
          * more than half of them (two classes evenly mixed run at 0.98 of
          * the three-class time: not worth a dozen more pieces) */
@@ -228,6 +247,8 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
             enough = can >= need;
         }
     }
+    for (int b = 0; b < nballast; ++b)
+        (void)hipMemRelease(ballast[b]);
     if (e != hipSuccess || made < need) {
         /* not this way: give everything back, allocate plainly */
         (void)hipGetLastError();
@@ -307,13 +328,12 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         P.count[k] = used[k];
     P.self_ms = self_ms;
     P.cross_ms = cross_ms;
-    /* mixed: no class holds more than 60 % of the pieces */
-    P.mixed = 1;
+    /* mixed: at least a third of the pieces lie outside the largest class */
+    int largest = 0;
     for (int k = 0; k < nclass; ++k)
-        if (10 * used[k] > 6 * need)
-            P.mixed = 0;
-    if (nclass < 2)
-        P.mixed = 0;
+        largest = used[k] > largest ? used[k] : largest;
+    P.mixed = nclass >= 2 && 3 * (need - largest) >= need;
+    P.ballast = nballast;
     *out = base;
     return hipSuccess;
 }

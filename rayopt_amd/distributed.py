@@ -88,6 +88,8 @@ _HELLO = "rt-mi355-hostgroup-2"
 _HEADER = struct.Struct("<4sBBHQ4q")
 _NONE, _FLOAT, _INT, _BYTES, _F64, _I64, _BOOL, _STR = range(8)
 _MAX_PAYLOAD = 1 << 32
+_PROCESS_START = time.time()
+_STALE_S = 600.     # a rendezvous file older than this process by more: stale
 
 
 def _encode(obj):
@@ -155,6 +157,18 @@ def _recv(sock):
         _recv_exact(sock, _HEADER.size))
     if magic != _MAGIC or nbytes > _MAX_PAYLOAD:
         raise ConnectionError("not a host-group frame")
+    # the header is the peer's claim: checked BEFORE the payload is read
+    if not 0 <= ndim <= 4 or any(d < 0 for d in dims[:ndim]):
+        raise ConnectionError("host group: bad frame shape")
+    if kind in (_F64, _I64):
+        count = 1
+        for d in dims[:ndim]:
+            count *= d
+        if count*8 != nbytes:
+            raise ConnectionError("host group: frame of %d bytes for a "
+                                  "shape of %d values" % (nbytes, count))
+    elif kind in (_BOOL, _INT, _FLOAT) and nbytes != 8:
+        raise ConnectionError("host group: bad scalar frame")
     return _decode(kind, ndim, dims, _recv_exact(sock, nbytes))
 
 
@@ -180,6 +194,17 @@ def rendezvous_path(env=None):
     env = os.environ if env is None else env
     path = env.get("RT_RDZV_FILE")
     if path:
+        # a file named inside a directory other users can write to (/tmp/x)
+        # is kept in a private directory of this user next to it instead
+        d = os.path.dirname(os.path.abspath(path)) or "."
+        try:
+            st = os.lstat(d)
+            shared = st.st_uid != os.getuid() or bool(st.st_mode & 0o077)
+        except OSError:
+            shared = False      # does not exist yet: _private_dir makes it
+        if shared:
+            return os.path.join(d, "rt_rdzv_%d" % os.getuid(),
+                                os.path.basename(path))
         return path
     tag = "%d_%s_%s" % (os.getuid(), env.get("MASTER_PORT", "0"),
                         env.get("TORCHELASTIC_RUN_ID", "none"))
@@ -230,6 +255,10 @@ def _read_published(path):
         if st.st_uid != os.getuid() or st.st_mode & 0o077:
             raise PermissionError("host group: %s is not private to this "
                                   "user" % path)
+        # what an earlier launch left behind (same port, same run id) is not
+        # this launch's rank 0: the ranks of one launch start within minutes
+        if st.st_mtime < _PROCESS_START - _STALE_S:
+            raise ValueError("stale rendezvous file")
         fields = f.read().split()
     return int(fields[0]), fields[1]
 

@@ -13,7 +13,7 @@ field in the reference -- is answered by the aiming kernel.
 """
 import numpy as np
 
-from .geometric_trace import GeometricTrace
+from ..geometric_trace import GeometricTrace
 
 BORROWED = ("rays", "rays_point", "rays_line", "rays_clipping",
             "rays_paraxial", "resize", "plot", "print_trace")
@@ -52,8 +52,8 @@ def _device_pupil(reference_pupil, engine_factory):
     object pupil the paraxial trace left in ``system.object.pupil``), same
     return value ``(z, a[2][2])``; the reference's own code handles what the
     kernel does not model (``pupil.aim`` off, an explicit ``stop`` index)."""
-    from .aiming import FieldAimer
-    from .engine import get_engine
+    from ..aiming import FieldAimer
+    from ..engine import get_engine
 
     def pupil(self, yo, l=None, stop=None, **kwargs):
         pup = self.object.pupil

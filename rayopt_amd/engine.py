@@ -300,12 +300,12 @@ class Engine:
         behind them (0 = plain hipMalloc), MiB per piece, pieces created on
         the way, classes seen, pieces kept per class, ``mixed`` and the pair
         test's two launch times."""
-        info = (ctypes.c_int*8)()
+        info = (ctypes.c_int*10)()
         ms = (ctypes.c_double*2)()
         self._check(self.lib.rt_placement(self.ctx, info, ms), "rt_placement")
         return {"pieces": info[0], "piece_mib": info[1], "created": info[2],
                 "classes": info[3], "per_class": [info[4], info[5], info[6]],
-                "mixed": bool(info[7]),
+                "mixed": bool(info[7]), "ballast_blocks": info[8],
                 "pair_test_ms": {"same_piece": ms[0], "other_class": ms[1]}}
 
     def selftest_arith(self, seed, n, span=100):
@@ -343,6 +343,21 @@ class Engine:
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         self._check(self.lib.rt_comm_init(self.ctx, buf, nranks, rank),
                     "rt_comm_init")
+
+    def comm_info(self, max_devices=16):
+        """What the communicator says about itself (rt_comm_info)."""
+        info = (ctypes.c_int*4)()
+        lt = (ctypes.c_int*max_devices)()
+        hp = (ctypes.c_int*max_devices)()
+        self._check(self.lib.rt_comm_info(self.ctx, info, lt, hp,
+                                          max_devices), "rt_comm_info")
+        nd = min(info[3], max_devices)
+        names = {1: "HyperTransport", 2: "PCIe", 3: "InfiniBand", 4: "xGMI"}
+        return {"nranks_seen": info[0], "rank_seen": info[1],
+                "rccl_version_code": info[2], "devices_visible": info[3],
+                "links": [{"device": d, "type": names.get(lt[d], lt[d]),
+                           "hops": hp[d]} for d in range(nd)
+                          if d != self.device]}
 
     def gather_final(self, which, surf, counts, root, d_dst):
         counts = np.ascontiguousarray(counts, dtype=np.int64)

@@ -205,12 +205,14 @@ class GeometricTrace(Trace):
         self._device = device
         self._options = dict(options)
         # "device": all fields aimed by one kernel, iterated to 1e-9;
-        # "reference": rayopt's own procedure and tolerances, field by field
-        # (rayopt_amd/aiming_reference.py) -- for numbers that must match
-        # rayopt's
+        # "reference": rayopt's procedure and tolerances, field by field, as
+        # this package restates it (rayopt_amd/aiming_reference.py) -- for
+        # numbers that must match rayopt's; "rayopt": the same with the
+        # INSTALLED rayopt's own methods (rayopt_amd/dropin/aiming_rayopt.py)
         self._aiming = self._options.pop("aiming", "device")
-        if self._aiming not in ("device", "reference"):
-            raise ValueError("aiming must be 'device' or 'reference'")
+        if self._aiming not in ("device", "reference", "rayopt"):
+            raise ValueError(
+                "aiming must be 'device', 'reference' or 'rayopt'")
         if engine is not None:
             self._apply_options()
 
@@ -654,10 +656,11 @@ class GeometricTrace(Trace):
     def _pupil(self, yo, l, rim=False, given=None):
         """(z (1,), a (1,2,2)) of one field, by the configured aiming;
         ``given``: the caller's wavelength argument, None if defaulted."""
-        if self._aiming == "reference":
+        if self._aiming != "device":
             from .aiming_reference import reference_aimer
             z, a = reference_aimer(self.system, self._aux_engine(), l,
-                                   -1 if rim else None, given).pupil(yo)
+                                   -1 if rim else None, given,
+                                   self._aiming).pupil(yo)
             return np.array([z]), a[None]
         from .aiming import FieldAimer
         return FieldAimer(self.system, l, self._aux_engine(),
@@ -730,12 +733,12 @@ class GeometricTrace(Trace):
         fields = np.linspace(0, 1, nrays)[:, None]*np.atleast_2d(yo)
         e = np.zeros((3, 2))
         e[(1, 2), (1, 0)] = eps
-        if self._aiming == "reference":
+        if self._aiming != "device":
             # field after field, each chief ray started from the previous
             # field's pupil distance (rayopt/geometric_trace.py:223-226)
             from .aiming_reference import reference_aimer
             aimer = reference_aimer(self.system, self._aux_engine(), l, None,
-                                    wavelength)
+                                    wavelength, self._aiming)
             zk, p = aimer.pupil((0., 0.))
             z, a = [], p[None]
             for field in fields:

@@ -868,17 +868,20 @@ class System(DesignMixin, list):
         marginal rays are aimed as the object pupil's ``aim`` flag says
         (``stop=-1``: marginal rays to the rim of the limiting aperture).
         ``aiming="device"``: the batched kernel, iterated to 1e-9;
-        ``"reference"``: rayopt's own solvers, tolerances and guess cache
-        (rayopt_amd/aiming_reference.py)."""
+        ``"reference"``: rayopt's procedure -- solvers, tolerances, guess
+        cache -- as rayopt_amd/aiming_reference.py restates it; ``"rayopt"``:
+        the installed rayopt's own methods on device traces
+        (rayopt_amd/dropin/aiming_rayopt.py)."""
         if stop not in (None, -1):
             raise NotImplementedError("pupil(): stop is None or -1")
         if engine is None:
             from .engine import get_engine
             engine = get_engine()
         wavelength = self.wavelengths[0] if l is None else l
-        if aiming == "reference":
+        if aiming in ("reference", "rayopt"):
             from .aiming_reference import reference_aimer
-            return reference_aimer(self, engine, wavelength, stop, l).pupil(yo)
+            return reference_aimer(self, engine, wavelength, stop, l,
+                                   aiming).pupil(yo)
         from .aiming import FieldAimer
         z, a = FieldAimer(self, wavelength, engine, aim=None).pupil(
             [yo], rim=(stop == -1))

@@ -309,6 +309,48 @@ def cmd_resident(a):
         del g4
 
 
+def cmd_c4check(a):
+    """Why does bench.py's C4 record (shared engine, after C3 and C2) time
+    slower than a fresh context?  The same flow, with a resident sweep."""
+    ra, P, _build, Engine = _imports()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import digest_cases as dc
+    from bench import workload_rays, kernel_ms_of
+    s4 = ra.system_from_yaml(P.ASPHERE_PHONE)
+    y4, u4 = dc.bundle(10_000_000, .6, 10., 4)
+    y4[:, 1] -= .5*np.tan(np.radians(10.))
+    l4 = s4.wavelengths[0]
+
+    def sweep(tag, g):
+        eng = g.engine
+        res = {"bench_way": kernel_ms_of(g, True)}
+        for lds in (32768, 28672, 24576, 0):
+            eng.set_option("resident_lds", lds)
+            res[str(lds)] = steady(eng, .4)
+        eng.set_option("resident_lds", -1)
+        res["auto_steady"] = steady(eng, .4)
+        res["bench_way_again"] = kernel_ms_of(g, True)
+        out(tag=tag, placement=eng.placement(), ms=res)
+
+    g = ra.GeometricTrace(s4, engine=Engine(0))
+    g.rays_given(y4, u4, l4)
+    sweep("fresh context", g)
+    del g
+    s3 = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = workload_rays(10_000_000, 0)
+    g3 = ra.GeometricTrace(s3, device=0)
+    g3.rays_given(y, u)
+    g3.propagate(clip=True)
+    del g3
+    g = ra.GeometricTrace(s4, device=0)
+    g.rays_given(y4, u4, l4)
+    sweep("shared engine after C3 (10 pieces of 13 x 10^7)", g)
+    small = ra.GeometricTrace(s4, device=0)
+    small.rays_given(y4[:100_000], u4[:100_000], l4)
+    small.propagate(clip=True)
+    sweep("... after another trace used the engine (re-seeded)", g)
+
+
 def cmd_pmc_summary(a):
     """For each pass directory: per (context, setting) mean of every counter
     over the trace-kernel dispatches of that block."""
@@ -370,6 +412,8 @@ def main():
     p = sub.add_parser("resident")
     p.add_argument("--rays", type=int, default=10_000_000)
     p.set_defaults(fn=cmd_resident)
+    p = sub.add_parser("c4check")
+    p.set_defaults(fn=cmd_c4check)
     p = sub.add_parser("pmc-summary")
     p.add_argument("dir")
     p.set_defaults(fn=cmd_pmc_summary)

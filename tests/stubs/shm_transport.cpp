@@ -245,6 +245,30 @@ ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t type, int peer,
                      reinterpret_cast<comm *>(handle), stream});
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t handle, int *count)
+{
+    if (!handle || !count)
+        return ncclInvalidArgument;
+    *count = reinterpret_cast<const comm *>(handle)->nranks;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t handle, int *rank)
+{
+    if (!handle || !rank)
+        return ncclInvalidArgument;
+    *rank = reinterpret_cast<const comm *>(handle)->rank;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGetVersion(int *version)
+{
+    if (!version)
+        return ncclInvalidArgument;
+    *version = -1; /* not RCCL: the stand-in */
+    return ncclSuccess;
+}
+
 const char *ncclGetErrorString(ncclResult_t r)
 {
     switch (r) {

@@ -196,22 +196,40 @@ def test_analysis_replay_on_the_engine_double(name):
                                                   engine=OracleEngine()))
 
 
-def _installed_rayopt():
-    """aiming="reference" binds the INSTALLED rayopt's own solver methods to
-    device traces (rayopt_amd/aiming_reference.py): the package has to be
-    importable -- here the unmodified reference (oracle/_ref on a GPU box)."""
+def _installed_rayopt(kind):
+    """aiming="rayopt" binds the INSTALLED rayopt's own solver methods to
+    device traces (rayopt_amd/dropin/aiming_rayopt.py): the package has to be
+    importable -- here the unmodified reference (oracle/_ref on a GPU box).
+    aiming="reference" (rayopt_amd/aiming_reference.py) needs no rayopt."""
+    if kind != "rayopt":
+        return
     from oracle import refshim
     if not refshim.available():
         pytest.skip("no importable rayopt (oracle/_ref not built)")
     refshim.load()
 
 
+# What the two groups of tests below prove -- they are different claims:
+#
+#  * "..._with_the_reference_aiming": rayopt's aiming PROCEDURE (its solvers,
+#    tolerances, guess cache -- restated, or rayopt's own methods) driven by
+#    this engine's one-ray traces reproduces the recorded Analysis to 1e-13:
+#    evidence for the TRACES (and the launch-ray generation) under a solver
+#    that is not ours.  It says nothing about FieldAimer.
+#  * "test_analysis_replay_on_the_engine_double / _on_the_device": this
+#    package's own aimer, FieldAimer (all fields in one kernel, iterated to
+#    1e-9), against an Analysis recorded with rayopt's aimer, which stops at
+#    1e-3: agreement to the reference's SOLVER tolerance is all that can be
+#    asked (TOLERANCES above); FieldAimer's own accuracy is pinned by
+#    tests/test_aiming.py (defining conditions to 1e-9).
+
+@pytest.mark.parametrize("kind", ["reference", "rayopt"])
 @pytest.mark.parametrize("name", NAMES)
-def test_analysis_replay_with_the_reference_aiming(name):
+def test_analysis_replay_with_the_reference_aiming(name, kind):
     from fake_engine import OracleEngine
-    _installed_rayopt()
+    _installed_rayopt(kind)
     replay(name, lambda system: ra.GeometricTrace(
-        system, engine=OracleEngine(), aiming="reference"), EXACT)
+        system, engine=OracleEngine(), aiming=kind), EXACT)
 
 
 @pytest.mark.gpu
@@ -221,8 +239,9 @@ def test_analysis_replay_on_the_device(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["reference", "rayopt"])
 @pytest.mark.parametrize("name", NAMES)
-def test_analysis_replay_on_the_device_with_the_reference_aiming(name):
-    _installed_rayopt()
-    replay(name, lambda system: ra.GeometricTrace(system, aiming="reference"),
+def test_analysis_replay_on_the_device_with_the_reference_aiming(name, kind):
+    _installed_rayopt(kind)
+    replay(name, lambda system: ra.GeometricTrace(system, aiming=kind),
            EXACT_DEVICE)

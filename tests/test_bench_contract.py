@@ -85,6 +85,19 @@ def test_single_process_line():
     gb = d["generated_batch"]
     assert gb["value"] > 0 and gb["rays"] == 200000
     assert gb["finite_fraction_at_image"] > .9
+    # where the arrays live (small batch: plain hipMalloc, two per CU)
+    pl = r["placement"]
+    assert pl["pieces"] == 0 and pl["workgroups_per_cu_cap"] == 2
+    # the device-side consumers on the resident batch
+    calls = {c["call"].split()[0].rstrip(","): c for c in d["consumers"]}
+    assert {"rms", "refocus_shift", "spot_stats", "row_rmax", "opd_rays",
+            "aim_pupil"} <= set(calls), calls.keys()
+    for name in ("rms", "refocus_shift", "spot_stats", "row_rmax"):
+        assert calls[name]["ms"] > 0 and calls[name]["bytes_read"] > 0
+    assert "error" not in calls["opd_rays"], calls["opd_rays"]
+    assert "error" not in calls["aim_pupil"], calls["aim_pupil"]
+    if kind == "reference":
+        assert calls["rms"]["cpu_reference"]["seconds"] > 0
 
 
 def test_self_spawned_single_rank_multi_process_path():

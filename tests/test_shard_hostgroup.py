@@ -256,3 +256,58 @@ def test_rendezvous_is_private_to_the_user(tmp_path):
     # directory of its own
     p = D.rendezvous_path({"MASTER_PORT": "29500"})
     assert ("_%d_29500_" % os.getuid()) in p and p.endswith("/rdzv")
+
+
+def test_a_frame_header_is_checked_before_its_payload_is_read():
+    """ndim, dims and the byte count of a frame are the peer's claims: a frame
+    whose shape does not add up to its payload is refused as a broken
+    connection (not a ValueError out of reshape), without waiting for bytes
+    that will never come."""
+    a, b = socket.socketpair()
+    b.settimeout(2.)
+    try:
+        good = D._encode(np.arange(6.).reshape(2, 3))
+        magic, kind, ndim, pad, nbytes, *dims = D._HEADER.unpack(
+            good[:D._HEADER.size])
+        for bad in (dict(ndim=7), dict(dims=[2, 4, 0, 0]), dict(nbytes=40),
+                    dict(dims=[-2, -3, 0, 0])):
+            hdr = D._HEADER.pack(magic, kind, bad.get("ndim", ndim), pad,
+                                 bad.get("nbytes", nbytes),
+                                 *bad.get("dims", dims))
+            a.sendall(hdr)          # no payload follows
+            with pytest.raises(ConnectionError):
+                D._recv(b)
+        scalar = D._encode(3)
+        hdr = bytearray(scalar[:D._HEADER.size])
+        fields = list(D._HEADER.unpack(bytes(hdr)))
+        fields[4] = 16
+        a.sendall(D._HEADER.pack(*fields))
+        with pytest.raises(ConnectionError):
+            D._recv(b)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_rendezvous_file_in_a_shared_directory_and_stale_files(tmp_path):
+    """RT_RDZV_FILE=/tmp/x style paths (a directory others can write to) are
+    kept in a private directory of this user next to it; a file an earlier
+    launch left behind is not this launch's rank 0."""
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    p = D.rendezvous_path({"RT_RDZV_FILE": str(shared / "x")})
+    assert p == str(shared / ("rt_rdzv_%d" % os.getuid()) / "x")
+    D._publish(p, "4321 tok\n")
+    assert os.stat(os.path.dirname(p)).st_mode & 0o777 == 0o700
+    assert D._read_published(p) == (4321, "tok")
+    # a private directory is used as given
+    own = tmp_path / "own"
+    own.mkdir(mode=0o700)
+    assert D.rendezvous_path({"RT_RDZV_FILE": str(own / "x")}) == \
+        str(own / "x")
+    # stale: older than this process by more than the allowance
+    old = time.time() - D._STALE_S - 3600
+    os.utime(p, (old, old))
+    with pytest.raises(ValueError, match="stale"):
+        D._read_published(p)

@@ -37,7 +37,7 @@ def test_sequences_on_the_shipped_asphere_arithmetic():
                RT_MI355_EXACT_ASPHERE="0")
     out = subprocess.run(
         [sys.executable, os.path.join(root, "tests", "tools", "fuzz_state.py"),
-         "9000", "9075"], env=env, capture_output=True, text=True,
+         "9000", "9110"], env=env, capture_output=True, text=True,
         timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     last = out.stdout.strip().splitlines()[-1]
