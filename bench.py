@@ -180,7 +180,7 @@ def cpu_one_core(table, system, y, u, clip, S, g, L, sample, l):
     from oracle import refshim
     from rayopt_amd import prescriptions as P
     m = min(sample, y.shape[0])
-    mp = min(m, 2_000_000)          # the port: a bounded slice of the sample
+    mp = min(m, 1_000_000)          # the port: a bounded slice of the sample
     ys, us = y[:m], u[:m]
     tn.propagate(table, ys[:100000], us[:100000], clip=clip)   # warm
     t0 = time.perf_counter()
@@ -678,14 +678,16 @@ def main():
                          "(overrides --rays; 100000000 at --gpus 8 is "
                          "BASELINE configs[4])")
     ap.add_argument("--no-clip", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=5_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=3_000_000,
                     help="rays of the workload the reference is timed on, "
                          "one process (0: skip every CPU leg); the default "
-                         "is ~8 s of rayopt on one core")
+                         "is ~4 s of rayopt on one core")
     ap.add_argument("--cpu-procs", type=int, default=-1,
-                    help="processes of the all-cores leg of the numpy port "
+                    help="processes of the many-cores leg of the reference "
                          "(forked before the GPU is touched); -1 = one per "
-                         "host core, 0 = skip")
+                         "host core but at most 64 (forking and warming 256 "
+                         "interpreters costs more wall time than the "
+                         "measurement), -2 = one per host core, 0 = skip")
     ap.add_argument("--settle", type=float, default=0.3,
                     help="seconds of untimed launches during setup so the "
                          "device reaches its sustained clocks (boxes of the "
@@ -797,15 +799,17 @@ def main():
     t0 = time.perf_counter()
     y, u = workload_rays(n, rank)
     cpu_all = None
-    procs = os.cpu_count() if args.cpu_procs < 0 else args.cpu_procs
+    procs = (min(64, os.cpu_count()) if args.cpu_procs == -1 else
+             os.cpu_count() if args.cpu_procs < 0 else args.cpu_procs)
     if procs > 1 and args.cpu_sample > 0 and rank == 0 and not dist_mode:
         try:            # forks: before this process opens the GPU
             from oracle import refshim
             if refshim.available():
                 cpu_all = reference_on_processes(
                     P.DOUBLE_GAUSS, y, u, system.wavelengths[0], clip, procs)
-                cpu_all["port_value"] = cpu_port_on_processes(
-                    system, y, u, clip, procs)["value"]
+                if args.extras:
+                    cpu_all["port_value"] = cpu_port_on_processes(
+                        system, y, u, clip, procs)["value"]
             else:
                 cpu_all = cpu_port_on_processes(system, y, u, clip, procs)
         except Exception as err:      # a reported extra, never fatal
@@ -867,13 +871,22 @@ def main():
     plain = not dist_mode and not args.option
 
     image_only = unclipped = full_i = engine_leg = None
-    if args.extras and plain:
+    if plain and (args.extras or (
+            world == 1 and not args.no_configs and
+            not os.environ.get("RT_BENCH_CHILD") and
+            not _profiled_from_outside(os.environ))):
         # extension: keep only the image row (merit-function use): the
-        # kernel leaves the HBM roofline for the FP64 one
+        # kernel leaves the HBM roofline for the FP64 one.  (Not under a
+        # profiler: see the note at the configs below.)
         def step_image():
             g.propagate(clip=clip, keep=[0, -1])
+        job.timed(step_image, 40, 10, False)     # its own settled state
+        if tele is not None:
+            tele.mark("imgrow:begin")
         e_img, ev_img, _ = job.timed(step_image, args.steps, args.warmup,
                                      False)
+        if tele is not None:
+            tele.mark("imgrow:end")
         image_only = (e_img, ev_img/args.steps)
     if args.extras and plain and clip:
         # the reference's default: propagate(clip=False); the u rows of the
@@ -1194,6 +1207,27 @@ def main():
                 out["roofline"]["frac_at_observed_hbm_clock"] = \
                     achieved/(HBM_PEAK_GBS*uclk/HBM_NOMINAL_MHZ)
             out["telemetry"] = t
+            w = t.get("imgrow") or {}
+            clk = (w.get("gfxclk_mhz") or [None]*3)[1]
+            try:
+                with open(os.path.join(ROOT, "profiles",
+                                       "valu_counters.json")) as f:
+                    c = json.load(f)["kinds"]["C3 image row only"]
+            except (OSError, ValueError, KeyError):
+                c = None
+            if c and clk and "image_row_only" in out:
+                io = out["image_row_only"]
+                cyc = 1024*clk*1e6*io["kernel_ms"]*1e-3
+                sc = n/c["rays"]
+                io.update(
+                    bound="fp64 valu issue", gfxclk_mhz_observed=clk,
+                    power_limited_fraction=w.get("power_limited_fraction"),
+                    valu_wave_instructions_per_launch=c["SQ_INSTS_VALU"]*sc,
+                    valu_issue_frac=c["SQ_INSTS_VALU"]*sc*4/cyc,
+                    valu_busy_frac=c["SQ_ACTIVE_INST_VALU"]*sc*4/cyc,
+                    flop_equivalent_note="SURVEY 8(d): not an HBM leg; the "
+                    "ceiling is 1024 SIMDs x gfx clock / 4 cycles per FP64 "
+                    "wave-instruction (profiles/valu_counters.json)")
     # (not under a profiler: every rt_trace_kernel launch rocprofv3 sees in
     # this command is then the headline workload, so that its average can be
     # held against roofline.kernel_ms)
@@ -1353,12 +1387,49 @@ def run_configs(ra, device, args):
         rec, _ = reference_one_process(text, y, u, l, clip, m)
         return {k: rec[k] for k in ("value", "rays", "seconds", "kind")}
 
-    def record(name, system, g, n, l, clip, generated, parity, ref, note=""):
+    counters = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_counters.json")) as f:
+            counters = json.load(f)["kinds"]
+    except (OSError, ValueError, KeyError):
+        pass
+    tele = Telemetry(device, period=0.01)
+    windows = []
+
+    def valu_roofline(rec, kind, n, ms, clock_mhz):
+        """The FP64-issue ceiling: VALU wave-instructions per launch (PMC
+        profile of the same workload, profiles/valu_counters.json, scaled to
+        n rays) x 4 cycles / (1024 SIMDs x the gfx clock observed during
+        THIS measurement x launch time).  `busy` uses SQ_ACTIVE_INST_VALU
+        (quad-cycles the VALUs were executing, quarter-rate v_rcp / v_rsq
+        included) instead of the instruction count."""
+        c = counters.get(kind)
+        if not c or not clock_mhz:
+            return
+        scale = n/c["rays"]
+        cyc = 1024*clock_mhz*1e6*ms*1e-3
+        rec["valu"] = {
+            "wave_instructions_per_launch": c["SQ_INSTS_VALU"]*scale,
+            "per_ray_surface_op": c["SQ_INSTS_VALU"]*scale*64/(
+                n*rec["surfaces"]),
+            "gfxclk_mhz_observed": clock_mhz,
+            "valu_issue_frac": c["SQ_INSTS_VALU"]*scale*4/cyc,
+            "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"]*scale*4/cyc,
+            "source": "profiles/valu_counters.json (rocprofv3 --pmc, round "
+                      "4) + this run's clock and launch time"}
+
+    def record(name, system, g, n, l, clip, generated, parity, ref, note="",
+               kind=None):
         ls = np.atleast_1d(l)
         tables = np.stack([pack_system(system, lk,
                                        system.refractive_index(lk, 0))[0]
                            for lk in ls])
+        if tele is not None:
+            tele.mark("%d:begin" % len(windows))
         ms = kernel_ms_of(g, clip)
+        if tele is not None:
+            tele.mark("%d:end" % len(windows))
+        windows.append(kind)
         rb, uni = (None, None) if generated else input_bytes(g.engine, n)
         alg, per_op = algorithmic_bytes(tables, n, clip, generated,
                                         read_bytes=rb)
@@ -1378,6 +1449,7 @@ def run_configs(ra, device, args):
         pl = g.engine.placement()
         rec["placement"] = {k: pl[k] for k in ("pieces", "piece_mib",
                                                "per_class", "mixed")}
+        rec["_kind"] = kind
         if note:
             rec["note"] = note
         out.append(rec)
@@ -1419,10 +1491,10 @@ def run_configs(ra, device, args):
     y, u = dc.bundle(n4, .6, 10., 4)
     y[:, 1] -= .5*np.tan(np.radians(10.))
     l4 = s4.wavelengths[0]
-    ref4 = reference_rate(P.ASPHERE_PHONE, y, u, l4, True, 10**4)
+    ref4 = reference_rate(P.ASPHERE_PHONE, y, u, l4, True, 3000)
     if ref4 is not None:
         ref4["note"] = ("per-ray scipy.optimize.newton in a Python loop "
-                        "(rayopt/elements.py:333-349): timed on 10^4 rays "
+                        "(rayopt/elements.py:333-349): timed on 3000 rays "
                         "and extrapolated, BASELINE.md 3.4")
     for label, opts in (("default (FMA / rcp / rsq Newton, 1e-8 contract)",
                          {}), ("exact_asphere=True (the reference's bits)",
@@ -1452,6 +1524,25 @@ def run_configs(ra, device, args):
         out[-1]["finite_fraction_at_image_sampled"] = float(
             np.isfinite(ulast).mean())
         del g
+    # what bounds each config: the store streams (HBM) or FP64 issue
+    t = tele.stop() if tele is not None else None
+    for k, rec in enumerate(out):
+        kind = rec.pop("_kind", None)
+        w = (t or {}).get(str(k)) or {}
+        clock = (w.get("gfxclk_mhz") or [None]*3)[1]
+        if w:
+            rec["telemetry"] = {
+                "gfxclk_mhz": clock,
+                "socket_power_w": (w.get("socket_power_w") or [None]*3)[1],
+                "power_limited_fraction": w.get("power_limited_fraction")}
+        valu_roofline(rec, kind, rec["rays"], rec["kernel_ms"], clock)
+        v = rec.get("valu")
+        if rec["kernel_ms"] < .05:
+            rec["bound"] = "launch latency"
+        elif v and v["valu_busy_frac"] > rec["frac"]:
+            rec["bound"] = "fp64 valu issue"
+        else:
+            rec["bound"] = "hbm"
     return out
 
 

@@ -529,10 +529,15 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * the pieces lie outside the largest class (store-bound traces then run four
  * workgroups per CU instead of two), [8] = blocks of ballast (4-8 GiB each)
  * held during the search so that it moved on through the device memory
- * (pieces come in runs of one class), [9] = 0; ms[0] / ms[1] = the pair test's launch time inside one piece /
+ * (pieces come in runs of one class), [9] = what the classes alone said
+ * before the measurement below; ms[2] = GB/s of the trace's own store
+ * pattern (56 B per ray and element) written over the arrays as laid out,
+ * measured at rt_reserve for arrays >= 4 GiB (0: not measured; three
+ * launches): below 6550 GB/s -- the memory behaves like one class whatever
+ * the pair tests said, seen on one box -- [7] is cleared; ms[0] / ms[1] = the pair test's launch time inside one piece /
  * across two classes.
  */
-int rt_placement(rt_ctx *ctx, int info[10], double ms[2]);
+int rt_placement(rt_ctx *ctx, int info[10], double ms[3]);
 
 /* device scratch owned by the context (e.g. gather destination on root) */
 int rt_scratch(rt_ctx *ctx, int64_t bytes, void **out);

@@ -96,6 +96,9 @@ struct rt_place {
     int count[RT_PLACE_CLASSES]; /* pieces of each class among the n */
     int mixed;       /* >= a third of the pieces outside the largest class */
     float self_ms, cross_ms; /* pair test: same piece / another class */
+    float store_gbps; /* the trace's store pattern over the arrays as laid
+                         out (0: not measured) */
+    int class_mix;    /* what the classes alone said (before the pattern) */
 };
 
 struct rt_ctx {

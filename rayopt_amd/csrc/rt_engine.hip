@@ -134,8 +134,10 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
     }
     if (2 * stored < stop - start)
         return 0;
-    if (newton) /* default arithmetic: five per CU in mixed memory, else four */
-        return c->opt_fast ? (c->place.mixed ? 28672 : 32768) : 0;
+    if (newton) /* default arithmetic: six per CU in mixed memory (0.88-0.94
+                   ms on two boxes; five: 0.88-0.95, four: 0.90-0.98, no cap:
+                   0.88-0.94), four where the memory is of one class */
+        return c->opt_fast ? (c->place.mixed ? 24576 : 32768) : 0;
     /* store bound: four workgroups per CU where the arrays lie in a mix of
      * memory classes (rt_place.h: 1.08 ms against 1.23 with two; three: 1.09,
      * five: 1.13), two where they do not -- two per CU is the setting that
@@ -510,10 +512,17 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
                               rt_tiles_bytes(tiles)));
         ctx->uni_cap = tiles;
     }
+    const bool fresh = ctx->ld != ld || ctx->buf_nsurf != ctx->nsurf;
     ctx->n = nrays;
     ctx->ld = ld;
     ctx->buf_nsurf = ctx->nsurf;
     ctx->traced = 0;
+    /* placed arrays in a new layout: measure the store pattern over them
+     * (nothing lives in the rows yet) */
+    if (ctx->place.base && fresh && !rt_lab_variant(ctx)) {
+        ctx->place.mixed = ctx->place.class_mix;
+        rt_place_verify(ctx, rt_layout(ctx), ctx->nsurf, ld);
+    }
     memset(ctx->i_alias, 0, sizeof ctx->i_alias);
     memset(ctx->u_alias, 0, sizeof ctx->u_alias);
     memset(ctx->valid, 0, sizeof ctx->valid);
@@ -1400,7 +1409,7 @@ int rt_selftest_arith(rt_ctx *ctx, uint64_t seed, int64_t n, int span,
     return RT_OK;
 }
 
-int rt_placement(rt_ctx *ctx, int info[10], double ms[2])
+int rt_placement(rt_ctx *ctx, int info[10], double ms[3])
 {
     if (!ctx || !info || !ms)
         return rt_fail(ctx, RT_ERR_ARG, "rt_placement: NULL argument");
@@ -1413,9 +1422,10 @@ int rt_placement(rt_ctx *ctx, int info[10], double ms[2])
         info[4 + k] = p.count[k];
     info[7] = p.mixed;
     info[8] = p.ballast;
-    info[9] = 0;
+    info[9] = p.class_mix;
     ms[0] = p.self_ms;
     ms[1] = p.cross_ms;
+    ms[2] = p.store_gbps;
     return RT_OK;
 }
 

@@ -120,8 +120,15 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     if (!c->opt_place || bytes < RT_PLACE_MIN_BYTES)
         return hipMalloc(out, bytes);
 
-    /* pieces of 1 GiB; smaller arrays: three pieces, >= 512 MiB each */
+    /* pieces of 1 GiB (RT_MI355_PIECE_MIB: another size, for measurements);
+     * smaller arrays: three pieces, >= 512 MiB each */
     size_t piece = (size_t)1 << 30;
+    {
+        const char *e = getenv("RT_MI355_PIECE_MIB");
+        const long mib = e ? atol(e) : 0;
+        if (mib >= 512 && mib <= 65536)
+            piece = (size_t)mib << 20;
+    }
     if (bytes < 3 * piece) {
         const size_t q = (size_t)128 << 20;
         piece = ((bytes + 2) / 3 + q - 1) / q * q;
@@ -334,8 +341,64 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         largest = used[k] > largest ? used[k] : largest;
     P.mixed = nclass >= 2 && 3 * (need - largest) >= need;
     P.ballast = nballast;
+    P.class_mix = P.mixed;
     *out = base;
     return hipSuccess;
+}
+
+/*
+ * The proof of the pudding: the trace's own store pattern -- y0 y1 y2 u0 u1
+ * u2 t of every element, one ray per lane -- over the arrays as they are now
+ * laid out, three launches.  Classes are a model (three on most boxes seen;
+ * one box traced at the slow level in a mix that should have been fast):
+ * what decides between four and two workgroups per CU is this measurement.
+ * Levels of the bare pattern: 7.0 / 6.3 / 5.65 TB/s.  Rows are overwritten:
+ * called from rt_reserve, before anything lives in them.
+ */
+#define RT_PLACE_FAST_GBPS 6550. /* at and above: the fast level */
+#define RT_PLACE_VERIFY_BYTES ((size_t)4 << 30)
+
+__global__ __launch_bounds__(256) void rt_place_rows_kernel(rt_lay a, int L,
+                                                            long long n)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n)
+        return;
+    const double v = 1e-9 * (double)r;
+    for (int s = 1; s < L; ++s) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.Y[(long long)s * a.ss + c * a.cs + r] = v + c;
+            a.U[(long long)s * a.ss + c * a.cs + r] = v - c;
+        }
+        a.T[(long long)s * a.ssT + r] = v;
+    }
+}
+
+static void rt_place_verify(rt_ctx *c, rt_lay lay, int L, long long ld)
+{
+    rt_place &P = c->place;
+    P.store_gbps = 0.f;
+    const size_t bytes = (size_t)56 * (L - 1) * ld;
+    if (!P.base || L < 2 || bytes < RT_PLACE_VERIFY_BYTES)
+        return; /* short kernels measure their own ramp, not the memory */
+    const unsigned grid = (unsigned)((ld + 255) / 256);
+    hipLaunchKernelGGL(rt_place_rows_kernel, dim3(grid), dim3(256), 32768,
+                       c->stream, lay, L, ld);
+    if (hipEventRecord(c->k0, c->stream) != hipSuccess)
+        return;
+    for (int k = 0; k < 3; ++k)
+        hipLaunchKernelGGL(rt_place_rows_kernel, dim3(grid), dim3(256), 32768,
+                           c->stream, lay, L, ld);
+    float ms = 0.f;
+    if (hipEventRecord(c->k1, c->stream) == hipSuccess &&
+        hipEventSynchronize(c->k1) == hipSuccess &&
+        hipEventElapsedTime(&ms, c->k0, c->k1) == hipSuccess && ms > 0.f) {
+        P.store_gbps = (float)(3. * (double)bytes / (ms * 1e-3) / 1e9);
+        if (P.store_gbps < RT_PLACE_FAST_GBPS)
+            P.mixed = 0; /* whatever the classes say: two per CU here */
+    }
+    (void)hipGetLastError();
 }
 
 #endif /* RT_PLACE_H */

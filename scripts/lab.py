@@ -351,6 +351,247 @@ def cmd_c4check(a):
     sweep("... after another trace used the engine (re-seeded)", g)
 
 
+def cmd_nsweep(a):
+    """Launch time and fraction of the HBM spec over the number of rays: C3
+    shape (five field bundles built on the device, 16 B/ray read, and
+    host-seeded up to 10^7) and C2 shape (three wavelength groups, one
+    launch).  One fresh context per size: its own placement."""
+    ra, P, _build, Engine = _imports()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import digest_cases as dc
+    from bench import workload_rays, FIELD_FRACTIONS, BUNDLE_RADIUS
+
+    def measure(eng, propagate):
+        propagate()
+        for _ in range(10):
+            propagate()
+        res = {}
+        for lds in (-1, 65536, 32768, 0):
+            eng.set_option("resident_lds", lds)
+            propagate()
+            t_end = time.time() + .3
+            ms = []
+            while time.time() < t_end:
+                eng.event_record(0)
+                for _ in range(5):
+                    propagate()
+                eng.event_record(1)
+                ms.append(eng.event_elapsed(0, 1)/5)
+            res[str(lds)] = float(np.median(ms[len(ms)//3:]))
+        eng.set_option("resident_lds", -1)
+        return res
+
+    s3 = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    nf = len(FIELD_FRACTIONS)
+    for n in a.sizes:
+        m = n//nf//64*64
+        eng = Engine(0)
+        g = ra.GeometricTrace(s3, engine=eng)
+        g.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS],
+                      dc.disc_points(m, 91), P.DOUBLE_GAUSS_PUPIL_Z,
+                      BUNDLE_RADIUS)
+        res = measure(eng, lambda: g.propagate(clip=True))
+        alg = m*nf*(56*12 + 16)
+        out(shape="C3 built on the device", rays=m*nf,
+            placement=eng.placement(), ms=res,
+            frac_auto=alg/(res["-1"]*1e-3)/8e12)
+        if n <= 10_000_000:
+            y, u = workload_rays(n, 0)
+            g.rays_given(y, u)
+            res = measure(eng, lambda: g.propagate(clip=True))
+            uni, tiles = eng.input_uniform()
+            rb = sum(8*(n - 64*q) + 8*q for q in uni) + 4*tiles
+            out(shape="C3 host-seeded", rays=n, placement=eng.placement(),
+                ms=res, frac_auto=(n*56*12 + rb)/(res["-1"]*1e-3)/8e12)
+        del g
+        eng.close()
+    s2 = ra.system_from_yaml(P.COOKE % dict(
+        air="air", sk16="SCHOTT-SK|N-SK16", f2="SCHOTT-F|N-F2"))
+    ls = [587.56e-9, 656.27e-9, 486.13e-9]
+    for n in a.sizes:
+        if n > 30_000_000:
+            continue
+        per = n//3//64*64
+        y2, u2 = dc.bundle(per, 5.5, 5., 0)
+        eng = Engine(0)
+        g2 = ra.GeometricTrace(s2, engine=eng)
+        g2.rays_given(y2, u2, l=ls)
+        res = measure(eng, lambda: g2.propagate(clip=True))
+        uni, tiles = eng.input_uniform()
+        rb = sum(8*(3*per - 64*q) + 8*q for q in uni) + 4*tiles
+        out(shape="C2 three wavelength groups", rays=3*per,
+            placement=eng.placement(), ms=res,
+            frac_auto=(3*per*56*8 + rb)/(res["-1"]*1e-3)/8e12)
+        del g2
+        eng.close()
+
+
+KINDS_NOTE = ("C3 host-seeded clip", "C3 image row only", "C2 3 x 10^6 rays",
+              "C4 default", "C4 exact")
+
+
+def cmd_kinds(a):
+    """A fixed schedule of trace launches per kind of trace, for a
+    `rocprofv3 --pmc` pass (counters per kind: `kinds-summary`).  Without a
+    profiler it prints the launch times and the gfx clock per kind."""
+    ra, P, _build, Engine = _imports()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import digest_cases as dc
+    from bench import workload_rays, Telemetry
+    count = [0]
+    tele = Telemetry(0, period=0.01) if a.telemetry else None
+    recs = []
+
+    def run(name, g, propagate):
+        propagate()
+        count[0] += 1
+        for _ in range(a.warm):
+            propagate()
+        count[0] += a.warm
+        first = count[0]
+        if tele is not None:
+            tele.mark("%d:begin" % len(recs))
+        eng = g.engine
+        t_end = time.time() + a.seconds
+        ms = []
+        while True:
+            eng.event_record(0)
+            for _ in range(a.launches):
+                propagate()
+            eng.event_record(1)
+            ms.append(eng.event_elapsed(0, 1)/a.launches)
+            count[0] += a.launches
+            if time.time() >= t_end:
+                break
+        if tele is not None:
+            tele.mark("%d:end" % len(recs))
+        recs.append({"kind": name, "first": first, "count": count[0] - first,
+                     "ms": float(np.median(ms)),
+                     "placement_mixed": eng.placement()["mixed"]})
+
+    n = a.rays
+    s3 = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = workload_rays(n, 0)
+    g = ra.GeometricTrace(s3, engine=Engine(0))
+    g.rays_given(y, u)
+    run("C3 host-seeded clip", g, lambda: g.propagate(clip=True))
+    run("C3 image row only", g, lambda: g.propagate(clip=True, keep=[0, -1]))
+    del g
+    s2 = ra.system_from_yaml(P.COOKE % dict(
+        air="air", sk16="SCHOTT-SK|N-SK16", f2="SCHOTT-F|N-F2"))
+    y2, u2 = dc.bundle(10**6, 5.5, 5., 0)
+    g2 = ra.GeometricTrace(s2, engine=Engine(0))
+    g2.rays_given(y2, u2, l=[587.56e-9, 656.27e-9, 486.13e-9])
+    run("C2 3 x 10^6 rays", g2, lambda: g2.propagate(clip=True))
+    del g2
+    s4 = ra.system_from_yaml(P.ASPHERE_PHONE)
+    y4, u4 = dc.bundle(n, .6, 10., 4)
+    y4[:, 1] -= .5*np.tan(np.radians(10.))
+    for label, opts in (("C4 default", {}), ("C4 exact", {"exact_asphere": 1})):
+        g4 = ra.GeometricTrace(s4, engine=Engine(0), **opts)
+        g4.rays_given(y4, u4, s4.wavelengths[0])
+        run(label, g4, lambda: g4.propagate(clip=True))
+        del g4
+    t = tele.stop() if tele is not None else None
+    for k, r in enumerate(recs):
+        w = (t or {}).get(str(k)) or {}
+        r["gfxclk_mhz"] = (w.get("gfxclk_mhz") or [None]*3)[1]
+        r["socket_power_w"] = (w.get("socket_power_w") or [None]*3)[1]
+        r["power_limited_fraction"] = w.get("power_limited_fraction")
+        out(**r)
+
+
+def cmd_sizes(a):
+    """A fixed schedule of C3 traces (built on the device) per batch size,
+    for `rocprofv3 --pmc` passes: what grows with N?  (`kinds-summary` reads
+    the result; the kind is the size.)"""
+    ra, P, _build, Engine = _imports()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import digest_cases as dc
+    from bench import FIELD_FRACTIONS, BUNDLE_RADIUS
+    s3 = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    nf = len(FIELD_FRACTIONS)
+    count = 0
+    for n in a.sizes:
+        if a.piece_mib:
+            os.environ["RT_MI355_PIECE_MIB"] = str(a.piece_mib)
+        m = n//nf//64*64
+        eng = Engine(0)
+        g = ra.GeometricTrace(s3, engine=eng)
+        g.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS],
+                      dc.disc_points(m, 91), P.DOUBLE_GAUSS_PUPIL_Z,
+                      BUNDLE_RADIUS)
+        for lds in a.caps:
+            eng.set_option("resident_lds", lds)
+            g.propagate(clip=True)
+            for _ in range(a.warm):
+                g.propagate(clip=True)
+            count += 1 + a.warm
+            if a.settle:        # (not under a profiler: a fixed schedule)
+                steady(eng, a.settle)
+            first = count
+            ms = block_ms_fn(eng, lambda: g.propagate(clip=True), a.launches)
+            count += a.launches
+            out(kind="%d rays, resident_lds %d" % (m*nf, lds), rays=m*nf,
+                resident_lds=lds, first=first, count=a.launches, ms=ms,
+                per_1e7=ms*1e7/(m*nf), placement=eng.placement())
+        del g
+        eng.close()
+
+
+def block_ms_fn(eng, fn, launches):
+    eng.event_record(0)
+    for _ in range(launches):
+        fn()
+    eng.event_record(1)
+    return eng.event_elapsed(0, 1)/launches
+
+
+def cmd_kinds_summary(a):
+    """Counters per kind from a `rocprofv3 --pmc` pass of `kinds`, joined with
+    the launch times and clocks of a plain run of the same command:
+    VALU issue = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x gfx clock x launch
+    time), the ceiling of a kernel that is bound by FP64 issue."""
+    plain = {}
+    for l in open(a.plain):
+        if l.startswith("{"):
+            r = json.loads(l)
+            plain[r["kind"]] = r
+    table = collections.OrderedDict()
+    for sched in sorted(glob.glob(os.path.join(a.dir, "pass*.jsonl"))):
+        tag = os.path.basename(sched)[:-6]
+        recs = [json.loads(l) for l in open(sched) if l.startswith("{")]
+        files = glob.glob(os.path.join(a.dir, tag, "**",
+                                       "*counter_collection.csv"),
+                          recursive=True)
+        rows = [r for f in files for r in csv.DictReader(open(f))
+                if "rt_trace" in r["Kernel_Name"]]
+        by_counter = collections.defaultdict(dict)
+        for r in rows:
+            by_counter[r["Counter_Name"]][int(r["Dispatch_Id"])] = \
+                float(r["Counter_Value"])
+        for name, d in by_counter.items():
+            ids = sorted(d)
+            for rec in recs:
+                sel = ids[rec["first"]:rec["first"] + rec["count"]]
+                if sel:
+                    table.setdefault(rec["kind"], {})[name] = float(
+                        np.mean([d[i] for i in sel]))
+    for kind, c in table.items():
+        p = plain.get(kind, {})
+        rec = {"kind": kind, "counters_per_launch": c, "ms": p.get("ms"),
+               "gfxclk_mhz": p.get("gfxclk_mhz"),
+               "socket_power_w": p.get("socket_power_w"),
+               "power_limited_fraction": p.get("power_limited_fraction")}
+        if p.get("ms") and p.get("gfxclk_mhz") and "SQ_INSTS_VALU" in c:
+            rec["valu_issue_frac"] = c["SQ_INSTS_VALU"]*4/(
+                1024*p["gfxclk_mhz"]*1e6*p["ms"]*1e-3)
+        if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
+            rec["active_inst_valu_over_busy_cycles"] = \
+                c["SQ_ACTIVE_INST_VALU"]/c["SQ_BUSY_CYCLES"]
+        out(**rec)
+
+
 def cmd_pmc_summary(a):
     """For each pass directory: per (context, setting) mean of every counter
     over the trace-kernel dispatches of that block."""
@@ -412,6 +653,35 @@ def main():
     p = sub.add_parser("resident")
     p.add_argument("--rays", type=int, default=10_000_000)
     p.set_defaults(fn=cmd_resident)
+    p = sub.add_parser("nsweep")
+    p.add_argument("--sizes", type=int, nargs="*", default=[
+        100_000, 300_000, 1_000_000, 2_000_000, 3_000_000, 5_000_000,
+        10_000_000, 20_000_000, 50_000_000, 100_000_000])
+    p.set_defaults(fn=cmd_nsweep)
+    p = sub.add_parser("kinds")
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.add_argument("--launches", type=int, default=8)
+    p.add_argument("--warm", type=int, default=8)
+    p.add_argument("--seconds", type=float, default=0.)
+    p.add_argument("--telemetry", type=int, default=0)
+    p.set_defaults(fn=cmd_kinds)
+    p = sub.add_parser("sizes")
+    p.add_argument("--sizes", type=int, nargs="*",
+                   default=[10_000_000, 20_000_000, 50_000_000])
+    p.add_argument("--caps", type=int, nargs="*", default=[32768, 65536])
+    p.add_argument("--launches", type=int, default=6)
+    p.add_argument("--warm", type=int, default=4)
+    p.add_argument("--piece-mib", type=int, default=0)
+    p.add_argument("--settle", type=float, default=0.,
+                   help="seconds of untimed launches before the timed block "
+                        "(a context's first launches run at idle clocks: "
+                        "without it the times are NOT comparable -- session "
+                        "13 / 14 fell for that)")
+    p.set_defaults(fn=cmd_sizes)
+    p = sub.add_parser("kinds-summary")
+    p.add_argument("dir")
+    p.add_argument("plain")
+    p.set_defaults(fn=cmd_kinds_summary)
     p = sub.add_parser("c4check")
     p.set_defaults(fn=cmd_c4check)
     p = sub.add_parser("pmc-summary")
