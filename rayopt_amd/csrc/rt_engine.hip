@@ -144,9 +144,17 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
      * does not care where it writes (1.22-1.25 ms in any allocation; four:
      * 1.35 in a bad one) -- and where most elements store their i rows too
      * (tilted systems: ten streams per element, 1.49 against 1.52) */
-    if (!c->place.mixed || 2 * stored_i > stored)
+    if (2 * stored_i > stored)
         return 65536;
-    return 32768;
+    if (c->place.mixed)
+        return 32768;
+    /* plain allocations: small batches are short kernels whose launch ramp
+     * wants every wavefront (3*10^5 rays: 0.049 ms uncapped, 0.058 with two
+     * per CU), mid-size ones four per CU (2*10^6 rays of C2: 0.202 against
+     * 0.226) -- profiles/r04_final/nsweep.jsonl */
+    if ((size_t)c->cap_doubles * sizeof(double) < RT_PLACE_MIN_BYTES)
+        return c->n < ((int64_t)1 << 19) ? 0 : 32768;
+    return 65536;
 }
 
 /* the result arrays: class-mixed pieces (rt_place.h); the laboratory build
