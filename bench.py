@@ -880,14 +880,16 @@ def main():
         # profiler: see the note at the configs below.)
         def step_image():
             g.propagate(clip=clip, keep=[0, -1])
-        job.timed(step_image, 40, 10, False)     # its own settled state
+        job.timed(step_image, 300, 10, False)    # its own settled state
         if tele is not None:
             tele.mark("imgrow:begin")
-        e_img, ev_img, _ = job.timed(step_image, args.steps, args.warmup,
+        # (~0.5 s: amdsmi's clock is a moving average of about that length)
+        e_img, ev_img, _ = job.timed(step_image, max(args.steps, 900), 0,
                                      False)
         if tele is not None:
             tele.mark("imgrow:end")
-        image_only = (e_img, ev_img/args.steps)
+        image_only = (e_img/max(args.steps, 900)*args.steps,
+                      ev_img/max(args.steps, 900))
     if args.extras and plain and clip:
         # the reference's default: propagate(clip=False); the u rows of the
         # elements that do not bend the ray are not written either
@@ -1308,11 +1310,14 @@ def algorithmic_bytes(tables, n, clip, generated=False, alias=True,
     return n*per_op + read_bytes, per_op/(L - 1)
 
 
-def kernel_ms_of(g, clip, settle_s=.25, per_block=10, blocks=5):
+def kernel_ms_of(g, clip, settle_s=.3, per_block=10, dwell_s=.5, mark=None):
     """Launch time of one propagate() of the resident batch, measured like
     the headline's: after a settle phase of back-to-back launches (clocks and
     power filter in their loaded state), HIP events around blocks of
-    back-to-back launches; the median block / launches per block."""
+    back-to-back launches for ``dwell_s`` seconds; the median block / launches
+    per block.  ``mark(label)``: called at the begin and the end of the dwell
+    phase (the telemetry window: amdsmi's clocks are ~0.5 s moving averages,
+    a shorter window would report the state before it)."""
     eng = g.engine
     g.propagate(clip=clip)
     eng.sync()
@@ -1329,13 +1334,18 @@ def kernel_ms_of(g, clip, settle_s=.25, per_block=10, blocks=5):
         for _ in range(per):
             g.propagate(clip=clip)
         eng.sync()
+    if mark is not None:
+        mark("begin")
     t = []
-    for _ in range(blocks):
+    t_end = time.perf_counter() + dwell_s
+    while time.perf_counter() < t_end or len(t) < 5:
         eng.event_record(0)
         for _ in range(per):
             g.propagate(clip=clip)
         eng.event_record(1)
         t.append(eng.event_elapsed(0, 1)/per)
+    if mark is not None:
+        mark("end")
     return float(np.median(t))
 
 
@@ -1424,11 +1434,10 @@ def run_configs(ra, device, args):
         tables = np.stack([pack_system(system, lk,
                                        system.refractive_index(lk, 0))[0]
                            for lk in ls])
-        if tele is not None:
-            tele.mark("%d:begin" % len(windows))
-        ms = kernel_ms_of(g, clip)
-        if tele is not None:
-            tele.mark("%d:end" % len(windows))
+        k = len(windows)
+        ms = kernel_ms_of(g, clip, mark=(
+            (lambda what: tele.mark("%d:%s" % (k, what)))
+            if tele is not None else None))
         windows.append(kind)
         rb, uni = (None, None) if generated else input_bytes(g.engine, n)
         alg, per_op = algorithmic_bytes(tables, n, clip, generated,
@@ -1483,7 +1492,7 @@ def run_configs(ra, device, args):
     record("C2 Cooke triplet, 10^6 rays x 3 wavelengths, one launch", s2, g,
            3*len(y), ls, True, False,
            subsample_parity(ra, device, s2, y, u, ls, True, {}, 64*1500),
-           ref)
+           ref, kind="C2 3 x 10^6 rays")
     del g
     # C4: aspheric phone lens, 10^7 rays: default and exact arithmetic
     s4 = ra.system_from_yaml(P.ASPHERE_PHONE)
@@ -1503,7 +1512,8 @@ def run_configs(ra, device, args):
         g.rays_given(y, u, l4)
         record("C4 aspheric phone lens, %d rays, %s" % (n4, label), s4, g,
                n4, l4, True, False,
-               subsample_parity(ra, device, s4, y, u, l4, True, opts), ref4)
+               subsample_parity(ra, device, s4, y, u, l4, True, opts), ref4,
+               kind="C4 exact" if opts else "C4 default")
         del g
     del y, u
     # C5 on ONE GPU: double-Gauss, 10^8 rays built on the device (104 GB)
@@ -1519,7 +1529,8 @@ def run_configs(ra, device, args):
         record("C5 on one GPU: double-Gauss, %d rays built on the device"
                % (m*nf), s5, g, m*nf, s5.wavelengths[0], True, True, None,
                None, "the 8-GPU form shards these rays and gathers y[L-1] "
-               "over RCCL (bench.py --gpus 8 --total-rays 100000000)")
+               "over RCCL (bench.py --gpus 8 --total-rays 100000000)",
+               kind="C3 host-seeded clip")
         ulast = np.asarray(g.u[-1])[::997, 0]
         out[-1]["finite_fraction_at_image_sampled"] = float(
             np.isfinite(ulast).mean())

@@ -62,6 +62,12 @@ def test_single_process_line():
     assert [n[:2] for n in names] == ["C3", "C1", "C2", "C4", "C4", "C5"]
     for r in d["configs"][1:]:
         assert r["kernel_ms"] > 0 and r["algorithmic_bytes_per_launch"] > 0
+        assert r["bound"] in ("hbm", "fp64 valu issue", "launch latency")
+        if r["config"].startswith("C4") and r.get("telemetry", {}).get(
+                "gfxclk_mhz"):
+            # the FP64-issue roofline: instructions of the committed PMC
+            # profile x this run's clock and launch time
+            assert 0 < r["valu"]["valu_issue_frac"] < 1.5, r["valu"]
         par = r["parity_subsample"]
         if par is not None:
             assert par["nan_masks_equal"] is True
