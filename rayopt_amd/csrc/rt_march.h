@@ -36,7 +36,7 @@ __device__ __forceinline__ void rt_load(const double *__restrict__ p,
     }
 }
 
-template <int R, bool NT>
+template <int R, int NT>
 __device__ __forceinline__ void rt_store(double *__restrict__ p,
                                          const double (&v)[R])
 {
@@ -49,8 +49,20 @@ __device__ __forceinline__ void rt_store(double *__restrict__ p,
         for (int r = 0; r < R; ++r)
             x[r] = v[r];
     }
-    if constexpr (NT)
+    /* NT: 0 ordinary store, 1 non-temporal; 2 / 3 / 4 (measurements, one
+     * ray per lane only): "sc1 nt", "sc0 sc1 nt", "sc1" */
+    if constexpr (NT == 1)
         __builtin_nontemporal_store(x, reinterpret_cast<V *>(p));
+    else if constexpr (NT == 2 && R == 1)
+        asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(p), "v"(x)
+                     : "memory");
+    else if constexpr (NT == 3 && R == 1)
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p),
+                     "v"(x)
+                     : "memory");
+    else if constexpr (NT == 4 && R == 1)
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(x)
+                     : "memory");
     else
         *reinterpret_cast<V *>(p) = x;
 }
@@ -75,7 +87,7 @@ __device__ __forceinline__ void rt_load_state(const rt_lay &a, int srow,
 }
 
 /* the rows of one element for the R rays at column `col` */
-template <int R, bool NT>
+template <int R, int NT>
 __device__ __forceinline__ void rt_store_rows(
     unsigned flags, int s, const rt_lay &a, int64_t col,
     const double (&y)[R][3], const double (&u)[R][3],
@@ -103,7 +115,7 @@ __device__ __forceinline__ void rt_store_rows(
 }
 
 /* all elements start..stop-1 for the R rays of this lane; state in VGPRs */
-template <int R, bool NT>
+template <int R, int NT>
 __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
                                          int start, int stop, int clip,
                                          const rt_lay &a, int64_t col,

@@ -9,6 +9,15 @@
 
 #include "rt_march.h"
 
+/* the rows are written once and not read again by the kernel: non-temporal
+ * stores.  In mixed memory (rt_place.h) 1.100 -> 1.025 ms for the headline
+ * trace, same process, two builds; in one-class memory they had been worth
+ * +-0.3 % (round 2).  -DRT_ROWS_NT=0: ordinary stores; 2, 3, 4: other cache
+ * policies (rt_march.h), for measurements */
+#ifndef RT_ROWS_NT
+#define RT_ROWS_NT 1
+#endif
+
 /*
  * THE kernel: one lane owns one ray, state in VGPRs across the whole surface
  * loop, surface table through scalar loads, 7-10 coalesced 512-byte stores
@@ -75,7 +84,7 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
     } else {
         rt_load_state<1>(a, start - 1, col, y, u);
     }
-    rt_march<1, false>(surf, start, stop, clip, a, col, y, u);
+    rt_march<1, RT_ROWS_NT>(surf, start, stop, clip, a, col, y, u);
 }
 
 /*
@@ -124,7 +133,7 @@ rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
         }
         a.T[col] = 0.;
     }
-    rt_march<1, false>(surf, 1, stop, clip, a, col, y, u);
+    rt_march<1, RT_ROWS_NT>(surf, 1, stop, clip, a, col, y, u);
 }
 
 /*
@@ -253,7 +262,7 @@ rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
             double iv[1][3], t[1];
             rt_step<1>(S, flags, clip, y, u, iv, t);
             if (has)
-                rt_store_rows<1, false>(flags, s, a, col0 + idx, y, u, iv, t);
+                rt_store_rows<1, RT_ROWS_NT>(flags, s, a, col0 + idx, y, u, iv, t);
             rt_leave<1>(S, flags, y, u);
         }
         if (!(flags & RT_F_NOSTORE)) {

@@ -539,6 +539,153 @@ def cmd_sizes(a):
         eng.close()
 
 
+def cmd_variants(a):
+    """The laboratory kernel's variants again, now that the arrays lie in
+    mixed memory (the balance between the store streams and the FP64 side has
+    moved since they were rejected): rays per lane, non-temporal stores, XCD
+    dealing, workgroup size -- all against the laboratory kernel's own
+    default (48 B per ray read, no tile notes), same process, same arrays."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    n = a.rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = workload_rays(n, 0)
+    eng = Engine(0, lib_path=lab_lib())
+    g = ra.GeometricTrace(system, engine=eng)
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    base = np.array(g.y[-1])
+    steady(eng, 1.)
+    defaults = dict(rays_per_thread=1, nontemporal=0, xcd_remap=0, block=256,
+                    lds_pad=32768)
+    variants = [{}, dict(lds_pad=40960), dict(lds_pad=49152),
+                dict(rays_per_thread=2), dict(rays_per_thread=2, lds_pad=65536),
+                dict(rays_per_thread=2, lds_pad=40960),
+                dict(nontemporal=1 - a.nt), dict(xcd_remap=1),
+                dict(block=128, lds_pad=16384), dict(block=512, lds_pad=65536),
+                dict(rays_per_thread=4, lds_pad=65536),
+                dict(rays_per_thread=2, xcd_remap=1), {}]
+    defaults["nontemporal"] = a.nt
+    for v in variants:
+        opts = dict(defaults, **v)
+        for k, val in opts.items():
+            eng.set_option(k, val)
+        g.propagate(clip=True)
+        same = bool(np.array_equal(np.array(g.y[-1]), base, equal_nan=True))
+        ms = [steady(eng, .5) for _ in range(2)]
+        out(variant=v or "laboratory default", ms=ms, bit_identical=same,
+            placement_mixed=eng.placement()["mixed"])
+    for k, val in defaults.items():
+        eng.set_option(k, val)
+    eng.set_option("lds_pad", 0)
+    g.propagate(clip=True)
+    out(variant="shipped kernel (tile notes, 16.6 B/ray read)",
+        ms=[steady(eng, .5) for _ in range(2)])
+
+
+def cmd_libab(a):
+    """Same-process A/B of two BUILDS of the library (e.g. a -D variant):
+    placed contexts of each, alternating steady blocks per kind of trace, the
+    image rows compared, the consumers on the freshly traced rows timed."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    libs = {"A": a.lib_a or _build.LIB, "B": a.lib_b}
+    n = a.rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    L = len(system)
+    y, u = workload_rays(n, 0)
+    traces = {}
+    for tag, path in libs.items():
+        g = ra.GeometricTrace(system, engine=Engine(0, lib_path=path))
+        g.rays_given(y, u)
+        g.propagate(clip=True)
+        traces[tag] = g
+    rows = {t: np.array(g.y[-1]) for t, g in traces.items()}
+    same = bool(np.array_equal(rows["A"], rows["B"], equal_nan=True))
+    for kind, kw in (("clip", dict(clip=True)), ("unclipped", dict(clip=False)),
+                     ("image row only", dict(clip=True, keep=[0, -1]))):
+        res = {"A": [], "B": []}
+        for rep in range(a.reps):
+            for tag in ("A", "B") if rep % 2 == 0 else ("B", "A"):
+                g = traces[tag]
+                g.propagate(**kw)
+                t_end = time.time() + .6
+                ms = []
+                while time.time() < t_end:
+                    g.engine.event_record(0)
+                    for _ in range(10):
+                        g.propagate(**kw)
+                    g.engine.event_record(1)
+                    ms.append(g.engine.event_elapsed(0, 1)/10)
+                res[tag].append(float(np.median(ms[len(ms)//3:])))
+        out(kind=kind, libs={t: os.path.basename(p) for t, p in libs.items()},
+            image_rows_bit_identical=same,
+            ms_A=float(np.median(res["A"])), ms_B=float(np.median(res["B"])),
+            all_A=res["A"], all_B=res["B"],
+            placement={t: traces[t].engine.placement()["per_class"]
+                       for t in traces})
+    # consumers right after a trace (are the rows still in the Infinity Cache?)
+    for tag, g in traces.items():
+        eng = g.engine
+        cons = {}
+        for name, fn in (("rms", lambda: g.rms()),
+                         ("refocus_shift", lambda: eng.refocus_shift(L - 1)),
+                         ("row_rmax", lambda: eng.row_rmax(L - 1))):
+            t = []
+            for _ in range(12):
+                g.propagate(clip=True)
+                eng.sync()
+                t0 = time.perf_counter()
+                fn()
+                t.append((time.perf_counter() - t0)*1e3)
+            cons[name] = float(np.median(t))
+        out(consumers_first_call_after_a_trace_ms=cons, lib=tag)
+
+
+def cmd_spacing(a):
+    """Is it the distance between the rows or the size of the batch that
+    slows traces above 10^7 rays?  A batch of N rays traced whole, and in
+    pieces of 10^7 rays (rt_trace_chunk: the same row spacing, a launch the
+    size of the headline's)."""
+    ra, P, _build, Engine = _imports()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import digest_cases as dc
+    from bench import FIELD_FRACTIONS, BUNDLE_RADIUS
+    s3 = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    nf = len(FIELD_FRACTIONS)
+    for n in a.sizes:
+        m = n//nf//64*64
+        eng = Engine(0)
+        g = ra.GeometricTrace(s3, engine=eng)
+        g.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS],
+                      dc.disc_points(m, 91), P.DOUBLE_GAUSS_PUPIL_Z,
+                      BUNDLE_RADIUS)
+        g.propagate(clip=True)
+        whole = steady(eng, .5)
+        q = max(1, round(m*nf/10_000_000))
+        L = len(s3)
+
+        def pieces():
+            for k in range(q):
+                eng.trace_chunk(1, L, True, k, q)
+        for _ in range(5):
+            pieces()
+        t_end = time.time() + .5
+        ms = []
+        while time.time() < t_end:
+            eng.event_record(0)
+            for _ in range(3):
+                pieces()
+            eng.event_record(1)
+            ms.append(eng.event_elapsed(0, 1)/3)
+        out(rays=m*nf, whole_ms=whole, per_1e7=whole*1e7/(m*nf), pieces=q,
+            in_pieces_ms=float(np.median(ms)),
+            in_pieces_per_1e7=float(np.median(ms))*1e7/(m*nf),
+            placement=eng.placement())
+        del g
+        eng.close()
+
+
 def block_ms_fn(eng, fn, launches):
     eng.event_record(0)
     for _ in range(launches):
@@ -665,6 +812,21 @@ def main():
     p.add_argument("--seconds", type=float, default=0.)
     p.add_argument("--telemetry", type=int, default=0)
     p.set_defaults(fn=cmd_kinds)
+    p = sub.add_parser("variants")
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.add_argument("--nt", type=int, default=1,
+                   help="the baseline's row stores: 1 non-temporal")
+    p.set_defaults(fn=cmd_variants)
+    p = sub.add_parser("libab")
+    p.add_argument("lib_b")
+    p.add_argument("--lib-a", default=None)
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.add_argument("--reps", type=int, default=4)
+    p.set_defaults(fn=cmd_libab)
+    p = sub.add_parser("spacing")
+    p.add_argument("--sizes", type=int, nargs="*",
+                   default=[10_000_000, 20_000_000, 50_000_000])
+    p.set_defaults(fn=cmd_spacing)
     p = sub.add_parser("sizes")
     p.add_argument("--sizes", type=int, nargs="*",
                    default=[10_000_000, 20_000_000, 50_000_000])

@@ -73,7 +73,8 @@ def test_matches_reference_golden(name, arith):
     dict(alias_i=0), dict(compact=2), dict(compact=2, compact_every=1),
     dict(regenerate=0, fuse_generate=0), dict(resident_lds=0),
     dict(resident_lds=65536), dict(resident_lds=20480),
-    dict(uniform_input=0)])
+    dict(uniform_input=0), dict(range_shortcuts=0),
+    dict(range_shortcuts=0, resident_lds=32768)])
 @pytest.mark.parametrize("key", ["double_gauss", "asphere_phone", "torture"])
 def test_kernel_variants_are_bit_identical(key, options):
     system = ra.system_from_yaml(P.ALL[key])
