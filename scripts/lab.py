@@ -642,6 +642,53 @@ def cmd_libab(a):
         out(consumers_first_call_after_a_trace_ms=cons, lib=tag)
 
 
+def cmd_compact(a):
+    """Where the compacting kernel (ballots + LDS exchange, opt-in) pays: an
+    over-filled C3 batch (most rays vignetted at the first elements) traced
+    for its image row only -- dead rays are wasted FP64 issue there -- and
+    with every row stored (where it cannot pay)."""
+    ra, P, _build, Engine = _imports()
+    from rayopt_amd.bundles import multi_field_bundle
+    from bench import FIELD_FRACTIONS
+    n = a.rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    fields = [f*P.DOUBLE_GAUSS_FIELD_DEG for f in FIELD_FRACTIONS]
+    for scale in a.scales:
+        y, u = multi_field_bundle(n, 17.*scale, fields, seed=5,
+                                  z_pupil=P.DOUBLE_GAUSS_PUPIL_Z)
+        eng = Engine(0)
+        g = ra.GeometricTrace(system, engine=eng)
+        g.rays_given(y, u)
+        g.propagate(clip=True)
+        alive = float(np.isfinite(np.asarray(g.u[-1])[:, 0]).mean())
+        ref = np.array(g.y[-1])
+        for keep, label in (([0, -1], "image row only"), (None, "every row")):
+            res = {}
+            for compact in (0, 2):
+                eng.set_option("compact", compact)
+                g.propagate(clip=True, keep=keep)
+                same = bool(np.array_equal(np.array(g.y[-1]), ref,
+                                           equal_nan=True))
+                res["compact=%d" % compact] = steady(eng, .5, clip=True) \
+                    if keep is None else None
+                if keep is not None:
+                    t_end = time.time() + .5
+                    ms = []
+                    while time.time() < t_end:
+                        eng.event_record(0)
+                        for _ in range(10):
+                            g.propagate(clip=True, keep=keep)
+                        eng.event_record(1)
+                        ms.append(eng.event_elapsed(0, 1)/10)
+                    res["compact=%d" % compact] = float(np.median(ms))
+                res["same_bits_%d" % compact] = same
+            eng.set_option("compact", 0)
+            out(bundle_radius_scale=scale, alive_at_image=alive, rows=label,
+                ms=res)
+        del g
+        eng.close()
+
+
 def cmd_spacing(a):
     """Is it the distance between the rows or the size of the batch that
     slows traces above 10^7 rays?  A batch of N rays traced whole, and in
@@ -823,6 +870,10 @@ def main():
     p.add_argument("--rays", type=int, default=10_000_000)
     p.add_argument("--reps", type=int, default=4)
     p.set_defaults(fn=cmd_libab)
+    p = sub.add_parser("compact")
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.add_argument("--scales", type=float, nargs="*", default=[1., 1.6, 2.5])
+    p.set_defaults(fn=cmd_compact)
     p = sub.add_parser("spacing")
     p.add_argument("--sizes", type=int, nargs="*",
                    default=[10_000_000, 20_000_000, 50_000_000])

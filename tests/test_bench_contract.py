@@ -59,7 +59,8 @@ def test_single_process_line():
         assert t.get("error")
     # one record per BASELINE config
     names = [r["config"] for r in d["configs"]]
-    assert [n[:2] for n in names] == ["C3", "C1", "C2", "C4", "C4", "C5"]
+    assert [n[:2] for n in names] == ["C3", "C1", "C2", "C3", "C4", "C4",
+                                      "C5"]
     for r in d["configs"][1:]:
         assert r["kernel_ms"] > 0 and r["algorithmic_bytes_per_launch"] > 0
         assert r["bound"] in ("hbm", "fp64 valu issue", "launch latency")
