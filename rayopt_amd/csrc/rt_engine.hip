@@ -148,12 +148,13 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
         return 65536;
     if (c->place.mixed)
         return 32768;
-    /* plain allocations: small batches are short kernels whose launch ramp
+    /* plain allocations: two per CU (the setting that does not care where
+     * it writes), except small batches, short kernels whose launch ramp
      * wants every wavefront (3*10^5 rays: 0.049 ms uncapped, 0.058 with two
-     * per CU), mid-size ones four per CU (2*10^6 rays of C2: 0.202 against
-     * 0.226) -- profiles/r04_final/nsweep.jsonl */
-    if ((size_t)c->cap_doubles * sizeof(double) < RT_PLACE_MIN_BYTES)
-        return c->n < ((int64_t)1 << 19) ? 0 : 32768;
+     * per CU) -- profiles/r04_final/nsweep.jsonl */
+    if ((size_t)c->cap_doubles * sizeof(double) < RT_PLACE_MIN_BYTES &&
+        c->n < ((int64_t)1 << 19))
+        return 0;
     return 65536;
 }
 

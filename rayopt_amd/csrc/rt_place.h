@@ -121,7 +121,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         return hipMalloc(out, bytes);
 
     /* pieces of 1 GiB (RT_MI355_PIECE_MIB: another size, for measurements);
-     * smaller arrays: three pieces, >= 512 MiB each */
+     * arrays below 3 GiB: pieces of 512 MiB */
     size_t piece = (size_t)1 << 30;
     {
         const char *e = getenv("RT_MI355_PIECE_MIB");
@@ -129,10 +129,11 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         if (mib >= 512 && mib <= 65536)
             piece = (size_t)mib << 20;
     }
-    if (bytes < 3 * piece) {
-        const size_t q = (size_t)128 << 20;
-        piece = ((bytes + 2) / 3 + q - 1) / q * q;
-    }
+    if (bytes < 3 * piece)
+        piece >>= 1; /* 512 MiB: a power of two, i.e. ONE block of the
+                        device's buddy allocator -- a 768 MiB piece is two
+                        blocks that may lie in two classes, and its "one
+                        piece" time is then already the fast one */
     const int need = (int)((bytes + piece - 1) / piece);
     size_t align = piece & (~piece + 1); /* largest power of two dividing it */
     const int cap = need + 24; /* pieces created and classified at most */

@@ -17,6 +17,13 @@
 #ifndef RT_ROWS_NT
 #define RT_ROWS_NT 1
 #endif
+/* the launch rows are read once per trace (-DRT_INPUT_NT=1: non-temporal
+ * loads, measured in round 4) */
+#if defined(RT_INPUT_NT) && RT_INPUT_NT
+#define RT_INPUT_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define RT_INPUT_LOAD(p) (*(p))
+#endif
 
 /*
  * THE kernel: one lane owns one ray, state in VGPRs across the whole surface
@@ -51,11 +58,11 @@ __device__ __forceinline__ void rt_load_state_tiles(
         if ((m >> c) & 1)
             y[0][c] = tl.first[c * tl.stride + tile];
         else
-            y[0][c] = a.Y[srow * a.ss + c * a.cs + col];
+            y[0][c] = RT_INPUT_LOAD(&a.Y[srow * a.ss + c * a.cs + col]);
         if ((m >> (3 + c)) & 1)
             u[0][c] = tl.first[(3 + c) * tl.stride + tile];
         else
-            u[0][c] = a.U[srow * a.ss + c * a.cs + col];
+            u[0][c] = RT_INPUT_LOAD(&a.U[srow * a.ss + c * a.cs + col]);
     }
 }
 

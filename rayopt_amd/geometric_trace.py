@@ -24,7 +24,7 @@ import numpy as np
 from . import _lib
 from ._lib import RT_Y, RT_U, RT_I, RT_T
 from .engine import Engine, get_engine
-from .pack import pack_system, resolve_range
+from .pack import pack_system, pack_tables, resolve_range
 
 
 class Trace:
@@ -318,10 +318,7 @@ class GeometricTrace(Trace):
         elif np.ndim(self.l) == 0:
             table, ns = pack_system(self.system, self.l, n_init, start, stop)
         else:
-            packed = [pack_system(self.system, l, n0, start, stop)
-                      for l, n0 in zip(self.l, n_init)]
-            table = np.stack([t for t, _ in packed])
-            ns = np.stack([n for _, n in packed])
+            table, ns = pack_tables(self.system, self.l, n_init, start, stop)
         self.engine.upload_system(table)
         self._packed = (resolve_range(self.length, start, stop), ns)
         return table, ns

@@ -594,6 +594,11 @@ def cmd_libab(a):
     system = ra.system_from_yaml(P.DOUBLE_GAUSS)
     L = len(system)
     y, u = workload_rays(n, 0)
+    if a.per_ray_directions:    # nothing but z = 0 uniform across a tile
+        rng = np.random.default_rng(3)
+        u[:, 0] += 1e-7*rng.standard_normal(n)
+        u[:, 1] += 1e-7*rng.standard_normal(n)
+        u[:, 2] = np.sqrt(1. - u[:, 0]**2 - u[:, 1]**2)
     traces = {}
     for tag, path in libs.items():
         g = ra.GeometricTrace(system, engine=Engine(0, lib_path=path))
@@ -869,6 +874,7 @@ def main():
     p.add_argument("--lib-a", default=None)
     p.add_argument("--rays", type=int, default=10_000_000)
     p.add_argument("--reps", type=int, default=4)
+    p.add_argument("--per-ray-directions", type=int, default=0)
     p.set_defaults(fn=cmd_libab)
     p = sub.add_parser("compact")
     p.add_argument("--rays", type=int, default=10_000_000)

@@ -103,3 +103,35 @@ def test_in_place_offset_matches_the_reference():
         for sysm in (rs, ms):
             sysm[3].offset[1] += .3
             sysm[5].offset[2] -= .01
+
+
+def test_tables_of_a_polychromatic_batch_are_the_single_tables():
+    """pack_tables (one pass over the elements' notes for all wavelengths, a
+    whole-table cache entry per wavelength) returns what pack_system returns
+    wavelength by wavelength -- before and after an edit of the system."""
+    import rayopt_amd as ra
+    from rayopt_amd import prescriptions as P
+    from rayopt_amd.pack import pack_system, pack_tables
+    s = ra.system_from_yaml(P.COOKE % dict(
+        air="air", sk16="SCHOTT-SK|N-SK16", f2="SCHOTT-F|N-F2"))
+    ls = [587.56e-9, 656.27e-9, 486.13e-9]
+    n0 = [s.refractive_index(l, 0) for l in ls]
+    for edit in (None, "curvature", "offset"):
+        if edit == "curvature":
+            s[2].curvature *= 1.01
+        elif edit == "offset":
+            s[3].offset[1] += 1e-3
+        for _ in range(2):          # second round: every table from its cache
+            tables, ns = pack_tables(s, ls, n0, 1, None)
+            for k, (l, n) in enumerate(zip(ls, n0)):
+                t1, n1 = pack_system(ra.system_from_dict(s.dict()), l, n, 1,
+                                     None) if edit is None else \
+                    pack_system(s, l, n, 1, None)
+                if edit is None:
+                    assert tables[k].tobytes() == \
+                        pack_system(s, l, n, 1, None)[0].tobytes()
+                else:
+                    assert tables[k].tobytes() == t1.tobytes()
+                    assert np.array_equal(ns[k], n1, equal_nan=True)
+    # three different tables (dispersion), one geometry
+    assert len({tables[k].tobytes() for k in range(3)}) == 3
