@@ -93,3 +93,43 @@ def test_what_cannot_be_chunked_says_so():
     with pytest.raises(ra.EngineError, match="chunk"):
         g.engine.trace_chunk(1, 0, True, 3, 3)
     assert g.engine.chunk_bounds(1000, 0, 1) == (0, 1000)
+
+
+def test_rows_are_not_read_whole_in_the_middle_of_a_step_in_pieces():
+    """Until the last piece of a step has been traced the rows hold new and
+    old columns side by side: every whole-row reader says so instead of
+    handing out the mixture; the pieces themselves can be issued in any order
+    and a complete step (or an unchunked trace) opens the rows again."""
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    L = len(system)
+    y, u = disc_bundle(5000, 12., 2., 5)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    want = np.array(g.y[-1])
+    eng = g.engine
+    system[4].distance *= 1.001             # the next trace changes the rows
+    g._upload_table(1, L, g.n[0])
+    eng.trace_chunk(1, L, True, 2, 3)
+    for call in (lambda: eng.download(0, L - 1, L), lambda: eng.rms(L - 1),
+                 lambda: eng.row_rmax(L - 1), lambda: eng.device_ptr(0, 1),
+                 lambda: eng.refocus_shift(L - 1)):
+        with pytest.raises(ra.EngineError, match="pieces of the current step"):
+            call()
+    eng.trace_chunk(1, L, True, 0, 3)
+    eng.trace_chunk(1, L, True, 0, 3)       # a piece twice: still one piece
+    with pytest.raises(ra.EngineError, match="2 of 3 pieces"):
+        eng.download(0, L - 1, L)
+    eng.trace_chunk(1, L, True, 1, 3)
+    got = eng.download(0, L - 1, L)         # complete: readable again
+    h = ra.GeometricTrace(system)
+    h.rays_given(y, u)
+    h.propagate(clip=True)
+    assert np.array_equal(got[0].T, np.array(h.y[-1]), equal_nan=True)
+    assert not np.array_equal(got[0].T, want, equal_nan=True)
+    # an unchunked trace ends an unfinished step in pieces as well
+    eng.trace_chunk(1, L, True, 0, 4)
+    with pytest.raises(ra.EngineError):
+        eng.rms(L - 1)
+    eng.trace(1, L, True)
+    assert np.isfinite(eng.rms(L - 1))

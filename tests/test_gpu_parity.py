@@ -328,7 +328,14 @@ def test_rccl_gather_single_rank_pipeline():
     y, u = _c3_rays(100003)
     g = gpu_trace(system, y, u, None, True)
     eng = g.engine
+    with pytest.raises(ra.EngineError, match="rt_comm_init first"):
+        eng.comm_info()
     eng.comm_init(eng.comm_unique_id(), 1, 0)
+    # what the communicator says of itself (RCCL, not the stand-in)
+    info = eng.comm_info()
+    assert info["nranks_seen"] == 1 and info["rank_seen"] == 0
+    assert info["rccl_version_code"] > 20000 and info["devices_visible"] >= 1
+    assert all(l["device"] != eng.device for l in info["links"])
     counts = np.array([g.nrays], dtype=np.int64)
     d_dst = eng.scratch(g.nrays*3*8)
     L = len(system)
