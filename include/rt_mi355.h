@@ -445,7 +445,11 @@ typedef struct rt_opd_args {
 int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa);
 int rt_sizeof_opd_args(void);
 
-/* raw device pointer to row `surf` of an array (interop, collectives) */
+/* raw device pointer to row `surf` of an array (interop, collectives).  The
+ * arrays of a large batch live in a virtual-memory mapping (rt_placement):
+ * an ordinary device pointer for kernels, hipMemcpy and RCCL on this device,
+ * but not something hipIpcGetMemHandle accepts -- copy a row out (rt_scratch)
+ * to share it with another process */
 int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out);
 
 /*
