@@ -11,8 +11,10 @@ rt_probes.hip (rejected kernel variants, bandwidth probes, measurement
 options).  Only the measurement scripts load it (``RT_MI355_LIB``).
 
 ``-ffp-contract=off`` is part of the numerical contract (see csrc/rt_math.h):
-numpy never fuses a multiply into an add and parity with the reference is
-judged at 1e-10.
+numpy never fuses a multiply into an add, and planes / spheres / conics are
+held to the reference's BITS (1e-10 is only the contract's outer bound); even
+aspheres run on explicitly fused arithmetic by default (1e-8 contract) and
+on scipy's operations with ``exact_asphere``.
 """
 import os
 import shutil

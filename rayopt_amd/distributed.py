@@ -87,7 +87,7 @@ _MAGIC = b"RTHG"
 _HELLO = "rt-mi355-hostgroup-2"
 _HEADER = struct.Struct("<4sBBHQ4q")
 _NONE, _FLOAT, _INT, _BYTES, _F64, _I64, _BOOL, _STR = range(8)
-_MAX_PAYLOAD = 1 << 32
+_MAX_PAYLOAD = 1 << 30     # a frame: at most 1 GiB (rows of 10^8 rays: 0.8 GB)
 _PROCESS_START = time.time()
 _STALE_S = 600.     # a rendezvous file older than this process by more: stale
 
