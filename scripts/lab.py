@@ -694,6 +694,36 @@ def cmd_compact(a):
         eng.close()
 
 
+def cmd_noinput(a):
+    """Upper bound of what hiding the launch-row reads could buy: the
+    laboratory kernel with non-temporal stores, its six input components
+    read per lane (48 B per ray) against "uniform_fix" masks that take them
+    from the wavefront's first column through the scalar path (the results
+    are wrong for those components; the arithmetic and the stores are the
+    same)."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    n = a.rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = workload_rays(n, 0)
+    eng = Engine(0, lib_path=lab_lib())
+    g = ra.GeometricTrace(system, engine=eng)
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    steady(eng, 1.)
+    eng.set_option("nontemporal", 1)
+    for lds in (32768, 65536):
+        eng.set_option("lds_pad", lds)
+        for mask, what in ((0, "48 B per ray read"),
+                           (0b111100, "y0 y1 read (16 B per ray)"),
+                           (0b111111, "nothing read per lane")):
+            eng.set_option("uniform_fix", mask)
+            g.propagate(clip=True)
+            out(lds_pad=lds, uniform_fix=mask, what=what,
+                ms=[steady(eng, .5) for _ in range(2)])
+    eng.set_option("uniform_fix", 0)
+
+
 def cmd_spacing(a):
     """Is it the distance between the rows or the size of the batch that
     slows traces above 10^7 rays?  A batch of N rays traced whole, and in
@@ -880,6 +910,9 @@ def main():
     p.add_argument("--rays", type=int, default=10_000_000)
     p.add_argument("--scales", type=float, nargs="*", default=[1., 1.6, 2.5])
     p.set_defaults(fn=cmd_compact)
+    p = sub.add_parser("noinput")
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.set_defaults(fn=cmd_noinput)
     p = sub.add_parser("spacing")
     p.add_argument("--sizes", type=int, nargs="*",
                    default=[10_000_000, 20_000_000, 50_000_000])
