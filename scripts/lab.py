@@ -724,6 +724,58 @@ def cmd_noinput(a):
     eng.set_option("uniform_fix", 0)
 
 
+def cmd_optab(a):
+    """Same-context A/B of one engine option (same arrays, alternating steady
+    blocks), for collimated bundles and bundles with per-ray directions; the
+    rows compared bit for bit."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    n = a.rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    L = len(system)
+    for shape in ("collimated", "per-ray directions"):
+        y, u = workload_rays(n, 0)
+        if shape != "collimated":
+            rng = np.random.default_rng(3)
+            u[:, 0] += 1e-7*rng.standard_normal(n)
+            u[:, 1] += 1e-7*rng.standard_normal(n)
+            u[:, 2] = np.sqrt(1. - u[:, 0]**2 - u[:, 1]**2)
+        eng = Engine(0)
+        g = ra.GeometricTrace(system, engine=eng)
+        g.rays_given(y, u)
+        g.propagate(clip=True)
+        steady(eng, .6)
+        for kw_name, kw in (("clip", dict(clip=True)),
+                            ("unclipped", dict(clip=False))):
+            res = {v: [] for v in a.values}
+            rows = {}
+            for rep in range(a.reps):
+                for v in (a.values if rep % 2 == 0 else a.values[::-1]):
+                    eng.set_option(a.option, v)
+                    g.propagate(**kw)
+                    if rep == 0:
+                        rows[v] = [np.array(eng.download(w, 1, L))
+                                   for w in (0, 1, 3)]
+                    t_end = time.time() + .5
+                    ms = []
+                    while time.time() < t_end:
+                        eng.event_record(0)
+                        for _ in range(10):
+                            g.propagate(**kw)
+                        eng.event_record(1)
+                        ms.append(eng.event_elapsed(0, 1)/10)
+                    res[v].append(float(np.median(ms[len(ms)//3:])))
+            same = all(np.array_equal(p, q, equal_nan=True)
+                       for v in a.values[1:]
+                       for p, q in zip(rows[a.values[0]], rows[v]))
+            out(bundles=shape, trace=kw_name, option=a.option,
+                ms={str(v): float(np.median(t)) for v, t in res.items()},
+                all={str(v): t for v, t in res.items()}, bit_identical=same,
+                placement=eng.placement()["per_class"])
+        del g
+        eng.close()
+
+
 def cmd_spacing(a):
     """Is it the distance between the rows or the size of the batch that
     slows traces above 10^7 rays?  A batch of N rays traced whole, and in
@@ -913,6 +965,12 @@ def main():
     p = sub.add_parser("noinput")
     p.add_argument("--rays", type=int, default=10_000_000)
     p.set_defaults(fn=cmd_noinput)
+    p = sub.add_parser("optab")
+    p.add_argument("option")
+    p.add_argument("values", type=int, nargs="+")
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.add_argument("--reps", type=int, default=4)
+    p.set_defaults(fn=cmd_optab)
     p = sub.add_parser("spacing")
     p.add_argument("--sizes", type=int, nargs="*",
                    default=[10_000_000, 20_000_000, 50_000_000])
