@@ -776,6 +776,45 @@ def cmd_optab(a):
         eng.close()
 
 
+def cmd_floor(a):
+    """The store floor under the trace: the trace kernel's own store pattern
+    without arithmetic and without reads (rt_probe 8), ordinary and
+    non-temporal stores, in placed arrays, per cap on the resident
+    workgroups; next to it the trace itself and the FP64 side alone."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    n = a.rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    y, u = workload_rays(n, 0)
+    eng = Engine(0, lib_path=lab_lib())
+    g = ra.GeometricTrace(system, engine=eng)
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    steady(eng, 1.)
+    res = {"trace_ms": steady(eng, .6)}
+    g.propagate(clip=True, keep=[0, -1])
+    t_end = time.time() + .5
+    ms = []
+    while time.time() < t_end:
+        eng.event_record(0)
+        for _ in range(10):
+            g.propagate(clip=True, keep=[0, -1])
+        eng.event_record(1)
+        ms.append(eng.event_elapsed(0, 1)/10)
+    res["image_row_only_ms"] = float(np.median(ms))
+    g.propagate(clip=True)
+    for store in (0, 1):
+        eng.set_option("probe_store", store)
+        for lds in (65536, 32768, 0):
+            eng.set_option("lds_pad", lds)
+            pm = [eng.probe(8)[0] for _ in range(40)]
+            res["pattern_%s_lds_%d" % ("nt" if store else "plain", lds)] = \
+                float(np.median(pm[10:]))
+    eng.set_option("lds_pad", 0)
+    eng.set_option("probe_store", 0)
+    out(placement=eng.placement()["per_class"], **res)
+
+
 def cmd_spacing(a):
     """Is it the distance between the rows or the size of the batch that
     slows traces above 10^7 rays?  A batch of N rays traced whole, and in
@@ -971,6 +1010,9 @@ def main():
     p.add_argument("--rays", type=int, default=10_000_000)
     p.add_argument("--reps", type=int, default=4)
     p.set_defaults(fn=cmd_optab)
+    p = sub.add_parser("floor")
+    p.add_argument("--rays", type=int, default=10_000_000)
+    p.set_defaults(fn=cmd_floor)
     p = sub.add_parser("spacing")
     p.add_argument("--sizes", type=int, nargs="*",
                    default=[10_000_000, 20_000_000, 50_000_000])
