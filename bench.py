@@ -1227,7 +1227,10 @@ def main():
                     valu_wave_instructions_per_launch=c["SQ_INSTS_VALU"]*sc,
                     valu_issue_frac=c["SQ_INSTS_VALU"]*sc*4/cyc,
                     valu_busy_frac=c["SQ_ACTIVE_INST_VALU"]*sc*4/cyc,
-                    flop_equivalent_note="SURVEY 8(d): not an HBM leg; the "
+                    flop_equivalents_per_s=io["value"]*190.,
+                    flop_equivalent_note="SURVEY 8(d): not an HBM leg (~190 "
+                    "flop-equivalents per ray-surface op: 70 flop + 3 sqrt + "
+                    "4 div); the "
                     "ceiling is 1024 SIMDs x gfx clock / 4 cycles per FP64 "
                     "wave-instruction (profiles/valu_counters.json)")
     # (not under a profiler: every rt_trace_kernel launch rocprofv3 sees in
