@@ -938,7 +938,7 @@ def main():
     placement["note"] = (
         "the speed of the trace's simultaneous row streams is a property of "
         "the physical memory behind the arrays (bare store pattern: 7.0 / "
-        "6.3 / 5.65 TB/s); arrays >= 1.5 GiB are built from pieces whose "
+        "6.3 / 5.65 TB/s); arrays > 1.5 GiB are built from pieces whose "
         "class is measured at allocation (~1 ms each) and mixed "
         "(csrc/rt_place.h); results do not depend on it")
     gather_ms = gather_exposed = None

@@ -521,7 +521,7 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * 6.3 / 5.65 TB/s for the bare store pattern of C3; pieces of device memory
  * fall into classes, and streams dealt over pieces of two or three classes
  * run at the fast level, streams inside one class -- every plain hipMalloc of
- * 10 GB seen -- at the slow one: csrc/rt_place.h).  Arrays of >= 1.5 GiB are
+ * 10 GB seen -- at the slow one: csrc/rt_place.h).  Arrays of > 1.5 GiB are
  * therefore built from pieces (hipMemCreate, 1 GiB; 512 MiB below 3 GiB) whose class the library measures at rt_reserve with a ~1 ms pair
  * test each, an even mix of classes mapped behind one address range, the
  * surplus released (option "placement", default 1; RT_MI355_PLACEMENT=0 for

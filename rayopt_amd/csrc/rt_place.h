@@ -37,7 +37,11 @@
 #include "rt_ctx.h"
 
 #define RT_PLACE_ROWS 84         /* 12 elements x (y0 y1 y2 u0 u1 u2 t) */
-#define RT_PLACE_MIN_BYTES ((size_t)3 << 29) /* below 1.5 GiB: hipMalloc */
+/* up to 1.5 GiB: hipMalloc.  Above it there are at least four pieces of
+ * 512 MiB, two per class: with three the rows of Y, U and T fall on the
+ * classes in lumps ([2, 1]: two thirds of the streams in one class) and the
+ * trace is as often slower as faster (profiles/r04_probes/session26) */
+#define RT_PLACE_MIN_BYTES (((size_t)3 << 29) + 1)
 #define RT_PLACE_SAME 0.91f      /* pair / self time above this: same class */
 
 struct rt_place_rows {
