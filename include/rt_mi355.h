@@ -536,7 +536,7 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * before the measurement below; ms[2] = GB/s of the trace's own store
  * pattern (56 B per ray and element) written over the arrays as laid out,
  * measured at rt_reserve for arrays >= 4 GiB (0: not measured; three
- * launches): below 6550 GB/s -- the memory behaves like one class whatever
+ * launches): below 5950 GB/s -- the memory behaves like one class whatever
  * the pair tests said, seen on one box -- [7] is cleared; ms[0] / ms[1] = the pair test's launch time inside one piece /
  * across two classes.
  */

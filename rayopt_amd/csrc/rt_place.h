@@ -357,10 +357,13 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
  * laid out, three launches.  Classes are a model (three on most boxes seen;
  * one box traced at the slow level in a mix that should have been fast):
  * what decides between four and two workgroups per CU is this measurement.
- * Levels of the bare pattern: 7.0 / 6.3 / 5.65 TB/s.  Rows are overwritten:
+ * Levels of the bare pattern: 7.0 / 6.3 / 5.65 TB/s (mixed / partly mixed /
+ * one class); 18 placed contexts on three boxes: 6.73-7.04.  Rows are overwritten:
  * called from rt_reserve, before anything lives in them.
  */
-#define RT_PLACE_FAST_GBPS 6550. /* at and above: the fast level */
+/* below this the arrays behave like ONE class (5.65 TB/s; four workgroups per
+ * CU then lose to two); the middle level (6.3) still takes four better */
+#define RT_PLACE_FAST_GBPS 5950.
 #define RT_PLACE_VERIFY_BYTES ((size_t)4 << 30)
 
 __global__ __launch_bounds__(256) void rt_place_rows_kernel(rt_lay a, int L,
