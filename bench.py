@@ -1606,13 +1606,22 @@ def run_consumers(ra, g, system, n, nf, cpu):
             r["note"] = note
         return r
     out = []
-    out.append(rec("rms (centroid + spread: two passes over y0, y1)",
-                   timed(lambda: g.rms()), 32*n,
-                   "rayopt/geometric_trace.py:171-183"))
-    out.append(rec("refocus_shift (two passes over y0 y1 i0 i1 i2)",
-                   timed(lambda: eng.refocus_shift(L - 1)), 80*n,
-                   "rayopt/geometric_trace.py:82-97 (the sums; the "
-                   "re-propagate of :98-99 is one more trace)"))
+    def both(name, fn, nbytes, replaces):
+        # the shipped one-pass reduction, and the two passes it replaced
+        r = rec(name, timed(fn), nbytes, replaces)
+        eng.set_option("consumers_one_pass", 0)
+        try:
+            r["two_pass_ms"] = timed(fn)
+        finally:
+            eng.set_option("consumers_one_pass", 1)
+        return r
+    out.append(both("rms (one pass over y0, y1, shifted by ray 0)",
+                    lambda: g.rms(), 16*n,
+                    "rayopt/geometric_trace.py:171-183"))
+    out.append(both("refocus_shift (one pass over y0 y1 i0 i1 i2)",
+                    lambda: eng.refocus_shift(L - 1), 40*n,
+                    "rayopt/geometric_trace.py:82-97 (the sums; the "
+                    "re-propagate of :98-99 is one more trace)"))
     out.append(rec("spot_stats, %d field bundles (two passes over y0, y1)"
                    % nf, timed(lambda: eng.spot_stats(L - 1, n//nf, nf)),
                    32*n, "per-field rms of rayopt/analysis.py spot diagrams"))

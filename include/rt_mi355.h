@@ -371,7 +371,8 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * (rt_placement), "range_shortcuts" (1 = default: IEEE quotients and square
  * roots run without the compiler's range scaffolding where the operands are
  * checked to be inside [2^-100, 2^100] -- the same bits from a third fewer
- * instructions, RT_F_RANGE; 0 = the compiler's sequences everywhere).
+ * instructions, RT_F_RANGE; 0 = the compiler's sequences everywhere),
+ * "consumers_one_pass" (1 = default, see rt_rms; 0 = always two passes).
  * Measurement-only variants and the memory-system probes live in a separate
  * laboratory build (include/rt_mi355_probes.h), not in this library.
  */
@@ -399,6 +400,13 @@ int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst);
  * rt_refocus_shift: the least-squares focus shift of refocus(at) (:82-97):
  *             u = i_xy/i_z, rays with finite u, centred y and u,
  *             t = -<w y, u>/<w u, u>.  Does not touch the system.
+ *             Both read their rows ONCE: the sums are taken of coordinates
+ *             shifted by ray 0 of the batch and centred by subtraction
+ *             afterwards; the last kernel reports what the subtraction
+ *             started from, and if it cost more than six bits (ray 0 far
+ *             outside the bundle, or vignetted) the call repeats with the
+ *             two passes (mean, then spread) of the textbook.  Tolerance
+ *             against numpy either way: 1e-12 (rms), 1e-9 (the ratio).
  * rt_opd_rays: per-ray part of GeometricTrace.opd (:101-131, the rows the
  *             reference returns for resample=0): out[3][n] = (x, y, t) on the
  *             reference sphere, t in waves.

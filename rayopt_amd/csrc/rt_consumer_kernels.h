@@ -126,6 +126,179 @@ __global__ void rt_finalize_kernel(const double *__restrict__ partials,
     }
 }
 
+/*
+ * A thread's share of rays lo..hi of C rows, as 16-byte loads, two per row in
+ * flight.  A reduction is a pure read stream: this chip wants ~16 MB in
+ * flight (8 TB/s x ~2 us), and 8-byte loads in a grid-stride loop had a
+ * quarter of that (rms at 10^7 rays: 3.7 TB/s).  `tid` of `nthreads` is the
+ * thread's place among those that share the range; the ray -> thread map is
+ * fixed, so sums are run-to-run identical.
+ */
+template <int C, class F>
+__device__ __forceinline__ void rt_stream_rows(const double *const (&row)[C],
+                                               int64_t lo, int64_t hi,
+                                               int64_t tid, int64_t nthreads,
+                                               F &&use)
+{
+    double v[C];
+    if ((lo & 1) && lo < hi) { /* rows are 16-byte aligned at even rays */
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                v[c] = row[c][lo];
+            use(v);
+        }
+        ++lo;
+    }
+    const int64_t n2 = hi > lo ? (hi - lo) >> 1 : 0;
+    int64_t p = tid;
+    for (; p + nthreads < n2; p += 2 * nthreads) {
+        double2 a[C], b[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            a[c] = ((const double2 *)(row[c] + lo))[p];
+            b[c] = ((const double2 *)(row[c] + lo))[p + nthreads];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            v[c] = a[c].x;
+        use(v);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            v[c] = a[c].y;
+        use(v);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            v[c] = b[c].x;
+        use(v);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            v[c] = b[c].y;
+        use(v);
+    }
+    if (p < n2) {
+        double2 a[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            a[c] = ((const double2 *)(row[c] + lo))[p];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            v[c] = a[c].x;
+        use(v);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            v[c] = a[c].y;
+        use(v);
+    }
+    if (hi > lo && ((hi - lo) & 1) && tid == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            v[c] = row[c][hi - 1];
+        use(v);
+    }
+}
+
+#define RT_RED_TID ((int64_t)blockIdx.x * blockDim.x + threadIdx.x)
+#define RT_RED_NTHREADS ((int64_t)gridDim.x * blockDim.x)
+
+/* one wavefront adds the K columns of the per-workgroup partials side by
+ * side (per column in the order of rt_finalize_kernel); every lane returns
+ * with the sums */
+template <int K>
+__device__ __forceinline__ void rt_partial_sums(const double *__restrict__ p,
+                                                int nblocks, double (&s)[K])
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        s[k] = 0.;
+    for (int b = threadIdx.x; b < nblocks; b += 64)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            s[k] += p[(int64_t)b * K + k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        for (int off = 32; off > 0; off >>= 1)
+            s[k] += __shfl_down(s[k], off);
+        s[k] = __shfl(s[k], 0);
+    }
+}
+
+/*
+ * rms about the mean in ONE pass: sums of the coordinates shifted by ray 0
+ * (d = y - y[0]), then  sum w |d - m|^2 = sum w d^2 - 2 m . sum w d +
+ * |m|^2 sum w  with m = sum d / n.  Shifted by a ray of the bundle the
+ * subtraction costs a few bits at most (|m| ~ spot size); how many is
+ * reported (out[1] = sum w d^2 before the subtraction) and the caller falls
+ * back to the two passes below when it is more than six.  With ref >= 0 the
+ * centre is that ray and nothing is subtracted.  W: per-ray weights.
+ * acc: sum dx, sum dy, sum w d^2 [, sum w dx, sum w dy, sum w].
+ */
+template <bool W>
+__global__ void rt_rms_shifted_kernel(const double *__restrict__ Yrow,
+                                      const double *__restrict__ w,
+                                      int64_t ref, int64_t n, int64_t ld,
+                                      double *__restrict__ partials)
+{
+    const int64_t k0 = ref >= 0 ? ref : 0;
+    const double x0 = Yrow[k0], y0 = Yrow[ld + k0];
+    constexpr int K = W ? 6 : 3;
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        acc[k] = 0.;
+    if constexpr (W) {
+        const double *const rows[3] = {Yrow, Yrow + ld, w};
+        rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
+                       [&](const double(&v)[3]) {
+                           const double dx = v[0] - x0, dy = v[1] - y0;
+                           const double r = dx * dx + dy * dy;
+                           acc[0] += dx;
+                           acc[1] += dy;
+                           acc[2] += r * v[2];
+                           acc[3] += v[2] * dx;
+                           acc[4] += v[2] * dy;
+                           acc[5] += v[2];
+                       });
+    } else {
+        const double *const rows[2] = {Yrow, Yrow + ld};
+        rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
+                       [&](const double(&v)[2]) {
+                           const double dx = v[0] - x0, dy = v[1] - y0;
+                           acc[0] += dx;
+                           acc[1] += dy;
+                           acc[2] += dx * dx + dy * dy;
+                       });
+    }
+    rt_block_reduce<K>(acc, partials);
+}
+
+/* out[0] = sum w |y - centre|^2, out[1] = the same about ray 0 (what the
+ * subtraction started from); out may be pinned host memory */
+template <bool W>
+__global__ void rt_rms_finish_kernel(const double *__restrict__ partials,
+                                     int nblocks, int centred, double n,
+                                     double *__restrict__ out)
+{
+    double s[W ? 6 : 3];
+    rt_partial_sums(partials, nblocks, s);
+    double A = s[2], swx, swy, sw;
+    if constexpr (W) {
+        swx = s[3];
+        swy = s[4];
+        sw = s[5];
+    } else { /* w = 1/n for every ray */
+        A /= n;
+        swx = s[0] / n;
+        swy = s[1] / n;
+        sw = 1.;
+    }
+    if (threadIdx.x == 0) {
+        const double mx = centred ? s[0] / n : 0., my = centred ? s[1] / n : 0.;
+        out[0] = A - 2. * (mx * swx + my * swy) + (mx * mx + my * my) * sw;
+        out[1] = A;
+    }
+}
+
 /* sum of x and y of one row (rms: y.mean(0)) */
 __global__ void rt_sum_xy_kernel(const double *__restrict__ Yrow, int64_t n,
                                  int64_t ld, double *__restrict__ partials)
@@ -157,6 +330,108 @@ __global__ void rt_rms_kernel(const double *__restrict__ Yrow,
         acc[0] += r * (w ? w[j] : wconst);
     }
     rt_block_reduce<1>(acc, partials);
+}
+
+/*
+ * The refocus sums in ONE pass, shifted by ray 0 (y' = y - y[0], u' = u -
+ * u[0]): over rays with finite u = i_xy / i_z
+ *   acc: count, sum y' (2), sum u' (2), sum w y'.u', sum w |u'|^2,
+ *        sum w |y'|^2 [, sum w, sum w y' (2), sum w u' (2)]
+ * and the centred dots follow by subtraction in rt_refocus_finish_kernel.
+ */
+template <bool W>
+__global__ void rt_refocus_shifted_kernel(const double *__restrict__ Yrow,
+                                          const double *__restrict__ Irow,
+                                          const double *__restrict__ w,
+                                          int64_t n, int64_t ld,
+                                          double *__restrict__ partials)
+{
+    const double iz0 = Irow[2 * ld];
+    const double ky0 = Yrow[0], ky1 = Yrow[ld];
+    const double ku0 = Irow[0] / iz0, ku1 = Irow[ld] / iz0;
+    constexpr int K = W ? 13 : 8;
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        acc[k] = 0.;
+    auto use = [&](double y0, double y1, double i0, double i1, double iz,
+                   double wk) {
+        const double ux = i0 / iz, uy = i1 / iz;
+        if (isfinite(ux) && isfinite(uy)) {
+            const double a0 = y0 - ky0, a1 = y1 - ky1;
+            const double b0 = ux - ku0, b1 = uy - ku1;
+            acc[0] += 1.;
+            acc[1] += a0;
+            acc[2] += a1;
+            acc[3] += b0;
+            acc[4] += b1;
+            if constexpr (W) {
+                acc[5] += (wk * a0) * b0 + (wk * a1) * b1;
+                acc[6] += (wk * b0) * b0 + (wk * b1) * b1;
+                acc[7] += (wk * a0) * a0 + (wk * a1) * a1;
+                acc[8] += wk;
+                acc[9] += wk * a0;
+                acc[10] += wk * a1;
+                acc[11] += wk * b0;
+                acc[12] += wk * b1;
+            } else {
+                acc[5] += a0 * b0 + a1 * b1;
+                acc[6] += b0 * b0 + b1 * b1;
+                acc[7] += a0 * a0 + a1 * a1;
+            }
+        }
+    };
+    if constexpr (W) {
+        const double *const rows[6] = {Yrow,        Yrow + ld,     Irow,
+                                       Irow + ld,   Irow + 2 * ld, w};
+        rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
+                       [&](const double(&v)[6]) {
+                           use(v[0], v[1], v[2], v[3], v[4], v[5]);
+                       });
+    } else {
+        const double *const rows[5] = {Yrow, Yrow + ld, Irow, Irow + ld,
+                                       Irow + 2 * ld};
+        rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
+                       [&](const double(&v)[5]) {
+                           use(v[0], v[1], v[2], v[3], v[4], 1.);
+                       });
+    }
+    rt_block_reduce<K>(acc, partials);
+}
+
+/* out[0] = <w yc, uc>, out[1] = <w uc, uc>, out[2] = <w yc, yc> (c: centred
+ * on the means over the finite rays), out[3] / out[4] = what the
+ * subtractions for [1] / [2] started from */
+template <bool W>
+__global__ void rt_refocus_finish_kernel(const double *__restrict__ partials,
+                                         int nblocks, double *__restrict__ out)
+{
+    double s[13];
+    if constexpr (W) {
+        rt_partial_sums(partials, nblocks, s);
+    } else { /* w = 1 for every ray */
+        double t[8];
+        rt_partial_sums(partials, nblocks, t);
+        for (int k = 0; k < 8; ++k)
+            s[k] = t[k];
+        s[8] = t[0];
+        s[9] = t[1];
+        s[10] = t[2];
+        s[11] = t[3];
+        s[12] = t[4];
+    }
+    if (threadIdx.x == 0) {
+        const double my0 = s[1] / s[0], my1 = s[2] / s[0];
+        const double mu0 = s[3] / s[0], mu1 = s[4] / s[0];
+        out[0] = s[5] - (mu0 * s[9] + mu1 * s[10]) -
+                 (my0 * s[11] + my1 * s[12]) + (my0 * mu0 + my1 * mu1) * s[8];
+        out[1] = s[6] - 2. * (mu0 * s[11] + mu1 * s[12]) +
+                 (mu0 * mu0 + mu1 * mu1) * s[8];
+        out[2] = s[7] - 2. * (my0 * s[9] + my1 * s[10]) +
+                 (my0 * my0 + my1 * my1) * s[8];
+        out[3] = s[6];
+        out[4] = s[7];
+    }
 }
 
 /* refocus pass A: over rays with finite u = i_xy/i_z: count, sum y, sum u */
@@ -215,15 +490,15 @@ __global__ void rt_r2max_kernel(const double *__restrict__ Yrow, int64_t n,
 {
     __shared__ double sm[RT_RED_THREADS / 64][2];
     double mx = 0., bad = 0.;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
-        const double x = Yrow[j], y = Yrow[ld + j];
-        const double r2 = x * x + y * y;
-        if (r2 != r2)
-            bad = 1.;
-        else
-            mx = r2 > mx ? r2 : mx;
-    }
+    const double *const rows[2] = {Yrow, Yrow + ld};
+    rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
+                   [&](const double(&v)[2]) {
+                       const double r2 = v[0] * v[0] + v[1] * v[1];
+                       if (r2 != r2)
+                           bad = 1.;
+                       else
+                           mx = r2 > mx ? r2 : mx;
+                   });
     for (int off = 32; off > 0; off >>= 1) {
         const double o = __shfl_down(mx, off), b = __shfl_down(bad, off);
         mx = o > mx ? o : mx;
@@ -245,6 +520,28 @@ __global__ void rt_r2max_kernel(const double *__restrict__ Yrow, int64_t n,
     }
 }
 
+/* second level of rt_r2max_kernel: out[0] = max r^2, out[1] = 1 if any ray
+ * was NaN; out may be pinned host memory */
+__global__ void rt_r2max_finish_kernel(const double *__restrict__ partials,
+                                       int nblocks, double *__restrict__ out)
+{
+    double mx = 0., bad = 0.;
+    for (int b = threadIdx.x; b < nblocks; b += 64) {
+        const double m = partials[(int64_t)b * 2], x = partials[(int64_t)b * 2 + 1];
+        mx = m > mx ? m : mx;
+        bad = x > bad ? x : bad;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(mx, off), b = __shfl_down(bad, off);
+        mx = o > mx ? o : mx;
+        bad = b > bad ? b : bad;
+    }
+    if (threadIdx.x == 0) {
+        out[0] = mx;
+        out[1] = bad;
+    }
+}
+
 /*
  * Per-group spot statistics: the batch is `gridDim.y` contiguous groups of
  * group_rays rays (field x wavelength bundles as rt_generate_rays lays them
@@ -254,6 +551,7 @@ __global__ void rt_r2max_kernel(const double *__restrict__ Yrow, int64_t n,
  * stats[g] = {count, mean x, mean y, sum w d^2 / sum w, max d^2, sum w}.
  */
 #define RT_GRP_STATS 6
+#define RT_GROUP_PINNED 4096 /* groups whose stats are written to the host */
 
 /* pass A: count, sum x, sum y, sum w over the finite rays of group g */
 __global__ void rt_group_sums_kernel(const double *__restrict__ Yrow,
@@ -263,36 +561,44 @@ __global__ void rt_group_sums_kernel(const double *__restrict__ Yrow,
 {
     const int64_t base = (int64_t)blockIdx.y * group_rays;
     double acc[4] = {0., 0., 0., 0.};
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-         j < group_rays; j += (int64_t)gridDim.x * blockDim.x) {
-        const double x = Yrow[base + j], y = Yrow[ld + base + j];
+    auto use = [&](double x, double y, double wk) {
         if (isfinite(x) && isfinite(y)) {
             acc[0] += 1.;
             acc[1] += x;
             acc[2] += y;
-            acc[3] += w ? w[base + j] : 1.;
+            acc[3] += wk;
         }
+    };
+    if (w) {
+        const double *const rows[3] = {Yrow, Yrow + ld, w};
+        rt_stream_rows(rows, base, base + group_rays, RT_RED_TID,
+                       RT_RED_NTHREADS,
+                       [&](const double(&v)[3]) { use(v[0], v[1], v[2]); });
+    } else {
+        const double *const rows[2] = {Yrow, Yrow + ld};
+        rt_stream_rows(rows, base, base + group_rays, RT_RED_TID,
+                       RT_RED_NTHREADS,
+                       [&](const double(&v)[2]) { use(v[0], v[1], 1.); });
     }
     rt_block_reduce<4>(acc, partials + (int64_t)blockIdx.y * gridDim.x * 4);
 }
 
-/* one thread per group adds its pb partials in index order */
+/* one wavefront per group adds its pb partials (lane l takes b = l, l + 64,
+ * ..., then a fixed shuffle tree) */
 __global__ void rt_group_centroid_kernel(const double *__restrict__ partials,
                                          int pb, int ngroups,
                                          double *__restrict__ stats)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups)
-        return;
-    double a[4] = {0., 0., 0., 0.};
-    for (int b = 0; b < pb; ++b)
-        for (int k = 0; k < 4; ++k)
-            a[k] += partials[((int64_t)g * pb + b) * 4 + k];
-    double *s = stats + (int64_t)g * RT_GRP_STATS;
-    s[0] = a[0];
-    s[1] = a[1] / a[0];
-    s[2] = a[2] / a[0];
-    s[5] = a[3];
+    const int g = blockIdx.x;
+    double a[4];
+    rt_partial_sums(partials + (int64_t)g * pb * 4, pb, a);
+    if (threadIdx.x == 0) {
+        double *s = stats + (int64_t)g * RT_GRP_STATS;
+        s[0] = a[0];
+        s[1] = a[1] / a[0];
+        s[2] = a[2] / a[0];
+        s[5] = a[3];
+    }
 }
 
 /* pass B: sum w d^2 and max d^2 about the centroid of group g */
@@ -307,15 +613,24 @@ __global__ void rt_group_spread_kernel(const double *__restrict__ Yrow,
     const double x0 = stats[(int64_t)blockIdx.y * RT_GRP_STATS + 1];
     const double y0 = stats[(int64_t)blockIdx.y * RT_GRP_STATS + 2];
     double sum = 0., mx = 0.;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-         j < group_rays; j += (int64_t)gridDim.x * blockDim.x) {
-        const double x = Yrow[base + j], y = Yrow[ld + base + j];
+    auto use = [&](double x, double y, double wk) {
         if (isfinite(x) && isfinite(y)) {
             const double dx = x - x0, dy = y - y0;
             const double r = dx * dx + dy * dy;
-            sum += r * (w ? w[base + j] : 1.);
+            sum += r * wk;
             mx = r > mx ? r : mx;
         }
+    };
+    if (w) {
+        const double *const rows[3] = {Yrow, Yrow + ld, w};
+        rt_stream_rows(rows, base, base + group_rays, RT_RED_TID,
+                       RT_RED_NTHREADS,
+                       [&](const double(&v)[3]) { use(v[0], v[1], v[2]); });
+    } else {
+        const double *const rows[2] = {Yrow, Yrow + ld};
+        rt_stream_rows(rows, base, base + group_rays, RT_RED_TID,
+                       RT_RED_NTHREADS,
+                       [&](const double(&v)[2]) { use(v[0], v[1], 1.); });
     }
     for (int off = 32; off > 0; off >>= 1) {
         sum += __shfl_down(sum, off);
@@ -339,22 +654,35 @@ __global__ void rt_group_spread_kernel(const double *__restrict__ Yrow,
     }
 }
 
+/* the finished stats go to `final` (the device array itself, or pinned host
+ * memory) */
 __global__ void rt_group_finish_kernel(const double *__restrict__ partials,
                                        int pb, int ngroups,
-                                       double *__restrict__ stats)
+                                       const double *stats, double *final)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups)
-        return;
+    const int g = blockIdx.x;
     double sum = 0., mx = 0.;
-    for (int b = 0; b < pb; ++b) {
+    for (int b = threadIdx.x; b < pb; b += 64) {
         const double *p = partials + ((int64_t)g * pb + b) * 2;
         sum += p[0];
         mx = p[1] > mx ? p[1] : mx;
     }
-    double *s = stats + (int64_t)g * RT_GRP_STATS;
-    s[3] = sum / s[5];
-    s[4] = s[0] > 0. ? mx : __builtin_nan("");
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_down(sum, off);
+        const double o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if (threadIdx.x != 0)
+        return;
+    const double *s = stats + (int64_t)g * RT_GRP_STATS;
+    double *f = final + (int64_t)g * RT_GRP_STATS;
+    const double cnt = s[0], sw = s[5];
+    f[0] = cnt;
+    f[1] = s[1];
+    f[2] = s[2];
+    f[3] = sum / sw;
+    f[4] = cnt > 0. ? mx : __builtin_nan("");
+    f[5] = sw;
 }
 
 /* reference-ray columns the opd kernel needs, all wave-uniform */

@@ -137,7 +137,9 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_partials)
         RT_HIP(ctx, hipMalloc((void **)&ctx->d_partials,
-                              sizeof(double) * (RT_RED_BLOCKS * 8 + 16)));
+                              sizeof(double) * (RT_RED_BLOCKS * 16 + 16)));
+    if (!ctx->h_res)
+        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_res, 8 * sizeof(double)));
     return rt_gen_flush(ctx);
 }
 
@@ -151,7 +153,7 @@ static inline unsigned rt_red_blocks(int64_t n)
 /* device-side second level of a reduction: k sums -> ctx->d_partials tail */
 static inline double *rt_reduced(rt_ctx *ctx, int slot)
 {
-    return ctx->d_partials + (size_t)RT_RED_BLOCKS * 8 + slot;
+    return ctx->d_partials + (size_t)RT_RED_BLOCKS * 16 + slot;
 }
 
 int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
@@ -163,8 +165,39 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
         return rt_fail(ctx, RT_ERR_ARG, "rt_rms: bad argument");
     const double *Yrow = rt_row(ctx, RT_Y, surf);
     const unsigned blocks = rt_red_blocks(ctx->n);
-    /* both passes and their second levels are queued back to back; the host
-     * waits once, for one double */
+    if (ctx->opt_onepass) {
+        /* one pass over the row, shifted by a ray of the bundle; its last
+         * kernel leaves the scalars in pinned memory */
+        if (ctx->d_w)
+            hipLaunchKernelGGL(rt_rms_shifted_kernel<true>, dim3(blocks),
+                               dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
+                               ctx->d_w, ref, ctx->n, ctx->ld,
+                               ctx->d_partials);
+        else
+            hipLaunchKernelGGL(rt_rms_shifted_kernel<false>, dim3(blocks),
+                               dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
+                               ctx->d_w, ref, ctx->n, ctx->ld,
+                               ctx->d_partials);
+        if (ctx->d_w)
+            hipLaunchKernelGGL(rt_rms_finish_kernel<true>, dim3(1), dim3(64),
+                               0, ctx->stream, ctx->d_partials, (int)blocks,
+                               ref < 0 ? 1 : 0, (double)ctx->n, ctx->h_res);
+        else
+            hipLaunchKernelGGL(rt_rms_finish_kernel<false>, dim3(1), dim3(64),
+                               0, ctx->stream, ctx->d_partials, (int)blocks,
+                               ref < 0 ? 1 : 0, (double)ctx->n, ctx->h_res);
+        RT_HIP(ctx, hipGetLastError());
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double r = ctx->h_res[0], a = ctx->h_res[1];
+        /* NaN stays NaN (one vignetted ray poisons the reference's mean
+         * too); otherwise the subtraction may have cost six bits */
+        if (ref >= 0 || r != r || a != a || (r >= 0. && r * 64. >= a)) {
+            *rms = sqrt(r);
+            return RT_OK;
+        }
+    }
+    /* two passes (mean, then spread about it) and their second levels,
+     * queued back to back; the host waits once */
     if (ref < 0) {
         hipLaunchKernelGGL(rt_sum_xy_kernel, dim3(blocks),
                            dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, ctx->n,
@@ -178,13 +211,10 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
                        rt_reduced(ctx, 0), ref, ctx->n, ctx->ld,
                        ctx->d_partials);
     hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
-                       ctx->d_partials, (int)blocks, 1, rt_reduced(ctx, 2));
+                       ctx->d_partials, (int)blocks, 1, ctx->h_res);
     RT_HIP(ctx, hipGetLastError());
-    double sum;
-    RT_HIP(ctx, hipMemcpyAsync(&sum, rt_reduced(ctx, 2), sizeof sum,
-                               hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *rms = sqrt(sum);
+    *rms = sqrt(ctx->h_res[0]);
     return RT_OK;
 }
 
@@ -195,21 +225,15 @@ int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax)
         return rc;
     if (!rmax)
         return rt_fail(ctx, RT_ERR_ARG, "rt_row_rmax: NULL");
-    hipLaunchKernelGGL(rt_r2max_kernel, dim3(RT_RED_BLOCKS),
-                       dim3(RT_RED_THREADS), 0, ctx->stream,
-                       rt_row(ctx, RT_Y, surf), ctx->n, ctx->ld,
+    const unsigned blocks = rt_red_blocks(ctx->n);
+    hipLaunchKernelGGL(rt_r2max_kernel, dim3(blocks), dim3(RT_RED_THREADS), 0,
+                       ctx->stream, rt_row(ctx, RT_Y, surf), ctx->n, ctx->ld,
                        ctx->d_partials);
-    double host[RT_RED_BLOCKS * 2];
+    hipLaunchKernelGGL(rt_r2max_finish_kernel, dim3(1), dim3(64), 0,
+                       ctx->stream, ctx->d_partials, (int)blocks, ctx->h_res);
     RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipMemcpyAsync(host, ctx->d_partials, sizeof host,
-                               hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double mx = 0., bad = 0.;
-    for (int b = 0; b < RT_RED_BLOCKS; ++b) {
-        mx = host[2 * b] > mx ? host[2 * b] : mx;
-        bad = host[2 * b + 1] > bad ? host[2 * b + 1] : bad;
-    }
-    *rmax = bad ? __builtin_nan("") : sqrt(mx);
+    *rmax = ctx->h_res[1] != 0. ? __builtin_nan("") : sqrt(ctx->h_res[0]);
     return RT_OK;
 }
 
@@ -240,11 +264,19 @@ int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
         RT_HIP(ctx, hipMalloc((void **)&ctx->d_group, need * sizeof(double)));
         ctx->group_cap = need;
     }
+    /* a few groups: the last kernel writes the finished stats into pinned
+     * memory and no copy follows it (a pageable 240-byte D2H costs as much as
+     * a pass over the row); the centroids stay on the device for pass B */
+    if (ngroups <= RT_GROUP_PINNED && !ctx->h_group)
+        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_group,
+                                  sizeof(double) * RT_GRP_STATS *
+                                      RT_GROUP_PINNED));
     double *stats = ctx->d_group;
+    double *final = ngroups <= RT_GROUP_PINNED ? ctx->h_group : stats;
     double *partials = stats + (size_t)ngroups * RT_GRP_STATS;
     const double *Yrow = rt_row(ctx, RT_Y, surf);
     const dim3 grid((unsigned)pb, (unsigned)ngroups), block(RT_RED_THREADS);
-    const dim3 fgrid((unsigned)((ngroups + 63) / 64)), fblock(64);
+    const dim3 fgrid((unsigned)ngroups), fblock(64); /* a wavefront each */
     hipLaunchKernelGGL(rt_group_sums_kernel, grid, block, 0, ctx->stream, Yrow,
                        ctx->d_w, group_rays, ctx->ld, partials);
     hipLaunchKernelGGL(rt_group_centroid_kernel, fgrid, fblock, 0, ctx->stream,
@@ -252,12 +284,15 @@ int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
     hipLaunchKernelGGL(rt_group_spread_kernel, grid, block, 0, ctx->stream,
                        Yrow, ctx->d_w, group_rays, ctx->ld, stats, partials);
     hipLaunchKernelGGL(rt_group_finish_kernel, fgrid, fblock, 0, ctx->stream,
-                       partials, (int)pb, ngroups, stats);
+                       partials, (int)pb, ngroups, stats, final);
     RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipMemcpyAsync(out, stats,
-                               sizeof(double) * RT_GRP_STATS * ngroups,
-                               hipMemcpyDeviceToHost, ctx->stream));
+    if (final == stats)
+        RT_HIP(ctx, hipMemcpyAsync(out, stats,
+                                   sizeof(double) * RT_GRP_STATS * ngroups,
+                                   hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (final != stats)
+        memcpy(out, final, sizeof(double) * RT_GRP_STATS * ngroups);
     return RT_OK;
 }
 
@@ -270,8 +305,37 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
         return rt_fail(ctx, RT_ERR_ARG, "rt_refocus_shift: NULL");
     const double *Yrow = rt_row(ctx, RT_Y, surf);
     const double *Irow = rt_row(ctx, RT_I, surf);
-    double d[2];
     const unsigned blocks = rt_red_blocks(ctx->n);
+    if (ctx->opt_onepass) {
+        if (ctx->d_w)
+            hipLaunchKernelGGL(rt_refocus_shifted_kernel<true>, dim3(blocks),
+                               dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
+                               Irow, ctx->d_w, ctx->n, ctx->ld,
+                               ctx->d_partials);
+        else
+            hipLaunchKernelGGL(rt_refocus_shifted_kernel<false>, dim3(blocks),
+                               dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
+                               Irow, ctx->d_w, ctx->n, ctx->ld,
+                               ctx->d_partials);
+        if (ctx->d_w)
+            hipLaunchKernelGGL(rt_refocus_finish_kernel<true>, dim3(1),
+                               dim3(64), 0, ctx->stream, ctx->d_partials,
+                               (int)blocks, ctx->h_res);
+        else
+            hipLaunchKernelGGL(rt_refocus_finish_kernel<false>, dim3(1),
+                               dim3(64), 0, ctx->stream, ctx->d_partials,
+                               (int)blocks, ctx->h_res);
+        RT_HIP(ctx, hipGetLastError());
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double *h = ctx->h_res;
+        /* ray 0 vignetted (nothing finite), or the shift by it cost more
+         * than six bits of <u,u> or <y,y>: the two passes below */
+        if (h[0] == h[0] && h[1] > 0. && h[1] * 64. >= h[3] && h[2] >= 0. &&
+            h[2] * 64. >= h[4] && h[3] - h[3] == 0. && h[4] - h[4] == 0.) {
+            *shift = -h[0] / h[1];
+            return RT_OK;
+        }
+    }
     hipLaunchKernelGGL(rt_refocus_sums_kernel, dim3(blocks),
                        dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow, ctx->n,
                        ctx->ld, ctx->d_partials);
@@ -282,12 +346,10 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
                        ctx->d_w, 1. / (double)ctx->n, rt_reduced(ctx, 0),
                        ctx->n, ctx->ld, ctx->d_partials);
     hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
-                       ctx->d_partials, (int)blocks, 2, rt_reduced(ctx, 5));
+                       ctx->d_partials, (int)blocks, 2, ctx->h_res);
     RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipMemcpyAsync(d, rt_reduced(ctx, 5), sizeof d,
-                               hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *shift = -d[0] / d[1];
+    *shift = -ctx->h_res[0] / ctx->h_res[1];
     return RT_OK;
 }
 

@@ -148,9 +148,13 @@ struct rt_ctx {
     double *d_w;  /* ray weights, NULL = uniform 1/n */
     size_t w_cap;
     int64_t w_n;  /* rays the weights were given for (must equal n) */
-    double *d_partials; /* RT_RED_BLOCKS x 8 doubles + 16 reduced values */
+    double *d_partials; /* RT_RED_BLOCKS x 16 doubles + 16 reduced values */
+    double *h_res; /* pinned, 8 doubles: where a consumer's last kernel writes
+                    * its scalars (no D2H copy after it) */
     double *d_group;    /* rt_spot_stats: stats | partials */
     size_t group_cap;   /* doubles */
+    double *h_group;    /* pinned: the stats as rt_group_finish_kernel writes
+                         * them (up to RT_GROUP_PINNED groups) */
     struct rt_opd_ref *d_opd_ref;
 
     /* kernel choices */
@@ -158,6 +162,7 @@ struct rt_ctx {
     int opt_fuse; /* build generated rays inside the first trace */
     int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
     int opt_range; /* quotients / roots without range scaffolding (RT_F_RANGE) */
+    int opt_onepass; /* rms / refocus sums in one pass over the rows */
     int opt_resident; /* bytes of unused dynamic LDS per workgroup of the
                          trace kernels: caps the workgroups resident per CU
                          (160 KB / bytes); -1 = chosen per trace */

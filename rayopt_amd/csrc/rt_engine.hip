@@ -261,6 +261,7 @@ int rt_create(int device, rt_ctx **out)
     }
     c->opt_resident = -1;
     c->opt_range = 1;
+    c->opt_onepass = 1;
     {
         const char *e = getenv("RT_MI355_PLACEMENT");
         c->opt_place = (e && !atoi(e)) ? 0 : 1;
@@ -347,6 +348,10 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_w);
     if (ctx->d_partials)
         (void)hipFree(ctx->d_partials);
+    if (ctx->h_res)
+        (void)hipHostFree(ctx->h_res);
+    if (ctx->h_group)
+        (void)hipHostFree(ctx->h_group);
     if (ctx->d_group)
         (void)hipFree(ctx->d_group);
     if (ctx->d_gen)
@@ -1233,6 +1238,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         ctx->opt_range = value ? 1 : 0;
     } else if (!strcmp(key, "uniform_input")) {
         ctx->opt_uniform = value ? 1 : 0;
+    } else if (!strcmp(key, "consumers_one_pass")) {
+        ctx->opt_onepass = value ? 1 : 0;
     } else if (!strcmp(key, "placement")) {
         /* takes effect with the next allocation of the result arrays */
         ctx->opt_place = value ? 1 : 0;

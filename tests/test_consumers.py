@@ -224,3 +224,86 @@ def test_device_spot_stats_vs_oracle(groups, per):
         tr.engine.spot_stats(len(system) - 1, per + 1, groups)
     with pytest.raises(ra.EngineError):
         tr.engine.spot_stats(3, per, groups)      # row not stored (keep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 257, 1001, 99_999, 1_000_002])
+def test_one_pass_reductions_vs_two_pass_and_numpy(n):
+    """rt_rms / rt_refocus_shift / rt_row_rmax sum in ONE pass over the rows
+    (shifted by ray 0, 16-byte loads: csrc/rt_consumer_kernels.h).  Against
+    the two-pass kernels ("consumers_one_pass" = 0) and against numpy on the
+    rows the device produced, for ray counts around every boundary of the
+    load pattern (odd, one pair, one wavefront, beyond the grid)."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    y, u = ra.bundles.disc_bundle(n, 12., 9., 21,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    rng = np.random.default_rng(n)
+    w = rng.random(n) + .1
+    tr = ra.GeometricTrace(system)
+    L = len(system)
+    for weights in (None, w/w.sum(), w):                # w need not sum to 1
+        tr.rays_given(y, u, None, weights, n//2)
+        tr.propagate(clip=False)
+        Y, I = np.asarray(tr.y[-1]), np.asarray(tr.i[-1])
+        assert np.isfinite(Y).all()
+        got = {}
+        for one in (1, 0):
+            tr.engine.set_option("consumers_one_pass", one)
+            got[one] = (tr.rms(), tr.rms(ref=n//2), tr.rms(i=3),
+                        tr.engine.refocus_shift(L - 1) if n > 2 else 0.,
+                        tr.engine.row_rmax(L - 1))
+        tr.engine.set_option("consumers_one_pass", 1)
+        want = (cn.rms(Y, weights), cn.rms(Y, weights, n//2),
+                cn.rms(np.asarray(tr.y[3]), weights),
+                cn.refocus_shift(Y, I, weights) if n > 2 else 0.,
+                np.sqrt(np.square(Y[:, :2]).sum(1).max()))
+        for k, rtol in enumerate((1e-12, 1e-12, 1e-12, 1e-9, 1e-15)):
+            assert got[1][k] == pytest.approx(want[k], rel=rtol, abs=1e-300), k
+            assert got[0][k] == pytest.approx(want[k], rel=rtol, abs=1e-300), k
+        assert got[1] == (tr.rms(), tr.rms(ref=n//2), tr.rms(i=3),
+                          tr.engine.refocus_shift(L - 1) if n > 2 else 0.,
+                          tr.engine.row_rmax(L - 1))     # run-to-run identical
+
+
+@pytest.mark.gpu
+def test_one_pass_reductions_fall_back_when_the_shift_is_poor():
+    """Ray 0 far outside the bundle: the shifted sums would cancel (|mean -
+    ray 0| >> spot size); the library notices (what the subtraction started
+    from is reported by the kernel) and runs the two passes.  Same tolerance
+    as ever.  Ray 0 vignetted: refocus (which leaves such rays out) still
+    answers; rms is NaN as in the reference."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    n = 50_000
+    y, u = ra.bundles.disc_bundle(n, 2., 9., 5,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    tr = ra.GeometricTrace(system)
+    L = len(system)
+    # a tight bundle and one ray of another field
+    u2 = u.copy()
+    u2[0, 1] += .02
+    u2[0] /= np.sqrt(np.square(u2[0]).sum())
+    tr.rays_given(y, u2, None, None, 1)
+    tr.propagate(clip=False)
+    Y, I = np.asarray(tr.y[-1]), np.asarray(tr.i[-1])
+    d = Y[:, :2] - Y[1:, :2].mean(0)
+    assert np.hypot(*d[0]) > 30*np.sqrt(np.square(d[1:]).sum(1).mean())
+    # the poor shift as numpy sees it: |m|^2 >> variance
+    assert tr.rms() == pytest.approx(cn.rms(Y, None), rel=1e-12)
+    assert tr.engine.refocus_shift(L - 1) == pytest.approx(
+        cn.refocus_shift(Y, I, None), rel=1e-9)
+    # the same rows with a far-away origin: every ray is "far from zero" but
+    # close to ray 0 -- the case the shift is there for
+    tr.rays_given(y, u, None, None, 1)
+    tr.propagate(clip=False)
+    Y = np.asarray(tr.y[-1])
+    assert tr.rms() == pytest.approx(cn.rms(Y, None), rel=1e-12)
+    # ray 0 vignetted
+    y3 = y.copy()
+    y3[0, :2] = 500.
+    tr.rays_given(y3, u, None, None, 1)
+    tr.propagate(clip=True)
+    Y, I = np.asarray(tr.y[-1]), np.asarray(tr.i[-1])
+    assert np.isnan(Y[0, 0]) and np.isfinite(Y[1:]).all()
+    assert np.isnan(tr.rms())
+    assert tr.engine.refocus_shift(L - 1) == pytest.approx(
+        cn.refocus_shift(Y, I, None), rel=1e-9)
