@@ -1597,18 +1597,35 @@ def run_consumers(ra, g, system, n, nf, cpu):
             fn()
         return (time.perf_counter() - t0)/reps*1e3
 
-    def rec(name, ms, nbytes, replaces, note=""):
+    def device_ms(fn, reps=10):
+        # the call's kernels alone, between HIP events on the engine's stream
+        # (option "consumer_events"; the wall time above includes the launch
+        # and the host's wait for the scalar)
+        eng.set_option("consumer_events", 1)
+        try:
+            ms = []
+            for _ in range(reps):
+                fn()
+                ms.append(eng.kernel_ms())
+        finally:
+            eng.set_option("consumer_events", 0)
+        return float(np.mean(ms))
+
+    def rec(name, ms, nbytes, replaces, note="", fn=None):
         r = {"call": name, "ms": ms, "bytes_read": nbytes,
              "GBps": nbytes/(ms*1e-3)/1e9,
              "frac": nbytes/(ms*1e-3)/1e9/HBM_PEAK_GBS,
              "replaces": replaces}
+        if fn is not None:
+            r["kernel_ms"] = device_ms(fn)
+            r["kernel_frac"] = nbytes/(r["kernel_ms"]*1e-3)/1e9/HBM_PEAK_GBS
         if note:
             r["note"] = note
         return r
     out = []
     def both(name, fn, nbytes, replaces):
         # the shipped one-pass reduction, and the two passes it replaced
-        r = rec(name, timed(fn), nbytes, replaces)
+        r = rec(name, timed(fn), nbytes, replaces, fn=fn)
         eng.set_option("consumers_one_pass", 0)
         try:
             r["two_pass_ms"] = timed(fn)
@@ -1624,10 +1641,12 @@ def run_consumers(ra, g, system, n, nf, cpu):
                     "re-propagate of :98-99 is one more trace)"))
     out.append(rec("spot_stats, %d field bundles (two passes over y0, y1)"
                    % nf, timed(lambda: eng.spot_stats(L - 1, n//nf, nf)),
-                   32*n, "per-field rms of rayopt/analysis.py spot diagrams"))
+                   32*n, "per-field rms of rayopt/analysis.py spot diagrams",
+                   fn=lambda: eng.spot_stats(L - 1, n//nf, nf)))
     out.append(rec("row_rmax (one pass over y0, y1)",
                    timed(lambda: eng.row_rmax(L - 1)), 16*n,
-                   "rayopt/geometric_trace.py:185-193 resize()"))
+                   "rayopt/geometric_trace.py:185-193 resize()",
+                   fn=lambda: eng.row_rmax(L - 1)))
     try:
         nrows = L - 1
         ms = timed(lambda: g.opd_rays(radius=100.), reps=4)

@@ -372,7 +372,9 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * roots run without the compiler's range scaffolding where the operands are
  * checked to be inside [2^-100, 2^100] -- the same bits from a third fewer
  * instructions, RT_F_RANGE; 0 = the compiler's sequences everywhere),
- * "consumers_one_pass" (1 = default, see rt_rms; 0 = always two passes).
+ * "consumers_one_pass" (1 = default, see rt_rms; 0 = always two passes),
+ * "consumer_events" (measurement: 1 = the reductions bracket their kernels
+ * with the events rt_kernel_ms reads; default 0).
  * Measurement-only variants and the memory-system probes live in a separate
  * laboratory build (include/rt_mi355_probes.h), not in this library.
  */

@@ -143,6 +143,21 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
     return rt_gen_flush(ctx);
 }
 
+/* measurement only (option "consumer_events"): the kernels of a consumer
+ * between the events rt_kernel_ms reads */
+#define RT_CONSUMER_BEGIN(ctx)                                              \
+    do {                                                                    \
+        if ((ctx)->opt_cevents)                                             \
+            RT_HIP(ctx, hipEventRecord((ctx)->k0, (ctx)->stream));          \
+    } while (0)
+#define RT_CONSUMER_END(ctx)                                                \
+    do {                                                                    \
+        if ((ctx)->opt_cevents) {                                           \
+            RT_HIP(ctx, hipEventRecord((ctx)->k1, (ctx)->stream));          \
+            (ctx)->traced = 1;                                              \
+        }                                                                   \
+    } while (0)
+
 /* workgroups of a reduction over n rays: no more than there is work for */
 static inline unsigned rt_red_blocks(int64_t n)
 {
@@ -166,26 +181,31 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
     const double *Yrow = rt_row(ctx, RT_Y, surf);
     const unsigned blocks = rt_red_blocks(ctx->n);
     if (ctx->opt_onepass) {
-        /* one pass over the row, shifted by a ray of the bundle; its last
-         * kernel leaves the scalars in pinned memory */
-        if (ctx->d_w)
+        /* one pass over the row, shifted by a ray of the bundle; its second
+         * level leaves the scalars in pinned memory.  (Finishing in the last
+         * workgroup to arrive -- one launch, ticket + device-scope fences --
+         * was built and measured: the 1024 L2 write-backs / invalidates of
+         * the fences cost 17 us, the launch they save 5:
+         * profiles/r04_probes/session30.) */
+        RT_CONSUMER_BEGIN(ctx);
+        if (ctx->d_w) {
             hipLaunchKernelGGL(rt_rms_shifted_kernel<true>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
                                ctx->d_w, ref, ctx->n, ctx->ld,
                                ctx->d_partials);
-        else
+            hipLaunchKernelGGL(rt_rms_finish_kernel<true>, dim3(1), dim3(64),
+                               0, ctx->stream, ctx->d_partials, (int)blocks,
+                               ref < 0 ? 1 : 0, (double)ctx->n, ctx->h_res);
+        } else {
             hipLaunchKernelGGL(rt_rms_shifted_kernel<false>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
                                ctx->d_w, ref, ctx->n, ctx->ld,
                                ctx->d_partials);
-        if (ctx->d_w)
-            hipLaunchKernelGGL(rt_rms_finish_kernel<true>, dim3(1), dim3(64),
-                               0, ctx->stream, ctx->d_partials, (int)blocks,
-                               ref < 0 ? 1 : 0, (double)ctx->n, ctx->h_res);
-        else
             hipLaunchKernelGGL(rt_rms_finish_kernel<false>, dim3(1), dim3(64),
                                0, ctx->stream, ctx->d_partials, (int)blocks,
                                ref < 0 ? 1 : 0, (double)ctx->n, ctx->h_res);
+        }
+        RT_CONSUMER_END(ctx);
         RT_HIP(ctx, hipGetLastError());
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const double r = ctx->h_res[0], a = ctx->h_res[1];
@@ -198,6 +218,7 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
     }
     /* two passes (mean, then spread about it) and their second levels,
      * queued back to back; the host waits once */
+    RT_CONSUMER_BEGIN(ctx);
     if (ref < 0) {
         hipLaunchKernelGGL(rt_sum_xy_kernel, dim3(blocks),
                            dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, ctx->n,
@@ -212,6 +233,7 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
                        ctx->d_partials);
     hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
                        ctx->d_partials, (int)blocks, 1, ctx->h_res);
+    RT_CONSUMER_END(ctx);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *rms = sqrt(ctx->h_res[0]);
@@ -226,11 +248,13 @@ int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax)
     if (!rmax)
         return rt_fail(ctx, RT_ERR_ARG, "rt_row_rmax: NULL");
     const unsigned blocks = rt_red_blocks(ctx->n);
+    RT_CONSUMER_BEGIN(ctx);
     hipLaunchKernelGGL(rt_r2max_kernel, dim3(blocks), dim3(RT_RED_THREADS), 0,
                        ctx->stream, rt_row(ctx, RT_Y, surf), ctx->n, ctx->ld,
                        ctx->d_partials);
     hipLaunchKernelGGL(rt_r2max_finish_kernel, dim3(1), dim3(64), 0,
                        ctx->stream, ctx->d_partials, (int)blocks, ctx->h_res);
+    RT_CONSUMER_END(ctx);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *rmax = ctx->h_res[1] != 0. ? __builtin_nan("") : sqrt(ctx->h_res[0]);
@@ -277,6 +301,7 @@ int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
     const double *Yrow = rt_row(ctx, RT_Y, surf);
     const dim3 grid((unsigned)pb, (unsigned)ngroups), block(RT_RED_THREADS);
     const dim3 fgrid((unsigned)ngroups), fblock(64); /* a wavefront each */
+    RT_CONSUMER_BEGIN(ctx);
     hipLaunchKernelGGL(rt_group_sums_kernel, grid, block, 0, ctx->stream, Yrow,
                        ctx->d_w, group_rays, ctx->ld, partials);
     hipLaunchKernelGGL(rt_group_centroid_kernel, fgrid, fblock, 0, ctx->stream,
@@ -285,6 +310,7 @@ int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
                        Yrow, ctx->d_w, group_rays, ctx->ld, stats, partials);
     hipLaunchKernelGGL(rt_group_finish_kernel, fgrid, fblock, 0, ctx->stream,
                        partials, (int)pb, ngroups, stats, final);
+    RT_CONSUMER_END(ctx);
     RT_HIP(ctx, hipGetLastError());
     if (final == stats)
         RT_HIP(ctx, hipMemcpyAsync(out, stats,
@@ -307,24 +333,25 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
     const double *Irow = rt_row(ctx, RT_I, surf);
     const unsigned blocks = rt_red_blocks(ctx->n);
     if (ctx->opt_onepass) {
-        if (ctx->d_w)
+        RT_CONSUMER_BEGIN(ctx);
+        if (ctx->d_w) {
             hipLaunchKernelGGL(rt_refocus_shifted_kernel<true>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
                                Irow, ctx->d_w, ctx->n, ctx->ld,
                                ctx->d_partials);
-        else
+            hipLaunchKernelGGL(rt_refocus_finish_kernel<true>, dim3(1),
+                               dim3(64), 0, ctx->stream, ctx->d_partials,
+                               (int)blocks, ctx->h_res);
+        } else {
             hipLaunchKernelGGL(rt_refocus_shifted_kernel<false>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
                                Irow, ctx->d_w, ctx->n, ctx->ld,
                                ctx->d_partials);
-        if (ctx->d_w)
-            hipLaunchKernelGGL(rt_refocus_finish_kernel<true>, dim3(1),
-                               dim3(64), 0, ctx->stream, ctx->d_partials,
-                               (int)blocks, ctx->h_res);
-        else
             hipLaunchKernelGGL(rt_refocus_finish_kernel<false>, dim3(1),
                                dim3(64), 0, ctx->stream, ctx->d_partials,
                                (int)blocks, ctx->h_res);
+        }
+        RT_CONSUMER_END(ctx);
         RT_HIP(ctx, hipGetLastError());
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const double *h = ctx->h_res;
@@ -336,6 +363,7 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
             return RT_OK;
         }
     }
+    RT_CONSUMER_BEGIN(ctx);
     hipLaunchKernelGGL(rt_refocus_sums_kernel, dim3(blocks),
                        dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow, ctx->n,
                        ctx->ld, ctx->d_partials);
@@ -347,6 +375,7 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
                        ctx->n, ctx->ld, ctx->d_partials);
     hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
                        ctx->d_partials, (int)blocks, 2, ctx->h_res);
+    RT_CONSUMER_END(ctx);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *shift = -ctx->h_res[0] / ctx->h_res[1];

@@ -163,6 +163,7 @@ struct rt_ctx {
     int opt_fast; /* aspheric elements on the fast arithmetic (RT_F_FAST) */
     int opt_range; /* quotients / roots without range scaffolding (RT_F_RANGE) */
     int opt_onepass; /* rms / refocus sums in one pass over the rows */
+    int opt_cevents; /* the consumers bracket their kernels with k0 / k1 */
     int opt_resident; /* bytes of unused dynamic LDS per workgroup of the
                          trace kernels: caps the workgroups resident per CU
                          (160 KB / bytes); -1 = chosen per trace */

@@ -1240,6 +1240,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         ctx->opt_uniform = value ? 1 : 0;
     } else if (!strcmp(key, "consumers_one_pass")) {
         ctx->opt_onepass = value ? 1 : 0;
+    } else if (!strcmp(key, "consumer_events")) {
+        ctx->opt_cevents = value ? 1 : 0;
     } else if (!strcmp(key, "placement")) {
         /* takes effect with the next allocation of the result arrays */
         ctx->opt_place = value ? 1 : 0;

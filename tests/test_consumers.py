@@ -307,3 +307,30 @@ def test_one_pass_reductions_fall_back_when_the_shift_is_poor():
     assert np.isnan(tr.rms())
     assert tr.engine.refocus_shift(L - 1) == pytest.approx(
         cn.refocus_shift(Y, I, None), rel=1e-9)
+
+
+@pytest.mark.gpu
+def test_reductions_repeat_bit_for_bit():
+    """500 calls of each reduction on 3*10^6 rays, two contexts on the same
+    device interleaved (their partials and pinned scalars must not be
+    shared): every answer the same bits."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    n = 3_000_000
+    y, u = ra.bundles.disc_bundle(n, 12., 5., 1,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    a, b = ra.GeometricTrace(system), ra.GeometricTrace(system)
+    L = len(system)
+    for tr, m in ((a, n), (b, n//3)):
+        tr.rays_given(y[:m], u[:m])
+        tr.propagate(clip=False)
+    first = {}
+    for rep in range(500):
+        for tr in (a, b):
+            got = (tr.rms(), tr.engine.refocus_shift(L - 1),
+                   tr.engine.row_rmax(L - 1), tr.rms(ref=5))
+            assert np.isfinite(got).all()
+            assert first.setdefault(id(tr), got) == got, rep
+    Y = np.asarray(a.y[-1])
+    assert first[id(a)][0] == pytest.approx(cn.rms(Y, None), rel=1e-12)
+    assert first[id(a)][2] == pytest.approx(
+        np.sqrt(np.square(Y[:, :2]).sum(1).max()), rel=1e-15)
