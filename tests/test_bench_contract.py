@@ -101,6 +101,9 @@ def test_single_process_line():
             "aim_pupil"} <= set(calls), calls.keys()
     for name in ("rms", "refocus_shift", "spot_stats", "row_rmax"):
         assert calls[name]["ms"] > 0 and calls[name]["bytes_read"] > 0
+        # the kernels alone (HIP events) fit inside the call's wall time
+        assert 0 < calls[name]["kernel_ms"] < calls[name]["ms"]
+    assert calls["rms"]["two_pass_ms"] > 0
     assert "error" not in calls["opd_rays"], calls["opd_rays"]
     assert "error" not in calls["aim_pupil"], calls["aim_pupil"]
     if kind == "reference":
