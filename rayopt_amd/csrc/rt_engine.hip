@@ -611,27 +611,52 @@ static int rt_copy_threads(void)
     return n;
 }
 
-static void rt_memcpy_mt(void *dst, const void *src, size_t len)
+/* a staging copy on up to 16 threads: `start` leaves the first part to the
+ * caller's `finish`, so that the caller can do something else in between
+ * (rt_d2h: issue the next DMA) */
+struct rt_copy_team {
+    std::thread workers[16];
+    int started;
+    void *dst;
+    const void *src;
+    size_t first;
+};
+
+static void rt_copy_start(rt_copy_team *team, void *dst, const void *src,
+                          size_t len)
 {
     const int nt = rt_copy_threads();
-    if (nt == 1 || len < ((size_t)4 << 20)) {
-        memcpy(dst, src, len);
+    team->started = 0;
+    team->dst = dst;
+    team->src = src;
+    team->first = len;
+    if (nt == 1 || len < ((size_t)4 << 20))
         return;
-    }
     const size_t part = (len / nt + 4095) & ~(size_t)4095;
-    std::thread workers[16];
-    int started = 0;
+    team->first = part < len ? part : len;
     for (int t = 1; t < nt; ++t) {
         const size_t off = (size_t)t * part;
         if (off >= len)
             break;
         const size_t n = len - off < part ? len - off : part;
-        workers[started++] = std::thread(
+        team->workers[team->started++] = std::thread(
             [=] { memcpy((char *)dst + off, (const char *)src + off, n); });
     }
-    memcpy(dst, src, part < len ? part : len);
-    for (int t = 0; t < started; ++t)
-        workers[t].join();
+}
+
+static void rt_copy_finish(rt_copy_team *team)
+{
+    memcpy(team->dst, team->src, team->first);
+    for (int t = 0; t < team->started; ++t)
+        team->workers[t].join();
+    team->started = 0;
+}
+
+static void rt_memcpy_mt(void *dst, const void *src, size_t len)
+{
+    rt_copy_team team;
+    rt_copy_start(&team, dst, src, len);
+    rt_copy_finish(&team);
 }
 
 /*
@@ -683,27 +708,46 @@ int rt_d2h(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
             RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
                                                 hipEventDisableTiming));
         }
+    /* chunk i-1 leaves its staging buffer on the copy threads while the DMA
+     * of chunk i fills the other one.  The threads are started BEFORE the
+     * DMA is issued: hipMemcpyAsync device -> pinned host returns only when
+     * the copy is done on this runtime (measured: issued first, the two
+     * halves of the pipeline ran one after the other, 8.5 ms per 240 MB
+     * whatever the number of threads) */
     const size_t nchunk = (bytes + RT_PIN_CHUNK - 1) / RT_PIN_CHUNK;
+    rt_copy_team team;
     for (size_t i = 0; i <= nchunk; ++i) {
-        if (i < nchunk) { /* start the DMA of chunk i */
+        if (i > 0) { /* chunk i-1 has landed: start draining it */
+            const size_t off = (i - 1) * RT_PIN_CHUNK;
+            const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
+                                                          : RT_PIN_CHUNK;
+            hipError_t e = hipEventSynchronize(ctx->pin_done[(i - 1) & 1]);
+            if (e != hipSuccess)
+                return rt_fail(ctx, RT_ERR_HIP, "rt_d2h: %s",
+                               hipGetErrorString(e));
+            rt_copy_start(&team, (char *)dst + off, ctx->h_pin[(i - 1) & 1],
+                          len);
+        }
+        hipError_t e = hipSuccess;
+        if (i < nchunk) { /* the DMA of chunk i into the other buffer */
             const size_t off = i * RT_PIN_CHUNK;
             const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
                                                           : RT_PIN_CHUNK;
             if (ctx->pin_busy[i & 1]) /* an upload may still read it */
-                RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[i & 1]));
-            RT_HIP(ctx, hipMemcpyAsync(ctx->h_pin[i & 1],
-                                       (const char *)src + off, len,
-                                       hipMemcpyDeviceToHost, ctx->stream));
-            RT_HIP(ctx, hipEventRecord(ctx->pin_done[i & 1], ctx->stream));
+                e = hipEventSynchronize(ctx->pin_done[i & 1]);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(ctx->h_pin[i & 1], (const char *)src + off,
+                                   len, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipEventRecord(ctx->pin_done[i & 1], ctx->stream);
         }
-        if (i > 0) { /* drain chunk i-1 while chunk i is in flight */
-            const size_t off = (i - 1) * RT_PIN_CHUNK;
-            const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
-                                                          : RT_PIN_CHUNK;
-            RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[(i - 1) & 1]));
-            rt_memcpy_mt((char *)dst + off, ctx->h_pin[(i - 1) & 1], len);
+        if (i > 0) { /* the threads are joined whatever the DMA said */
+            rt_copy_finish(&team);
             ctx->pin_busy[(i - 1) & 1] = 0;
         }
+        if (e != hipSuccess)
+            return rt_fail(ctx, RT_ERR_HIP, "rt_d2h: %s",
+                           hipGetErrorString(e));
     }
     return RT_OK;
 }

@@ -867,6 +867,66 @@ def block_ms_fn(eng, fn, launches):
     return eng.event_elapsed(0, 1)/launches
 
 
+def cmd_hostpath(a):
+    """Where the host-side time of the calls that return big arrays goes:
+    rows down to fresh / reused numpy arrays, one ray's column, the pieces
+    of opd_rays."""
+    ra, P, _build, Engine = _imports()
+    from rayopt_amd._lib import RT_Y, RT_U, RT_T
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    n = int(a.rays)
+    y, u = ra.bundles.disc_bundle(n, 17., 5., 1, P.DOUBLE_GAUSS_PUPIL_Z)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    g.propagate(clip=False)
+    eng, L = g.engine, len(system)
+    eng.sync()
+
+    def wall(fn, reps=5):
+        fn()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            t.append((time.perf_counter() - t0)*1e3)
+        return float(np.median(t)), float(min(t))
+    mb = 24*n/1e6
+    keep = np.empty((1, 3, n))
+    rec = {"rays": n, "row_MB": mb}
+    rec["download_row_fresh_ms"] = wall(lambda: eng.download(RT_Y, L - 1, L))
+    rec["download_row_reused_ms"] = wall(
+        lambda: eng.download(RT_Y, L - 1, L, out=keep))
+    rec["np_empty_and_fill_ms"] = wall(lambda: np.empty((1, 3, n)).fill(0.))
+    rec["np_copy_of_resident_ms"] = wall(lambda: keep.copy())
+    rec["download_ray_ms"] = wall(lambda: eng.download_ray(RT_T, 5), 20)
+    rec["opd_rays_ms"] = wall(lambda: g.opd_rays(radius=100.))
+    rec["opd_kernel_ms"] = eng.kernel_ms()
+    rec["upload_rays_ms"] = wall(lambda: g.rays_given(y, u))
+    # what a pool of pinned host buffers would give: allocation cost once,
+    # then direct DMA into memory that is neither faulted nor staged
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    ptr = ctypes.c_void_p()
+    nbytes = 24*n
+    t0 = time.perf_counter()
+    assert hip.hipHostMalloc(ctypes.byref(ptr), ctypes.c_size_t(nbytes), 0) == 0
+    rec["hipHostMalloc_ms"] = (time.perf_counter() - t0)*1e3
+    src = eng.device_ptr(RT_Y, L - 1)
+
+    def direct():
+        assert hip.hipMemcpy(ptr, ctypes.c_void_p(src),
+                             ctypes.c_size_t(nbytes), 2) == 0
+    rec["direct_D2H_into_pinned_ms"] = wall(direct)
+    view = np.ctypeslib.as_array(
+        (ctypes.c_double*(3*n)).from_address(ptr.value))
+    rec["numpy_sum_over_pinned_ms"] = wall(lambda: view.sum())
+    rec["numpy_sum_over_pageable_ms"] = wall(lambda: keep.sum())
+    t0 = time.perf_counter()
+    assert hip.hipHostFree(ptr) == 0
+    rec["hipHostFree_ms"] = (time.perf_counter() - t0)*1e3
+    out(**rec)
+
+
 def cmd_kinds_summary(a):
     """Counters per kind from a `rocprofv3 --pmc` pass of `kinds`, joined with
     the launch times and clocks of a plain run of the same command:
@@ -1036,6 +1096,9 @@ def main():
     p.set_defaults(fn=cmd_kinds_summary)
     p = sub.add_parser("c4check")
     p.set_defaults(fn=cmd_c4check)
+    p = sub.add_parser("hostpath")
+    p.add_argument("--rays", type=float, default=1e7)
+    p.set_defaults(fn=cmd_hostpath)
     p = sub.add_parser("pmc-summary")
     p.add_argument("dir")
     p.set_defaults(fn=cmd_pmc_summary)
