@@ -277,9 +277,11 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     /* pick `need` pieces round-robin over the classes (an even mix, as far
      * as the counts allow), in that order along the address range */
     int *pick = (int *)calloc(need, sizeof(int));
+    hipMemGenericAllocationHandle_t *kept =
+        (hipMemGenericAllocationHandle_t *)calloc(need, sizeof *kept);
     int next[RT_PLACE_CLASSES] = {0}, taken = 0, q = 0, idle = 0;
     int used[RT_PLACE_CLASSES] = {0};
-    while (taken < need && idle < nclass) {
+    while (pick && taken < need && idle < nclass) {
         int k = next[q];
         while (k < made && cls[k] != q)
             ++k;
@@ -298,9 +300,9 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         (void)hipMemUnmap((char *)scratch + (size_t)k * piece, piece);
     (void)hipMemAddressFree(scratch, (size_t)cap * piece);
     void *base = NULL;
-    e = hipMemAddressReserve(&base, (size_t)need * piece, align, NULL, 0);
-    hipMemGenericAllocationHandle_t *kept =
-        (hipMemGenericAllocationHandle_t *)calloc(need, sizeof *kept);
+    e = pick && kept && taken == need ? hipSuccess : hipErrorOutOfMemory;
+    if (e == hipSuccess)
+        e = hipMemAddressReserve(&base, (size_t)need * piece, align, NULL, 0);
     int nm = 0;
     for (; e == hipSuccess && nm < need; ++nm) {
         e = hipMemMap((char *)base + (size_t)nm * piece, piece, 0,
@@ -320,9 +322,11 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     free(pick);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        for (int k = 0; k < nm; ++k) {
-            (void)hipMemUnmap((char *)base + (size_t)k * piece, piece);
-            (void)hipMemRelease(kept[k]);
+        for (int k = 0; k < nm && kept; ++k) {
+            if (kept[k]) { /* mapped */
+                (void)hipMemUnmap((char *)base + (size_t)k * piece, piece);
+                (void)hipMemRelease(kept[k]);
+            }
         }
         if (base)
             (void)hipMemAddressFree(base, (size_t)need * piece);
@@ -358,8 +362,8 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
  * one box traced at the slow level in a mix that should have been fast):
  * what decides between four and two workgroups per CU is this measurement.
  * Levels of the bare pattern: 7.0 / 6.3 / 5.65 TB/s (mixed / partly mixed /
- * one class); 18 placed contexts on three boxes: 6.73-7.04.  Rows are overwritten:
- * called from rt_reserve, before anything lives in them.
+ * one class); 18 placed contexts on three boxes: 6.73-7.04.  Rows are
+ * overwritten: called from rt_reserve, before anything lives in them.
  */
 /* below this the arrays behave like ONE class (5.65 TB/s; four workgroups per
  * CU then lose to two); the middle level (6.3) still takes four better */
