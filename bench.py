@@ -108,6 +108,17 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+_T0 = time.perf_counter()
+LAPS = []       # (what just finished, seconds since the interpreter got here)
+
+
+def lap(label):
+    """Where the wall time of this command goes (stderr + `wall_s`)."""
+    t = time.perf_counter() - _T0
+    LAPS.append((label, round(t, 2)))
+    log("[bench %6.2f s] %s" % (t, label))
+
+
 def workload_rays(n, rank):
     from rayopt_amd import prescriptions as P
     from rayopt_amd.bundles import multi_field_bundle
@@ -796,8 +807,10 @@ def main():
         counts = np.full(world, args.rays, dtype=np.int64)
     n = int(counts[rank])
 
+    lap("imports, system")
     t0 = time.perf_counter()
     y, u = workload_rays(n, rank)
+    lap("workload rays on the host")
     cpu_all = None
     procs = (min(64, os.cpu_count()) if args.cpu_procs == -1 else
              os.cpu_count() if args.cpu_procs < 0 else args.cpu_procs)
@@ -814,6 +827,8 @@ def main():
                 cpu_all = cpu_port_on_processes(system, y, u, clip, procs)
         except Exception as err:      # a reported extra, never fatal
             cpu_all = {"error": repr(err)[:200]}
+    lap("reference on %d forked processes" % procs if cpu_all else
+        "(no many-process CPU leg)")
     if world == 1:
         check_device()
     g = ra.GeometricTrace(system, device=local_rank)
@@ -824,6 +839,7 @@ def main():
     g.rays_given(y, u)          # rays resident in HBM from here on
     log("[rank %d] %d rays generated + uploaded in %.2f s" % (
         rank, n, time.perf_counter() - t0))
+    lap("context, arrays placed, rays uploaded")
 
     # RCCL communicator for the gather of the final intercepts (only where
     # there is an exchange); no fallback: without it the job fails
@@ -864,6 +880,7 @@ def main():
     if tele is not None:
         tele.mark("settle:begin")
     settle(g, args.settle, clip)    # setup, not part of W or K
+    lap("settle")
     if tele is not None:
         tele.mark("settle:end")
 
@@ -930,6 +947,7 @@ def main():
         else None)
     if tele is not None:
         tele.mark("loop:end")
+    lap("image-row / engine legs, warm-up and the timed loop")
     # where the result arrays live: pieces of device memory in a measured mix
     # of memory classes (rt_placement); store-bound traces then run four
     # workgroups per CU from the first launch on, two otherwise
@@ -1000,6 +1018,7 @@ def main():
     generated = None
     if not dist_mode and plain and not args.no_api_leg:
         generated = run_generated(ra, system, local_rank, n, clip, args)
+        lap("generated batch")
 
     configs4 = None
     if dist_mode and world > 1 and not args.no_configs4 and \
@@ -1041,6 +1060,7 @@ def main():
         try:
             t0 = time.perf_counter()
             traffic, traffic_detail = traffic_live(n, clip)
+            lap("live traffic (two rocprofv3 --pmc child runs)")
             traffic_source = (
                 "measured in this run: rocprofv3 --kernel-trace --pmc "
                 "FETCH_SIZE / WRITE_SIZE (separate passes, %d + %d launches "
@@ -1251,6 +1271,7 @@ def main():
                 run_configs(ra, local_rank, args)
         except Exception as err:      # reported extras, never fatal
             out["configs"] = {"error": repr(err)[:300]}
+        lap("configs C1 C2 C3' C4 C4x C5 (with their parity subsamples)")
     if world == 1 and not dist_mode and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_one_core(table, system, y, u, clip, S, g, L,
                                            args.cpu_sample, g.l)
@@ -1260,6 +1281,7 @@ def main():
             out["cpu_baseline_c"] = cpu_c_oracle(table, y, u, clip, S, g, L)
         except Exception as err:      # a reported extra, never fatal
             out["cpu_baseline_c"] = {"error": repr(err)[:200]}
+        lap("cpu_baseline: reference on one core, C port")
     if world == 1 and not dist_mode and plain and not args.no_configs and \
             not os.environ.get("RT_BENCH_CHILD") and \
             not _profiled_from_outside(os.environ):
@@ -1269,6 +1291,12 @@ def main():
                 out.get("cpu_baseline"))
         except Exception as err:      # reported extras, never fatal
             out["consumers"] = {"error": repr(err)[:300]}
+        lap("consumers")
+    if rank == 0:
+        out["wall_s"] = {"since_start": LAPS,
+                         "note": "seconds since this interpreter reached "
+                                 "bench.py, after each phase (stderr carries "
+                                 "the same lines)"}
     emit(json.dumps(out))
     if dist_mode:
         group.barrier()

@@ -104,6 +104,9 @@ def test_single_process_line():
         # the kernels alone (HIP events) fit inside the call's wall time
         assert 0 < calls[name]["kernel_ms"] < calls[name]["ms"]
     assert calls["rms"]["two_pass_ms"] > 0
+    # where the command's wall time went
+    laps = d["wall_s"]["since_start"]
+    assert laps and all(b[1] >= a[1] for a, b in zip(laps, laps[1:]))
     assert "error" not in calls["opd_rays"], calls["opd_rays"]
     assert "error" not in calls["aim_pupil"], calls["aim_pupil"]
     if kind == "reference":
