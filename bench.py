@@ -1586,6 +1586,52 @@ def run_configs(ra, device, args):
         out[-1]["finite_fraction_at_image_sampled"] = float(
             np.isfinite(ulast).mean())
         del g
+        # the same rays as TEN batches of a tenth each, ten contexts traced
+        # in turn: above ~1.1*10^7 rays the 84 concurrent row streams of one
+        # batch cover more than 8 GiB of addresses and the trace slows
+        # (DESIGN.md section 9); batches below that do not, however many
+        try:
+            parts = 10
+            mk = m//parts//64*64
+            gs = []
+            for i in range(parts):
+                gk = ra.GeometricTrace(s5, device=device)
+                gk.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS],
+                               dc.disc_points(mk, 92 + i),
+                               P.DOUBLE_GAUSS_PUPIL_Z, BUNDLE_RADIUS)
+                gk.propagate(clip=True)
+                gs.append(gk)
+
+            def turn():
+                for gk in gs:
+                    gk.engine.trace(1, 0, True)
+                for gk in gs:
+                    gk.engine.sync()
+            t_end = time.time() + .5
+            while time.time() < t_end:
+                turn()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                turn()
+            ms = (time.perf_counter() - t0)/20*1e3
+            tables = np.stack([pack_system(
+                s5, s5.wavelengths[0],
+                s5.refractive_index(s5.wavelengths[0], 0))[0]])
+            alg = parts*algorithmic_bytes(tables, mk*nf, True, True)[0]
+            out[-1]["as_ten_batches_in_turn"] = {
+                "rays": parts*mk*nf, "batches": parts,
+                "ms_per_turn_wall": ms,
+                "value": parts*mk*nf*(len(s5) - 1)/(ms*1e-3),
+                "algorithmic_bytes_per_turn": alg,
+                "frac": alg/(ms*1e-3)/1e9/HBM_PEAK_GBS,
+                "note": "wall clock around 20 turns of ten propagate() "
+                        "launches (one context each) and their syncs"}
+            log("[configs] C5 as ten batches of %d rays in turn: %.4f ms, "
+                "frac %.3f" % (mk*nf, ms,
+                               out[-1]["as_ten_batches_in_turn"]["frac"]))
+            del gs
+        except Exception as err:      # a reported extra, never fatal
+            out[-1]["as_ten_batches_in_turn"] = {"error": repr(err)[:200]}
     # what bounds each config: the store streams (HBM) or FP64 issue
     t = tele.stop() if tele is not None else None
     for k, rec in enumerate(out):

@@ -166,10 +166,11 @@ int rt_lab_set_option(rt_ctx *ctx, const char *key, int value)
     } else if (!strcmp(key, "tile_rays")) {
         /* tile-major layout (rt_lay.h); takes effect with the next
          * rt_reserve / rt_set_rays */
-        if (value && (value < 64 || value > 65536 || (value & (value - 1))))
+        if (value && (value < 64 || value > (1 << 24) ||
+                      (value & (value - 1))))
             return rt_fail(ctx, RT_ERR_ARG,
                            "tile_rays must be 0 or a power of two in "
-                           "[64, 65536]");
+                           "[64, 2^24]");
         if (value != l.tile) {
             RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             l.tile = value;

@@ -867,6 +867,86 @@ def block_ms_fn(eng, fn, launches):
     return eng.event_elapsed(0, 1)/launches
 
 
+def cmd_superblock(a):
+    """The knee above 1.1*10^7 rays: contexts below it traced in turn stay
+    fast (`alternate`), a big batch traced in pieces does not (`spacing`) --
+    so it is the address span the 84 concurrent row streams cover.  The
+    laboratory's tile-major layout with tiles of 2^21..2^23 rays keeps that
+    span per tile below 8 GiB whatever the batch: SoA against it, same
+    laboratory kernel, same contexts."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    lib = lab_lib()
+    for n in a.sizes:
+        y, u = workload_rays(n, 0)
+        eng = Engine(0, lib_path=lib)
+        g = ra.GeometricTrace(system, engine=eng)
+        rec = {"rays": n, "kernel": "laboratory (48 B per ray read)"
+               if a.lab else "the shipped rt_trace_kernel (tile notes, "
+               "non-temporal stores) of the laboratory build"}
+        for tile in [0] + a.tiles:
+            eng.set_option("tile_rays", tile)
+            g.rays_given(y, u)
+            g.propagate(clip=True)
+            eng.set_option("lds_pad" if a.lab else "resident_lds", a.lds)
+            steady(eng, .4)
+            ms = steady(eng, .6)
+            slots = -(-n//tile)*tile if tile else -(-n//64)*64
+            eng.set_option("lds_pad" if a.lab else "resident_lds",
+                           0 if a.lab else -1)
+            rec["tile_%d" % tile] = {
+                "ms": ms, "slots_traced": slots,
+                "per_1e7_slots": ms*1e7/slots,
+                "span_GiB_of_concurrent_streams":
+                    (13*10*tile*8 if tile else 13*10*n*8)/2**30,
+                "placement": eng.placement()["per_class"]}
+        out(**rec)
+        del g
+        eng.close()
+
+
+def cmd_alternate(a):
+    """Is the knee above 1.1*10^7 rays the reach of the address translation
+    ACROSS launches?  K contexts of --rays rays each (every one below the
+    knee) traced in turn A B C A B C ...: if a trace finds the translations
+    of its arrays evicted by the traces in between, each runs like a slice
+    of one big batch."""
+    ra, P, _build, Engine = _imports()
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import digest_cases as dc
+    from bench import FIELD_FRACTIONS, BUNDLE_RADIUS
+    s3 = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    nf = len(FIELD_FRACTIONS)
+    m = int(a.rays)//nf//64*64
+    gs = []
+    for k in range(a.contexts):
+        g = ra.GeometricTrace(s3, engine=Engine(0))
+        g.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS],
+                      dc.disc_points(m, 91), P.DOUBLE_GAUSS_PUPIL_Z,
+                      BUNDLE_RADIUS)
+        g.propagate(clip=True)
+        gs.append(g)
+    steady(gs[0].engine, 1.)
+    alone = [steady(g.engine, .5) for g in gs]
+    for group in range(1, a.contexts + 1):
+        use = gs[:group]
+        for _ in range(20):
+            for g in use:
+                g.engine.trace(1, 0, True)
+        ms = [[] for _ in use]
+        for _ in range(40):
+            for i, g in enumerate(use):
+                g.engine.trace(1, 0, True)
+                g.engine.sync()
+                ms[i].append(g.engine.kernel_ms())
+        out(rays_per_context=m*nf, contexts_in_turn=group,
+            written_GiB_in_turn=group*m*nf*728/2**30,
+            alone_ms=alone[:group],
+            in_turn_ms=[float(np.median(x)) for x in ms],
+            placement=[g.engine.placement()["per_class"] for g in use])
+
+
 def cmd_hostpath(a):
     """Where the host-side time of the calls that return big arrays goes:
     rows down to fresh / reused numpy arrays, one ray's column, the pieces
@@ -1096,6 +1176,19 @@ def main():
     p.set_defaults(fn=cmd_kinds_summary)
     p = sub.add_parser("c4check")
     p.set_defaults(fn=cmd_c4check)
+    p = sub.add_parser("superblock")
+    p.add_argument("--sizes", type=lambda v: int(float(v)), nargs="+",
+                   default=[10_000_000, 20_000_000])
+    p.add_argument("--tiles", type=int, nargs="+",
+                   default=[1 << 21, 1 << 22, 1 << 23])
+    p.add_argument("--lds", type=int, default=32768)
+    p.add_argument("--lab", action="store_true",
+                   help="the laboratory kernel instead of the shipped one")
+    p.set_defaults(fn=cmd_superblock)
+    p = sub.add_parser("alternate")
+    p.add_argument("--rays", type=float, default=5e6)
+    p.add_argument("--contexts", type=int, default=4)
+    p.set_defaults(fn=cmd_alternate)
     p = sub.add_parser("hostpath")
     p.add_argument("--rays", type=float, default=1e7)
     p.set_defaults(fn=cmd_hostpath)
