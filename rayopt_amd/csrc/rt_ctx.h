@@ -56,6 +56,10 @@ struct rt_lab {
     int block;        /* threads per workgroup of the lab kernels */
     int lds;          /* bytes of unused dynamic LDS per workgroup */
     int tile;         /* tile-major result layout, rays per tile */
+    int tile_planes;  /* inside a tile the planes of SoA ([Y|U|I|T][L][3][TR])
+                       * instead of [L][10][TR]: "super-blocked SoA" */
+    int tile_pad;     /* ... with rows TR + tile_pad doubles apart */
+    int tile_shipped; /* tile layouts run the shipped kernel, not the lab one */
     int uniform_fix;  /* input components read as if wave-uniform (mask) */
     int gate_log2, gate_window; /* chip-wide read windows */
     int probe_store;  /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
@@ -263,6 +267,22 @@ static inline rt_lay rt_layout(const rt_ctx *c)
 {
     rt_lay a;
 #ifdef RT_BUILD_PROBES
+    if (c->lab.tile && c->lab.tile_planes) {
+        /* [tile][Y U I: [L][3][TR] | T: [L][TR]]: a tile is a batch of TR
+         * rays in the documented SoA layout */
+        const int64_t tr = c->lab.tile, pitch = tr + c->lab.tile_pad;
+        const int64_t lp = (int64_t)c->buf_nsurf * pitch;
+        a.Y = c->d_buf;
+        a.U = c->d_buf + 3 * lp;
+        a.I = c->d_buf + 6 * lp;
+        a.T = c->d_buf + 9 * lp;
+        a.cs = pitch;
+        a.ss = 3 * pitch;
+        a.ssT = pitch;
+        a.ts = 10 * lp;
+        a.tshift = __builtin_ctzll((unsigned long long)tr);
+        return a;
+    }
     if (c->lab.tile) { /* [tile][L][10][TR] */
         const int64_t tr = c->lab.tile;
         a.Y = c->d_buf;

@@ -482,6 +482,9 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #ifdef RT_BUILD_PROBES
     size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld + RT_LAB_SLACK;
+    if (ctx->lab.tile && ctx->lab.tile_planes) /* padded rows inside a tile */
+        need += (size_t)ctx->nsurf * 10 * (size_t)(ld / ctx->lab.tile) *
+                (size_t)ctx->lab.tile_pad;
     if (ctx->lab.alloc_round == 99) {
         size_t p2 = 1;
         while (p2 < need)

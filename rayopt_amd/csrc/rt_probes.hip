@@ -137,7 +137,7 @@ bool rt_lab_variant(const rt_ctx *c)
 {
     const rt_lab &l = c->lab;
     return l.r != 1 || l.nt || l.xcd || l.block != RT_BLOCK || l.lds ||
-           l.tile || l.uniform_fix || l.gate_log2;
+           (l.tile && !l.tile_shipped) || l.uniform_fix || l.gate_log2;
 }
 
 int rt_lab_set_option(rt_ctx *ctx, const char *key, int value)
@@ -178,6 +178,18 @@ int rt_lab_set_option(rt_ctx *ctx, const char *key, int value)
             ctx->n = 0;
             memset(ctx->valid, 0, sizeof ctx->valid);
         }
+    } else if (!strcmp(key, "tile_planes")) {
+        /* set before tile_rays (which lays the arrays out anew) */
+        l.tile_planes = value ? 1 : 0;
+    } else if (!strcmp(key, "tile_shipped_kernel")) {
+        /* a tile layout alone does not select the laboratory kernel: the
+         * shipped rt_trace_kernel (which addresses through rt_col in this
+         * build) runs in it */
+        l.tile_shipped = value ? 1 : 0;
+    } else if (!strcmp(key, "tile_pad")) {
+        if (value < 0 || value > (1 << 22) || value % 64)
+            return rt_fail(ctx, RT_ERR_ARG, "tile_pad: k*64 doubles");
+        l.tile_pad = value;
     } else if (!strcmp(key, "alloc_vmm_mb")) {
         /* takes effect with the next allocation */
         if (value < 0 || value > 65536)

@@ -882,10 +882,17 @@ def cmd_superblock(a):
         y, u = workload_rays(n, 0)
         eng = Engine(0, lib_path=lib)
         g = ra.GeometricTrace(system, engine=eng)
-        rec = {"rays": n, "kernel": "laboratory (48 B per ray read)"
+        rec = {"rays": n, "row_pad_doubles": a.pad if a.planes else 0,
+               "inside_a_tile": "[Y|U|I|T][element][3][TR] (SoA)"
+               if a.planes else "[element][10 components][TR]",
+               "kernel": "laboratory (48 B per ray read)"
                if a.lab else "the shipped rt_trace_kernel (tile notes, "
                "non-temporal stores) of the laboratory build"}
         for tile in [0] + a.tiles:
+            eng.set_option("tile_planes", 1 if a.planes else 0)
+            eng.set_option("tile_shipped_kernel", 0 if a.lab else 1)
+            eng.set_option("tile_pad", a.pad if a.planes else 0)
+            eng.set_option("tile_rays", 0)
             eng.set_option("tile_rays", tile)
             g.rays_given(y, u)
             g.propagate(clip=True)
@@ -1184,6 +1191,11 @@ def main():
     p.add_argument("--lds", type=int, default=32768)
     p.add_argument("--lab", action="store_true",
                    help="the laboratory kernel instead of the shipped one")
+    p.add_argument("--planes", action="store_true",
+                   help="inside a tile the planes of SoA (super-blocked SoA)")
+    p.add_argument("--pad", type=int, default=0,
+                   help="with --planes: doubles between the rows of a tile "
+                        "beyond its rays (rows not a power of two apart)")
     p.set_defaults(fn=cmd_superblock)
     p = sub.add_parser("alternate")
     p.add_argument("--rays", type=float, default=5e6)
