@@ -60,6 +60,7 @@ struct rt_lab {
                        * instead of [L][10][TR]: "super-blocked SoA" */
     int tile_pad;     /* ... with rows TR + tile_pad doubles apart */
     int tile_shipped; /* tile layouts run the shipped kernel, not the lab one */
+    int t_before_i;   /* planes in the order Y | U | T | I */
     int uniform_fix;  /* input components read as if wave-uniform (mask) */
     int gate_log2, gate_window; /* chip-wide read windows */
     int probe_store;  /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
@@ -254,6 +255,12 @@ static inline double *rt_arr(const rt_ctx *c, int which)
     /* Y,U,I are [L][3][ld]; T is [L][ld] */
     const size_t plane = (size_t)c->buf_nsurf * 3 * (size_t)c->ld;
 #ifdef RT_BUILD_PROBES
+    if (c->lab.t_before_i) { /* Y | U | T | I: the written planes together */
+        const size_t off = which == RT_T ? 2 * plane
+                         : which == RT_I ? 2 * plane + plane / 3
+                                         : (size_t)which * plane;
+        return c->d_buf + c->lab.base_off + off;
+    }
     return c->d_buf + c->lab.base_off + (size_t)which * plane;
 #else
     return c->d_buf + (size_t)which * plane;

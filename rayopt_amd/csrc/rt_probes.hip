@@ -181,6 +181,14 @@ int rt_lab_set_option(rt_ctx *ctx, const char *key, int value)
     } else if (!strcmp(key, "tile_planes")) {
         /* set before tile_rays (which lays the arrays out anew) */
         l.tile_planes = value ? 1 : 0;
+    } else if (!strcmp(key, "t_before_i")) {
+        if ((value != 0) != l.t_before_i) {
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            l.t_before_i = value ? 1 : 0;
+            ctx->ld = 0; /* the next rt_reserve lays the arrays out anew */
+            ctx->n = 0;
+            memset(ctx->valid, 0, sizeof ctx->valid);
+        }
     } else if (!strcmp(key, "tile_shipped_kernel")) {
         /* a tile layout alone does not select the laboratory kernel: the
          * shipped rt_trace_kernel (which addresses through rt_col in this

@@ -913,6 +913,36 @@ def cmd_superblock(a):
         eng.close()
 
 
+def cmd_planes(a):
+    """Is it the ADDRESS SPAN of the concurrently written rows that makes
+    the knee?  The planes in the order Y | U | T | I instead of Y | U | I | T
+    (the i rows are served from u rows and never written: a 3 L ld gap
+    inside the written span); same context, same rays, shipped kernel."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    lib = lab_lib()
+    for n in a.sizes:
+        y, u = workload_rays(n, 0)
+        eng = Engine(0, lib_path=lib)
+        g = ra.GeometricTrace(system, engine=eng)
+        rec = {"rays": n}
+        for rep in range(2):
+            for order in (0, 1):
+                eng.set_option("t_before_i", order)
+                g.rays_given(y, u)
+                g.propagate(clip=True)
+                steady(eng, .4)
+                ms = steady(eng, .6)
+                rec.setdefault("Y|U|T|I" if order else "Y|U|I|T", []).append(
+                    ms*1e7/n)
+        rec["placement"] = eng.placement()["per_class"]
+        rec["resident"] = eng.placement()["mixed"]
+        out(**rec)
+        del g
+        eng.close()
+
+
 def cmd_alternate(a):
     """Is the knee above 1.1*10^7 rays the reach of the address translation
     ACROSS launches?  K contexts of --rays rays each (every one below the
@@ -1197,6 +1227,10 @@ def main():
                    help="with --planes: doubles between the rows of a tile "
                         "beyond its rays (rows not a power of two apart)")
     p.set_defaults(fn=cmd_superblock)
+    p = sub.add_parser("planes")
+    p.add_argument("--sizes", type=lambda v: int(float(v)), nargs="+",
+                   default=[10_000_000, 12_500_000, 15_000_000, 20_000_000])
+    p.set_defaults(fn=cmd_planes)
     p = sub.add_parser("alternate")
     p.add_argument("--rays", type=float, default=5e6)
     p.add_argument("--contexts", type=int, default=4)
