@@ -1488,7 +1488,9 @@ def run_configs(ra, device, args):
                "cpu_reference": ref}
         pl = g.engine.placement()
         rec["placement"] = {k: pl[k] for k in ("pieces", "piece_mib",
-                                               "per_class", "mixed")}
+                                               "per_class", "mixed",
+                                               "created", "ballast_blocks",
+                                               "search_ms")}
         rec["_kind"] = kind
         if note:
             rec["note"] = note

@@ -36,8 +36,9 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2 /* 2: rt_surface.rc, rt_selftest_arith, rt_comm_info;
-                           the default asphere arithmetic; no rt_probe */
+#define RT_ABI_VERSION 3 /* 2: rt_surface.rc, rt_selftest_arith, rt_comm_info;
+                           the default asphere arithmetic; no rt_probe
+                           3: rt_placement fills ms[8] (search times) */
 #define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
 #define RT_MAX_SURFACES 256 /* elements per System */
 
@@ -547,10 +548,14 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * pattern (56 B per ray and element) written over the arrays as laid out,
  * measured at rt_reserve for arrays >= 4 GiB (0: not measured; three
  * launches): below 5950 GB/s -- the memory behaves like one class whatever
- * the pair tests said, seen on one box -- [7] is cleared; ms[0] / ms[1] = the pair test's launch time inside one piece /
- * across two classes.
+ * the pair tests said, seen on one box -- [7] is cleared; ms[0] / ms[1] = the
+ * pair test's launch time inside one piece / across two classes; ms[3] =
+ * wall milliseconds the search took at rt_reserve, of which ms[4] creating,
+ * mapping and testing pieces, ms[5] creating and releasing ballast, ms[6]
+ * unmapping, releasing the surplus and mapping the final range; ms[7] = the
+ * verification.
  */
-int rt_placement(rt_ctx *ctx, int info[10], double ms[3]);
+int rt_placement(rt_ctx *ctx, int info[10], double ms[8]);
 
 /* device scratch owned by the context (e.g. gather destination on root) */
 int rt_scratch(rt_ctx *ctx, int64_t bytes, void **out);

@@ -16,7 +16,7 @@ F_ROTATED, F_CURVED, F_CONIC, F_ASPH, F_ALT, F_REFRACT, F_MIRROR = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40)
 F_FAST = 0x400          # set by the library (default; "exact_asphere" clears)
 RT_Y, RT_U, RT_I, RT_T = 0, 1, 2, 3
-RT_ABI_VERSION = 2      # include/rt_mi355.h
+RT_ABI_VERSION = 3      # include/rt_mi355.h
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 
 SURFACE_DTYPE = np.dtype([

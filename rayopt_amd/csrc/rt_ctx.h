@@ -104,6 +104,10 @@ struct rt_place {
     float store_gbps; /* the trace's store pattern over the arrays as laid
                          out (0: not measured) */
     int class_mix;    /* what the classes alone said (before the pattern) */
+    /* wall time of the search (rt_place_alloc): all of it, the pieces
+     * (create, map, pair tests), the ballast, unmapping / releasing / the
+     * final mapping; and of the verification */
+    float search_ms, pieces_ms, ballast_ms, remap_ms, verify_ms;
 };
 
 struct rt_ctx {

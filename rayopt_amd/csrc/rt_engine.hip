@@ -1474,7 +1474,7 @@ int rt_selftest_arith(rt_ctx *ctx, uint64_t seed, int64_t n, int span,
     return RT_OK;
 }
 
-int rt_placement(rt_ctx *ctx, int info[10], double ms[3])
+int rt_placement(rt_ctx *ctx, int info[10], double ms[8])
 {
     if (!ctx || !info || !ms)
         return rt_fail(ctx, RT_ERR_ARG, "rt_placement: NULL argument");
@@ -1491,6 +1491,11 @@ int rt_placement(rt_ctx *ctx, int info[10], double ms[3])
     ms[0] = p.self_ms;
     ms[1] = p.cross_ms;
     ms[2] = p.store_gbps;
+    ms[3] = p.search_ms;
+    ms[4] = p.pieces_ms;
+    ms[5] = p.ballast_ms;
+    ms[6] = p.remap_ms;
+    ms[7] = p.verify_ms;
     return RT_OK;
 }
 

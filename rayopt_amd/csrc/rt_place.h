@@ -35,6 +35,13 @@
 #define RT_PLACE_H
 
 #include "rt_ctx.h"
+#include <chrono>
+
+static inline double rt_place_now_ms(void)
+{
+    return std::chrono::duration<double, std::milli>(
+               std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 #define RT_PLACE_ROWS 84         /* 12 elements x (y0 y1 y2 u0 u1 u2 t) */
 /* up to 1.5 GiB: hipMalloc.  Above it there are at least four pieces of
@@ -123,6 +130,8 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     memset(&P, 0, sizeof P);
     if (!c->opt_place || bytes < RT_PLACE_MIN_BYTES)
         return hipMalloc(out, bytes);
+    const double t_start = rt_place_now_ms();
+    double t_ballast = 0.;
 
     /* pieces of 1 GiB (RT_MI355_PIECE_MIB: another size, for measurements);
      * arrays below 3 GiB: pieces of 512 MiB */
@@ -241,10 +250,12 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         if (count[cls[k]] > (need + 1) / 2 && made >= (need + 1) / 2 + 1 &&
             nballast < max_ballast) {
             const size_t hop = (size_t)(hops_in_a_row < 3 ? 4 : 8) << 30;
+            const double tb = rt_place_now_ms();
             if (hipMemCreate(&ballast[nballast], hop, &prop, 0) == hipSuccess)
                 ++nballast;
             else
                 (void)hipGetLastError(); /* the device is full: no hopping */
+            t_ballast += rt_place_now_ms() - tb;
             ++hops_in_a_row;
         } else {
             hops_in_a_row = 0;
@@ -259,8 +270,10 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
             enough = can >= need;
         }
     }
+    const double t_found = rt_place_now_ms(), t_created = t_ballast;
     for (int b = 0; b < nballast; ++b)
         (void)hipMemRelease(ballast[b]);
+    t_ballast += rt_place_now_ms() - t_found;
     if (e != hipSuccess || made < need) {
         /* not this way: give everything back, allocate plainly */
         (void)hipGetLastError();
@@ -351,6 +364,11 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     P.mixed = nclass >= 2 && 3 * (need - largest) >= need;
     P.ballast = nballast;
     P.class_mix = P.mixed;
+    const double t_end = rt_place_now_ms();
+    P.search_ms = (float)(t_end - t_start);
+    P.ballast_ms = (float)t_ballast;
+    P.pieces_ms = (float)(t_found - t_start - t_created);
+    P.remap_ms = (float)(t_end - t_found - (t_ballast - t_created));
     *out = base;
     return hipSuccess;
 }
@@ -391,6 +409,7 @@ static void rt_place_verify(rt_ctx *c, rt_lay lay, int L, long long ld)
 {
     rt_place &P = c->place;
     P.store_gbps = 0.f;
+    const double t_start = rt_place_now_ms();
     const size_t bytes = (size_t)56 * (L - 1) * ld;
     if (!P.base || L < 2 || bytes < RT_PLACE_VERIFY_BYTES)
         return; /* short kernels measure their own ramp, not the memory */
@@ -411,6 +430,7 @@ static void rt_place_verify(rt_ctx *c, rt_lay lay, int L, long long ld)
             P.mixed = 0; /* whatever the classes say: two per CU here */
     }
     (void)hipGetLastError();
+    P.verify_ms = (float)(rt_place_now_ms() - t_start);
 }
 
 #endif /* RT_PLACE_H */

@@ -301,14 +301,16 @@ class Engine:
         the way, classes seen, pieces kept per class, ``mixed`` and the pair
         test's two launch times."""
         info = (ctypes.c_int*10)()
-        ms = (ctypes.c_double*3)()
+        ms = (ctypes.c_double*8)()
         self._check(self.lib.rt_placement(self.ctx, info, ms), "rt_placement")
         return {"pieces": info[0], "piece_mib": info[1], "created": info[2],
                 "classes": info[3], "per_class": [info[4], info[5], info[6]],
                 "mixed": bool(info[7]), "ballast_blocks": info[8],
                 "classes_mixed": bool(info[9]),
                 "store_pattern_GBps": ms[2],
-                "pair_test_ms": {"same_piece": ms[0], "other_class": ms[1]}}
+                "pair_test_ms": {"same_piece": ms[0], "other_class": ms[1]},
+                "search_ms": {"all": ms[3], "pieces": ms[4], "ballast": ms[5],
+                              "remap": ms[6], "verify": ms[7]}}
 
     def selftest_arith(self, seed, n, span=100):
         """rt_selftest_arith: mismatch counts (refraction quotient, table
