@@ -984,6 +984,33 @@ def cmd_alternate(a):
             placement=[g.engine.placement()["per_class"] for g in use])
 
 
+def cmd_consumers(a):
+    """The reductions on the resident headline batch, 20 calls each -- for a
+    `rocprofv3 --kernel-trace --stats` pass whose rows stand beside the
+    `consumers` records of bench.py."""
+    ra, P, _build, Engine = _imports()
+    from bench import workload_rays, FIELD_FRACTIONS
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    n = int(a.rays)
+    y, u = workload_rays(n, 0)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    eng, L, nf = g.engine, len(system), len(FIELD_FRACTIONS)
+    calls = {"rms": lambda: g.rms(),
+             "refocus_shift": lambda: eng.refocus_shift(L - 1),
+             "spot_stats": lambda: eng.spot_stats(L - 1, n//nf, nf),
+             "row_rmax": lambda: eng.row_rmax(L - 1)}
+    for name, fn in calls.items():
+        fn()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(a.calls):
+            fn()
+        out(call=name, rays=n, calls=a.calls,
+            wall_ms_per_call=(time.perf_counter() - t0)/a.calls*1e3)
+
+
 def cmd_hostpath(a):
     """Where the host-side time of the calls that return big arrays goes:
     rows down to fresh / reused numpy arrays, one ray's column, the pieces
@@ -1235,6 +1262,10 @@ def main():
     p.add_argument("--rays", type=float, default=5e6)
     p.add_argument("--contexts", type=int, default=4)
     p.set_defaults(fn=cmd_alternate)
+    p = sub.add_parser("consumers")
+    p.add_argument("--rays", type=float, default=1e7)
+    p.add_argument("--calls", type=int, default=20)
+    p.set_defaults(fn=cmd_consumers)
     p = sub.add_parser("hostpath")
     p.add_argument("--rays", type=float, default=1e7)
     p.set_defaults(fn=cmd_hostpath)
