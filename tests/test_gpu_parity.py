@@ -423,6 +423,35 @@ def test_optimiser_as_caller():
     assert f1 < 0.5*f0 and nfev > 20
 
 
+def test_big_job_in_batches_example():
+    """examples/big_job_in_batches.py: a job traced as several batches (what
+    DESIGN.md section 9 recommends above 10^7 rays per batch); the per-field
+    statistics combined from the batches are those of the same rays traced
+    as one batch."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "examples", "big_job_in_batches.py")
+    spec = importlib.util.spec_from_file_location("big_job_in_batches", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cnt, centroid, rms, traces = mod.main(total=600_000, batch=200_000,
+                                          verbose=False)
+    assert len(traces) == 3
+    per = traces[0].nrays//len(mod.FIELDS)
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    g = ra.GeometricTrace(system)
+    g.rays_fields(mod.FIELDS,
+                  np.concatenate([mod.pupil_points(per, b) for b in range(3)]),
+                  np.full(len(mod.FIELDS), P.DOUBLE_GAUSS_PUPIL_Z), 17.)
+    g.propagate(clip=True)
+    s = g.spot_stats(group_rays=3*per)
+    assert 0 < (s[:, 0] < 3*per).sum()            # some bundles are clipped
+    assert np.array_equal(cnt, s[:, 0])
+    np.testing.assert_allclose(centroid, s[:, 1:3], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(rms, np.sqrt(s[:, 3]), rtol=1e-10)
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129])
 def test_ragged_small_batches(n):
     """N not a multiple of the 64-ray padding, down to a single ray."""
