@@ -1102,6 +1102,21 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
     /* the window as the kernels see it: the arrays shifted by `lo` columns,
      * `cols` columns long (the last window takes the padding up to ld) */
     rt_lay lay = rt_layout(ctx);
+#ifdef RT_BUILD_PROBES
+    if (ctx->lab.tile) {
+        /* a tile layout: windows are whole tiles, the arrays are shifted by
+         * tiles (laboratory: one launch per block of a super-blocked SoA) */
+        if (lo % ctx->lab.tile)
+            return rt_fail(ctx, RT_ERR_ARG,
+                           "rt_trace_chunk in a tile layout: pieces must "
+                           "begin on tile boundaries");
+        const int64_t shift = lo / ctx->lab.tile * lay.ts;
+        lay.Y += shift - lo; /* (the common shift by lo follows) */
+        lay.U += shift - lo;
+        lay.I += shift - lo;
+        lay.T += shift - lo;
+    }
+#endif
     lay.Y += lo;
     lay.U += lo;
     lay.I += lo;

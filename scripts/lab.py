@@ -899,12 +899,32 @@ def cmd_superblock(a):
             eng.set_option("lds_pad" if a.lab else "resident_lds", a.lds)
             steady(eng, .4)
             ms = steady(eng, .6)
+            per_block = None
+            if tile and a.per_block and n % tile == 0:
+                # one launch per block (rt_trace_chunk on tile boundaries)
+                q, L = n//tile, len(system)
+
+                def blocks():
+                    for k in range(q):
+                        eng.trace_chunk(1, L, True, k, q)
+                for _ in range(5):
+                    blocks()
+                t_end, mb = time.time() + .6, []
+                while time.time() < t_end:
+                    eng.event_record(0)
+                    for _ in range(3):
+                        blocks()
+                    eng.event_record(1)
+                    mb.append(eng.event_elapsed(0, 1)/3)
+                per_block = float(np.median(mb))
             slots = -(-n//tile)*tile if tile else -(-n//64)*64
             eng.set_option("lds_pad" if a.lab else "resident_lds",
                            0 if a.lab else -1)
             rec["tile_%d" % tile] = {
                 "ms": ms, "slots_traced": slots,
                 "per_1e7_slots": ms*1e7/slots,
+                "one_launch_per_block_per_1e7":
+                    per_block*1e7/slots if per_block else None,
                 "span_GiB_of_concurrent_streams":
                     (13*10*tile*8 if tile else 13*10*n*8)/2**30,
                 "placement": eng.placement()["per_class"]}
@@ -1250,6 +1270,8 @@ def main():
                    help="the laboratory kernel instead of the shipped one")
     p.add_argument("--planes", action="store_true",
                    help="inside a tile the planes of SoA (super-blocked SoA)")
+    p.add_argument("--per-block", action="store_true",
+                   help="also: one launch per block (whole-tile batches)")
     p.add_argument("--pad", type=int, default=0,
                    help="with --planes: doubles between the rows of a tile "
                         "beyond its rays (rows not a power of two apart)")
