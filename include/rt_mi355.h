@@ -26,6 +26,20 @@
  *
  * The Python side exposes them with the reference's shapes (L,N,3)/(L,N)
  * (rayopt/geometric_trace.py:41-47) as strided numpy views, no transpose.
+ *
+ * Large batches are cut into BLOCKS (rt_blocks: nblk blocks of bs rays,
+ * ld = nblk * bs): every block holds its rays in the layout above with
+ * ld -> bs, and block b begins bts doubles after block 0:
+ *
+ *      element (array, s, c) of ray j = base[array] + (j / bs) bts
+ *                                       + (s 3 + c) bs + j % bs
+ *
+ * One block (nblk = 1: every batch whose arrays stay below ~11 GB, i.e. up
+ * to 1.05e7 rays through 13 elements) is the plain layout.  Rows further
+ * apart than that are written more slowly (the device's address translation
+ * falls behind streams that reach over more than ~10 one-GiB regions); see
+ * csrc/rt_lay.h.  rt_download / rt_upload_row / the reductions / the gather
+ * hide the blocks; rt_device_ptr users see them.
  */
 #ifndef RT_MI355_H
 #define RT_MI355_H
@@ -38,7 +52,8 @@ extern "C" {
 
 #define RT_ABI_VERSION 3 /* 2: rt_surface.rc, rt_selftest_arith, rt_comm_info;
                            the default asphere arithmetic; no rt_probe
-                           3: rt_placement fills ms[8] (search times) */
+                           3: rt_placement fills ms[8] (search times);
+                              large batches in blocks (rt_blocks) */
 #define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
 #define RT_MAX_SURFACES 256 /* elements per System */
 
@@ -181,7 +196,10 @@ int rt_upload_system_groups(rt_ctx *ctx, const rt_surface *surf, int nsurf,
  */
 int rt_reserve(rt_ctx *ctx, int64_t nrays);
 int64_t rt_nrays(const rt_ctx *ctx);
-int64_t rt_ld(const rt_ctx *ctx); /* padded ray stride of the SoA arrays */
+int64_t rt_ld(const rt_ctx *ctx); /* ray slots of the arrays (nblk * bs) */
+/* info[0] = blocks the batch is cut into, [1] = rays per block = distance of
+ * the rows in doubles, [2] = doubles from one block to the next (0: one) */
+int rt_blocks(const rt_ctx *ctx, int64_t info[3]);
 int rt_nsurf(const rt_ctx *ctx);
 
 /*
@@ -373,6 +391,10 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * roots run without the compiler's range scaffolding where the operands are
  * checked to be inside [2^-100, 2^100] -- the same bits from a third fewer
  * instructions, RT_F_RANGE; 0 = the compiler's sequences everywhere),
+ * "block_rays" (0 = default: large batches are cut into blocks of ~9 GB, see
+ * the layout above; B > 0: every batch of more than B rays is cut into
+ * blocks of about B rays -- for tests; RT_MI355_BLOCK_RAYS=B does the same
+ * for every context of the process; takes effect with the next rt_reserve),
  * "consumers_one_pass" (1 = default, see rt_rms; 0 = always two passes),
  * "consumer_events" (measurement: 1 = the reductions bracket their kernels
  * with the events rt_kernel_ms reads; default 0).
@@ -456,7 +478,9 @@ typedef struct rt_opd_args {
 int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa);
 int rt_sizeof_opd_args(void);
 
-/* raw device pointer to row `surf` of an array (interop, collectives).  The
+/* raw device pointer to row `surf` of an array, i.e. to its part in block 0
+ * (rt_blocks: the other blocks' parts follow bts doubles apart; one block
+ * unless the batch is large) -- interop, collectives.  The
  * arrays of a large batch live in a virtual-memory mapping (rt_placement):
  * an ordinary device pointer for kernels, hipMemcpy and RCCL on this device,
  * but not something hipIpcGetMemHandle accepts -- copy a row out (rt_scratch)

@@ -81,6 +81,7 @@ SIGNATURES = {
     "rt_reserve": (ctypes.c_int, [_ctx, ctypes.c_int64]),
     "rt_nrays": (ctypes.c_int64, [_ctx]),
     "rt_ld": (ctypes.c_int64, [_ctx]),
+    "rt_blocks": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_int64)]),
     "rt_nsurf": (ctypes.c_int, [_ctx]),
     "rt_set_rays": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_int64, ctypes.c_int]),

@@ -163,11 +163,12 @@ static int rt_gather_window(rt_ctx *ctx, int which, int surf,
      * it.  The snapshot must wait for the gather that used this slot last. */
     if (ctx->gather_pending[p])
         RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gathered[p], 0));
-    const double *src = rt_row(ctx, which, surf) + lo;
-    if (mine > 0)
-        RT_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage[p], mine * sizeof(double),
-                                     src, ctx->ld * sizeof(double),
-                                     mine * sizeof(double), nc,
+    const double *src = rt_row(ctx, which, surf);
+    RT_FOR_SEGMENTS(ctx, g, lo, lo + mine) /* block by block of the batch */
+        RT_HIP(ctx, hipMemcpy2DAsync(ctx->d_stage[p] + (g.ray - lo),
+                                     mine * sizeof(double), src + g.off,
+                                     ctx->bs * sizeof(double),
+                                     (size_t)g.cnt * sizeof(double), nc,
                                      hipMemcpyDeviceToDevice, ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->staged[p], ctx->stream));
     RT_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->staged[p], 0));

@@ -201,6 +201,41 @@ __device__ __forceinline__ void rt_stream_rows(const double *const (&row)[C],
 #define RT_RED_TID ((int64_t)blockIdx.x * blockDim.x + threadIdx.x)
 #define RT_RED_NTHREADS ((int64_t)gridDim.x * blockDim.x)
 
+/* how the rays of a row lie in memory (rt_lay.h): ld doubles between the
+ * components of a row (= rays per block), ts doubles from one block of the
+ * batch to the next (0: one block, the plain layout) */
+struct rt_pitch {
+    int64_t ld, ts;
+};
+#define RT_AT(p, j) rt_block_col((p).ld, (p).ts, (j))
+
+/* rt_stream_rows over rays lo..hi of a batch in blocks: block by block, each
+ * a contiguous range.  ts[c] = doubles from block to block of row c (the
+ * weights are one plain array: p.ld) */
+template <int C, class F>
+__device__ __forceinline__ void rt_stream_blocks(const double *const (&row)[C],
+                                                 const int64_t (&ts)[C],
+                                                 rt_pitch p, int64_t lo,
+                                                 int64_t hi, int64_t tid,
+                                                 int64_t nthreads, F &use)
+{
+    if (!p.ts) {
+        rt_stream_rows(row, lo, hi, tid, nthreads, use);
+        return;
+    }
+    for (int64_t b = lo / p.ld; b * p.ld < hi; ++b) {
+        const int64_t first = b * p.ld;
+        const double *rb[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            rb[c] = row[c] + b * ts[c];
+        const double *const(&rows)[C] = rb;
+        rt_stream_rows(rows, (lo > first ? lo : first) - first,
+                       (hi < first + p.ld ? hi : first + p.ld) - first, tid,
+                       nthreads, use);
+    }
+}
+
 /* one wavefront adds the K columns of the per-workgroup partials side by
  * side (per column in the order of rt_finalize_kernel); every lane returns
  * with the sums */
@@ -236,10 +271,10 @@ __device__ __forceinline__ void rt_partial_sums(const double *__restrict__ p,
 template <bool W>
 __global__ void rt_rms_shifted_kernel(const double *__restrict__ Yrow,
                                       const double *__restrict__ w,
-                                      int64_t ref, int64_t n, int64_t ld,
+                                      int64_t ref, int64_t n, rt_pitch p,
                                       double *__restrict__ partials)
 {
-    const int64_t k0 = ref >= 0 ? ref : 0;
+    const int64_t ld = p.ld, k0 = RT_AT(p, ref >= 0 ? ref : 0);
     const double x0 = Yrow[k0], y0 = Yrow[ld + k0];
     constexpr int K = W ? 6 : 3;
     double acc[K];
@@ -248,26 +283,28 @@ __global__ void rt_rms_shifted_kernel(const double *__restrict__ Yrow,
         acc[k] = 0.;
     if constexpr (W) {
         const double *const rows[3] = {Yrow, Yrow + ld, w};
-        rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
-                       [&](const double(&v)[3]) {
-                           const double dx = v[0] - x0, dy = v[1] - y0;
-                           const double r = dx * dx + dy * dy;
-                           acc[0] += dx;
-                           acc[1] += dy;
-                           acc[2] += r * v[2];
-                           acc[3] += v[2] * dx;
-                           acc[4] += v[2] * dy;
-                           acc[5] += v[2];
-                       });
+        const int64_t ts[3] = {p.ts, p.ts, ld};
+        auto use = [&](const double(&v)[3]) {
+            const double dx = v[0] - x0, dy = v[1] - y0;
+            const double r = dx * dx + dy * dy;
+            acc[0] += dx;
+            acc[1] += dy;
+            acc[2] += r * v[2];
+            acc[3] += v[2] * dx;
+            acc[4] += v[2] * dy;
+            acc[5] += v[2];
+        };
+        rt_stream_blocks(rows, ts, p, 0, n, RT_RED_TID, RT_RED_NTHREADS, use);
     } else {
         const double *const rows[2] = {Yrow, Yrow + ld};
-        rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
-                       [&](const double(&v)[2]) {
-                           const double dx = v[0] - x0, dy = v[1] - y0;
-                           acc[0] += dx;
-                           acc[1] += dy;
-                           acc[2] += dx * dx + dy * dy;
-                       });
+        const int64_t ts[2] = {p.ts, p.ts};
+        auto use = [&](const double(&v)[2]) {
+            const double dx = v[0] - x0, dy = v[1] - y0;
+            acc[0] += dx;
+            acc[1] += dy;
+            acc[2] += dx * dx + dy * dy;
+        };
+        rt_stream_blocks(rows, ts, p, 0, n, RT_RED_TID, RT_RED_NTHREADS, use);
     }
     rt_block_reduce<K>(acc, partials);
 }
@@ -301,11 +338,13 @@ __global__ void rt_rms_finish_kernel(const double *__restrict__ partials,
 
 /* sum of x and y of one row (rms: y.mean(0)) */
 __global__ void rt_sum_xy_kernel(const double *__restrict__ Yrow, int64_t n,
-                                 int64_t ld, double *__restrict__ partials)
+                                 rt_pitch p, double *__restrict__ partials)
 {
+    const int64_t ld = p.ld;
     double acc[2] = {0., 0.};
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = RT_AT(p, k);
         acc[0] += Yrow[j];
         acc[1] += Yrow[ld + j];
     }
@@ -316,18 +355,20 @@ __global__ void rt_sum_xy_kernel(const double *__restrict__ Yrow, int64_t n,
 __global__ void rt_rms_kernel(const double *__restrict__ Yrow,
                               const double *__restrict__ w, double wconst,
                               const double *__restrict__ sums, int64_t ref,
-                              int64_t n, int64_t ld,
+                              int64_t n, rt_pitch p,
                               double *__restrict__ partials)
 {
     /* centre: ray `ref`, or the plain mean from the sums of pass A */
-    const double x0 = ref >= 0 ? Yrow[ref] : sums[0] / (double)n;
-    const double y0 = ref >= 0 ? Yrow[ld + ref] : sums[1] / (double)n;
+    const int64_t ld = p.ld, kr = ref >= 0 ? RT_AT(p, ref) : 0;
+    const double x0 = ref >= 0 ? Yrow[kr] : sums[0] / (double)n;
+    const double y0 = ref >= 0 ? Yrow[ld + kr] : sums[1] / (double)n;
     double acc[1] = {0.};
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = RT_AT(p, k);
         const double dx = Yrow[j] - x0, dy = Yrow[ld + j] - y0;
         const double r = dx * dx + dy * dy;
-        acc[0] += r * (w ? w[j] : wconst);
+        acc[0] += r * (w ? w[k] : wconst);
     }
     rt_block_reduce<1>(acc, partials);
 }
@@ -343,9 +384,10 @@ template <bool W>
 __global__ void rt_refocus_shifted_kernel(const double *__restrict__ Yrow,
                                           const double *__restrict__ Irow,
                                           const double *__restrict__ w,
-                                          int64_t n, int64_t ld,
+                                          int64_t n, rt_pitch p,
                                           double *__restrict__ partials)
 {
+    const int64_t ld = p.ld;
     const double iz0 = Irow[2 * ld];
     const double ky0 = Yrow[0], ky1 = Yrow[ld];
     const double ku0 = Irow[0] / iz0, ku1 = Irow[ld] / iz0;
@@ -384,17 +426,21 @@ __global__ void rt_refocus_shifted_kernel(const double *__restrict__ Yrow,
     if constexpr (W) {
         const double *const rows[6] = {Yrow,        Yrow + ld,     Irow,
                                        Irow + ld,   Irow + 2 * ld, w};
-        rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
-                       [&](const double(&v)[6]) {
-                           use(v[0], v[1], v[2], v[3], v[4], v[5]);
-                       });
+        const int64_t ts[6] = {p.ts, p.ts, p.ts, p.ts, p.ts, ld};
+        auto each = [&](const double(&v)[6]) {
+            use(v[0], v[1], v[2], v[3], v[4], v[5]);
+        };
+        rt_stream_blocks(rows, ts, p, 0, n, RT_RED_TID, RT_RED_NTHREADS,
+                         each);
     } else {
         const double *const rows[5] = {Yrow, Yrow + ld, Irow, Irow + ld,
                                        Irow + 2 * ld};
-        rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
-                       [&](const double(&v)[5]) {
-                           use(v[0], v[1], v[2], v[3], v[4], 1.);
-                       });
+        const int64_t ts[5] = {p.ts, p.ts, p.ts, p.ts, p.ts};
+        auto each = [&](const double(&v)[5]) {
+            use(v[0], v[1], v[2], v[3], v[4], 1.);
+        };
+        rt_stream_blocks(rows, ts, p, 0, n, RT_RED_TID, RT_RED_NTHREADS,
+                         each);
     }
     rt_block_reduce<K>(acc, partials);
 }
@@ -437,12 +483,14 @@ __global__ void rt_refocus_finish_kernel(const double *__restrict__ partials,
 /* refocus pass A: over rays with finite u = i_xy/i_z: count, sum y, sum u */
 __global__ void rt_refocus_sums_kernel(const double *__restrict__ Yrow,
                                        const double *__restrict__ Irow,
-                                       int64_t n, int64_t ld,
+                                       int64_t n, rt_pitch p,
                                        double *__restrict__ partials)
 {
+    const int64_t ld = p.ld;
     double acc[5] = {0., 0., 0., 0., 0.};
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = RT_AT(p, k);
         const double iz = Irow[2 * ld + j];
         const double ux = Irow[j] / iz, uy = Irow[ld + j] / iz;
         if (isfinite(ux) && isfinite(uy)) {
@@ -462,19 +510,21 @@ __global__ void rt_refocus_dots_kernel(const double *__restrict__ Yrow,
                                        const double *__restrict__ w,
                                        double wconst,
                                        const double *__restrict__ sums,
-                                       int64_t n, int64_t ld,
+                                       int64_t n, rt_pitch p,
                                        double *__restrict__ partials)
 {
     /* means over the finite rays from the sums of pass A */
+    const int64_t ld = p.ld;
     const double my0 = sums[1] / sums[0], my1 = sums[2] / sums[0];
     const double mu0 = sums[3] / sums[0], mu1 = sums[4] / sums[0];
     double acc[2] = {0., 0.};
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = RT_AT(p, k);
         const double iz = Irow[2 * ld + j];
         const double ux = Irow[j] / iz, uy = Irow[ld + j] / iz;
         if (isfinite(ux) && isfinite(uy)) {
-            const double wk = w ? w[j] : wconst;
+            const double wk = w ? w[k] : wconst;
             const double y0 = Yrow[j] - my0, y1 = Yrow[ld + j] - my1;
             const double u0 = ux - mu0, u1 = uy - mu1;
             acc[0] += (wk * y0) * u0 + (wk * y1) * u1;
@@ -486,19 +536,20 @@ __global__ void rt_refocus_dots_kernel(const double *__restrict__ Yrow,
 
 /* max over rays of x^2 + y^2 of one row; NaN if any ray is NaN (np.max) */
 __global__ void rt_r2max_kernel(const double *__restrict__ Yrow, int64_t n,
-                                int64_t ld, double *__restrict__ partials)
+                                rt_pitch p, double *__restrict__ partials)
 {
     __shared__ double sm[RT_RED_THREADS / 64][2];
     double mx = 0., bad = 0.;
-    const double *const rows[2] = {Yrow, Yrow + ld};
-    rt_stream_rows(rows, 0, n, RT_RED_TID, RT_RED_NTHREADS,
-                   [&](const double(&v)[2]) {
-                       const double r2 = v[0] * v[0] + v[1] * v[1];
-                       if (r2 != r2)
-                           bad = 1.;
-                       else
-                           mx = r2 > mx ? r2 : mx;
-                   });
+    const double *const rows[2] = {Yrow, Yrow + p.ld};
+    const int64_t ts[2] = {p.ts, p.ts};
+    auto use = [&](const double(&v)[2]) {
+        const double r2 = v[0] * v[0] + v[1] * v[1];
+        if (r2 != r2)
+            bad = 1.;
+        else
+            mx = r2 > mx ? r2 : mx;
+    };
+    rt_stream_blocks(rows, ts, p, 0, n, RT_RED_TID, RT_RED_NTHREADS, use);
     for (int off = 32; off > 0; off >>= 1) {
         const double o = __shfl_down(mx, off), b = __shfl_down(bad, off);
         mx = o > mx ? o : mx;
@@ -556,9 +607,10 @@ __global__ void rt_r2max_finish_kernel(const double *__restrict__ partials,
 /* pass A: count, sum x, sum y, sum w over the finite rays of group g */
 __global__ void rt_group_sums_kernel(const double *__restrict__ Yrow,
                                      const double *__restrict__ w,
-                                     int64_t group_rays, int64_t ld,
+                                     int64_t group_rays, rt_pitch p,
                                      double *__restrict__ partials)
 {
+    const int64_t ld = p.ld;
     const int64_t base = (int64_t)blockIdx.y * group_rays;
     double acc[4] = {0., 0., 0., 0.};
     auto use = [&](double x, double y, double wk) {
@@ -571,14 +623,16 @@ __global__ void rt_group_sums_kernel(const double *__restrict__ Yrow,
     };
     if (w) {
         const double *const rows[3] = {Yrow, Yrow + ld, w};
-        rt_stream_rows(rows, base, base + group_rays, RT_RED_TID,
-                       RT_RED_NTHREADS,
-                       [&](const double(&v)[3]) { use(v[0], v[1], v[2]); });
+        const int64_t ts[3] = {p.ts, p.ts, ld};
+        auto each = [&](const double(&v)[3]) { use(v[0], v[1], v[2]); };
+        rt_stream_blocks(rows, ts, p, base, base + group_rays, RT_RED_TID,
+                         RT_RED_NTHREADS, each);
     } else {
         const double *const rows[2] = {Yrow, Yrow + ld};
-        rt_stream_rows(rows, base, base + group_rays, RT_RED_TID,
-                       RT_RED_NTHREADS,
-                       [&](const double(&v)[2]) { use(v[0], v[1], 1.); });
+        const int64_t ts[2] = {p.ts, p.ts};
+        auto each = [&](const double(&v)[2]) { use(v[0], v[1], 1.); };
+        rt_stream_blocks(rows, ts, p, base, base + group_rays, RT_RED_TID,
+                         RT_RED_NTHREADS, each);
     }
     rt_block_reduce<4>(acc, partials + (int64_t)blockIdx.y * gridDim.x * 4);
 }
@@ -604,11 +658,12 @@ __global__ void rt_group_centroid_kernel(const double *__restrict__ partials,
 /* pass B: sum w d^2 and max d^2 about the centroid of group g */
 __global__ void rt_group_spread_kernel(const double *__restrict__ Yrow,
                                        const double *__restrict__ w,
-                                       int64_t group_rays, int64_t ld,
+                                       int64_t group_rays, rt_pitch p,
                                        const double *__restrict__ stats,
                                        double *__restrict__ partials)
 {
     __shared__ double sm[RT_RED_THREADS / 64][2];
+    const int64_t ld = p.ld;
     const int64_t base = (int64_t)blockIdx.y * group_rays;
     const double x0 = stats[(int64_t)blockIdx.y * RT_GRP_STATS + 1];
     const double y0 = stats[(int64_t)blockIdx.y * RT_GRP_STATS + 2];
@@ -623,14 +678,16 @@ __global__ void rt_group_spread_kernel(const double *__restrict__ Yrow,
     };
     if (w) {
         const double *const rows[3] = {Yrow, Yrow + ld, w};
-        rt_stream_rows(rows, base, base + group_rays, RT_RED_TID,
-                       RT_RED_NTHREADS,
-                       [&](const double(&v)[3]) { use(v[0], v[1], v[2]); });
+        const int64_t ts[3] = {p.ts, p.ts, ld};
+        auto each = [&](const double(&v)[3]) { use(v[0], v[1], v[2]); };
+        rt_stream_blocks(rows, ts, p, base, base + group_rays, RT_RED_TID,
+                         RT_RED_NTHREADS, each);
     } else {
         const double *const rows[2] = {Yrow, Yrow + ld};
-        rt_stream_rows(rows, base, base + group_rays, RT_RED_TID,
-                       RT_RED_NTHREADS,
-                       [&](const double(&v)[2]) { use(v[0], v[1], 1.); });
+        const int64_t ts[2] = {p.ts, p.ts};
+        auto each = [&](const double(&v)[2]) { use(v[0], v[1], 1.); };
+        rt_stream_blocks(rows, ts, p, base, base + group_rays, RT_RED_TID,
+                         RT_RED_NTHREADS, each);
     }
     for (int off = 32; off > 0; off >>= 1) {
         sum += __shfl_down(sum, off);
@@ -737,11 +794,12 @@ __global__ void rt_opd_kernel(rt_opd_args a, const rt_opd_ref *__restrict__ ref,
                               const double *__restrict__ Y,
                               const double *__restrict__ U,
                               const double *__restrict__ T, int64_t n,
-                              int64_t ld, double *__restrict__ out)
+                              rt_pitch p, double *__restrict__ out)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n)
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
         return;
+    const int64_t ld = p.ld, j = RT_AT(p, k); /* where ray k lies in a row */
     /* t = (t[:after+1] - t[:after+1, ref]).sum(0): row by row */
     double t = 0.;
     for (int s = 0; s < a.nrows; ++s) {
@@ -773,9 +831,9 @@ __global__ void rt_opd_kernel(rt_opd_args a, const rt_opd_ref *__restrict__ ref,
     rt_opd_point(a, ref->yi, yr, ur, tr, pr);
     t += (ti - tr) * a.n_after;
     t = -t / a.lscale;
-    out[j] = py[0] - pr[0];
-    out[n + j] = py[1] - pr[1];
-    out[2 * n + j] = t;
+    out[k] = py[0] - pr[0];
+    out[n + k] = py[1] - pr[1];
+    out[2 * n + k] = t;
 }
 
 #endif /* RT_CONSUMER_KERNELS_H */

@@ -158,6 +158,13 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
         }                                                                   \
     } while (0)
 
+/* how the rows lie in memory, as the reduction kernels take it */
+static inline rt_pitch rt_pitch_of(const rt_ctx *ctx)
+{
+    rt_pitch p = {ctx->bs, ctx->bts};
+    return p;
+}
+
 /* workgroups of a reduction over n rays: no more than there is work for */
 static inline unsigned rt_red_blocks(int64_t n)
 {
@@ -191,7 +198,7 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
         if (ctx->d_w) {
             hipLaunchKernelGGL(rt_rms_shifted_kernel<true>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
-                               ctx->d_w, ref, ctx->n, ctx->ld,
+                               ctx->d_w, ref, ctx->n, rt_pitch_of(ctx),
                                ctx->d_partials);
             hipLaunchKernelGGL(rt_rms_finish_kernel<true>, dim3(1), dim3(64),
                                0, ctx->stream, ctx->d_partials, (int)blocks,
@@ -199,7 +206,7 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
         } else {
             hipLaunchKernelGGL(rt_rms_shifted_kernel<false>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
-                               ctx->d_w, ref, ctx->n, ctx->ld,
+                               ctx->d_w, ref, ctx->n, rt_pitch_of(ctx),
                                ctx->d_partials);
             hipLaunchKernelGGL(rt_rms_finish_kernel<false>, dim3(1), dim3(64),
                                0, ctx->stream, ctx->d_partials, (int)blocks,
@@ -222,14 +229,14 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
     if (ref < 0) {
         hipLaunchKernelGGL(rt_sum_xy_kernel, dim3(blocks),
                            dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, ctx->n,
-                           ctx->ld, ctx->d_partials);
+                           rt_pitch_of(ctx), ctx->d_partials);
         hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0,
                            ctx->stream, ctx->d_partials, (int)blocks, 2,
                            rt_reduced(ctx, 0));
     }
     hipLaunchKernelGGL(rt_rms_kernel, dim3(blocks), dim3(RT_RED_THREADS), 0,
                        ctx->stream, Yrow, ctx->d_w, 1. / (double)ctx->n,
-                       rt_reduced(ctx, 0), ref, ctx->n, ctx->ld,
+                       rt_reduced(ctx, 0), ref, ctx->n, rt_pitch_of(ctx),
                        ctx->d_partials);
     hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
                        ctx->d_partials, (int)blocks, 1, ctx->h_res);
@@ -250,7 +257,7 @@ int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax)
     const unsigned blocks = rt_red_blocks(ctx->n);
     RT_CONSUMER_BEGIN(ctx);
     hipLaunchKernelGGL(rt_r2max_kernel, dim3(blocks), dim3(RT_RED_THREADS), 0,
-                       ctx->stream, rt_row(ctx, RT_Y, surf), ctx->n, ctx->ld,
+                       ctx->stream, rt_row(ctx, RT_Y, surf), ctx->n, rt_pitch_of(ctx),
                        ctx->d_partials);
     hipLaunchKernelGGL(rt_r2max_finish_kernel, dim3(1), dim3(64), 0,
                        ctx->stream, ctx->d_partials, (int)blocks, ctx->h_res);
@@ -303,11 +310,12 @@ int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
     const dim3 fgrid((unsigned)ngroups), fblock(64); /* a wavefront each */
     RT_CONSUMER_BEGIN(ctx);
     hipLaunchKernelGGL(rt_group_sums_kernel, grid, block, 0, ctx->stream, Yrow,
-                       ctx->d_w, group_rays, ctx->ld, partials);
+                       ctx->d_w, group_rays, rt_pitch_of(ctx), partials);
     hipLaunchKernelGGL(rt_group_centroid_kernel, fgrid, fblock, 0, ctx->stream,
                        partials, (int)pb, ngroups, stats);
     hipLaunchKernelGGL(rt_group_spread_kernel, grid, block, 0, ctx->stream,
-                       Yrow, ctx->d_w, group_rays, ctx->ld, stats, partials);
+                       Yrow, ctx->d_w, group_rays, rt_pitch_of(ctx), stats,
+                       partials);
     hipLaunchKernelGGL(rt_group_finish_kernel, fgrid, fblock, 0, ctx->stream,
                        partials, (int)pb, ngroups, stats, final);
     RT_CONSUMER_END(ctx);
@@ -337,7 +345,7 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
         if (ctx->d_w) {
             hipLaunchKernelGGL(rt_refocus_shifted_kernel<true>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
-                               Irow, ctx->d_w, ctx->n, ctx->ld,
+                               Irow, ctx->d_w, ctx->n, rt_pitch_of(ctx),
                                ctx->d_partials);
             hipLaunchKernelGGL(rt_refocus_finish_kernel<true>, dim3(1),
                                dim3(64), 0, ctx->stream, ctx->d_partials,
@@ -345,7 +353,7 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
         } else {
             hipLaunchKernelGGL(rt_refocus_shifted_kernel<false>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
-                               Irow, ctx->d_w, ctx->n, ctx->ld,
+                               Irow, ctx->d_w, ctx->n, rt_pitch_of(ctx),
                                ctx->d_partials);
             hipLaunchKernelGGL(rt_refocus_finish_kernel<false>, dim3(1),
                                dim3(64), 0, ctx->stream, ctx->d_partials,
@@ -366,13 +374,13 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
     RT_CONSUMER_BEGIN(ctx);
     hipLaunchKernelGGL(rt_refocus_sums_kernel, dim3(blocks),
                        dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow, ctx->n,
-                       ctx->ld, ctx->d_partials);
+                       rt_pitch_of(ctx), ctx->d_partials);
     hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
                        ctx->d_partials, (int)blocks, 5, rt_reduced(ctx, 0));
     hipLaunchKernelGGL(rt_refocus_dots_kernel, dim3(blocks),
                        dim3(RT_RED_THREADS), 0, ctx->stream, Yrow, Irow,
                        ctx->d_w, 1. / (double)ctx->n, rt_reduced(ctx, 0),
-                       ctx->n, ctx->ld, ctx->d_partials);
+                       ctx->n, rt_pitch_of(ctx), ctx->d_partials);
     hipLaunchKernelGGL(rt_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream,
                        ctx->d_partials, (int)blocks, 2, ctx->h_res);
     RT_CONSUMER_END(ctx);
@@ -434,7 +442,7 @@ int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa)
     RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
     hipLaunchKernelGGL(rt_opd_kernel, dim3(grid), dim3(256), 0, ctx->stream,
                        *args, ctx->d_opd_ref, rt_arr(ctx, RT_Y),
-                       rt_arr(ctx, RT_U), rt_arr(ctx, RT_T), ctx->n, ctx->ld,
+                       rt_arr(ctx, RT_U), rt_arr(ctx, RT_T), ctx->n, rt_pitch_of(ctx),
                        (double *)ctx->d_scratch);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));

@@ -89,6 +89,12 @@ struct rt_lab {
  * Where the result arrays live (rt_place.h): pieces of device memory whose
  * "class" was measured, mapped behind one address range in an even mix.
  */
+/* batches whose planes pass RT_BLOCK_ONE bytes are cut into blocks of about
+ * RT_BLOCK_BYTES (rt_lay.h; measured: one block is fine up to 10.4 GB, the
+ * knee begins at 11.4; blocks of 8.7 GB reach what separate batches reach) */
+#define RT_BLOCK_ONE 11.0e9
+#define RT_BLOCK_BYTES 9.0e9
+
 #define RT_PLACE_CLASSES 4
 struct rt_place {
     void *base;      /* the mapped range (= d_buf), NULL: plain hipMalloc */
@@ -143,6 +149,11 @@ struct rt_ctx {
     double *d_buf; /* Y | U | I | T */
     size_t cap_doubles;
     int64_t n, ld;
+    /* the batch in blocks (rt_lay.h): ld = nblk * bs ray slots, rows bs
+     * doubles apart, bts doubles from block to block (0: one block, bs = ld) */
+    int64_t bs, bts;
+    int nblk;
+    int opt_block; /* rays per block asked for (0: chosen by rt_reserve) */
     int buf_nsurf; /* L the buffer is laid out for */
 
     void *d_scratch;
@@ -256,8 +267,8 @@ extern "C" RT_INTERNAL int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...);
 
 static inline double *rt_arr(const rt_ctx *c, int which)
 {
-    /* Y,U,I are [L][3][ld]; T is [L][ld] */
-    const size_t plane = (size_t)c->buf_nsurf * 3 * (size_t)c->ld;
+    /* block 0: Y,U,I are [L][3][bs]; T is [L][bs] */
+    const size_t plane = (size_t)c->buf_nsurf * 3 * (size_t)c->bs;
 #ifdef RT_BUILD_PROBES
     if (c->lab.t_before_i) { /* Y | U | T | I: the written planes together */
         const size_t off = which == RT_T ? 2 * plane
@@ -277,6 +288,7 @@ static inline int rt_ncomp(int which) { return which == RT_T ? 1 : 3; }
 static inline rt_lay rt_layout(const rt_ctx *c)
 {
     rt_lay a;
+    a.j0 = 0;
 #ifdef RT_BUILD_PROBES
     if (c->lab.tile && c->lab.tile_planes) {
         /* [tile][Y U I: [L][3][TR] | T: [L][TR]]: a tile is a batch of TR
@@ -290,8 +302,8 @@ static inline rt_lay rt_layout(const rt_ctx *c)
         a.cs = pitch;
         a.ss = 3 * pitch;
         a.ssT = pitch;
+        a.bs = tr;
         a.ts = 10 * lp;
-        a.tshift = __builtin_ctzll((unsigned long long)tr);
         return a;
     }
     if (c->lab.tile) { /* [tile][L][10][TR] */
@@ -302,20 +314,20 @@ static inline rt_lay rt_layout(const rt_ctx *c)
         a.T = c->d_buf + 9 * tr;
         a.cs = tr;
         a.ss = a.ssT = 10 * tr;
+        a.bs = tr;
         a.ts = (int64_t)c->buf_nsurf * 10 * tr;
-        a.tshift = __builtin_ctzll((unsigned long long)tr);
         return a;
     }
-    a.tshift = 8;
-    a.ts = 256;
 #endif
     a.Y = rt_arr(c, RT_Y);
     a.U = rt_arr(c, RT_U);
     a.I = rt_arr(c, RT_I);
     a.T = rt_arr(c, RT_T);
-    a.cs = c->ld;
-    a.ss = 3 * c->ld;
-    a.ssT = c->ld;
+    a.cs = c->bs;
+    a.ss = 3 * c->bs;
+    a.ssT = c->bs;
+    a.bs = c->bs;
+    a.ts = c->bts;
     return a;
 }
 
@@ -341,8 +353,30 @@ static inline double *rt_row(const rt_ctx *c, int which, int surf)
     if (which == RT_U && c->u_alias[surf])
         return rt_row(c, RT_I, surf); /* surf >= 1, and I[surf] never points
                                          back at U[surf] there */
-    return rt_arr(c, which) + (size_t)surf * rt_ncomp(which) * c->ld;
+    return rt_arr(c, which) + (size_t)surf * rt_ncomp(which) * c->bs;
 }
+
+/* the rays [lo, hi) of a row as contiguous segments, block by block:
+ * for (rt_seg s = rt_seg_first(c, lo, hi); s.cnt; s = rt_seg_next(c, s, hi))
+ * -- s.off doubles from the row's start in block 0, s.ray the first ray */
+struct rt_seg {
+    int64_t ray, cnt, off;
+};
+
+static inline rt_seg rt_seg_at(const rt_ctx *c, int64_t ray, int64_t hi)
+{
+    rt_seg s = {ray, 0, 0};
+    if (ray >= hi)
+        return s;
+    const int64_t b = c->bts ? ray / c->bs : 0;
+    const int64_t end = c->bts ? (b + 1) * c->bs : hi;
+    s.cnt = (end < hi ? end : hi) - ray;
+    s.off = rt_block_col(c->bs, c->bts, ray);
+    return s;
+}
+#define RT_FOR_SEGMENTS(c, s, lo, hi)                                       \
+    for (rt_seg s = rt_seg_at(c, lo, hi); s.cnt;                            \
+         s = rt_seg_at(c, s.ray + s.cnt, hi))
 
 extern "C" { /* (linkage only: none of these is exported) */
 /* rt_engine.hip */

@@ -65,8 +65,11 @@ int rt_detach(rt_ctx *c, int which, int surf)
     const double *src = rt_row(c, which, surf);
     alias[surf] = 0;
     double *dst = rt_row(c, which, surf);
-    RT_HIP(c, hipMemcpyAsync(dst, src, (size_t)3 * c->ld * sizeof(double),
-                             hipMemcpyDeviceToDevice, c->stream));
+    for (int b = 0; b < c->nblk; ++b) /* the three components, block by block */
+        RT_HIP(c, hipMemcpyAsync(dst + (size_t)b * c->bts,
+                                 src + (size_t)b * c->bts,
+                                 (size_t)3 * c->bs * sizeof(double),
+                                 hipMemcpyDeviceToDevice, c->stream));
     return RT_OK;
 }
 
@@ -262,6 +265,14 @@ int rt_create(int device, rt_ctx **out)
     c->opt_resident = -1;
     c->opt_range = 1;
     c->opt_onepass = 1;
+    {
+        /* RT_MI355_BLOCK_RAYS=B: every batch of more than B rays is cut into
+         * blocks of B (tests: the whole suite on a batch in blocks) */
+        const char *e = getenv("RT_MI355_BLOCK_RAYS");
+        c->opt_block = e ? atoi(e) : 0;
+        if (c->opt_block < 0)
+            c->opt_block = 0;
+    }
     {
         const char *e = getenv("RT_MI355_PLACEMENT");
         c->opt_place = (e && !atoi(e)) ? 0 : 1;
@@ -467,8 +478,30 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
         return rt_fail(ctx, RT_ERR_STATE,
                        "rt_reserve: rt_upload_system must come first");
     const int64_t quantum = rt_ld_quantum(ctx);
-    const int64_t ld = (nrays + quantum - 1) / quantum * quantum;
-    if (ld == ctx->ld && ctx->buf_nsurf == ctx->nsurf && ctx->d_buf) {
+    /* one block (the documented layout) as long as the planes of the batch
+     * stay below RT_BLOCK_ONE bytes; above it blocks of ~RT_BLOCK_BYTES, all
+     * of the same whole number of 256-ray workgroups (rt_lay.h) */
+    int64_t bs = (nrays + quantum - 1) / quantum * quantum;
+    int nblk = 1;
+    {
+        const double per_ray = 80. * ctx->nsurf;
+        int64_t want = 1; /* blocks asked for */
+        if (quantum != 64)
+            want = 1; /* a laboratory layout has the arrays */
+        else if (ctx->opt_block > 0)
+            want = (nrays + ctx->opt_block - 1) / ctx->opt_block;
+        else if (per_ray * (double)nrays > RT_BLOCK_ONE)
+            want = (int64_t)ceil(per_ray * (double)nrays / RT_BLOCK_BYTES);
+        if (want > 1) {
+            bs = ((nrays + want - 1) / want + RT_CB - 1) / RT_CB * RT_CB;
+            nblk = (int)((nrays + bs - 1) / bs);
+            if (nblk < 2) /* (rounding up to whole workgroups ate a block) */
+                bs = (nrays + quantum - 1) / quantum * quantum, nblk = 1;
+        }
+    }
+    const int64_t ld = bs * nblk;
+    if (ld == ctx->ld && bs == ctx->bs && ctx->buf_nsurf == ctx->nsurf &&
+        ctx->d_buf) {
         if (nrays != ctx->n) {
             ctx->gen_live = 0;
             ctx->uni_valid = 0;
@@ -502,6 +535,9 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
          * a failed allocation must not leave the old sizes without a buffer */
         ctx->n = 0;
         ctx->ld = 0;
+        ctx->bs = 0;
+        ctx->nblk = 0;
+        ctx->bts = 0;
         ctx->traced = 0;
         memset(ctx->valid, 0, sizeof ctx->valid);
         if (ctx->d_buf)
@@ -529,9 +565,13 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
                               rt_tiles_bytes(tiles)));
         ctx->uni_cap = tiles;
     }
-    const bool fresh = ctx->ld != ld || ctx->buf_nsurf != ctx->nsurf;
+    const bool fresh = ctx->ld != ld || ctx->bs != bs ||
+                       ctx->buf_nsurf != ctx->nsurf;
     ctx->n = nrays;
     ctx->ld = ld;
+    ctx->bs = bs;
+    ctx->nblk = nblk;
+    ctx->bts = nblk > 1 ? (int64_t)10 * ctx->nsurf * bs : 0;
     ctx->buf_nsurf = ctx->nsurf;
     ctx->traced = 0;
     /* placed arrays in a new layout: measure the store pattern over them
@@ -548,6 +588,16 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
 
 int64_t rt_nrays(const rt_ctx *ctx) { return ctx ? ctx->n : 0; }
 int64_t rt_ld(const rt_ctx *ctx) { return ctx ? ctx->ld : 0; }
+
+int rt_blocks(const rt_ctx *ctx, int64_t info[3])
+{
+    if (!ctx || !info)
+        return RT_ERR_ARG;
+    info[0] = ctx->nblk;
+    info[1] = ctx->bs;
+    info[2] = ctx->bts;
+    return RT_OK;
+}
 int rt_nsurf(const rt_ctx *ctx) { return ctx ? ctx->nsurf : 0; }
 
 int rt_need_scratch(rt_ctx *ctx, size_t bytes)
@@ -760,18 +810,24 @@ static int rt_rows_to_host(rt_ctx *ctx, double *dst, const double *src,
                            size_t nrow)
 {
     const size_t rb = (size_t)ctx->n * sizeof(double);
-    if (ctx->ld == ctx->n) /* no padding: one contiguous block */
+    if (ctx->ld == ctx->n && ctx->nblk == 1) /* no padding: one contiguous block */
         return rt_d2h(ctx, dst, src, rb * nrow);
-    if (rb >= RT_PIN_CHUNK / 8) {
-        for (size_t r = 0; r < nrow; ++r) {
-            int rc = rt_d2h(ctx, dst + r * ctx->n, src + r * ctx->ld, rb);
-            if (rc != RT_OK)
-                return rc;
+    /* segment by segment (one per block of the batch) */
+    RT_FOR_SEGMENTS(ctx, g, 0, ctx->n) {
+        const size_t sb = (size_t)g.cnt * sizeof(double);
+        if (sb >= RT_PIN_CHUNK / 8) {
+            for (size_t r = 0; r < nrow; ++r) {
+                int rc = rt_d2h(ctx, dst + r * ctx->n + g.ray,
+                                src + r * ctx->bs + g.off, sb);
+                if (rc != RT_OK)
+                    return rc;
+            }
+        } else {
+            RT_HIP(ctx, hipMemcpy2DAsync(dst + g.ray, rb, src + g.off,
+                                         ctx->bs * sizeof(double), sb, nrow,
+                                         hipMemcpyDeviceToHost, ctx->stream));
         }
-        return RT_OK;
     }
-    RT_HIP(ctx, hipMemcpy2DAsync(dst, rb, src, ctx->ld * sizeof(double), rb,
-                                 nrow, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -929,10 +985,11 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
         ctx->u_alias[surf] = 0;
     ctx->valid[surf] = 1;
     double *dst = rt_row(ctx, which, surf);
-    RT_HIP(ctx, hipMemcpy2DAsync(dst, ctx->ld * sizeof(double), src_soa,
-                                 ctx->n * sizeof(double),
-                                 ctx->n * sizeof(double), nc,
-                                 hipMemcpyHostToDevice, ctx->stream));
+    RT_FOR_SEGMENTS(ctx, g, 0, ctx->n)
+        RT_HIP(ctx, hipMemcpy2DAsync(dst + g.off, ctx->bs * sizeof(double),
+                                     src_soa + g.ray, ctx->n * sizeof(double),
+                                     (size_t)g.cnt * sizeof(double), nc,
+                                     hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -1099,28 +1156,11 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
     if (lo == 0)
         RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
     ctx->last_compact = 0;
-    /* the window as the kernels see it: the arrays shifted by `lo` columns,
-     * `cols` columns long (the last window takes the padding up to ld) */
+    /* the window as the kernels see it: rays lo + (0 .. cols) (the last
+     * window takes the padding slots up to ld); the arrays stay where they
+     * are, rt_col adds j0 (a window may begin anywhere in any block) */
     rt_lay lay = rt_layout(ctx);
-#ifdef RT_BUILD_PROBES
-    if (ctx->lab.tile) {
-        /* a tile layout: windows are whole tiles, the arrays are shifted by
-         * tiles (laboratory: one launch per block of a super-blocked SoA) */
-        if (lo % ctx->lab.tile)
-            return rt_fail(ctx, RT_ERR_ARG,
-                           "rt_trace_chunk in a tile layout: pieces must "
-                           "begin on tile boundaries");
-        const int64_t shift = lo / ctx->lab.tile * lay.ts;
-        lay.Y += shift - lo; /* (the common shift by lo follows) */
-        lay.U += shift - lo;
-        lay.I += shift - lo;
-        lay.T += shift - lo;
-    }
-#endif
-    lay.Y += lo;
-    lay.U += lo;
-    lay.I += lo;
-    lay.T += lo;
+    lay.j0 = lo;
     /* an empty trailing piece (lo == hi == n) launches nothing: the padding
      * columns belong to the last NON-empty piece */
     const int64_t cols = lo < hi ? (hi == ctx->n ? ctx->ld : hi) - lo : 0;
@@ -1300,6 +1340,12 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
         ctx->opt_range = value ? 1 : 0;
     } else if (!strcmp(key, "uniform_input")) {
         ctx->opt_uniform = value ? 1 : 0;
+    } else if (!strcmp(key, "block_rays")) {
+        /* takes effect with the next rt_reserve / rt_set_rays */
+        if (value < 0)
+            return rt_fail(ctx, RT_ERR_ARG, "block_rays: 0 (automatic) or a "
+                                            "number of rays");
+        ctx->opt_block = value;
     } else if (!strcmp(key, "consumers_one_pass")) {
         ctx->opt_onepass = value ? 1 : 0;
     } else if (!strcmp(key, "consumer_events")) {
@@ -1395,8 +1441,9 @@ int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
             continue;
         }
         RT_HIP(ctx, hipMemcpy2DAsync(dst + (size_t)j * nc, sizeof(double),
-                                     rt_row(ctx, which, j) + ray,
-                                     ctx->ld * sizeof(double), sizeof(double),
+                                     rt_row(ctx, which, j) +
+                                         rt_block_col(ctx->bs, ctx->bts, ray),
+                                     ctx->bs * sizeof(double), sizeof(double),
                                      nc, hipMemcpyDeviceToHost, ctx->stream));
     }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));

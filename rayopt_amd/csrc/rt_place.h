@@ -391,10 +391,11 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
 __global__ __launch_bounds__(256) void rt_place_rows_kernel(rt_lay a, int L,
                                                             long long n)
 {
-    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n)
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n)
         return;
-    const double v = 1e-9 * (double)r;
+    const double v = 1e-9 * (double)j;
+    const long long r = rt_col(a, j);
     for (int s = 1; s < L; ++s) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

@@ -78,7 +78,7 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
         /* ray groups with their own surface table (one wavelength each):
          * group boundaries are multiples of 64 rays, so the group -- and
          * with it every table read -- stays wave-uniform (SGPRs) */
-        const int64_t j0 = j - (int64_t)(threadIdx.x & 63);
+        const int64_t j0 = a.j0 + j - (int64_t)(threadIdx.x & 63);
         const int g = __builtin_amdgcn_readfirstlane((int)(j0 / group_rays));
         surf += (int64_t)g * nsurf;
     }
@@ -197,8 +197,8 @@ rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
     if (group_rays) /* a tile never straddles two groups (host checks) */
         surf += (tile0 / group_rays) * nsurf;
     /* SoA (the only layout this kernel is launched for): the tile's columns
-     * are consecutive */
-    const int64_t col0 = tile0;
+     * are consecutive -- blocks are whole tiles (rt_reserve) */
+    const int64_t col0 = rt_col(a, tile0);
     const bool exists = tile0 + tid < ld;
     bool has = exists;
     int idx = tid; /* the ray's column inside the tile */

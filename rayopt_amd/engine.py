@@ -76,6 +76,14 @@ class Engine:
     def ld(self):
         return int(self.lib.rt_ld(self.ctx))
 
+    def blocks(self):
+        """(blocks, rays per block = row pitch, doubles between blocks): how
+        a large batch is cut up on the device (rt_blocks); (1, ld, 0) for
+        the plain layout."""
+        info = (ctypes.c_int64*3)()
+        self._check(self.lib.rt_blocks(self.ctx, info), "rt_blocks")
+        return int(info[0]), int(info[1]), int(info[2])
+
     def set_rays(self, y, u):
         """Seed row 0 from host arrays, (N,3) ray-major or (3,N) via
         ``set_rays_soa``."""
