@@ -34,8 +34,8 @@
  *      element (array, s, c) of ray j = base[array] + (j / bs) bts
  *                                       + (s 3 + c) bs + j % bs
  *
- * One block (nblk = 1: every batch whose arrays stay below ~11 GB, i.e. up
- * to 1.05e7 rays through 13 elements) is the plain layout.  Rows further
+ * One block (nblk = 1: every batch whose arrays stay below 8.5 GB, i.e. up
+ * to 8.1e6 rays through 13 elements) is the plain layout.  Rows further
  * apart than that are written more slowly (the device's address translation
  * falls behind streams that reach over more than ~10 one-GiB regions); see
  * csrc/rt_lay.h.  rt_download / rt_upload_row / the reductions / the gather
@@ -391,7 +391,7 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * roots run without the compiler's range scaffolding where the operands are
  * checked to be inside [2^-100, 2^100] -- the same bits from a third fewer
  * instructions, RT_F_RANGE; 0 = the compiler's sequences everywhere),
- * "block_rays" (0 = default: large batches are cut into blocks of ~9 GB, see
+ * "block_rays" (0 = default: large batches are cut into blocks of <= 7 GB, see
  * the layout above; B > 0: every batch of more than B rays is cut into
  * blocks of about B rays -- for tests; RT_MI355_BLOCK_RAYS=B does the same
  * for every context of the process; takes effect with the next rt_reserve),

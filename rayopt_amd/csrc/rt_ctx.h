@@ -89,11 +89,13 @@ struct rt_lab {
  * Where the result arrays live (rt_place.h): pieces of device memory whose
  * "class" was measured, mapped behind one address range in an even mix.
  */
-/* batches whose planes pass RT_BLOCK_ONE bytes are cut into blocks of about
- * RT_BLOCK_BYTES (rt_lay.h; measured: one block is fine up to 10.4 GB, the
- * knee begins at 11.4; blocks of 8.7 GB reach what separate batches reach) */
-#define RT_BLOCK_ONE 11.0e9
-#define RT_BLOCK_BYTES 9.0e9
+/* batches whose planes pass RT_BLOCK_ONE bytes are cut into blocks of at most
+ * RT_BLOCK_BYTES (rt_lay.h).  Measured (C3, per 10^7 rays): one block of
+ * 8.7 GB 0.978 ms = two of 4.4; one block of 10.4 GB (10^7 rays) 1.007, two
+ * of 5.2 GB 0.994; one of 20.8 GB 1.18-1.19, three of 6.9 GB 0.96-1.07;
+ * blocks of 5.2 ... 8.7 GB all alike */
+#define RT_BLOCK_ONE 8.5e9
+#define RT_BLOCK_BYTES 7.0e9
 
 #define RT_PLACE_CLASSES 4
 struct rt_place {

@@ -6,7 +6,7 @@
  * and a ray's column is its index j.
  *
  * A batch whose rows would lie too far apart is cut into BLOCKS of bs rays
- * (rt_reserve: above ~1.06*10^7 rays for 13 elements), every block with its
+ * (rt_reserve: above 8.1*10^6 rays for 13 elements), every block with its
  * own Y | U | I | T planes in that same layout, bs the distance between
  * rows, ts doubles from one block to the next:
  *     element (array, s, c) of ray j  =

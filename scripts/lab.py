@@ -393,7 +393,7 @@ def cmd_nsweep(a):
         res = measure(eng, lambda: g.propagate(clip=True))
         alg = m*nf*(56*12 + 16)
         out(shape="C3 built on the device", rays=m*nf,
-            placement=eng.placement(), ms=res,
+            blocks=eng.blocks(), placement=eng.placement(), ms=res,
             frac_auto=alg/(res["-1"]*1e-3)/8e12)
         if n <= 10_000_000:
             y, u = workload_rays(n, 0)

@@ -174,18 +174,19 @@ def test_reductions_in_blocks(n, block):
 
 
 def test_the_automatic_choice():
-    """One block up to ~11 GB of planes; above it blocks of ~9 GB, whole
-    256-ray workgroups each.  (Sizes only: nothing is traced.)"""
+    """One block up to 8.5 GB of planes; above it blocks of at most 7 GB,
+    whole 256-ray workgroups each.  (Sizes only: nothing is traced.)"""
     system = ra.system_from_yaml(P.DOUBLE_GAUSS)          # 13 elements
     eng = ra.Engine()
+    eng.set_option("block_rays", 0)       # automatic, whatever the environment
     g = ra.GeometricTrace(system, engine=eng)
     y, u = disc_bundle(1000, 12., 0., 1, P.DOUBLE_GAUSS_PUPIL_Z)
     g.rays_given(y, u)                                    # uploads the table
-    for n, blocks in ((10_000_000, 1), (10_500_000, 1), (12_500_000, 2),
-                      (20_000_000, 3), (30_000_000, 4)):
+    for n, blocks in ((3_000_000, 1), (8_000_000, 1), (10_000_000, 2),
+                      (12_500_000, 2), (20_000_000, 3), (30_000_000, 5)):
         eng.reserve(n)
         nb, bs, bts = eng.blocks()
         assert nb == blocks, (n, nb)
         assert nb*bs >= n and (nb == 1 or bs % 256 == 0)
-        assert nb == 1 or 80*13*bs <= 9.1e9
+        assert nb == 1 or 80*13*bs <= 7.1e9
     eng.close()
