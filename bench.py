@@ -1589,9 +1589,9 @@ def run_configs(ra, device, args):
             np.isfinite(ulast).mean())
         del g
         # the same rays as TEN batches of a tenth each, ten contexts traced
-        # in turn: above ~1.1*10^7 rays the 84 concurrent row streams of one
-        # batch cover more than 8 GiB of addresses and the trace slows
-        # (DESIGN.md section 9); batches below that do not, however many
+        # in turn: the cross-check of the layout in blocks (csrc/rt_lay.h) --
+        # as ONE block this batch took 12.0 ms, the ten batches 10.3
+        # (DESIGN.md section 9); in blocks the two agree
         try:
             parts = 10
             mk = m//parts//64*64

@@ -1,12 +1,12 @@
-"""A job bigger than one batch should be: 3*10^7 rays (five field bundles of
-a double Gauss) traced as batches of 10^7 rays, one GeometricTrace each.
+"""A job traced as several batches: 3*10^7 rays (five field bundles of a
+double Gauss) as batches of 10^7 rays, one GeometricTrace each -- e.g. because
+the rays arrive in portions, or to keep a batch's host arrays small.  Each
+batch is an ordinary trace; the per-field statistics of the job are the
+ray-count-weighted combination of the batches' (parallel-axis theorem).
 
-Above ~1.1*10^7 rays the 84 row streams one batch of this 13-element system
-writes at once lie so far apart that the device's address translation no
-longer keeps up: 10^8 rays as ONE batch take 12.0 ms per
-trace, as TEN batches traced in turn 10.25 ms.  Nothing else changes: each
-batch is an ordinary trace, the per-field statistics of the job are the
-ray-count-weighted combination of the batches'.
+(Speed is no reason any more: the engine lays a big batch out in blocks
+itself, csrc/rt_lay.h -- 10^8 rays as one batch 10.4 ms per trace, as ten
+batches traced in turn 10.4 ms.  Before that layout one batch took 12.0 ms.)
 
     python examples/big_job_in_batches.py [total_rays] [rays_per_batch]
 """

@@ -424,10 +424,9 @@ def test_optimiser_as_caller():
 
 
 def test_big_job_in_batches_example():
-    """examples/big_job_in_batches.py: a job traced as several batches (what
-    DESIGN.md section 9 recommends above 10^7 rays per batch); the per-field
-    statistics combined from the batches are those of the same rays traced
-    as one batch."""
+    """examples/big_job_in_batches.py: a job traced as several batches; the
+    per-field statistics combined from the batches are those of the same
+    rays traced as one batch."""
     import importlib.util
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(
