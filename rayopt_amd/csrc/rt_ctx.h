@@ -358,6 +358,37 @@ static inline double *rt_row(const rt_ctx *c, int which, int surf)
     return rt_arr(c, which) + (size_t)surf * rt_ncomp(which) * c->bs;
 }
 
+/*
+ * How rt_reserve cuts a batch of nrays rays through nsurf elements: one block
+ * (the documented layout, rows `quantum`-padded) as long as the planes of the
+ * batch stay below RT_BLOCK_ONE bytes; above it the fewest blocks of at most
+ * RT_BLOCK_BYTES, all of the same whole number of 256-ray workgroups
+ * (rt_lay.h).  opt_block > 0: blocks of about that many rays instead (tests).
+ * A laboratory layout (quantum != 64) has the arrays to itself.
+ */
+static inline void rt_block_plan(int nsurf, int64_t opt_block, int64_t quantum,
+                                 int64_t nrays, int64_t *bs, int *nblk)
+{
+    *bs = (nrays + quantum - 1) / quantum * quantum;
+    *nblk = 1;
+    const double bytes = 80. * nsurf * (double)nrays;
+    int64_t want = 1; /* blocks asked for */
+    if (quantum != 64)
+        want = 1;
+    else if (opt_block > 0)
+        want = (nrays + opt_block - 1) / opt_block;
+    else if (bytes > RT_BLOCK_ONE)
+        want = (int64_t)ceil(bytes / RT_BLOCK_BYTES);
+    if (want > 1) {
+        const int64_t b = ((nrays + want - 1) / want + 255) / 256 * 256;
+        const int64_t k = (nrays + b - 1) / b;
+        if (k >= 2) { /* (else rounding up to whole workgroups ate a block) */
+            *bs = b;
+            *nblk = (int)k;
+        }
+    }
+}
+
 /* the rays [lo, hi) of a row as contiguous segments, block by block:
  * for (rt_seg s = rt_seg_first(c, lo, hi); s.cnt; s = rt_seg_next(c, s, hi))
  * -- s.off doubles from the row's start in block 0, s.ray the first ray */

@@ -470,6 +470,9 @@ int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf)
     return rt_upload_system_groups(ctx, surf, nsurf, 1);
 }
 
+static_assert(RT_BLOCK == 256 && RT_CB == 256,
+              "rt_block_plan cuts batches into whole 256-ray workgroups");
+
 int rt_reserve(rt_ctx *ctx, int64_t nrays)
 {
     if (!ctx || nrays < 1)
@@ -478,27 +481,9 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
         return rt_fail(ctx, RT_ERR_STATE,
                        "rt_reserve: rt_upload_system must come first");
     const int64_t quantum = rt_ld_quantum(ctx);
-    /* one block (the documented layout) as long as the planes of the batch
-     * stay below RT_BLOCK_ONE bytes; above it blocks of ~RT_BLOCK_BYTES, all
-     * of the same whole number of 256-ray workgroups (rt_lay.h) */
-    int64_t bs = (nrays + quantum - 1) / quantum * quantum;
-    int nblk = 1;
-    {
-        const double per_ray = 80. * ctx->nsurf;
-        int64_t want = 1; /* blocks asked for */
-        if (quantum != 64)
-            want = 1; /* a laboratory layout has the arrays */
-        else if (ctx->opt_block > 0)
-            want = (nrays + ctx->opt_block - 1) / ctx->opt_block;
-        else if (per_ray * (double)nrays > RT_BLOCK_ONE)
-            want = (int64_t)ceil(per_ray * (double)nrays / RT_BLOCK_BYTES);
-        if (want > 1) {
-            bs = ((nrays + want - 1) / want + RT_CB - 1) / RT_CB * RT_CB;
-            nblk = (int)((nrays + bs - 1) / bs);
-            if (nblk < 2) /* (rounding up to whole workgroups ate a block) */
-                bs = (nrays + quantum - 1) / quantum * quantum, nblk = 1;
-        }
-    }
+    int64_t bs;
+    int nblk;
+    rt_block_plan(ctx->nsurf, ctx->opt_block, quantum, nrays, &bs, &nblk);
     const int64_t ld = bs * nblk;
     if (ld == ctx->ld && bs == ctx->bs && ctx->buf_nsurf == ctx->nsurf &&
         ctx->d_buf) {

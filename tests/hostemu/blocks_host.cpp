@@ -1,0 +1,85 @@
+// Host-side check of the layout in blocks (csrc/rt_lay.h, rt_ctx.h): the
+// block plan of rt_reserve, the address of a ray, and the segments host-side
+// loops walk.  Compiled with hipcc, runs without a GPU.  Test infrastructure.
+#include "../../rayopt_amd/csrc/rt_ctx.h"
+#include <cstdio>
+#include <cstdlib>
+
+static long bad = 0;
+#define CHECK(c)                                                            \
+    do {                                                                    \
+        if (!(c)) {                                                         \
+            ++bad;                                                          \
+            if (bad < 20)                                                   \
+                printf("line %d: %s\n", __LINE__, #c);                      \
+        }                                                                   \
+    } while (0)
+
+int main()
+{
+    // the plan: expected block counts for 13 elements (1040 B per ray)
+    struct { int64_t n; int blocks; } want[] = {
+        {1, 1}, {64, 1}, {8000000, 1}, {8173076, 1}, {8173077, 2},
+        {10000000, 2}, {12500000, 2}, {13461538, 2}, {13461539, 3},
+        {20000000, 3}, {30000000, 5}, {100000000, 15}, {1000000000, 149}};
+    for (auto w : want) {
+        int64_t bs;
+        int nb;
+        rt_block_plan(13, 0, 64, w.n, &bs, &nb);
+        CHECK(nb == w.blocks);
+        CHECK(bs * nb >= w.n);
+        CHECK(nb == 1 ? bs % 64 == 0 && bs - w.n < 64
+                      : bs % 256 == 0 && bs * (nb - 1) < w.n);
+        CHECK(nb == 1 || 1040. * bs <= 7.0e9 + 1040. * 256);
+    }
+    // forced block sizes, every n: whole workgroups, no empty block
+    srand(7);
+    for (int t = 0; t < 200000; ++t) {
+        const int64_t n = 1 + rand() % 300000, b = 1 + rand() % 70000;
+        int64_t bs;
+        int nb;
+        rt_block_plan(2 + rand() % 255, b, 64, n, &bs, &nb);
+        CHECK(bs * nb >= n && bs * (nb - 1) < n);
+        CHECK(nb == 1 ? bs % 64 == 0 : bs % 256 == 0);
+        CHECK(nb == 1 || nb <= (n + b - 1) / b);
+        // a laboratory layout keeps one block
+        rt_block_plan(13, b, 4096, n, &bs, &nb);
+        CHECK(nb == 1 && bs % 4096 == 0 && bs >= n);
+    }
+    // addresses and segments
+    rt_ctx *c = (rt_ctx *)calloc(1, sizeof(rt_ctx));
+    for (int t = 0; t < 20000; ++t) {
+        const int L = 2 + rand() % 20;
+        const int64_t n = 1 + rand() % 200000;
+        int64_t bs;
+        int nb;
+        rt_block_plan(L, rand() % 3 ? 1 + rand() % 50000 : 0, 64, n, &bs, &nb);
+        c->n = n;
+        c->bs = bs;
+        c->nblk = nb;
+        c->ld = bs * nb;
+        c->bts = nb > 1 ? (int64_t)10 * L * bs : 0;
+        int64_t lo = rand() % n, hi = lo + rand() % (n - lo + 1);
+        int64_t next = lo, count = 0;
+        RT_FOR_SEGMENTS(c, g, lo, hi) {
+            CHECK(g.ray == next && g.cnt > 0);
+            CHECK(g.off == rt_block_col(c->bs, c->bts, g.ray));
+            // contiguous inside the segment, and inside one block
+            CHECK(rt_block_col(c->bs, c->bts, g.ray + g.cnt - 1) ==
+                  g.off + g.cnt - 1);
+            CHECK(g.ray / bs == (g.ray + g.cnt - 1) / bs);
+            next = g.ray + g.cnt;
+            ++count;
+        }
+        CHECK(next == (lo < hi ? hi : lo));
+        CHECK(count <= nb);
+        // no two rays share an address; rows of a block do not overlap the next block
+        const int64_t j = rand() % n, k = rand() % n;
+        CHECK((rt_block_col(bs, c->bts, j) == rt_block_col(bs, c->bts, k)) == (j == k));
+        if (nb > 1)
+            CHECK(rt_block_col(bs, c->bts, j) % c->bts < bs);
+    }
+    free(c);
+    printf("blocks_host: %ld failures\n", bad);
+    return bad != 0;
+}
