@@ -287,10 +287,11 @@ static inline double *rt_arr(const rt_ctx *c, int which)
 static inline int rt_ncomp(int which) { return which == RT_T ? 1 : 3; }
 
 /* addressing of the result arrays as the kernels see it (rt_lay.h) */
-static inline rt_lay rt_layout(const rt_ctx *c)
+static inline rt_lay rt_layout_planes(const rt_ctx *c)
 {
     rt_lay a;
     a.j0 = 0;
+    a.wgs = a.wmagic = a.wshift = a.w0 = 0;
 #ifdef RT_BUILD_PROBES
     if (c->lab.tile && c->lab.tile_planes) {
         /* [tile][Y U I: [L][3][TR] | T: [L][TR]]: a tile is a batch of TR
@@ -330,6 +331,14 @@ static inline rt_lay rt_layout(const rt_ctx *c)
     a.ssT = c->bs;
     a.bs = c->bs;
     a.ts = c->bts;
+    return a;
+}
+
+/* ... of the whole batch (a window of it: rt_lay_set_window afterwards) */
+static inline rt_lay rt_layout(const rt_ctx *c)
+{
+    rt_lay a = rt_layout_planes(c);
+    rt_lay_set_window(a, 0, c->ld);
     return a;
 }
 

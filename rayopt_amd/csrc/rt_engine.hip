@@ -189,6 +189,16 @@ static bool rt_in_range(double x)
     return a >= RT_RANGE_TINY && a <= 0x1p99; /* strictly inside the guard */
 }
 
+/* whatever replaces the launch rays, a row or the surface table ends a step
+ * that was being traced in pieces (rt_trace_chunk): the pieces traced so far
+ * belong to the old batch / table, and pieces of the new one must not count
+ * as the rest of the old step */
+static inline void rt_pieces_reset(rt_ctx *c)
+{
+    c->pieces_seen = c->pieces_total = 0;
+    memset(c->pieces_mask, 0, sizeof c->pieces_mask);
+}
+
 /* the compacting variant pays (one barrier per element) only where dead rays
  * are wasted FP64 issue, i.e. where rows are traced but not stored */
 static bool rt_use_compact(const rt_ctx *c, int start, int stop)
@@ -459,6 +469,17 @@ int rt_upload_system_groups(rt_ctx *ctx, const rt_surface *surf, int nsurf,
         return RT_OK;
     }
     memcpy(ctx->h_surf, surf, sizeof(rt_surface) * ntab);
+    /* the bits and the field the library fills in itself are the library's
+     * everywhere -- h_surf is read as it is by rt_aim_pupil and by the
+     * generation's first intercept, which never see the finalised table: a
+     * caller's stray RT_F_RANGE there would send sphere intercepts through
+     * rt_quot with rc = 0 */
+    for (size_t j = 0; j < ntab; ++j) {
+        ctx->h_surf[j].flags &= ~(RT_F_STORE_I | RT_F_NOSTORE | RT_F_SKIP_U |
+                                  RT_F_FAST | RT_F_RANGE);
+        ctx->h_surf[j].rc = 0.;
+    }
+    rt_pieces_reset(ctx); /* (an unchanged table returned above) */
     ctx->table_dirty = 1; /* finalised and sent by the next rt_trace */
     ctx->nsurf = nsurf;
     ctx->ngroups = ngroups;
@@ -470,7 +491,7 @@ int rt_upload_system(rt_ctx *ctx, const rt_surface *surf, int nsurf)
     return rt_upload_system_groups(ctx, surf, nsurf, 1);
 }
 
-static_assert(RT_BLOCK == 256 && RT_CB == 256,
+static_assert(RT_BLOCK == 256 && RT_CB == 256 && RT_LAY_WG == 256,
               "rt_block_plan cuts batches into whole 256-ray workgroups");
 
 int rt_reserve(rt_ctx *ctx, int64_t nrays)
@@ -485,6 +506,7 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     int nblk;
     rt_block_plan(ctx->nsurf, ctx->opt_block, quantum, nrays, &bs, &nblk);
     const int64_t ld = bs * nblk;
+    rt_pieces_reset(ctx);
     if (ld == ctx->ld && bs == ctx->bs && ctx->buf_nsurf == ctx->nsurf &&
         ctx->d_buf) {
         if (nrays != ctx->n) {
@@ -969,6 +991,7 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
     if (which == RT_U)
         ctx->u_alias[surf] = 0;
     ctx->valid[surf] = 1;
+    rt_pieces_reset(ctx); /* a step in pieces does not survive a new row */
     double *dst = rt_row(ctx, which, surf);
     RT_FOR_SEGMENTS(ctx, g, 0, ctx->n)
         RT_HIP(ctx, hipMemcpy2DAsync(dst + g.off, ctx->bs * sizeof(double),
@@ -1145,7 +1168,7 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
      * window takes the padding slots up to ld); the arrays stay where they
      * are, rt_col adds j0 (a window may begin anywhere in any block) */
     rt_lay lay = rt_layout(ctx);
-    lay.j0 = lo;
+    rt_lay_set_window(lay, lo, ctx->ld);
     /* an empty trailing piece (lo == hi == n) launches nothing: the padding
      * columns belong to the last NON-empty piece */
     const int64_t cols = lo < hi ? (hi == ctx->n ? ctx->ld : hi) - lo : 0;

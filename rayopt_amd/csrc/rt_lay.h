@@ -36,7 +36,41 @@ struct rt_lay {
     int64_t cs, ss, ssT;
     int64_t bs, ts; /* rays per block, doubles between blocks (0: one block) */
     int64_t j0;     /* first ray of the window the launch covers */
+    /* the block of a whole 256-ray workgroup without a division (rt_col_wg):
+     * blocks are whole workgroups and windows begin on workgroup borders, so
+     * the block index is one number per workgroup, w / wgs with w = the
+     * workgroup's index in the batch, formed on the scalar unit as
+     * (w * wmagic) >> wshift.  wgs = 0: not available (rt_col divides) */
+    uint32_t wgs, wmagic, wshift, w0;
 };
+
+#define RT_LAY_WG 256 /* rays per workgroup of the kernels that use rt_col_wg */
+
+/*
+ * Division of w < 2^24 by d <= 2^24 as a multiplication (Granlund &
+ * Montgomery 1994, theorem 4.2 with N = 24): l = ceil(log2 d),
+ * m = ceil(2^(24+l) / d) < 2^25, floor(w / d) = (w m) >> (24 + l).
+ * 2^32 rays (more than 288 GB hold) are 2^24 workgroups.
+ */
+__host__ __device__ inline void rt_lay_set_window(rt_lay &a, int64_t lo,
+                                                  int64_t ld)
+{
+    a.j0 = lo;
+    a.wgs = a.wmagic = a.wshift = a.w0 = 0;
+    if (!a.ts || a.bs % RT_LAY_WG || lo % RT_LAY_WG)
+        return;
+    const uint64_t d = (uint64_t)(a.bs / RT_LAY_WG);
+    const uint64_t wmax = (uint64_t)((ld + RT_LAY_WG - 1) / RT_LAY_WG);
+    if (d < 1 || d > ((uint64_t)1 << 24) || wmax >= ((uint64_t)1 << 24))
+        return;
+    uint32_t l = 0;
+    while (((uint64_t)1 << l) < d)
+        ++l;
+    a.wshift = 24 + l;
+    a.wmagic = (uint32_t)((((uint64_t)1 << a.wshift) + d - 1) / d);
+    a.wgs = (uint32_t)d;
+    a.w0 = (uint32_t)(lo / RT_LAY_WG);
+}
 
 /* where ray j of a row lies relative to the row's start in block 0 */
 __host__ __device__ __forceinline__ int64_t rt_block_col(int64_t bs, int64_t ts,
@@ -51,6 +85,27 @@ __host__ __device__ __forceinline__ int64_t rt_block_col(int64_t bs, int64_t ts,
 __device__ __forceinline__ int64_t rt_col(const rt_lay &a, int64_t j)
 {
     return rt_block_col(a.bs, a.ts, j + a.j0);
+}
+
+/* the block of workgroup `wg` of the launch (its index in the batch: + w0) */
+__host__ __device__ __forceinline__ uint64_t rt_wg_block(const rt_lay &a,
+                                                         uint32_t wg)
+{
+    return ((uint64_t)(wg + a.w0) * a.wmagic) >> a.wshift;
+}
+
+/* rt_col for kernels whose workgroups are RT_LAY_WG consecutive rays, wg =
+ * blockIdx.x: the block index comes from the scalar unit (a 64-bit division
+ * per thread on the vector unit was 3 % of the headline trace's VALU
+ * instructions), the thread adds one wave-uniform offset */
+__device__ __forceinline__ int64_t rt_col_wg(const rt_lay &a, int64_t j,
+                                             uint32_t wg)
+{
+    if (!a.ts)
+        return j + a.j0;
+    if (!a.wgs)
+        return rt_block_col(a.bs, a.ts, j + a.j0);
+    return j + a.j0 + (int64_t)rt_wg_block(a, wg) * (a.ts - a.bs);
 }
 
 #endif /* RT_LAY_H */

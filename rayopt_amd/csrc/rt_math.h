@@ -188,18 +188,51 @@ RT_HD double rt_conic_root(const rt_surface *__restrict__ S, unsigned flags,
     return (flags & RT_F_CURVED) ? rt_sqrt_unscaled(1. - S->kc2 * r2) : 1.;
 }
 
+/*
+ * The element's aspheric terms held in registers (wave-uniform: SGPRs) for
+ * the length of a Newton solve.  Read from the table inside the iteration
+ * they cost a scalar load and a wait each -- per term, per iterate (the ISA
+ * of round 4's exact path: fourteen dependent scalar-load round trips per
+ * iterate).  NA = the term-count class (4 / 7 / RT_MAX_ASPH); exactly `n`
+ * terms are evaluated, in the reference's order: the same operations on the
+ * same operands, the same bits.
+ */
+template <int NA> struct rt_asph_terms {
+    double a[NA], da[NA];
+    double c, kc2;
+    int n;
+};
+
+template <int NA>
+RT_HD void rt_asph_read(const rt_surface *__restrict__ S, unsigned flags,
+                        rt_asph_terms<NA> &A)
+{
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        A.a[i] = S->asph[i];
+        A.da[i] = S->dasph[i];
+    }
+    A.n = (flags & RT_F_ASPH) ? (S->nasph < NA ? S->nasph : NA) : 0;
+    A.c = S->c;
+    A.kc2 = S->kc2;
+}
+
 /* Spheroid.surface_sag(p) residual, elements.py:440-455 */
-RT_HD double rt_sag(const rt_surface *__restrict__ S, unsigned flags,
-                    double r2, double pz, double root)
+template <int NA>
+RT_HD double rt_sag_t(const rt_asph_terms<NA> &A, unsigned flags, double r2,
+                      double pz, double root)
 {
     double e = pz;
     if (flags & RT_F_CURVED)
-        e -= (S->c * r2) / (1. + root);
+        e -= (A.c * r2) / (1. + root);
     if (flags & RT_F_ASPH) {
         double d = 0.;
-        for (int i = S->nasph - 1; i >= 0; --i) {
-            d += S->asph[i];
-            d *= r2;
+#pragma unroll
+        for (int i = NA - 1; i >= 0; --i) {
+            if (i < A.n) {
+                d += A.a[i];
+                d *= r2;
+            }
         }
         e -= d;
     }
@@ -207,6 +240,29 @@ RT_HD double rt_sag(const rt_surface *__restrict__ S, unsigned flags,
 }
 
 /* x,y scale factor e of Spheroid.surface_normal, q = (x e, y e, 1), :457-475 */
+template <int NA>
+RT_HD double rt_normal_e_t(const rt_asph_terms<NA> &A, unsigned flags,
+                           double r2, double root)
+{
+    double e = 0.;
+    if (flags & RT_F_CURVED)
+        e -= A.c / root;
+    if (flags & RT_F_ASPH) {
+        double d = 0.;
+#pragma unroll
+        for (int i = NA - 1; i >= 0; --i) {
+            if (i < A.n) {
+                d *= r2;
+                d += A.da[i];
+            }
+        }
+        e -= d;
+    }
+    return e;
+}
+
+/* the same with the terms read from the table as they are needed (one
+ * evaluation per ray-surface op: the refraction's normal) */
 RT_HD double rt_normal_e(const rt_surface *__restrict__ S, unsigned flags,
                          double r2, double root)
 {
@@ -246,21 +302,25 @@ RT_HD bool rt_isclose(double p, double p0, double tol)
 /* One iterate for one ray, every operation as the reference's: returns true
  * when the ray is finished (res = the root, or NaN left in place), false when
  * s has been updated and the iteration goes on. */
-RT_HD bool rt_newton_iterate(const rt_surface *__restrict__ S, unsigned flags,
-                             const double (&y)[3], const double (&u)[3],
-                             double &s, double &res)
+template <int NA>
+RT_HD bool rt_newton_iterate_t(const rt_asph_terms<NA> &A, unsigned flags,
+                               const double (&y)[3], const double (&u)[3],
+                               double &s, double &res)
 {
     const double px = y[0] + s * u[0];
     const double py = y[1] + s * u[1];
     const double pz = y[2] + s * u[2];
     const double r2 = px * px + py * py;
-    const double root = rt_conic_root(S, flags, r2);
-    const double fval = rt_sag(S, flags, r2, pz, root);
+    /* sqrt(1 - (1+k) c^2 r^2), the one square root sag and normal share
+     * (rt_conic_root) */
+    const double root = (flags & RT_F_CURVED)
+                            ? rt_sqrt_unscaled(1. - A.kc2 * r2) : 1.;
+    const double fval = rt_sag_t<NA>(A, flags, r2, pz, root);
     if (fval == 0.) {
         res = s;
         return true;
     }
-    const double e = rt_normal_e(S, flags, r2, root);
+    const double e = rt_normal_e_t<NA>(A, flags, r2, root);
     /* np.dot(normal, u.T) of a (1,3) and a (3,1) array (:342): BLAS, i.e.
      * the fused chain of rt_dot3 */
     const double fder = rt_dot3(px * e, py * e, 1., u[0], u[1], u[2]);
@@ -275,11 +335,24 @@ RT_HD bool rt_newton_iterate(const rt_surface *__restrict__ S, unsigned flags,
     return false;
 }
 
-template <int R>
+/* ... with the terms read from the table (the rim points of the default
+ * arithmetic: a handful of rays) */
+RT_HD bool rt_newton_iterate(const rt_surface *__restrict__ S, unsigned flags,
+                             const double (&y)[3], const double (&u)[3],
+                             double &s, double &res)
+{
+    rt_asph_terms<RT_MAX_ASPH> A;
+    rt_asph_read<RT_MAX_ASPH>(S, flags, A);
+    return rt_newton_iterate_t<RT_MAX_ASPH>(A, flags, y, u, s, res);
+}
+
+template <int R, int NA>
 RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
                      const double (&y)[R][3], const double (&u)[R][3],
                      double (&s)[R])
 {
+    rt_asph_terms<NA> A; /* read once, before the iteration */
+    rt_asph_read<NA>(S, flags, A);
     bool live[R];
     double res[R];
     bool any = false;
@@ -299,7 +372,7 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
         for (int r = 0; r < R; ++r) {
             if (!live[r])
                 continue;
-            if (rt_newton_iterate(S, flags, y[r], u[r], s[r], res[r]))
+            if (rt_newton_iterate_t<NA>(A, flags, y[r], u[r], s[r], res[r]))
                 live[r] = false;
             else
                 any = true;
@@ -652,7 +725,9 @@ RT_HD void rt_intercept(const rt_surface *__restrict__ S, unsigned flags,
                          (rt_newton_fast<R, 7>(S, flags, y, iv, s)),
                          (rt_newton_fast<R, RT_MAX_ASPH>(S, flags, y, iv, s)));
     } else if (flags & RT_F_ASPH) {
-        rt_newton<R>(S, flags, y, iv, s);
+        RT_FAST_DISPATCH((rt_newton<R, 4>(S, flags, y, iv, s)),
+                         (rt_newton<R, 7>(S, flags, y, iv, s)),
+                         (rt_newton<R, RT_MAX_ASPH>(S, flags, y, iv, s)));
     } else if (!(flags & RT_F_CURVED)) {
 #pragma unroll
         for (int r = 0; r < R; ++r)

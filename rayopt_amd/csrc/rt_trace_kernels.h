@@ -82,7 +82,7 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
         const int g = __builtin_amdgcn_readfirstlane((int)(j0 / group_rays));
         surf += (int64_t)g * nsurf;
     }
-    const int64_t col = rt_col(a, j);
+    const int64_t col = rt_col_wg(a, j, blockIdx.x);
     double y[1][3], u[1][3];
     if (tiles.note) {
         const int tile = __builtin_amdgcn_readfirstlane(
@@ -129,7 +129,7 @@ rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
         rt_generate_ray(fields + j / npupil, pupil[2 * p], pupil[2 * p + 1],
                         &S0, y, u);
     }
-    const int64_t col = rt_col(a, w);
+    const int64_t col = rt_col_wg(a, w, blockIdx.x);
     if (store0) { /* first trace of the batch; later ones leave row 0 alone */
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -198,7 +198,7 @@ rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
         surf += (tile0 / group_rays) * nsurf;
     /* SoA (the only layout this kernel is launched for): the tile's columns
      * are consecutive -- blocks are whole tiles (rt_reserve) */
-    const int64_t col0 = rt_col(a, tile0);
+    const int64_t col0 = rt_col_wg(a, tile0, blockIdx.x);
     const bool exists = tile0 + tid < ld;
     bool has = exists;
     int idx = tid; /* the ray's column inside the tile */

@@ -115,6 +115,12 @@ def _encode(obj):
         raise TypeError("host group carries None, bool, int, float, str, "
                         "bytes and float64 / int64 arrays, not %r"
                         % type(obj))
+    if len(payload) > _MAX_PAYLOAD:
+        # the receiver refuses such a header and stops reading while this
+        # side would still be writing the payload: say it here instead
+        raise ValueError("host group: a frame carries at most %d bytes, this "
+                         "%s has %d -- send it in slices"
+                         % (_MAX_PAYLOAD, type(obj).__name__, len(payload)))
     return _HEADER.pack(_MAGIC, kind, ndim, 0, len(payload), *dims) + payload
 
 

@@ -79,6 +79,60 @@ int main()
         if (nb > 1)
             CHECK(rt_block_col(bs, c->bts, j) % c->bts < bs);
     }
+    // the block of a workgroup without a division (rt_lay_set_window,
+    // rt_wg_block): every workgroup of every window, against the division
+    for (int t = 0; t < 3000; ++t) {
+        rt_lay a = {};
+        const int64_t wgs = t < 40 ? 1 + t : 1 + rand() % 40000;
+        const int nb = 2 + rand() % 9;
+        a.bs = wgs * 256;
+        a.ts = 10 * (2 + rand() % 20) * a.bs;
+        const int64_t ld = a.bs * nb;
+        const int64_t lo = (int64_t)(rand() % (int)(ld / 256)) * 256;
+        rt_lay_set_window(a, lo, ld);
+        CHECK(a.wgs == wgs && a.j0 == lo && a.w0 == lo / 256);
+        const int64_t nwg = (ld - lo) / 256;
+        for (int64_t w = 0; w < nwg; w += (t < 200 ? 1 : 1 + rand() % 7)) {
+            const int64_t j = w * 256 + rand() % 256; // a ray of the window
+            CHECK((int64_t)rt_wg_block(a, (uint32_t)w) == (j + lo) / a.bs);
+            CHECK(j + a.j0 + (int64_t)rt_wg_block(a, (uint32_t)w) * (a.ts - a.bs) ==
+                  rt_block_col(a.bs, a.ts, j + lo));
+        }
+        // the last workgroup 2^24 - 2 of the largest batch the form covers
+        rt_lay_set_window(a, 0, ((int64_t)1 << 32) - 512);
+        CHECK(a.wgs == wgs);
+        for (uint32_t w : {0u, (uint32_t)wgs - 1, (uint32_t)wgs,
+                           (1u << 24) - 3, (1u << 24) - 2})
+            CHECK(rt_wg_block(a, w) == w / (uint64_t)wgs);
+        // windows off a workgroup border, blocks that are not whole
+        // workgroups and one block: the dividing form stays in charge
+        rt_lay_set_window(a, lo + 64, ld);
+        CHECK(a.wgs == 0 && a.j0 == lo + 64);
+        rt_lay_set_window(a, 0, (int64_t)1 << 32);
+        CHECK(a.wgs == 0);
+        a.bs += 64;
+        rt_lay_set_window(a, 0, ld);
+        CHECK(a.wgs == 0);
+        a.ts = 0;
+        rt_lay_set_window(a, 0, ld);
+        CHECK(a.wgs == 0);
+    }
+    // all divisors up to 5000 and a few large ones, every w at the edges
+    for (int64_t d = 1; d <= (1 << 24); d = d < 5000 ? d + 1 : d * 3 + 1) {
+        rt_lay a = {};
+        a.bs = d * 256;
+        a.ts = 100 * a.bs;
+        rt_lay_set_window(a, 0, ((int64_t)1 << 32) - 512);
+        CHECK(a.wgs == d);
+        for (uint64_t q = 0; q * d < (1u << 24) - 1; q += 1 + q / 64) {
+            for (int64_t e = -1; e <= 1; ++e) {
+                const int64_t w = (int64_t)(q * d) + e;
+                if (w < 0 || w >= (1 << 24) - 1)
+                    continue;
+                CHECK(rt_wg_block(a, (uint32_t)w) == (uint64_t)w / (uint64_t)d);
+            }
+        }
+    }
     free(c);
     printf("blocks_host: %ld failures\n", bad);
     return bad != 0;

@@ -133,3 +133,51 @@ def test_rows_are_not_read_whole_in_the_middle_of_a_step_in_pieces():
         eng.rms(L - 1)
     eng.trace(1, L, True)
     assert np.isfinite(eng.rms(L - 1))
+
+
+def test_a_new_batch_ends_a_step_in_pieces():
+    """a step in pieces that is abandoned half way (after_chunk
+    raised, say) must not be completed by pieces of the NEXT batch.  Whatever
+    replaces the rays, a row or the table starts the count again: the rows
+    read whole at once (they hold what the reference's arrays would -- stale
+    rows of the old batch), and pieces of the new batch count from zero."""
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    L = len(system)
+    y, u = disc_bundle(5000, 12., 2., 5)
+    y2, u2 = disc_bundle(5000, 9., 1., 6)
+    g = ra.GeometricTrace(system)
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    eng = g.engine
+    eng.trace_chunk(1, L, True, 0, 3)
+    with pytest.raises(ra.EngineError, match="1 of 3 pieces"):
+        eng.download(0, L - 1, L)
+    g.rays_given(y2, u2)                    # the step is abandoned here
+    eng.download(0, L - 1, L)               # no step in progress any more
+    g._upload_table(1, L, g.n[0])
+    eng.trace_chunk(1, L, True, 1, 3)
+    eng.trace_chunk(1, L, True, 2, 3)
+    # before the fix these two completed the old step and the image row was
+    # handed out with the first third of its columns from the old batch
+    with pytest.raises(ra.EngineError, match="2 of 3 pieces"):
+        eng.download(0, L - 1, L)
+    eng.trace_chunk(1, L, True, 0, 3)
+    got = eng.download(0, L - 1, L)
+    h = ra.GeometricTrace(system)
+    h.rays_given(y2, u2)
+    h.propagate(clip=True)
+    assert np.array_equal(got[0].T, np.array(h.y[-1]), equal_nan=True)
+    # a row upload and a changed table end a step as well
+    for spoil in (lambda: eng.upload_row(0, 0, np.ascontiguousarray(y2.T)),
+                  lambda: (system[4].__setattr__(
+                      "distance", system[4].distance*1.001),
+                      g._upload_table(1, L, g.n[0]))):
+        eng.trace_chunk(1, L, True, 0, 2)
+        with pytest.raises(ra.EngineError):
+            eng.rms(L - 1)
+        spoil()
+        eng.trace_chunk(1, L, True, 1, 2)
+        with pytest.raises(ra.EngineError, match="1 of 2 pieces"):
+            eng.rms(L - 1)
+        eng.trace_chunk(1, L, True, 0, 2)
+        assert np.isfinite(eng.rms(L - 1))

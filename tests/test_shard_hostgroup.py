@@ -289,6 +289,25 @@ def test_a_frame_header_is_checked_before_its_payload_is_read():
         b.close()
 
 
+def test_an_oversized_frame_is_refused_by_the_sender(monkeypatch):
+    """The receiver drops a header that claims more than _MAX_PAYLOAD bytes
+    and stops reading; a sender that wrote such a frame anyway would block in
+    sendall with the connection out of step.  The sender says so
+    before a byte leaves."""
+    monkeypatch.setattr(D, "_MAX_PAYLOAD", 1 << 10)
+    assert D._decode(*_parts(D._encode(np.zeros(128)))).shape == (128,)
+    with pytest.raises(ValueError, match="at most 1024 bytes"):
+        D._encode(np.zeros(129))
+    with pytest.raises(ValueError, match="slices"):
+        D._encode(b"x"*1025)
+
+
+def _parts(frame):
+    magic, kind, ndim, _, nbytes, *dims = D._HEADER.unpack(
+        frame[:D._HEADER.size])
+    return kind, ndim, dims, frame[D._HEADER.size:]
+
+
 def test_rendezvous_file_in_a_shared_directory_and_stale_files(tmp_path):
     """RT_RDZV_FILE=/tmp/x style paths (a directory others can write to) are
     kept in a private directory of this user next to it; a file an earlier
