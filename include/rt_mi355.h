@@ -50,10 +50,11 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3 /* 2: rt_surface.rc, rt_selftest_arith, rt_comm_info;
+#define RT_ABI_VERSION 4 /* 2: rt_surface.rc, rt_selftest_arith, rt_comm_info;
                            the default asphere arithmetic; no rt_probe
                            3: rt_placement fills ms[8] (search times);
-                              large batches in blocks (rt_blocks) */
+                              large batches in blocks (rt_blocks)
+                           4: rt_opd_stats, rt_opd_device, rt_download_rays */
 #define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
 #define RT_MAX_SURFACES 256 /* elements per System */
 
@@ -413,6 +414,12 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst);
 
 /* all surfaces of ONE ray: dst[L][ncomp] (print_trace, reference-ray terms) */
 int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst);
+/* all surfaces of the rays ray0, ray0 + stride, ... (count of them), gathered
+ * on the device: dst[L][ncomp][count] -- a sample of a batch too large to
+ * bring down (parity checks of 10^8-ray batches, plots).  Rows that were not
+ * stored come back as NaN. */
+int rt_download_rays(rt_ctx *ctx, int which, int64_t ray0, int64_t stride,
+                     int64_t count, double *dst);
 
 /*
  * Device-side consumers of the result arrays: the
@@ -477,6 +484,29 @@ typedef struct rt_opd_args {
 } rt_opd_args;
 int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa);
 int rt_sizeof_opd_args(void);
+/*
+ * rt_opd_stats: the same path differences WITHOUT the 24 B per ray over PCIe
+ * (GeometricTrace.opd, rayopt/geometric_trace.py:101-131, up to the point
+ * where the reference starts to resample): what most callers ask of an OPD
+ * map -- its weighted mean, rms and peak-to-valley per bundle -- is reduced
+ * on the device.  The batch is `ngroups` contiguous bundles of `group_rays`
+ * rays; args->ref is the index of the reference ray INSIDE a bundle (bundle
+ * g: ray g * group_rays + ref).  Over the rays of bundle g whose x, y and t
+ * are finite (the rays the reference keeps, :133-135), t in waves:
+ *   out[g][0] = number of such rays     out[g][1] = sum w
+ *   out[g][2] = sum w t / sum w         out[g][3] = rms about that mean
+ *   out[g][4] = min t   out[g][5] = max t   out[g][6] = max - min
+ *   out[g][7] = sqrt(sum w t^2 / sum w)  (rms about the reference ray)
+ * Weights: rt_set_weights, NULL = uniform.  out: ngroups x RT_OPD_STATS
+ * doubles (host).  keep != 0: x | y | t of every ray stay on the device as
+ * [3][nrays] doubles (rt_opd_device), for callers that plot or resample a
+ * part of them: rt_copy_to_host moves what they need.  rt_opd_rays leaves
+ * the same array behind.
+ */
+#define RT_OPD_STATS 8
+int rt_opd_stats(rt_ctx *ctx, const rt_opd_args *args, int64_t group_rays,
+                 int ngroups, int keep, double *out);
+int rt_opd_device(rt_ctx *ctx, double **x_y_t, int64_t *nrays);
 
 /* raw device pointer to row `surf` of an array, i.e. to its part in block 0
  * (rt_blocks: the other blocks' parts follow bts doubles apart; one block

@@ -790,18 +790,46 @@ __device__ __forceinline__ void rt_opd_point(const rt_opd_args &a,
     py[2] -= a.radius;
 }
 
-__global__ void rt_opd_kernel(rt_opd_args a, const rt_opd_ref *__restrict__ ref,
-                              const double *__restrict__ Y,
-                              const double *__restrict__ U,
-                              const double *__restrict__ T, int64_t n,
-                              rt_pitch p, double *__restrict__ out)
+/*
+ * The reference-ray columns of every bundle, gathered on the device (one
+ * thread per bundle): refs[g] = the rows of ray g * group_rays + a.ref.
+ */
+__global__ void rt_opd_refs_kernel(rt_opd_args a, const double *__restrict__ Y,
+                                   const double *__restrict__ U,
+                                   const double *__restrict__ T,
+                                   int64_t group_rays, int ngroups, rt_pitch p,
+                                   rt_opd_ref *__restrict__ refs)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n)
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups)
         return;
-    const int64_t ld = p.ld, j = RT_AT(p, k); /* where ray k lies in a row */
+    const int64_t ld = p.ld, j = RT_AT(p, (int64_t)g * group_rays + a.ref);
+    rt_opd_ref *r = refs + g;
+    for (int s = 0; s < a.nrows; ++s)
+        r->t[s] = T[(int64_t)s * ld + j];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        r->y0[c] = Y[(int64_t)c * ld + j];
+        r->u0[c] = U[(int64_t)c * ld + j];
+        r->ya[c] = Y[((int64_t)a.after * 3 + c) * ld + j];
+        r->ua[c] = U[((int64_t)a.after * 3 + c) * ld + j];
+        r->yi[c] = Y[((int64_t)a.image * 3 + c) * ld + j];
+    }
+}
+
+/* x, y on the reference sphere and the path difference t (waves) of ray k
+ * against the reference ray `ref` of its bundle: GeometricTrace.opd, :101-131,
+ * operation for operation */
+__device__ __forceinline__ void rt_opd_ray(const rt_opd_args &a,
+                                           const rt_opd_ref *__restrict__ ref,
+                                           const double *__restrict__ Y,
+                                           const double *__restrict__ U,
+                                           const double *__restrict__ T,
+                                           int64_t ld, int64_t j, double &x,
+                                           double &yy, double &t)
+{
     /* t = (t[:after+1] - t[:after+1, ref]).sum(0): row by row */
-    double t = 0.;
+    t = 0.;
     for (int s = 0; s < a.nrows; ++s) {
         const double d = T[(int64_t)s * ld + j] - ref->t[s];
         t = s ? t + d : d;
@@ -831,8 +859,149 @@ __global__ void rt_opd_kernel(rt_opd_args a, const rt_opd_ref *__restrict__ ref,
     rt_opd_point(a, ref->yi, yr, ur, tr, pr);
     t += (ti - tr) * a.n_after;
     t = -t / a.lscale;
-    out[k] = py[0] - pr[0];
-    out[n + k] = py[1] - pr[1];
+    x = py[0] - pr[0];
+    yy = py[1] - pr[1];
+}
+
+/*
+ * rt_opd_stats, first level: the path difference of every ray of bundle
+ * blockIdx.y and, over the rays where x, y and t are finite (what the
+ * reference keeps before it resamples, :133-135), the sums
+ *   count, sum w, sum w t, sum w t^2, min t, max t
+ * -- t is measured from the bundle's reference ray (t_ref = 0), so the plain
+ * sums lose nothing that matters at 1e-9.  keep: x | y | t of every ray go to
+ * out[3][n] as well (rt_opd_device).  One ray per lane and pass: 18-21
+ * independent 8-byte loads each, plenty in flight.
+ */
+#define RT_OPD_SUMS 6
+__global__ void rt_opd_stats_kernel(rt_opd_args a,
+                                    const rt_opd_ref *__restrict__ refs,
+                                    const double *__restrict__ Y,
+                                    const double *__restrict__ U,
+                                    const double *__restrict__ T,
+                                    const double *__restrict__ w,
+                                    int64_t group_rays, int64_t n, rt_pitch p,
+                                    double *__restrict__ out,
+                                    double *__restrict__ partials)
+{
+    __shared__ double sm[RT_RED_THREADS / 64][RT_OPD_SUMS];
+    const rt_opd_ref *ref = refs + blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.y * group_rays;
+    double cnt = 0., sw = 0., s1 = 0., s2 = 0.;
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (int64_t q = RT_RED_TID; q < group_rays; q += RT_RED_NTHREADS) {
+        const int64_t k = base + q;
+        double x, y, t;
+        rt_opd_ray(a, ref, Y, U, T, p.ld, RT_AT(p, k), x, y, t);
+        if (out) {
+            out[k] = x;
+            out[n + k] = y;
+            out[2 * n + k] = t;
+        }
+        if (isfinite(x) && isfinite(y) && isfinite(t)) {
+            const double wk = w ? w[k] : 1.;
+            cnt += 1.;
+            sw += wk;
+            s1 += wk * t;
+            s2 += wk * t * t;
+            lo = t < lo ? t : lo;
+            hi = t > hi ? t : hi;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off);
+        sw += __shfl_down(sw, off);
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+        const double l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sm[wave][0] = cnt;
+        sm[wave][1] = sw;
+        sm[wave][2] = s1;
+        sm[wave][3] = s2;
+        sm[wave][4] = lo;
+        sm[wave][5] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int v = 1; v < RT_RED_THREADS / 64; ++v) {
+            cnt += sm[v][0];
+            sw += sm[v][1];
+            s1 += sm[v][2];
+            s2 += sm[v][3];
+            lo = sm[v][4] < lo ? sm[v][4] : lo;
+            hi = sm[v][5] > hi ? sm[v][5] : hi;
+        }
+        double *q = partials +
+                    ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * RT_OPD_SUMS;
+        q[0] = cnt;
+        q[1] = sw;
+        q[2] = s1;
+        q[3] = s2;
+        q[4] = lo;
+        q[5] = hi;
+    }
+}
+
+/* second level, one wavefront per bundle: stats[g] = {count, sum w, mean,
+ * rms about the mean, min, max, peak to valley, rms about the reference ray}
+ * (RT_OPD_STATS doubles), into the device array or pinned host memory */
+__global__ void rt_opd_finish_kernel(const double *__restrict__ partials,
+                                     int pb, double *__restrict__ final)
+{
+    const int g = blockIdx.x;
+    double cnt = 0., sw = 0., s1 = 0., s2 = 0.;
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (int b = threadIdx.x; b < pb; b += 64) {
+        const double *q = partials + ((int64_t)g * pb + b) * RT_OPD_SUMS;
+        cnt += q[0];
+        sw += q[1];
+        s1 += q[2];
+        s2 += q[3];
+        lo = q[4] < lo ? q[4] : lo;
+        hi = q[5] > hi ? q[5] : hi;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off);
+        sw += __shfl_down(sw, off);
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+        const double l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (threadIdx.x != 0)
+        return;
+    double *f = final + (int64_t)g * RT_OPD_STATS;
+    const double nan = __builtin_nan("");
+    const double mean = s1 / sw, var = s2 / sw - mean * mean;
+    f[0] = cnt;
+    f[1] = sw;
+    f[2] = cnt > 0. ? mean : nan;
+    f[3] = cnt > 0. ? sqrt(var > 0. ? var : 0.) : nan;
+    f[4] = cnt > 0. ? lo : nan;
+    f[5] = cnt > 0. ? hi : nan;
+    f[6] = cnt > 0. ? hi - lo : nan;
+    f[7] = cnt > 0. ? sqrt(s2 / sw) : nan;
+}
+
+__global__ void rt_opd_kernel(rt_opd_args a, const rt_opd_ref *__restrict__ ref,
+                              const double *__restrict__ Y,
+                              const double *__restrict__ U,
+                              const double *__restrict__ T, int64_t n,
+                              rt_pitch p, double *__restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    double x, y, t;
+    rt_opd_ray(a, ref, Y, U, T, p.ld, RT_AT(p, k), x, y, t);
+    out[k] = x;
+    out[n + k] = y;
     out[2 * n + k] = t;
 }
 

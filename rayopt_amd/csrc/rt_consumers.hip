@@ -390,64 +390,166 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
     return RT_OK;
 }
 
+/* what rt_opd_rays and rt_opd_stats share: the arguments checked, the rows
+ * flushed, the reference-ray columns of every bundle gathered on the device */
+static int rt_opd_prepare(rt_ctx *ctx, const rt_opd_args *args,
+                          int64_t group_rays, int ngroups, const char *who)
+{
+    int rc = rt_consumer_ready(ctx, 0, who);
+    if (rc != RT_OK)
+        return rc;
+    const int L = ctx->buf_nsurf;
+    if (group_rays < 1 || ngroups < 1 || ngroups > RT_MAX_GROUPS ||
+        group_rays * (int64_t)ngroups != ctx->n)
+        return rt_fail(ctx, RT_ERR_ARG,
+                       "%s: %d bundles of %lld rays do not tile the %lld rays "
+                       "of the batch", who, ngroups, (long long)group_rays,
+                       (long long)ctx->n);
+    if (args->nrows < 0 || args->nrows > L || args->after < 0 ||
+        args->after >= L || args->image < 0 || args->image >= L ||
+        args->ref < 0 || args->ref >= group_rays)
+        return rt_fail(ctx, RT_ERR_ARG, "%s: index out of range", who);
+    for (int j = 0; j < L; ++j)
+        if (!ctx->valid[j] &&
+            (j < args->nrows || j == args->after || j == args->image))
+            return rt_fail(ctx, RT_ERR_STATE, "%s: row %d holds no data", who,
+                           j);
+    /* Y and U are read at their natural addresses */
+    rc = rt_detach(ctx, RT_U, args->after);
+    if (rc != RT_OK)
+        return rc;
+    if ((size_t)ngroups > ctx->opd_ref_cap) {
+        if (ctx->d_opd_ref)
+            (void)hipFree(ctx->d_opd_ref);
+        ctx->d_opd_ref = NULL;
+        ctx->opd_ref_cap = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_opd_ref,
+                              sizeof(rt_opd_ref) * (size_t)ngroups));
+        ctx->opd_ref_cap = (size_t)ngroups;
+    }
+    hipLaunchKernelGGL(rt_opd_refs_kernel, dim3((unsigned)((ngroups + 63) / 64)),
+                       dim3(64), 0, ctx->stream, *args, rt_arr(ctx, RT_Y),
+                       rt_arr(ctx, RT_U), rt_arr(ctx, RT_T), group_rays,
+                       ngroups, rt_pitch_of(ctx), ctx->d_opd_ref);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+/* the x | y | t array of the batch (24 B per ray), kept between calls */
+static int rt_opd_buffer(rt_ctx *ctx)
+{
+    const size_t need = (size_t)ctx->n * 3;
+    ctx->opd_n = 0;
+    if (need > ctx->opd_cap) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_opd)
+            (void)hipFree(ctx->d_opd);
+        ctx->d_opd = NULL;
+        ctx->opd_cap = 0;
+        hipError_t e = hipMalloc((void **)&ctx->d_opd, need * sizeof(double));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return rt_fail(ctx, RT_ERR_NOMEM, "opd: hipMalloc(%zu): %s",
+                           need * sizeof(double), hipGetErrorString(e));
+        }
+        ctx->opd_cap = need;
+    }
+    return RT_OK;
+}
+
 int rt_opd_rays(rt_ctx *ctx, const rt_opd_args *args, double *out_soa)
 {
     if (!ctx || !args || !out_soa)
         return rt_fail(ctx, RT_ERR_ARG, "rt_opd_rays: NULL argument");
-    int rc = rt_consumer_ready(ctx, 0, "rt_opd_rays");
-    if (rc != RT_OK)
-        return rc;
-    const int L = ctx->buf_nsurf;
-    if (args->nrows < 0 || args->nrows > L || args->after < 0 ||
-        args->after >= L || args->image < 0 || args->image >= L ||
-        args->ref < 0 || args->ref >= ctx->n)
-        return rt_fail(ctx, RT_ERR_ARG, "rt_opd_rays: index out of range");
-    for (int j = 0; j < L; ++j)
-        if (!ctx->valid[j] &&
-            (j < args->nrows || j == args->after || j == args->image))
-            return rt_fail(ctx, RT_ERR_STATE,
-                           "rt_opd_rays: row %d holds no data", j);
-    /* reference-ray columns: small strided D2H, then one struct upload */
-    rt_opd_ref href;
-    memset(&href, 0, sizeof href);
-    double col[RT_MAX_SURFACES * 3];
-    rc = rt_download_ray(ctx, RT_T, args->ref, col);
-    if (rc != RT_OK)
-        return rc;
-    memcpy(href.t, col, sizeof(double) * L);
-    rc = rt_download_ray(ctx, RT_Y, args->ref, col);
-    if (rc != RT_OK)
-        return rc;
-    memcpy(href.y0, col, sizeof(double) * 3);
-    memcpy(href.ya, col + 3 * args->after, sizeof(double) * 3);
-    memcpy(href.yi, col + 3 * args->image, sizeof(double) * 3);
-    rc = rt_download_ray(ctx, RT_U, args->ref, col);
-    if (rc != RT_OK)
-        return rc;
-    memcpy(href.u0, col, sizeof(double) * 3);
-    memcpy(href.ua, col + 3 * args->after, sizeof(double) * 3);
-    if (!ctx->d_opd_ref)
-        RT_HIP(ctx, hipMalloc((void **)&ctx->d_opd_ref, sizeof(rt_opd_ref)));
-    RT_HIP(ctx, hipMemcpyAsync(ctx->d_opd_ref, &href, sizeof href,
-                               hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t bytes = (size_t)ctx->n * 3 * sizeof(double);
-    rc = rt_need_scratch(ctx, bytes);
-    if (rc != RT_OK)
-        return rc;
-    rc = rt_detach(ctx, RT_U, args->after); /* read at its natural address */
+    int rc = rt_opd_prepare(ctx, args, ctx->n, 1, "rt_opd_rays");
+    if (rc == RT_OK)
+        rc = rt_opd_buffer(ctx);
     if (rc != RT_OK)
         return rc;
     const unsigned grid = (unsigned)((ctx->n + 255) / 256);
     RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
     hipLaunchKernelGGL(rt_opd_kernel, dim3(grid), dim3(256), 0, ctx->stream,
                        *args, ctx->d_opd_ref, rt_arr(ctx, RT_Y),
-                       rt_arr(ctx, RT_U), rt_arr(ctx, RT_T), ctx->n, rt_pitch_of(ctx),
-                       (double *)ctx->d_scratch);
+                       rt_arr(ctx, RT_U), rt_arr(ctx, RT_T), ctx->n,
+                       rt_pitch_of(ctx), ctx->d_opd);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
     ctx->traced = 1;
-    return rt_d2h(ctx, out_soa, ctx->d_scratch, bytes);
+    ctx->opd_n = ctx->n;
+    return rt_d2h(ctx, out_soa, ctx->d_opd,
+                  (size_t)ctx->n * 3 * sizeof(double));
+}
+
+int rt_opd_stats(rt_ctx *ctx, const rt_opd_args *args, int64_t group_rays,
+                 int ngroups, int keep, double *out)
+{
+    if (!ctx || !args || !out)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_opd_stats: NULL argument");
+    int rc = rt_opd_prepare(ctx, args, group_rays, ngroups, "rt_opd_stats");
+    if (rc == RT_OK && keep)
+        rc = rt_opd_buffer(ctx);
+    if (rc != RT_OK)
+        return rc;
+    /* enough workgroups per bundle to fill the chip (eight per CU), no more
+     * than it has rays for */
+    int64_t pb = 2048 / ngroups;
+    const int64_t fit = (group_rays + RT_RED_THREADS - 1) / RT_RED_THREADS;
+    pb = pb > fit ? fit : pb;
+    pb = pb < 1 ? 1 : pb;
+    const size_t need = (size_t)ngroups * (RT_OPD_STATS + (size_t)pb * RT_OPD_SUMS);
+    if (need > ctx->group_cap) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_group)
+            (void)hipFree(ctx->d_group);
+        ctx->d_group = nullptr;
+        ctx->group_cap = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_group, need * sizeof(double)));
+        ctx->group_cap = need;
+    }
+    if (ngroups <= RT_GROUP_PINNED && !ctx->h_opd)
+        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_opd,
+                                  sizeof(double) * RT_OPD_STATS *
+                                      RT_GROUP_PINNED));
+    double *stats = ctx->d_group;
+    double *final = ngroups <= RT_GROUP_PINNED ? ctx->h_opd : stats;
+    double *partials = stats + (size_t)ngroups * RT_OPD_STATS;
+    RT_HIP(ctx, hipEventRecord(ctx->k0, ctx->stream));
+    hipLaunchKernelGGL(rt_opd_stats_kernel, dim3((unsigned)pb, (unsigned)ngroups),
+                       dim3(RT_RED_THREADS), 0, ctx->stream, *args,
+                       ctx->d_opd_ref, rt_arr(ctx, RT_Y), rt_arr(ctx, RT_U),
+                       rt_arr(ctx, RT_T), ctx->d_w, group_rays, ctx->n,
+                       rt_pitch_of(ctx), keep ? ctx->d_opd : (double *)NULL,
+                       partials);
+    hipLaunchKernelGGL(rt_opd_finish_kernel, dim3((unsigned)ngroups), dim3(64),
+                       0, ctx->stream, partials, (int)pb, final);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
+    ctx->traced = 1;
+    if (final == stats)
+        RT_HIP(ctx, hipMemcpyAsync(out, stats,
+                                   sizeof(double) * RT_OPD_STATS * ngroups,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (final != stats)
+        memcpy(out, final, sizeof(double) * RT_OPD_STATS * ngroups);
+    if (keep)
+        ctx->opd_n = ctx->n;
+    return RT_OK;
+}
+
+int rt_opd_device(rt_ctx *ctx, double **x_y_t, int64_t *nrays)
+{
+    if (!ctx || !x_y_t)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_opd_device: NULL argument");
+    if (!ctx->d_opd || ctx->opd_n < 1 || ctx->opd_n != ctx->n)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_opd_device: no path differences of this batch on "
+                       "the device (rt_opd_stats with keep = 1, or "
+                       "rt_opd_rays, first)");
+    *x_y_t = ctx->d_opd;
+    if (nrays)
+        *nrays = ctx->opd_n;
+    return RT_OK;
 }
 
 } /* extern "C" */

@@ -177,7 +177,12 @@ struct rt_ctx {
     size_t group_cap;   /* doubles */
     double *h_group;    /* pinned: the stats as rt_group_finish_kernel writes
                          * them (up to RT_GROUP_PINNED groups) */
-    struct rt_opd_ref *d_opd_ref;
+    struct rt_opd_ref *d_opd_ref; /* reference-ray columns, one per bundle */
+    size_t opd_ref_cap;
+    double *d_opd;   /* x | y | t of the last rt_opd_rays / rt_opd_stats(keep) */
+    size_t opd_cap;  /* doubles */
+    int64_t opd_n;   /* rays it holds (0: nothing) */
+    double *h_opd;   /* pinned: where rt_opd_finish_kernel writes the stats */
 
     /* kernel choices */
     int opt_alias;

@@ -382,6 +382,10 @@ int rt_destroy(rt_ctx *ctx)
 #endif
     if (ctx->d_opd_ref)
         (void)hipFree(ctx->d_opd_ref);
+    if (ctx->d_opd)
+        (void)hipFree(ctx->d_opd);
+    if (ctx->h_opd)
+        (void)hipHostFree(ctx->h_opd);
     for (int k = 0; k < 2; ++k) {
         if (ctx->d_tab[k])
             (void)hipFree(ctx->d_tab[k]);
@@ -507,6 +511,7 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     rt_block_plan(ctx->nsurf, ctx->opt_block, quantum, nrays, &bs, &nblk);
     const int64_t ld = bs * nblk;
     rt_pieces_reset(ctx);
+    ctx->opd_n = 0; /* path differences kept on the device: of the old batch */
     if (ld == ctx->ld && bs == ctx->bs && ctx->buf_nsurf == ctx->nsurf &&
         ctx->d_buf) {
         if (nrays != ctx->n) {
@@ -1456,6 +1461,62 @@ int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
     }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
+}
+
+/* rays ray0, ray0 + stride, ... of one row (nc components) -> out[nc][count] */
+__global__ void rt_gather_rays_kernel(const double *__restrict__ row,
+                                      int64_t bs, int64_t bts, int nc,
+                                      int64_t ray0, int64_t stride,
+                                      int64_t count, double *__restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count)
+        return;
+    const int64_t col = rt_block_col(bs, bts, ray0 + k * stride);
+    for (int c = 0; c < nc; ++c)
+        out[(int64_t)c * count + k] = row[(int64_t)c * bs + col];
+}
+
+int rt_download_rays(rt_ctx *ctx, int which, int64_t ray0, int64_t stride,
+                     int64_t count, double *dst)
+{
+    if (ctx)
+        RT_ROWS_WHOLE(ctx, "rt_download_rays");
+    if (!ctx || !dst || which < RT_Y || which > RT_T || stride < 1 ||
+        count < 1)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_download_rays: bad argument");
+    if (!ctx->d_buf || ray0 < 0 || ray0 + (count - 1) * stride >= ctx->n)
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_download_rays: rays %lld + k * %lld, k < %lld, of "
+                       "%lld", (long long)ray0, (long long)stride,
+                       (long long)count, (long long)ctx->n);
+    if (rt_soa_only(ctx, "rt_download_rays") != RT_OK)
+        return RT_ERR_STATE;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = rt_gen_flush(ctx);
+    if (rc != RT_OK)
+        return rc;
+    const int nc = rt_ncomp(which), L = ctx->buf_nsurf;
+    const size_t bytes = (size_t)L * nc * (size_t)count * sizeof(double);
+    rc = rt_need_scratch(ctx, bytes);
+    if (rc != RT_OK)
+        return rc;
+    double *tmp = (double *)ctx->d_scratch;
+    for (int j = 0; j < L; ++j) {
+        double *out = tmp + (size_t)j * nc * (size_t)count;
+        if (!ctx->valid[j]) { /* row not stored: NaN, like a dead ray */
+            RT_HIP(ctx, hipMemsetAsync(out, 0xff, (size_t)nc * count *
+                                                      sizeof(double),
+                                       ctx->stream));
+            continue;
+        }
+        hipLaunchKernelGGL(rt_gather_rays_kernel,
+                           dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                           ctx->stream, rt_row(ctx, which, j), ctx->bs,
+                           ctx->bts, nc, ray0, stride, count, out);
+    }
+    RT_HIP(ctx, hipGetLastError());
+    return rt_d2h(ctx, dst, tmp, bytes);
 }
 
 int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)

@@ -242,6 +242,18 @@ class Engine:
                     "rt_download_ray")
         return out
 
+    def download_rays(self, which, ray0, stride, count):
+        """Every ``stride``-th ray from ``ray0`` on, ``count`` of them,
+        across all surfaces, gathered on the device: ``(L, count, 3)`` for
+        y / u / i, ``(L, count)`` for t (rt_download_rays) -- a sample of a
+        batch too large to bring down."""
+        L, nc = self.nsurf, 1 if which == RT_T else 3
+        out = np.empty((L, nc, int(count)))
+        self._check(self.lib.rt_download_rays(
+            self.ctx, which, int(ray0), int(stride), int(count),
+            out.ctypes.data), "rt_download_rays")
+        return out[:, 0] if which == RT_T else np.moveaxis(out, 1, 2)
+
     # -- device-side consumers ---------------------------------------------
     def set_weights(self, w):
         if w is None:
@@ -289,6 +301,31 @@ class Engine:
         self._check(self.lib.rt_opd_rays(self.ctx, args.ctypes.data,
                                          out.ctypes.data), "rt_opd_rays")
         return out
+
+    def opd_stats(self, args, group_rays=None, ngroups=1, keep=False):
+        """Per bundle ``[count, sum w, mean, rms about the mean, min, max,
+        peak to valley, rms about the reference ray]`` of the optical path
+        differences (waves), reduced on the device (rt_opd_stats): nothing
+        per ray crosses PCIe.  ``args["ref"]`` is the reference ray's index
+        inside a bundle; ``keep`` leaves x | y | t on the device
+        (:meth:`opd_device`)."""
+        args = np.ascontiguousarray(args, dtype=_lib.OPD_ARGS_DTYPE)
+        if group_rays is None:
+            group_rays = self.nrays//ngroups
+        out = np.empty((int(ngroups), _lib.RT_OPD_STATS))
+        self._check(self.lib.rt_opd_stats(
+            self.ctx, args.ctypes.data, int(group_rays), int(ngroups),
+            1 if keep else 0, out.ctypes.data), "rt_opd_stats")
+        return out
+
+    def opd_device(self):
+        """(device address, rays) of the ``[3][rays]`` array x | y | t the
+        last :meth:`opd_stats` (``keep=True``) or :meth:`opd_rays` left on
+        the device; :meth:`copy_to_host` moves the part a caller plots."""
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._check(self.lib.rt_opd_device(self.ctx, ctypes.byref(p),
+                                           ctypes.byref(n)), "rt_opd_device")
+        return p.value, n.value
 
     def device_ptr(self, which, surf):
         p = ctypes.c_void_p()

@@ -933,6 +933,31 @@ class GeometricTrace(Trace):
         on the image of ray ``ref``: ``x, y`` (exit-pupil coordinates) and
         ``t`` in waves -- what the reference's ``opd(resample=0)`` returns
         (rayopt/geometric_trace.py:101-131), computed by one fused kernel."""
+        x, y, t = self.engine.opd_rays(self._opd_args(radius, after, image))
+        return x, y, t
+
+    OPD_STATS = ("count", "sum_w", "mean", "rms", "min", "max", "pv",
+                 "rms_about_ref")
+
+    def opd_stats(self, radius=None, after=-2, image=-1, bundles=1,
+                  keep=False):
+        """Weighted mean / rms / peak-to-valley of the optical path
+        differences (waves) of every bundle, reduced on the device: the
+        per-ray values of :meth:`opd_rays` (rayopt/geometric_trace.py:
+        101-131, before the reference resamples) never cross PCIe.  The
+        batch is ``bundles`` contiguous bundles of equal size, each measured
+        against its own reference ray (``ref`` counts inside a bundle).
+        Returns an array ``(bundles, 8)``, columns :attr:`OPD_STATS`;
+        ``keep=True`` leaves x | y | t on the device
+        (``engine.opd_device()``)."""
+        per = self.nrays//bundles
+        if per*bundles != self.nrays:
+            raise ValueError("opd_stats: %d rays do not split into %d "
+                             "bundles" % (self.nrays, bundles))
+        args = self._opd_args(radius, after, image, per)
+        return self.engine.opd_stats(args, per, bundles, keep)
+
+    def _opd_args(self, radius, after, image, bundle_rays=None):
         if np.ndim(self.l):
             raise NotImplementedError("opd of a multi-wavelength batch: "
                                       "trace one wavelength per trace")
@@ -952,7 +977,7 @@ class GeometricTrace(Trace):
         args = np.zeros((), dtype=_lib.OPD_ARGS_DTYPE)
         args["nrows"], args["after"], args["image"] = nrows, after, image
         args["finite"] = bool(self.system.object.finite)
-        args["ref"] = range(self.nrays)[self.ref]
+        args["ref"] = range(bundle_rays or self.nrays)[self.ref]
         args["n0"], args["n_after"] = self.n[0], self.n[after]
         args["radius"] = radius
         args["lscale"] = self.l/self.system.scale
@@ -962,8 +987,7 @@ class GeometricTrace(Trace):
         args["rot_image"] = bool(ei.rotated)
         args["r_after"] = (ea.rot_normal if ea.rotated else eye).reshape(9)
         args["r_image"] = (ei.rot_normal if ei.rotated else eye).reshape(9)
-        x, y, t = self.engine.opd_rays(args)
-        return x, y, t
+        return args
 
     def opd(self, radius=None, after=-2, image=-1, resample=4):
         """OPD map: the per-ray values (device) optionally resampled onto a

@@ -334,3 +334,109 @@ def test_reductions_repeat_bit_for_bit():
     assert first[id(a)][0] == pytest.approx(cn.rms(Y, None), rel=1e-12)
     assert first[id(a)][2] == pytest.approx(
         np.sqrt(np.square(Y[:, :2]).sum(1).max()), rel=1e-15)
+
+
+def opd_stats_numpy(x, y, t, w=None):
+    """What rt_opd_stats promises, from per-ray values: over the rays where
+    x, y, t are finite (the rays the reference keeps,
+    rayopt/geometric_trace.py:133-135)."""
+    good = np.isfinite(x) & np.isfinite(y) & np.isfinite(t)
+    w = np.ones(len(t)) if w is None else np.asarray(w)
+    wg, tg = w[good], t[good]
+    if not good.any():
+        return np.r_[0., 0., [np.nan]*6]
+    mean = (wg*tg).sum()/wg.sum()
+    return np.array([good.sum(), wg.sum(), mean,
+                     np.sqrt((wg*(tg - mean)**2).sum()/wg.sum()),
+                     tg.min(), tg.max(), tg.max() - tg.min(),
+                     np.sqrt((wg*tg**2).sum()/wg.sum())])
+
+
+def assert_opd_stats(got, want, name):
+    assert got[0] == want[0], name
+    if want[0] == 0:
+        assert np.isnan(got[2:]).all(), name
+        return
+    scale = max(abs(want[4]), abs(want[5]), 1e-300)
+    # sums of 1e-9-accurate path differences (waves): absolute against the
+    # size of the map
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-12, err_msg=name)
+    np.testing.assert_allclose(got[2:], want[2:], rtol=0, atol=1e-9*scale,
+                               err_msg=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", consumer_golden_names())
+def test_opd_stats_match_reference(name):
+    """rt_opd_stats (mean / rms / P-V of the OPD, reduced on the device, no
+    per-ray copy) against the statistics of the REFERENCE's per-ray opd()
+    values (rayopt/geometric_trace.py:101-131, resample=0), weights and
+    vignetted rays included; the x | y | t array it can leave on the device
+    is the array rt_opd_rays returns, bit for bit."""
+    g = load_consumer_golden(name)
+    system = make_system(g)
+    tr = ra.GeometricTrace(system)
+    tr.rays_given(g["y0"], g["u0"], g["l"], g["w"], g["ref"])
+    tr.propagate(clip=g["clip"])
+    with np.errstate(all="ignore"):
+        want = opd_stats_numpy(g["opd_x"], g["opd_y"], g["opd_t"], g["w"])
+    got = tr.opd_stats(radius=g["radius"], keep=True)
+    assert got.shape == (1, 8)
+    assert_opd_stats(got[0], want, name)
+    ptr, n = tr.engine.opd_device()
+    assert n == tr.nrays
+    kept = tr.engine.copy_to_host(ptr, 3*n*8).reshape(3, n)
+    x, y, t = tr.opd(radius=g["radius"], resample=0)
+    assert np.array_equal(kept, np.array([x, y, t]), equal_nan=True)
+    # without keep nothing is left behind for this batch ...
+    tr.rays_given(g["y0"], g["u0"], g["l"], g["w"], g["ref"])
+    tr.propagate(clip=g["clip"])
+    assert_opd_stats(tr.opd_stats(radius=g["radius"])[0], want, name)
+    with pytest.raises(ra.EngineError, match="no path differences"):
+        tr.engine.opd_device()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,bundles,block", [(60_000, 5, 0), (64*300, 3, 4096),
+                                             (257*7, 7, 512), (1000, 1, 256)])
+def test_opd_stats_per_bundle(n, bundles, block):
+    """Several field bundles in one batch, each against its own reference
+    ray, in the plain layout and in blocks (bundles straddle blocks); the
+    per-bundle numbers are those of the bundle traced on its own."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    per = n//bundles
+    rng = np.random.default_rng(n)
+    ys, us = [], []
+    for k in range(bundles):
+        y, u = ra.bundles.disc_bundle(per, 15., 12.*k/max(bundles - 1, 1), k,
+                                      ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+        ys.append(y)
+        us.append(u)
+    y, u = np.concatenate(ys), np.concatenate(us)
+    w = rng.random(n) + .1
+    ref = per//3
+    for weights in (None, w):
+        tr = ra.GeometricTrace(system)
+        if block:
+            tr.engine.set_option("block_rays", block)
+        tr.rays_given(y, u, None, weights, ref)
+        tr.propagate(clip=True)
+        assert (tr.engine.blocks()[0] > 1) == bool(block)
+        got = tr.opd_stats(radius=100., bundles=bundles)
+        assert got.shape == (bundles, 8)
+        for k in range(bundles):
+            one = ra.GeometricTrace(system)
+            sl = slice(k*per, (k + 1)*per)
+            one.rays_given(y[sl], u[sl], None,
+                           None if weights is None else weights[sl], ref)
+            one.propagate(clip=True)
+            x1, y1, t1 = one.opd(radius=100., resample=0)
+            with np.errstate(all="ignore"):
+                want = opd_stats_numpy(x1, y1, t1,
+                                       None if weights is None
+                                       else weights[sl])
+            assert 0 < want[0] <= per
+            assert_opd_stats(got[k], want, "bundle %d" % k)
+    with pytest.raises(ValueError, match="do not split"):
+        tr.opd_stats(radius=100.,
+                     bundles=next(k for k in range(2, n) if n % k))

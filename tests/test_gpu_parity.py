@@ -516,6 +516,75 @@ def test_huge_batch_64bit_indexing():
     assert g.rms(i=1) > 0
 
 
+@pytest.mark.parametrize("n,block", [(100_003, 0), (100_003, 4096),
+                                     (5000, 256)])
+def test_download_rays_is_a_strided_view_of_the_rows(n, block):
+    """rt_download_rays (a sample of every row, gathered on the device)
+    against the same rays cut out of the downloaded rows: plain layout and
+    in blocks, served rows (i = u[j-1]), rows that were not stored."""
+    from rayopt_amd._lib import RT_Y, RT_U, RT_I, RT_T
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    L = len(system)
+    y, u = disc_bundle(n, 17., 9., 4, P.DOUBLE_GAUSS_PUPIL_Z)
+    g = ra.GeometricTrace(system)
+    if block:
+        g.engine.set_option("block_rays", block)
+    g.rays_given(y, u)
+    g.propagate(clip=True)
+    for ray0, stride, count in ((0, 1, 64), (3, 97, (n - 4)//97),
+                                (n - 1, 1, 1), (0, n - 1, 2)):
+        for which, rows in ((RT_Y, g.y), (RT_U, g.u), (RT_I, g.i),
+                            (RT_T, g.t)):
+            got = g.engine.download_rays(which, ray0, stride, count)
+            want = np.asarray(rows[:])[:, ray0:ray0 + count*stride:stride]
+            assert got.shape == want.shape
+            assert np.array_equal(got, want, equal_nan=True), (which, ray0)
+    g.propagate(clip=True, keep=[-1])
+    got = g.engine.download_rays(RT_Y, 0, 7, 100)
+    assert np.isnan(got[1:L - 1]).all() and np.isfinite(got[L - 1]).any()
+    for bad in ((0, 1, n + 1), (-1, 1, 1), (5, n, 2), (0, 0, 1)):
+        with pytest.raises(ra.EngineError):
+            g.engine.download_rays(RT_Y, *bad)
+
+
+def test_parity_sample_at_C5_size():
+    """BASELINE configs[4] on ONE GPU: 10^8 rays built on the device (104 GB
+    of results in 15 blocks).  Every 10^4-th ray -- 10^4 rays, spread over
+    all blocks and all five field bundles -- is gathered on the device
+    across all surfaces and compared with the oracle, which starts from the
+    launch rays the device itself built (row 0 of the same sample): bit for
+    bit, like every spherical system."""
+    import digest_cases as dc
+    from rayopt_amd._lib import RT_Y, RT_U, RT_I, RT_T
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    L = len(system)
+    fields = np.c_[np.zeros(5), (0, .35, .5, .7, 1.)]
+    per = 20_000_000
+    g = ra.GeometricTrace(system)
+    g.rays_fields(fields, dc.disc_points(per, 91), P.DOUBLE_GAUSS_PUPIL_Z,
+                  17.)
+    n = g.nrays
+    assert n == 100_000_000
+    g.propagate(clip=True)
+    nb, bs, _ = g.engine.blocks()
+    assert nb >= 14
+    stride, count = 10_000, n//10_000
+    cols = {w: g.engine.download_rays(w, 137, stride, count)
+            for w in (RT_Y, RT_U, RT_I, RT_T)}
+    rays = 137 + stride*np.arange(count)
+    assert len(np.unique(rays//bs)) == nb          # every block is sampled
+    assert len(np.unique(rays//per)) == 5          # and every bundle
+    y0, u0 = cols[RT_Y][0], cols[RT_U][0]
+    assert np.array_equal(cols[RT_I][0], u0) and not cols[RT_T][0].any()
+    want, _ = oracle_trace(system, y0, u0, g.l, True)
+    dead = 0
+    for w, ref in zip((RT_Y, RT_U, RT_I, RT_T), want):
+        got = cols[w][1:]
+        assert np.array_equal(got, ref, equal_nan=True), w
+        dead = max(dead, int(np.isnan(got[-1]).sum()))
+    assert 0 < dead < count//5                     # some rays vignette
+
+
 def test_element_level_methods():
     """Spheroid.propagate / .intercept on the device vs the oracle's
     element_propagate (rayopt/elements.py:306-315, 477-501)."""
