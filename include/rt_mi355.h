@@ -54,7 +54,8 @@ extern "C" {
                            the default asphere arithmetic; no rt_probe
                            3: rt_placement fills ms[8] (search times);
                               large batches in blocks (rt_blocks)
-                           4: rt_opd_stats, rt_opd_device, rt_download_rays */
+                           4: rt_opd_stats, rt_opd_device, rt_download_rays;
+                              rt_placement reports the ranges measured */
 #define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
 #define RT_MAX_SURFACES 256 /* elements per System */
 
@@ -386,8 +387,8 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * dynamic LDS per workgroup of the trace kernels, i.e. a cap of 160 KB / bytes
  * on the workgroups resident per CU: traces that store their rows run with two
  * workgroups per CU, which the memory side likes better than the seven the
- * registers allow, four where the arrays lie in a measured mix of memory
- * classes, rt_placement; FP64-bound traces are not capped), "placement"
+ * registers allow, four where the arrays' own store pattern measured at the fast
+ * level, rt_placement; FP64-bound traces are not capped), "placement"
  * (rt_placement), "range_shortcuts" (1 = default: IEEE quotients and square
  * roots run without the compiler's range scaffolding where the operands are
  * checked to be inside [2^-100, 2^100] -- the same bits from a third fewer
@@ -581,33 +582,27 @@ int rt_comm_sync(rt_ctx *ctx);
 int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
 
 /*
- * Where the result arrays live.  The speed of a trace's 7-10 simultaneous row
- * streams depends on the physical memory behind the arrays (measured: 7.0 /
- * 6.3 / 5.65 TB/s for the bare store pattern of C3; pieces of device memory
- * fall into classes, and streams dealt over pieces of two or three classes
- * run at the fast level, streams inside one class -- every plain hipMalloc of
- * 10 GB seen -- at the slow one: csrc/rt_place.h).  Arrays of > 1.5 GiB are
- * therefore built from pieces (hipMemCreate, 1 GiB; 512 MiB below 3 GiB) whose class the library measures at rt_reserve with a ~1 ms pair
- * test each, an even mix of classes mapped behind one address range, the
- * surplus released (option "placement", default 1; RT_MI355_PLACEMENT=0 for
+ * Where the result arrays live.  A trace's 7-10 simultaneous row streams run
+ * at one of two speeds (bare store pattern of C3: 6.7-7.0 or 5.6-5.9 TB/s),
+ * and which one is a property of the ADDRESS RANGE the memory is mapped
+ * behind, not of the memory: the same pieces in the same order run at either
+ * level behind different ranges; a plain hipMalloc of 10 GB is at the slow
+ * one (csrc/rt_place.h, profiles/r05_probes/README.md).  Arrays of > 1.5 GiB
+ * are therefore built from pieces (hipMemCreate, 1 GiB; 512 MiB below 3 GiB)
+ * mapped behind a range of their own, and at rt_reserve the batch's own store
+ * pattern (56 B per ray and element) is written over them and timed: below
+ * 6150 GB/s the same pieces are mapped behind another fresh range and
+ * measured again, at most four ranges (three above 16 GiB, two above 48), and
+ * the best one stays (option "placement", default 1; RT_MI355_PLACEMENT=0 for
  * the whole process; plain hipMalloc if anything on the way fails; results
  * never depend on it).  info[0] = pieces behind the arrays (0: hipMalloc),
- * [1] = MiB per piece, [2] = pieces created on the way, [3] = classes seen,
- * [4..6] = pieces of class 0 / 1 / 2 kept, [7] = 1 if at least a third of
- * the pieces lie outside the largest class (store-bound traces then run four
- * workgroups per CU instead of two), [8] = blocks of ballast (4-8 GiB each)
- * held during the search so that it moved on through the device memory
- * (pieces come in runs of one class), [9] = what the classes alone said
- * before the measurement below; ms[2] = GB/s of the trace's own store
- * pattern (56 B per ray and element) written over the arrays as laid out,
- * measured at rt_reserve for arrays >= 4 GiB (0: not measured; three
- * launches): below 5950 GB/s -- the memory behaves like one class whatever
- * the pair tests said, seen on one box -- [7] is cleared; ms[0] / ms[1] = the
- * pair test's launch time inside one piece / across two classes; ms[3] =
- * wall milliseconds the search took at rt_reserve, of which ms[4] creating,
- * mapping and testing pieces, ms[5] creating and releasing ballast, ms[6]
- * unmapping, releasing the surplus and mapping the final range; ms[7] = the
- * verification.
+ * [1] = MiB per piece, [2] = pieces created, [3] = ranges measured for the
+ * current layout, [4] = the one the arrays live behind, [5] = 1 if its
+ * pattern is at the fast level (store-bound traces then run four workgroups
+ * per CU instead of two), [6..9] = 0; ms[0..3] = GB/s of the pattern behind
+ * each range tried (0: not tried), ms[4] = the kept one's (0: not measured --
+ * a pattern below 0.5 GB tells nothing), ms[5] = wall milliseconds creating
+ * and mapping the pieces, ms[6] = measuring and re-mapping, ms[7] = 0.
  */
 int rt_placement(rt_ctx *ctx, int info[10], double ms[8]);
 

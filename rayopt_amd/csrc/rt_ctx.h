@@ -86,8 +86,9 @@ struct rt_lab {
 #endif
 
 /*
- * Where the result arrays live (rt_place.h): pieces of device memory whose
- * "class" was measured, mapped behind one address range in an even mix.
+ * Where the result arrays live (rt_place.h): pieces of device memory mapped
+ * behind one address range; the range is kept only if the batch's own store
+ * pattern runs at the fast level behind it.
  */
 /* batches whose planes pass RT_BLOCK_ONE bytes are cut into blocks of at most
  * RT_BLOCK_BYTES (rt_lay.h).  Measured (C3, per 10^7 rays): one block of
@@ -97,25 +98,20 @@ struct rt_lab {
 #define RT_BLOCK_ONE 8.5e9
 #define RT_BLOCK_BYTES 7.0e9
 
-#define RT_PLACE_CLASSES 4
+#define RT_PLACE_TRIES 4 /* address ranges measured at most per allocation */
 struct rt_place {
     void *base;      /* the mapped range (= d_buf), NULL: plain hipMalloc */
     size_t bytes, piece;
     int n;           /* pieces mapped */
     void *handles;   /* hipMemGenericAllocationHandle_t[n] */
-    int created;     /* pieces created on the way (the surplus was released) */
-    int ballast;     /* blocks of ballast held while searching */
-    int nclass;      /* classes seen */
-    int count[RT_PLACE_CLASSES]; /* pieces of each class among the n */
-    int mixed;       /* >= a third of the pieces outside the largest class */
-    float self_ms, cross_ms; /* pair test: same piece / another class */
-    float store_gbps; /* the trace's store pattern over the arrays as laid
-                         out (0: not measured) */
-    int class_mix;    /* what the classes alone said (before the pattern) */
-    /* wall time of the search (rt_place_alloc): all of it, the pieces
-     * (create, map, pair tests), the ballast, unmapping / releasing / the
-     * final mapping; and of the verification */
-    float search_ms, pieces_ms, ballast_ms, remap_ms, verify_ms;
+    int created;     /* pieces created (= n: there is no surplus any more) */
+    int tries;       /* address ranges measured for the current layout */
+    int kept;        /* ... and which of them the arrays live behind */
+    float gbps[RT_PLACE_TRIES]; /* the store pattern behind each */
+    float store_gbps; /* = gbps[kept] (0: not measured) */
+    int fast;         /* store_gbps at the fast level: four workgroups per CU */
+    float search_ms, tune_ms; /* wall time: pieces created and mapped /
+                                 measured and re-mapped */
 };
 
 struct rt_ctx {

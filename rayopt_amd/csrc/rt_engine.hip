@@ -140,7 +140,7 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
     if (newton) /* default arithmetic: six per CU in mixed memory (0.88-0.94
                    ms on two boxes; five: 0.88-0.95, four: 0.90-0.98, no cap:
                    0.88-0.94), four where the memory is of one class */
-        return c->opt_fast ? (c->place.mixed ? 24576 : 32768) : 0;
+        return c->opt_fast ? (c->place.fast ? 24576 : 32768) : 0;
     /* store bound: four workgroups per CU where the arrays lie in a mix of
      * memory classes (rt_place.h: 1.08 ms against 1.23 with two; three: 1.09,
      * five: 1.13), two where they do not -- two per CU is the setting that
@@ -149,7 +149,7 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
      * (tilted systems: ten streams per element, 1.49 against 1.52) */
     if (2 * stored_i > stored)
         return 65536;
-    if (c->place.mixed)
+    if (c->place.fast)
         return 32768;
     /* plain allocations: two per CU (the setting that does not care where
      * it writes), except small batches, short kernels whose launch ramp
@@ -589,8 +589,16 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     /* placed arrays in a new layout: measure the store pattern over them
      * (nothing lives in the rows yet) */
     if (ctx->place.base && fresh && !rt_lab_variant(ctx)) {
-        ctx->place.mixed = ctx->place.class_mix;
-        rt_place_verify(ctx, rt_layout(ctx), ctx->nsurf, ld);
+        rt_place_tune(ctx, ctx->nsurf, ld);
+        if (!ctx->d_buf) { /* (the mapping was lost on the way) */
+            rt_place_release(&ctx->place);
+            ctx->cap_doubles = 0;
+            ctx->n = ctx->ld = ctx->bs = 0;
+            ctx->nblk = 0;
+            ctx->bts = 0;
+            return rt_fail(ctx, RT_ERR_NOMEM,
+                           "rt_reserve: the arrays could not be mapped");
+        }
     }
     memset(ctx->i_alias, 0, sizeof ctx->i_alias);
     memset(ctx->u_alias, 0, sizeof ctx->u_alias);
@@ -1188,7 +1196,7 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
             ctx->uni_valid = 0; /* this launch writes row 0 */
         hipLaunchKernelGGL(rt_trace_gen_kernel, dim3(grid), dim3(RT_BLOCK),
                            lds, ctx->stream, ctx->d_surf, stop, clip, lay, cols,
-                           group_rays, ctx->nsurf,
+                           group_rays, ctx->nsurf, ctx->ngroups,
                            (const rt_field *)ctx->d_gen,
                            (const double *)((char *)ctx->d_gen + ctx->gen_fpad),
                            ctx->gen_np, ctx->gen_n, lo, ctx->gen_s0,
@@ -1199,7 +1207,7 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
                            dim3((unsigned)((ctx->ld + RT_CB - 1) / RT_CB)),
                            dim3(RT_CB), 0, ctx->stream, ctx->d_surf, start,
                            stop, clip, lay, ctx->ld, group_rays, ctx->nsurf,
-                           ctx->opt_compact_every);
+                           ctx->ngroups, ctx->opt_compact_every);
         RT_HIP(ctx, hipGetLastError());
         ctx->last_compact = 1;
 #ifdef RT_BUILD_PROBES
@@ -1215,7 +1223,7 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
             ctx, lo / 64, start == 1 && ctx->uni_valid && ctx->opt_uniform);
         hipLaunchKernelGGL(rt_trace_kernel, dim3(grid), dim3(RT_BLOCK), lds,
                            ctx->stream, ctx->d_surf, start, stop, clip, lay,
-                           cols, group_rays, ctx->nsurf, tiles);
+                           cols, group_rays, ctx->nsurf, ctx->ngroups, tiles);
         RT_HIP(ctx, hipGetLastError());
     }
     RT_HIP(ctx, hipEventRecord(ctx->k1, ctx->stream));
@@ -1610,23 +1618,19 @@ int rt_placement(rt_ctx *ctx, int info[10], double ms[8])
     if (!ctx || !info || !ms)
         return rt_fail(ctx, RT_ERR_ARG, "rt_placement: NULL argument");
     const rt_place &p = ctx->place;
+    memset(info, 0, 10 * sizeof(int));
+    memset(ms, 0, 8 * sizeof(double));
     info[0] = p.base ? p.n : 0;
     info[1] = (int)(p.piece >> 20);
     info[2] = p.created;
-    info[3] = p.nclass;
-    for (int k = 0; k < 3; ++k)
-        info[4 + k] = p.count[k];
-    info[7] = p.mixed;
-    info[8] = p.ballast;
-    info[9] = p.class_mix;
-    ms[0] = p.self_ms;
-    ms[1] = p.cross_ms;
-    ms[2] = p.store_gbps;
-    ms[3] = p.search_ms;
-    ms[4] = p.pieces_ms;
-    ms[5] = p.ballast_ms;
-    ms[6] = p.remap_ms;
-    ms[7] = p.verify_ms;
+    info[3] = p.tries;
+    info[4] = p.kept;
+    info[5] = p.fast;
+    for (int k = 0; k < RT_PLACE_TRIES && k < 4; ++k)
+        ms[k] = p.gbps[k];
+    ms[4] = p.store_gbps;
+    ms[5] = p.search_ms;
+    ms[6] = p.tune_ms;
     return RT_OK;
 }
 

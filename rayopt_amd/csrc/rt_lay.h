@@ -103,9 +103,11 @@ __device__ __forceinline__ int64_t rt_col_wg(const rt_lay &a, int64_t j,
 {
     if (!a.ts)
         return j + a.j0;
-    if (!a.wgs)
-        return rt_block_col(a.bs, a.ts, j + a.j0);
-    return j + a.j0 + (int64_t)rt_wg_block(a, wg) * (a.ts - a.bs);
+#ifndef RT_COL_DIVIDES /* (-DRT_COL_DIVIDES: the dividing form, for A/B runs) */
+    if (a.wgs)
+        return j + a.j0 + (int64_t)rt_wg_block(a, wg) * (a.ts - a.bs);
+#endif
+    return rt_block_col(a.bs, a.ts, j + a.j0);
 }
 
 #endif /* RT_LAY_H */

@@ -69,7 +69,7 @@ __device__ __forceinline__ void rt_load_state_tiles(
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
                 int clip, rt_lay a, int64_t ld, int64_t group_rays, int nsurf,
-                rt_tiles tiles)
+                int ngroups, rt_tiles tiles)
 {
     const int64_t j = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (j >= ld)
@@ -80,7 +80,10 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
          * with it every table read -- stays wave-uniform (SGPRs) */
         const int64_t j0 = a.j0 + j - (int64_t)(threadIdx.x & 63);
         const int g = __builtin_amdgcn_readfirstlane((int)(j0 / group_rays));
-        surf += (int64_t)g * nsurf;
+        /* wavefronts of padding slots beyond the last ray (a batch in blocks
+         * is padded to whole workgroups per block) take the last table: there
+         * is none behind it */
+        surf += (int64_t)(g < ngroups ? g : ngroups - 1) * nsurf;
     }
     const int64_t col = rt_col_wg(a, j, blockIdx.x);
     double y[1][3], u[1][3];
@@ -107,7 +110,7 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
                     rt_lay a, int64_t ld, int64_t group_rays, int nsurf,
-                    const rt_field *__restrict__ fields,
+                    int ngroups, const rt_field *__restrict__ fields,
                     const double *__restrict__ pupil, int64_t npupil,
                     int64_t n, int64_t j0, rt_surface S0, int store_i0,
                     int store0)
@@ -121,7 +124,7 @@ rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
     if (group_rays) {
         const int64_t jw = j - (int64_t)(threadIdx.x & 63);
         const int g = __builtin_amdgcn_readfirstlane((int)(jw / group_rays));
-        surf += (int64_t)g * nsurf;
+        surf += (int64_t)(g < ngroups ? g : ngroups - 1) * nsurf;
     }
     double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
     if (j < n) {
@@ -181,7 +184,8 @@ __device__ __forceinline__ void rt_store_nan_row(unsigned f, int s,
 __global__ void __launch_bounds__(RT_CB)
 rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
                         int stop, int clip, rt_lay a, int64_t ld,
-                        int64_t group_rays, int nsurf, int every)
+                        int64_t group_rays, int nsurf, int ngroups,
+                        int every)
 {
     __shared__ int cnt[2][RT_CB / 64]; /* by parity of the ROUND (the k-th
                                           time the question is asked): a
@@ -194,8 +198,10 @@ rt_trace_compact_kernel(const rt_surface *__restrict__ surf, int start,
                                               rows are NaN (0: alive) */
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t tile0 = (int64_t)blockIdx.x * RT_CB;
-    if (group_rays) /* a tile never straddles two groups (host checks) */
-        surf += (tile0 / group_rays) * nsurf;
+    if (group_rays) { /* a tile never straddles two groups (host checks) */
+        const int64_t g = tile0 / group_rays;
+        surf += (g < ngroups ? g : ngroups - 1) * nsurf;
+    }
     /* SoA (the only layout this kernel is launched for): the tile's columns
      * are consecutive -- blocks are whole tiles (rt_reserve) */
     const int64_t col0 = rt_col_wg(a, tile0, blockIdx.x);

@@ -52,8 +52,8 @@ def test_shipped_library_carries_no_laboratory(dll):
                                     _lib.LIB_PATH], text=True)
     assert "probe" not in syms and "_lab_" not in syms
     # the trace kernel's signature: table, start, stop, clip, layout, ld,
-    # group_rays, nsurf, the tile notes of row 0 -- and nothing else
-    assert "_Z15rt_trace_kernelPK10rt_surfaceiii6rt_laylli8rt_tiles\n" in \
+    # group_rays, nsurf, ngroups, the tile notes of row 0 -- and nothing else
+    assert "_Z15rt_trace_kernelPK10rt_surfaceiii6rt_layllii8rt_tiles\n" in \
         syms + "\n"
     probes = open(os.path.join(ROOT, "include", "rt_mi355_probes.h")).read()
     for name in _lib.PROBE_SIGNATURES:
