@@ -952,7 +952,7 @@ def main():
     # of memory classes (rt_placement); store-bound traces then run four
     # workgroups per CU from the first launch on, two otherwise
     placement = eng.placement()
-    placement["workgroups_per_cu_cap"] = 4 if placement["mixed"] else 2
+    placement["workgroups_per_cu_cap"] = 4 if placement["fast"] else 2
     placement["note"] = (
         "the speed of the trace's simultaneous row streams is a property of "
         "the physical memory behind the arrays (bare store pattern: 7.0 / "
@@ -1488,7 +1488,8 @@ def run_configs(ra, device, args):
                "cpu_reference": ref}
         pl = g.engine.placement()
         rec["placement"] = {k: pl[k] for k in ("pieces", "piece_mib",
-                                               "per_class", "mixed",
+                                               "per_class", "fast", "ranges_tried", "range_kept",
+                                               "store_pattern_GBps_per_range",
                                                "created", "ballast_blocks",
                                                "search_ms")}
         rec["_kind"] = kind

@@ -55,7 +55,8 @@ extern "C" {
                            3: rt_placement fills ms[8] (search times);
                               large batches in blocks (rt_blocks)
                            4: rt_opd_stats, rt_opd_device, rt_download_rays;
-                              rt_placement reports the ranges measured */
+                              rt_placement(info[16], ms[16]) reports the
+                              address ranges measured */
 #define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
 #define RT_MAX_SURFACES 256 /* elements per System */
 
@@ -387,7 +388,7 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * dynamic LDS per workgroup of the trace kernels, i.e. a cap of 160 KB / bytes
  * on the workgroups resident per CU: traces that store their rows run with two
  * workgroups per CU, which the memory side likes better than the seven the
- * registers allow, four where the arrays' own store pattern measured at the fast
+ * registers allow, four where the arrays' own store pattern was measured at the fast
  * level, rt_placement; FP64-bound traces are not capped), "placement"
  * (rt_placement), "range_shortcuts" (1 = default: IEEE quotients and square
  * roots run without the compiler's range scaffolding where the operands are
@@ -582,29 +583,42 @@ int rt_comm_sync(rt_ctx *ctx);
 int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
 
 /*
- * Where the result arrays live.  A trace's 7-10 simultaneous row streams run
- * at one of two speeds (bare store pattern of C3: 6.7-7.0 or 5.6-5.9 TB/s),
- * and which one is a property of the ADDRESS RANGE the memory is mapped
- * behind, not of the memory: the same pieces in the same order run at either
- * level behind different ranges; a plain hipMalloc of 10 GB is at the slow
- * one (csrc/rt_place.h, profiles/r05_probes/README.md).  Arrays of > 1.5 GiB
- * are therefore built from pieces (hipMemCreate, 1 GiB; 512 MiB below 3 GiB)
- * mapped behind a range of their own, and at rt_reserve the batch's own store
- * pattern (56 B per ray and element) is written over them and timed: below
- * 6150 GB/s the same pieces are mapped behind another fresh range and
- * measured again, at most four ranges (three above 16 GiB, two above 48), and
- * the best one stays (option "placement", default 1; RT_MI355_PLACEMENT=0 for
- * the whole process; plain hipMalloc if anything on the way fails; results
- * never depend on it).  info[0] = pieces behind the arrays (0: hipMalloc),
- * [1] = MiB per piece, [2] = pieces created, [3] = ranges measured for the
- * current layout, [4] = the one the arrays live behind, [5] = 1 if its
- * pattern is at the fast level (store-bound traces then run four workgroups
- * per CU instead of two), [6..9] = 0; ms[0..3] = GB/s of the pattern behind
- * each range tried (0: not tried), ms[4] = the kept one's (0: not measured --
- * a pattern below 0.5 GB tells nothing), ms[5] = wall milliseconds creating
- * and mapping the pieces, ms[6] = measuring and re-mapping, ms[7] = 0.
+ * Where the result arrays live.  The speed of a trace's 7-10 simultaneous row
+ * streams is not one number (bare store pattern of C3: 7.0 ... 5.65 TB/s on
+ * one box) and depends on WHICH pieces of device memory lie behind the arrays
+ * -- pieces fall into classes, streams dealt over two or three classes run
+ * faster than streams inside one, which is what a plain hipMalloc of 10 GB
+ * gets -- and on the ADDRESS RANGE they are mapped behind (the same pieces in
+ * the same order: 1.157 ms behind one range, 1.008 behind another);
+ * csrc/rt_place.h.  Arrays of > 1.5 GiB are therefore built from pieces
+ * (hipMemCreate, 1 GiB; 512 MiB below 3 GiB) whose class the library measures
+ * at rt_reserve with a ~1 ms pair test each, an even mix of classes mapped
+ * behind one address range of its own, the surplus released; then the
+ * batch's OWN store pattern (56 B per ray and element) is written over the
+ * arrays and timed, and while it stays below 6500 GB/s the same pieces are
+ * mapped behind another fresh range and measured again -- at most four ranges
+ * (three above 16 GiB, two above 48), the best one stays (option "placement",
+ * default 1; RT_MI355_PLACEMENT=0 for the whole process; plain hipMalloc if
+ * anything on the way fails; results never depend on it).
+ * info[0] = pieces behind the arrays (0: hipMalloc), [1] = MiB per piece,
+ * [2] = pieces created on the way, [3] = classes seen, [4..6] = pieces of
+ * class 0 / 1 / 2 kept, [7] = 1: store-bound traces run four workgroups per CU
+ * instead of two (the measured pattern is at or above 5950 GB/s; where no
+ * pattern was measured: at least a third of the pieces lie outside the
+ * largest class), [8] = blocks of ballast (4-8 GiB each) held during the
+ * search so that it moved on through the device memory (pieces come in runs
+ * of one class; search and ballast together never hold more than half of the
+ * memory that was free), [9] = what the classes alone said, [10] = address
+ * ranges measured for the current layout, [11] = the one kept, [12..15] = 0.
+ * ms[0] / ms[1] = the pair test's launch time inside one piece / across two
+ * classes, ms[2] = GB/s of the store pattern behind the kept range (0: not
+ * measured -- a pattern below 0.5 GB tells nothing), ms[3] = wall
+ * milliseconds the search took, of which ms[4] creating, mapping and testing
+ * pieces, ms[5] creating and releasing ballast, ms[6] unmapping, releasing
+ * the surplus and mapping the final range; ms[7] = measuring and re-mapping;
+ * ms[8..11] = GB/s behind each range tried (0: not tried), ms[12..15] = 0.
  */
-int rt_placement(rt_ctx *ctx, int info[10], double ms[8]);
+int rt_placement(rt_ctx *ctx, int info[16], double ms[16]);
 
 /* device scratch owned by the context (e.g. gather destination on root) */
 int rt_scratch(rt_ctx *ctx, int64_t bytes, void **out);

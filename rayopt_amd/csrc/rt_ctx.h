@@ -99,19 +99,29 @@ struct rt_lab {
 #define RT_BLOCK_BYTES 7.0e9
 
 #define RT_PLACE_TRIES 4 /* address ranges measured at most per allocation */
+#define RT_PLACE_CLASSES 4
 struct rt_place {
     void *base;      /* the mapped range (= d_buf), NULL: plain hipMalloc */
     size_t bytes, piece;
     int n;           /* pieces mapped */
     void *handles;   /* hipMemGenericAllocationHandle_t[n] */
-    int created;     /* pieces created (= n: there is no surplus any more) */
+    int created;     /* pieces created on the way (the surplus was released) */
+    int ballast;     /* blocks of ballast held while searching */
+    int nclass;      /* classes seen */
+    int count[RT_PLACE_CLASSES]; /* pieces of each class among the n */
+    int mixed;       /* >= a third of the pieces outside the largest class */
+    int class_mix;   /* (the same: what the classes alone said) */
+    float self_ms, cross_ms; /* pair test: same piece / another class */
     int tries;       /* address ranges measured for the current layout */
     int kept;        /* ... and which of them the arrays live behind */
-    float gbps[RT_PLACE_TRIES]; /* the store pattern behind each */
+    float gbps[RT_PLACE_TRIES]; /* the batch's store pattern behind each */
     float store_gbps; /* = gbps[kept] (0: not measured) */
-    int fast;         /* store_gbps at the fast level: four workgroups per CU */
-    float search_ms, tune_ms; /* wall time: pieces created and mapped /
-                                 measured and re-mapped */
+    int fast;         /* four workgroups per CU: store_gbps at the fast level
+                         (where nothing was measured: the classes are mixed) */
+    /* wall time of the search (rt_place_alloc): all of it, the pieces
+     * (create, map, pair tests), the ballast, unmapping / releasing / the
+     * final mapping; and of measuring / re-mapping (rt_place_tune) */
+    float search_ms, pieces_ms, ballast_ms, remap_ms, tune_ms;
 };
 
 struct rt_ctx {

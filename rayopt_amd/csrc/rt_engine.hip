@@ -1613,24 +1613,34 @@ int rt_selftest_arith(rt_ctx *ctx, uint64_t seed, int64_t n, int span,
     return RT_OK;
 }
 
-int rt_placement(rt_ctx *ctx, int info[10], double ms[8])
+int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
 {
     if (!ctx || !info || !ms)
         return rt_fail(ctx, RT_ERR_ARG, "rt_placement: NULL argument");
     const rt_place &p = ctx->place;
-    memset(info, 0, 10 * sizeof(int));
-    memset(ms, 0, 8 * sizeof(double));
+    memset(info, 0, 16 * sizeof(int));
+    memset(ms, 0, 16 * sizeof(double));
     info[0] = p.base ? p.n : 0;
     info[1] = (int)(p.piece >> 20);
     info[2] = p.created;
-    info[3] = p.tries;
-    info[4] = p.kept;
-    info[5] = p.fast;
-    for (int k = 0; k < RT_PLACE_TRIES && k < 4; ++k)
-        ms[k] = p.gbps[k];
-    ms[4] = p.store_gbps;
-    ms[5] = p.search_ms;
-    ms[6] = p.tune_ms;
+    info[3] = p.nclass;
+    for (int k = 0; k < 3; ++k)
+        info[4 + k] = p.count[k];
+    info[7] = p.fast;
+    info[8] = p.ballast;
+    info[9] = p.class_mix;
+    info[10] = p.base ? p.tries : 0;
+    info[11] = p.kept;
+    ms[0] = p.self_ms;
+    ms[1] = p.cross_ms;
+    ms[2] = p.store_gbps;
+    ms[3] = p.search_ms;
+    ms[4] = p.pieces_ms;
+    ms[5] = p.ballast_ms;
+    ms[6] = p.remap_ms;
+    ms[7] = p.tune_ms;
+    for (int k = 0; k < RT_PLACE_TRIES && k < 8; ++k)
+        ms[8 + k] = p.gbps[k];
     return RT_OK;
 }
 

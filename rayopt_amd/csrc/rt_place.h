@@ -2,42 +2,46 @@
  * rt_place.h -- WHERE the result arrays live in HBM.
  *
  * A trace writes 7-10 row streams per element at once (C3: 84 streams of
- * 40-80 MB).  The speed of that store pattern comes in two levels on MI355X
- * -- 6.7-7.0 TB/s or 5.6-5.9 -- and the trace follows it (C3 1.02 or 1.2 ms,
- * C2 0.207 or 0.259).  What decides the level (round 5, four boxes;
+ * 40-80 MB).  The speed of that store pattern is not one number on MI355X:
+ * 7.0 / 6.7 / 6.2 / 5.65 TB/s have all been measured for the same pattern on
+ * the same box, and the trace follows it (C3, one box, one process: 1.14 ms
+ * behind a pattern of 6.97 TB/s, 1.16 at 6.86, 1.22 at 6.7, 1.27-1.29 at
+ * 6.2-6.3, 1.28 in a plain hipMalloc).  Two things decide it, as far as four
+ * rounds of measurements can tell (profiles/r04_probes/README.md,
  * profiles/r05_probes/README.md):
  *
- *   * NOT which physical memory: the same ten 1 GiB pieces (hipMemCreate),
- *     in the same order, run the pattern at 1.157 ms behind one virtual
- *     address range and at 1.008 ms behind another (map_lab); 120
- *     arrangements of pieces drawn from all over the device memory -- one
- *     window, two or three far-apart windows, spread evenly -- are all alike
- *     inside one state of the range they are mapped into (arrange_lab
- *     "regions").  The "memory classes" of round 4 (pieces classified by a
- *     pair test, kept in an even mix) exist in that pair test -- short rows
- *     at EQUAL offsets in two pieces -- and nowhere in a real layout; the
- *     classification is gone;
- *   * NOT time, clocks or temperature: both levels are stable for 45 s side
- *     by side in one process, through idle gaps of 0.03-3 s (state_lab);
- *   * the ADDRESS RANGE the memory is mapped behind: pieces mapped ONCE into
- *     a reservation of their own are at the fast level in 12 of 12 cases and
- *     stay there; the same pieces behind a range that other mappings have
- *     used before run at either level, reproducibly per range (va_lab: two
- *     scans of one big reservation agree offset by offset); a plain hipMalloc
- *     is at the slow level (9 of 9 on four boxes; round 4: 5 of 8, 6 of 6).
- *     The mechanism is below what user space can see (page-table pages live
- *     in device memory too); the engine does not rely on an explanation.
+ *   * WHICH pieces of device memory lie behind the arrays (round 4): 1 GiB
+ *     pieces (hipMemCreate) fall into classes -- three on the boxes seen, in
+ *     runs of 1-26 consecutively created pieces; a pair of pieces of one
+ *     class runs a short-row store pattern at the slow level, a pair across
+ *     classes at the fast one.  Arrays built from consecutive pieces as the
+ *     driver hands them out, or a plain hipMalloc, sit at 6.2-6.7 / 5.65-6.0;
+ *     arrays built from an even MIX of classes at 6.9-7.0 (round 5, two
+ *     builds of this library alternating in one process, ten contexts each:
+ *     profiles/r05_probes/ab_r04_r05_builds_one_process.jsonl);
+ *   * WHERE they are mapped (round 5): the same ten pieces in the same order
+ *     run the pattern at 1.157 ms behind one virtual address range and at
+ *     1.008 ms behind another (map_lab, va_lab: reproducible per range, two
+ *     scans agree offset by offset); the level is stable over 45 s and across
+ *     idle gaps (state_lab).  This is what made C2 bimodal in round 4 -- 0.207
+ *     or 0.259 ms with the SAME class mix.  The mechanism is below what user
+ *     space can see (page tables live in device memory too); the engine does
+ *     not rely on an explanation, it measures.
  *
  * So large arrays are not hipMalloc'ed.  rt_place_alloc() creates pieces of
- * device memory and maps them behind one contiguous range -- an ordinary
- * device pointer to the rest of the engine -- and rt_place_tune(), once
- * rt_reserve knows the layout, MEASURES the batch's own store pattern over
- * the arrays; if that is below the fast level the same pieces are mapped
- * behind another fresh range and measured again (at most RT_PLACE_TRIES
- * ranges; the rejected reservations are held until the choice is made, so
- * that the allocator cannot hand them out again), and the best range stays.
- * 1-5 ms per range once per allocation (10^7 rays); hipMalloc if anything
- * fails: the placement is a matter of speed, never of results.
+ * device memory, finds the class of each with a pair test (42 short row
+ * streams in the piece, 42 in a representative of a known class: slow =
+ * same class), keeps a balanced mix, releases the rest and maps the kept
+ * pieces, classes interleaved, behind ONE contiguous range of its own -- what
+ * the rest of the engine sees is an ordinary device pointer.  rt_place_tune(),
+ * once rt_reserve knows the layout, then writes the batch's OWN store pattern
+ * over the arrays and times it; below RT_PLACE_GOOD_GBPS the same pieces are
+ * mapped behind another fresh range and measured again (at most
+ * RT_PLACE_TRIES ranges; the rejected reservations are held until the choice
+ * is made, so that the allocator cannot hand them out again), and the best
+ * range stays.  10-40 ms once per allocation.  Anything that fails on the way
+ * (no virtual memory management, out of memory for the surplus) falls back
+ * to hipMalloc: the placement is a matter of speed, never of results.
  */
 #ifndef RT_PLACE_H
 #define RT_PLACE_H
@@ -51,13 +55,69 @@ static inline double rt_place_now_ms(void)
                std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-/* up to 1.5 GiB: hipMalloc (kernels that short live on their launch ramp) */
+#define RT_PLACE_ROWS 84         /* 12 elements x (y0 y1 y2 u0 u1 u2 t) */
+/* up to 1.5 GiB: hipMalloc.  Above it there are at least four pieces of
+ * 512 MiB, two per class: with three the rows of Y, U and T fall on the
+ * classes in lumps ([2, 1]: two thirds of the streams in one class) and the
+ * trace is as often slower as faster (profiles/r04_probes/session26) */
 #define RT_PLACE_MIN_BYTES (((size_t)3 << 29) + 1)
-/* the store pattern at or above this: the fast level (7.0 / 6.3 TB/s seen;
- * the slow one is 5.6-5.9), four workgroups per CU; below it two */
-#define RT_PLACE_FAST_GBPS 6150.
-/* two measured ranges this far apart: both levels have been seen */
+#define RT_PLACE_SAME 0.91f      /* pair / self time above this: same class */
+/* the batch's own store pattern (rt_place_tune): at or above GOOD no other
+ * range is tried; below FAST the arrays behave like one class whatever the
+ * pair tests said (four workgroups per CU then lose to two); two ranges this
+ * far apart (GAP): both ends of what this memory does have been seen */
+#define RT_PLACE_GOOD_GBPS 6500.
+#define RT_PLACE_FAST_GBPS 5950.
 #define RT_PLACE_GAP 1.07
+
+struct rt_place_rows {
+    double *row[RT_PLACE_ROWS];
+};
+
+/* the trace kernel's store pattern, every row stream through a pointer */
+__global__ __launch_bounds__(256) void rt_place_pair_kernel(rt_place_rows tb,
+                                                             long long n)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n)
+        return;
+    const double a = 1e-9 * (double)r;
+    for (int s = 0; s < RT_PLACE_ROWS / 7; ++s) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            tb.row[s * 7 + j][r] = a + j;
+    }
+}
+
+/* rows 0..41 in piece a, 42..83 in piece b (a == b: all 84 in it) */
+static hipError_t rt_place_time(rt_ctx *c, double *a, double *b, long long n,
+                                float *ms)
+{
+    rt_place_rows tb;
+    for (int s = 0; s < RT_PLACE_ROWS; ++s) {
+        const int half = RT_PLACE_ROWS / 2;
+        if (a == b)
+            tb.row[s] = a + (long long)s * n;
+        else
+            tb.row[s] = (s < half ? a : b) + (long long)(s % half) * n;
+    }
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(rt_place_pair_kernel, dim3(grid), dim3(256), 32768,
+                       c->stream, tb, n);
+    hipError_t e = hipEventRecord(c->k0, c->stream);
+    for (int k = 0; k < 3 && e == hipSuccess; ++k)
+        hipLaunchKernelGGL(rt_place_pair_kernel, dim3(grid), dim3(256), 32768,
+                           c->stream, tb, n);
+    if (e == hipSuccess)
+        e = hipEventRecord(c->k1, c->stream);
+    if (e == hipSuccess)
+        e = hipEventSynchronize(c->k1);
+    if (e == hipSuccess)
+        e = hipEventElapsedTime(ms, c->k0, c->k1);
+    if (e == hipSuccess)
+        e = hipGetLastError();
+    return e;
+}
 
 static void rt_place_release(rt_place *p)
 {
@@ -114,6 +174,8 @@ static hipError_t rt_place_map(rt_ctx *c, rt_place *p, void **out)
     return hipSuccess;
 }
 
+
+
 static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
 {
     rt_place &P = c->place;
@@ -121,51 +183,277 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     if (!c->opt_place || bytes < RT_PLACE_MIN_BYTES)
         return hipMalloc(out, bytes);
     const double t_start = rt_place_now_ms();
+    double t_ballast = 0.;
+
     /* pieces of 1 GiB (RT_MI355_PIECE_MIB: another size, for measurements);
-     * arrays below 3 GiB: 512 MiB, so that no more than a piece is wasted */
+     * arrays below 3 GiB: pieces of 512 MiB */
     size_t piece = (size_t)1 << 30;
     {
         const char *e = getenv("RT_MI355_PIECE_MIB");
         const long mib = e ? atol(e) : 0;
-        if (mib >= 64 && mib <= 65536)
+        if (mib >= 512 && mib <= 65536)
             piece = (size_t)mib << 20;
     }
     if (bytes < 3 * piece)
-        piece >>= 1;
+        piece >>= 1; /* 512 MiB: a power of two, i.e. ONE block of the
+                        device's buddy allocator -- a 768 MiB piece is two
+                        blocks that may lie in two classes, and its "one
+                        piece" time is then already the fast one */
     const int need = (int)((bytes + piece - 1) / piece);
+    size_t align = piece & (~piece + 1); /* largest power of two dividing it */
+    const int cap = need + 24; /* pieces created and classified at most */
+    /* Pieces come in runs of one class (2-14 seen, 26+ on one box): once a
+     * class is oversupplied the search HOPS -- a block of ballast is created
+     * and held, unclassified, so that the next piece lies further on in the
+     * device memory -- until another class turns up.  Ballast and surplus
+     * pieces go back to the device before rt_place_alloc returns. */
+    const int max_ballast = 24;
+    hipMemGenericAllocationHandle_t ballast[24];
+    int nballast = 0, hops_in_a_row = 0;
+    /* what the search may hold beyond the `need` pieces it keeps -- surplus
+     * pieces and ballast -- stays below half of the memory that is free
+     * now: other contexts and processes allocate from the same device */
+    size_t extra = 0, budget = 0;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+            (void)hipGetLastError();
+        const size_t keep_b = (size_t)need * piece;
+        budget = free_b / 2 > keep_b ? (free_b / 2 - keep_b) / 1 : 0;
+        if (free_b < keep_b + 2 * piece) /* no room to choose from */
+            return hipMalloc(out, bytes);
+    }
+    /* short rows: 84 of them fit one piece */
+    const long long nprobe =
+        (long long)(piece / sizeof(double) / RT_PLACE_ROWS) / 256 * 256;
+
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = c->device;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = c->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+
     hipMemGenericAllocationHandle_t *h =
-        (hipMemGenericAllocationHandle_t *)calloc(need, sizeof *h);
-    int made = 0;
-    hipError_t e = h ? hipSuccess : hipErrorOutOfMemory;
-    for (; e == hipSuccess && made < need; ++made)
-        e = hipMemCreate(&h[made], piece, &prop, 0);
-    if (e != hipSuccess)
-        --made; /* the failed one holds nothing */
-    P.handles = h;
-    P.n = e == hipSuccess ? need : (made > 0 ? made : 0);
-    P.piece = piece;
-    P.bytes = (size_t)need * piece;
-    void *base = NULL;
+        (hipMemGenericAllocationHandle_t *)calloc(cap, sizeof *h);
+    unsigned char *cls = (unsigned char *)calloc(cap, 1);
+    void *scratch = NULL; /* every created piece at scratch + k * piece */
+    int made = 0, mapped = 0, nclass = 0, rep[RT_PLACE_CLASSES];
+    int count[RT_PLACE_CLASSES] = {0};
+    float self_ms = 0.f, cross_ms = 0.f;
+    hipError_t e = h && cls ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess)
-        e = rt_place_map(c, &P, &base);
-    if (e != hipSuccess) {
-        /* not this way (no virtual memory management, or the device is
-         * full): give everything back, allocate plainly */
+        e = hipMemAddressReserve(&scratch, (size_t)cap * piece, align, NULL, 0);
+    bool enough = false;
+    while (e == hipSuccess && made < cap && !enough) {
+        const int k = made;
+        if (made >= need && extra + piece > budget)
+            break; /* the surplus has reached its share of the free memory */
+        if (hipMemCreate(&h[k], piece, &prop, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            break; /* the device is full: what exists must do */
+        }
+        ++made;
+        if (made > need)
+            extra += piece;
+        double *pk = (double *)((char *)scratch + (size_t)k * piece);
+        e = hipMemMap(pk, piece, 0, h[k], 0);
+        if (e == hipSuccess) {
+            ++mapped;
+            e = hipMemSetAccess(pk, piece, &acc, 1);
+        }
+        if (e != hipSuccess)
+            break;
+        float ms = 0.f;
+        if (k == 0) {
+            /* the slow level: all rows in one piece -- repeated until two
+             * measurements agree to 2 % (a device coming out of idle) */
+            e = rt_place_time(c, pk, pk, nprobe, &ms);
+            for (int w = 0; w < 12 && e == hipSuccess; ++w) {
+                e = rt_place_time(c, pk, pk, nprobe, &self_ms);
+                const bool steady = fabsf(self_ms - ms) <= .02f * self_ms;
+                ms = self_ms;
+                if (steady)
+                    break;
+            }
+            if (e != hipSuccess)
+                break;
+            cls[0] = 0;
+            rep[0] = 0;
+            nclass = 1;
+            count[0] = 1;
+        } else {
+            /* pieces come in runs of one class: the previous one's first */
+            int order[RT_PLACE_CLASSES], no = 0;
+            order[no++] = cls[k - 1];
+            for (int q = 0; q < nclass; ++q)
+                if (q != cls[k - 1])
+                    order[no++] = q;
+            int found = -1;
+            for (int q = 0; q < no && found < 0; ++q) {
+                double *pr = (double *)((char *)scratch +
+                                        (size_t)rep[order[q]] * piece);
+                e = rt_place_time(c, pk, pr, nprobe, &ms);
+                if (e != hipSuccess)
+                    break;
+                if (ms > RT_PLACE_SAME * self_ms)
+                    found = order[q];
+                else
+                    cross_ms = ms;
+            }
+            if (e != hipSuccess)
+                break;
+            if (found < 0) {
+                if (nclass < RT_PLACE_CLASSES) {
+                    found = nclass++;
+                    rep[found] = k;
+                } else {
+                    found = RT_PLACE_CLASSES - 1; /* more kinds than room */
+                }
+            }
+            cls[k] = (unsigned char)found;
+            ++count[found];
+        }
+        if (count[cls[k]] > (need + 1) / 2 && made >= (need + 1) / 2 + 1 &&
+            nballast < max_ballast) {
+            const size_t hop = (size_t)(hops_in_a_row < 3 ? 4 : 8) << 30;
+            const double tb = rt_place_now_ms();
+            if (extra + hop > budget) {
+                /* (no room left to hop in) */
+            } else if (hipMemCreate(&ballast[nballast], hop, &prop, 0) ==
+                       hipSuccess) {
+                ++nballast;
+                extra += hop;
+            } else {
+                (void)hipGetLastError(); /* the device is full: no hopping */
+            }
+            t_ballast += rt_place_now_ms() - tb;
+            ++hops_in_a_row;
+        } else {
+            hops_in_a_row = 0;
+        }
+        /* enough when `need` pieces can be picked with no class holding
+         * more than half of them (two classes evenly mixed run at 0.98 of
+         * the three-class time: not worth a dozen more pieces) */
+        if (made >= need && nclass >= 2) {
+            int can = 0;
+            for (int q = 0; q < nclass; ++q)
+                can += count[q] < (need + 1) / 2 ? count[q] : (need + 1) / 2;
+            enough = can >= need;
+        }
+    }
+    const double t_found = rt_place_now_ms(), t_created = t_ballast;
+    for (int b = 0; b < nballast; ++b)
+        (void)hipMemRelease(ballast[b]);
+    t_ballast += rt_place_now_ms() - t_found;
+    if (e != hipSuccess || made < need) {
+        /* not this way: give everything back, allocate plainly */
         (void)hipGetLastError();
-        rt_place_release(&P);
+        for (int k = 0; k < mapped; ++k)
+            (void)hipMemUnmap((char *)scratch + (size_t)k * piece, piece);
+        for (int k = 0; k < made; ++k)
+            (void)hipMemRelease(h[k]);
+        if (scratch)
+            (void)hipMemAddressFree(scratch, (size_t)cap * piece);
+        free(h);
+        free(cls);
+        return hipMalloc(out, bytes);
+    }
+    /* pick `need` pieces round-robin over the classes (an even mix, as far
+     * as the counts allow), in that order along the address range */
+    int *pick = (int *)calloc(need, sizeof(int));
+    hipMemGenericAllocationHandle_t *kept =
+        (hipMemGenericAllocationHandle_t *)calloc(need, sizeof *kept);
+    int next[RT_PLACE_CLASSES] = {0}, taken = 0, q = 0, idle = 0;
+    int used[RT_PLACE_CLASSES] = {0};
+    while (pick && taken < need && idle < nclass) {
+        int k = next[q];
+        while (k < made && cls[k] != q)
+            ++k;
+        if (k < made) {
+            pick[taken++] = k;
+            next[q] = k + 1;
+            ++used[q];
+            idle = 0;
+        } else {
+            next[q] = made;
+            ++idle;
+        }
+        q = (q + 1) % nclass;
+    }
+    for (int k = 0; k < made; ++k)
+        (void)hipMemUnmap((char *)scratch + (size_t)k * piece, piece);
+    /* the scratch range goes back first: the final range then begins where
+     * the pair tests ran (measured against a range reserved while the
+     * scratch was still held, two builds alternating in one process: the
+     * store pattern 6750-6865 GB/s here, 6555-6676 there; where even this
+     * range is slow rt_place_tune tries others) */
+    (void)hipMemAddressFree(scratch, (size_t)cap * piece);
+    void *base = NULL;
+    e = pick && kept && taken == need ? hipSuccess : hipErrorOutOfMemory;
+    if (e == hipSuccess)
+        e = hipMemAddressReserve(&base, (size_t)need * piece, align, NULL, 0);
+    int nm = 0;
+    for (; e == hipSuccess && nm < need; ++nm) {
+        e = hipMemMap((char *)base + (size_t)nm * piece, piece, 0,
+                      h[pick[nm]], 0);
+        if (e == hipSuccess) {
+            kept[nm] = h[pick[nm]];
+            h[pick[nm]] = 0;
+        }
+    }
+    if (e == hipSuccess)
+        e = hipMemSetAccess(base, (size_t)need * piece, &acc, 1);
+    for (int k = 0; k < made; ++k) /* the surplus */
+        if (h[k])
+            (void)hipMemRelease(h[k]);
+    free(h);
+    free(cls);
+    free(pick);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (int k = 0; k < nm && kept; ++k) {
+            if (kept[k]) { /* mapped */
+                (void)hipMemUnmap((char *)base + (size_t)k * piece, piece);
+                (void)hipMemRelease(kept[k]);
+            }
+        }
+        if (base)
+            (void)hipMemAddressFree(base, (size_t)need * piece);
+        free(kept);
         return hipMalloc(out, bytes);
     }
     P.base = base;
-    P.created = need;
+    P.bytes = (size_t)need * piece;
+    P.piece = piece;
+    P.n = need;
+    P.handles = kept;
+    P.created = made;
+    P.nclass = nclass;
+    for (int k = 0; k < RT_PLACE_CLASSES; ++k)
+        P.count[k] = used[k];
+    P.self_ms = self_ms;
+    P.cross_ms = cross_ms;
+    /* mixed: at least a third of the pieces lie outside the largest class */
+    int largest = 0;
+    for (int k = 0; k < nclass; ++k)
+        largest = used[k] > largest ? used[k] : largest;
+    P.mixed = nclass >= 2 && 3 * (need - largest) >= need;
+    P.ballast = nballast;
+    P.class_mix = P.mixed;
+    P.fast = P.mixed; /* (until the pattern itself has been measured) */
     P.tries = 1;
-    P.search_ms = (float)(rt_place_now_ms() - t_start);
+    const double t_end = rt_place_now_ms();
+    P.search_ms = (float)(t_end - t_start);
+    P.ballast_ms = (float)t_ballast;
+    P.pieces_ms = (float)(t_found - t_start - t_created);
+    P.remap_ms = (float)(t_end - t_found - (t_ballast - t_created));
     *out = base;
     return hipSuccess;
 }
+
 
 /*
  * The trace's own store pattern -- y0 y1 y2 u0 u1 u2 t of every element, one
@@ -218,21 +506,20 @@ static float rt_place_measure(rt_ctx *c, int L, long long ld)
 }
 
 /*
- * Measure, and while the arrays are at the slow level map the same pieces
- * behind other fresh ranges: the best one stays (ctx->d_buf follows).  What
- * decides between four and two workgroups per CU (rt_resident_lds) is this
- * measurement.  Batches whose pattern is too short to tell the levels apart
- * (< 0.5 GB written) keep their first range.
+ * Measure, and while the pattern is below RT_PLACE_GOOD_GBPS map the same
+ * pieces behind other fresh ranges: the best one stays (ctx->d_buf follows).
+ * What decides between four and two workgroups per CU (rt_resident_lds) is
+ * this measurement, not the classes.  Batches whose pattern is too short to
+ * tell anything (< 0.5 GB written) keep their first range.
  */
 static void rt_place_tune(rt_ctx *c, int L, long long ld)
 {
     rt_place &P = c->place;
-    /* (a pattern too short to measure leaves what an earlier layout found
-     * out about the range the arrays live behind) */
+    /* (a pattern too short to measure leaves what the classes said, or
+     * what an earlier layout found out about the range) */
     if (!P.base || L < 2 || 56. * (L - 1) * (double)ld < 5e8)
         return;
     P.store_gbps = 0.f;
-    P.fast = 0;
     P.kept = 0;
     P.tune_ms = 0.f;
     for (int k = 0; k < RT_PLACE_TRIES; ++k)
@@ -250,8 +537,8 @@ static void rt_place_tune(rt_ctx *c, int L, long long ld)
             lo = P.gbps[k] < lo ? P.gbps[k] : lo;
             hi = P.gbps[k] > hi ? P.gbps[k] : hi;
         }
-        if (hi >= RT_PLACE_FAST_GBPS || hi >= RT_PLACE_GAP * lo)
-            break; /* at the fast level, or both levels seen */
+        if (hi >= RT_PLACE_GOOD_GBPS || hi >= RT_PLACE_GAP * lo)
+            break; /* as good as it gets, or both ends seen */
         /* the same pieces behind another range; the ranges tried so far
          * stay reserved so that the next one is a new one */
         if (hipStreamSynchronize(c->stream) != hipSuccess ||
@@ -329,7 +616,8 @@ static void rt_place_tune(rt_ctx *c, int L, long long ld)
     P.tries = n;
     P.kept = best;
     P.store_gbps = P.gbps[best];
-    P.fast = P.store_gbps >= RT_PLACE_FAST_GBPS;
+    if (P.store_gbps > 0.f) /* whatever the classes said */
+        P.fast = P.store_gbps >= RT_PLACE_FAST_GBPS;
     P.tune_ms = (float)(rt_place_now_ms() - t_start);
 }
 

@@ -342,19 +342,24 @@ class Engine:
 
     def placement(self):
         """Where the result arrays live (rt_placement): dict with the pieces
-        behind them (0 = plain hipMalloc), MiB per piece, the address ranges
-        the store pattern was measured behind (GB/s each), which one was
-        kept, and ``fast``: its pattern is at the fast level."""
-        info = (ctypes.c_int*10)()
-        ms = (ctypes.c_double*8)()
+        behind them (0 = plain hipMalloc), MiB per piece, pieces created on
+        the way, classes seen, pieces kept per class, the address ranges the
+        batch's store pattern was measured behind (GB/s each), which one was
+        kept, and ``fast``: four workgroups per CU."""
+        info = (ctypes.c_int*16)()
+        ms = (ctypes.c_double*16)()
         self._check(self.lib.rt_placement(self.ctx, info, ms), "rt_placement")
         return {"pieces": info[0], "piece_mib": info[1], "created": info[2],
-                "ranges_tried": info[3], "range_kept": info[4],
-                "fast": bool(info[5]),
-                "store_pattern_GBps_per_range": [ms[k] for k in
-                                                 range(max(info[3], 0))],
-                "store_pattern_GBps": ms[4],
-                "search_ms": {"pieces": ms[5], "tune": ms[6]}}
+                "classes": info[3], "per_class": [info[4], info[5], info[6]],
+                "fast": bool(info[7]), "ballast_blocks": info[8],
+                "classes_mixed": bool(info[9]),
+                "ranges_tried": info[10], "range_kept": info[11],
+                "store_pattern_GBps_per_range": [ms[8 + k] for k in
+                                                 range(max(info[10], 0))],
+                "store_pattern_GBps": ms[2],
+                "pair_test_ms": {"same_piece": ms[0], "other_class": ms[1]},
+                "search_ms": {"all": ms[3], "pieces": ms[4], "ballast": ms[5],
+                              "remap": ms[6], "tune": ms[7]}}
 
     def selftest_arith(self, seed, n, span=100):
         """rt_selftest_arith: mismatch counts (refraction quotient, table

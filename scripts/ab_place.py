@@ -48,6 +48,7 @@ def load(path):
                                  ctypes.POINTER(ctypes.c_double)]
     lib.rt_download.argtypes = [P_, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                 P_]
+    lib.rt_set_option.argtypes = [P_, ctypes.c_char_p, ctypes.c_int]
     return lib
 
 
@@ -56,9 +57,10 @@ def check(lib, ctx, rc, what):
         raise RuntimeError("%s: %s" % (what, lib.rt_last_error(ctx).decode()))
 
 
-def one(lib, tables, y, u, copies, L):
+def one(lib, tables, y, u, copies, L, placed=1):
     ctx = P_()
     check(lib, None, lib.rt_create(0, ctypes.byref(ctx)), "create")
+    check(lib, ctx, lib.rt_set_option(ctx, b"placement", placed), "option")
     t = np.ascontiguousarray(tables)
     check(lib, ctx, lib.rt_upload_system_groups(ctx, t.ctypes.data, L,
                                                 len(tables)), "upload")
@@ -83,8 +85,8 @@ def one(lib, tables, y, u, copies, L):
         lib.rt_event_record(ctx, 1)
         lib.rt_event_elapsed(ctx, 0, 1, ctypes.byref(ms))
         ts.append(ms.value/per)
-    info = (ctypes.c_int*10)()
-    pm = (ctypes.c_double*8)()
+    info = (ctypes.c_int*16)()
+    pm = (ctypes.c_double*16)()
     lib.rt_placement(ctx, info, pm)
     n = len(y)*copies
     img = np.empty((3, n))
@@ -116,9 +118,12 @@ def main():
     want = {}
     for k in range(turns):
         for name, tab, y, u, copies, L in shapes:
-            for tag, lib in (("r04", old), ("r05", new)):
+            for tag, lib, placed in (("r04", old, 1), ("r05", new, 1),
+                                     ("r04 hipMalloc", old, 0),
+                                     ("r05 hipMalloc", new, 0)):
                 ms, info, pm, img = one(lib, tab, np.ascontiguousarray(y),
-                                        np.ascontiguousarray(u), copies, L)
+                                        np.ascontiguousarray(u), copies, L,
+                                        placed)
                 same = np.array_equal(want.setdefault(name, img), img,
                                       equal_nan=True)
                 print(json.dumps({"shape": name, "turn": k, "build": tag,

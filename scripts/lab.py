@@ -467,7 +467,7 @@ def cmd_kinds(a):
             tele.mark("%d:end" % len(recs))
         recs.append({"kind": name, "first": first, "count": count[0] - first,
                      "ms": float(np.median(ms)),
-                     "placement_mixed": eng.placement()["mixed"]})
+                     "placement_mixed": eng.placement()["fast"]})
 
     n = a.rays
     s3 = ra.system_from_yaml(P.DOUBLE_GAUSS)
@@ -574,7 +574,7 @@ def cmd_variants(a):
         same = bool(np.array_equal(np.array(g.y[-1]), base, equal_nan=True))
         ms = [steady(eng, .5) for _ in range(2)]
         out(variant=v or "laboratory default", ms=ms, bit_identical=same,
-            placement_mixed=eng.placement()["mixed"])
+            placement_mixed=eng.placement()["fast"])
     for k, val in defaults.items():
         eng.set_option(k, val)
     eng.set_option("lds_pad", 0)
@@ -957,7 +957,7 @@ def cmd_planes(a):
                 rec.setdefault("Y|U|T|I" if order else "Y|U|I|T", []).append(
                     ms*1e7/n)
         rec["placement"] = eng.placement()["per_class"]
-        rec["resident"] = eng.placement()["mixed"]
+        rec["resident"] = eng.placement()["fast"]
         out(**rec)
         del g
         eng.close()

@@ -52,7 +52,14 @@ def test_large_arrays_are_placed_and_results_do_not_depend_on_it():
             # them, the documented fallback: pieces == 0)
             assert info["pieces"] == 0 or (
                 info["pieces"]*info["piece_mib"]*2**20 >= L*10*eng.ld*8 and
-                info["created"] == info["pieces"])
+                sum(info["per_class"]) <= info["pieces"] and
+                info["created"] >= info["pieces"])
+            # the search says what it cost (10-40 ms typically; no bound
+            # asserted: the first kernel of a process loads its code object)
+            t = info["search_ms"]
+            assert info["pieces"] == 0 or t["all"] > 0
+            assert t["pieces"] + t["ballast"] + t["remap"] <= \
+                t["all"]*1.01 + .01
             if info["pieces"]:
                 # the batch's own store pattern was measured behind 1-4
                 # address ranges and the best one kept
@@ -62,15 +69,14 @@ def test_large_arrays_are_placed_and_results_do_not_depend_on_it():
                 assert 0 <= info["range_kept"] < k
                 assert info["store_pattern_GBps"] == max(rates) == \
                     rates[info["range_kept"]]
-                assert info["fast"] == (info["store_pattern_GBps"] >= 6150.)
-                # a further range is tried only while the level is slow and
-                # no gap has shown
-                assert k == 1 or max(rates[:k - 1]) < 6150.
-                assert info["search_ms"]["pieces"] > 0
-                assert info["search_ms"]["tune"] > 0
+                assert info["fast"] == (info["store_pattern_GBps"] >= 5950.)
+                # a further range is tried only while the pattern is below
+                # "good" and no gap has shown
+                assert k == 1 or max(rates[:k - 1]) < 6500.
+                assert t["tune"] > 0
         else:
             assert info["pieces"] == 0 and not info["fast"]
-            assert info["search_ms"]["pieces"] == 0.
+            assert info["search_ms"]["all"] == 0.
         got[placed] = _rows(eng, L)
         # every resident setting, the same bits
         for lds in (65536, 32768, 0):
