@@ -401,8 +401,6 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * "consumers_one_pass" (1 = default, see rt_rms; 0 = always two passes),
  * "consumer_events" (measurement: 1 = the reductions bracket their kernels
  * with the events rt_kernel_ms reads; default 0).
- * Measurement-only variants and the memory-system probes live in a separate
- * laboratory build (include/rt_mi355_probes.h), not in this library.
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
 
@@ -595,11 +593,12 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * at rt_reserve with a ~1 ms pair test each, an even mix of classes mapped
  * behind one address range of its own, the surplus released; then the
  * batch's OWN store pattern (56 B per ray and element) is written over the
- * arrays and timed, and while it stays below 6500 GB/s the same pieces are
- * mapped behind another fresh range and measured again -- at most four ranges
- * (three above 16 GiB, two above 48), the best one stays (option "placement",
- * default 1; RT_MI355_PLACEMENT=0 for the whole process; plain hipMalloc if
- * anything on the way fails; results never depend on it).
+ * arrays and timed; while it stays below 6900 GB/s the same pieces are
+ * mapped behind a second fresh range and, for arrays up to 16 GiB, ANOTHER
+ * set of pieces is searched, classified and measured while the first is held
+ * (at most three sets); the best stays (option "placement", default 1;
+ * RT_MI355_PLACEMENT=0 for the whole process; plain hipMalloc if anything on
+ * the way fails; results never depend on it).
  * info[0] = pieces behind the arrays (0: hipMalloc), [1] = MiB per piece,
  * [2] = pieces created on the way, [3] = classes seen, [4..6] = pieces of
  * class 0 / 1 / 2 kept, [7] = 1: store-bound traces run four workgroups per CU
@@ -609,14 +608,16 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * search so that it moved on through the device memory (pieces come in runs
  * of one class; search and ballast together never hold more than half of the
  * memory that was free), [9] = what the classes alone said, [10] = address
- * ranges measured for the current layout, [11] = the one kept, [12..15] = 0.
+ * ranges measured for the kept set of pieces, [11] = the one kept, [12] =
+ * sets of pieces tried, [13..15] = 0.
  * ms[0] / ms[1] = the pair test's launch time inside one piece / across two
  * classes, ms[2] = GB/s of the store pattern behind the kept range (0: not
  * measured -- a pattern below 0.5 GB tells nothing), ms[3] = wall
  * milliseconds the search took, of which ms[4] creating, mapping and testing
  * pieces, ms[5] creating and releasing ballast, ms[6] unmapping, releasing
  * the surplus and mapping the final range; ms[7] = measuring and re-mapping;
- * ms[8..11] = GB/s behind each range tried (0: not tried), ms[12..15] = 0.
+ * ms[8..11] = GB/s behind each range tried (0: not tried), ms[12..14] = GB/s
+ * of each set of pieces tried (its best range), ms[15] = 0.
  */
 int rt_placement(rt_ctx *ctx, int info[16], double ms[16]);
 

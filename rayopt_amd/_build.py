@@ -5,10 +5,10 @@ the trace), rt_consumers.hip (aiming, rms / refocus / spot statistics / opd),
 rt_comm.hip (RCCL gather).  Kept next to the package so that it travels with
 a snapshot of the repository; git-ignored.
 
-``librt_mi355_probes.so`` -- the laboratory (``python -m rayopt_amd._build
-probes``): the same sources compiled with ``-DRT_BUILD_PROBES`` plus
-rt_probes.hip (rejected kernel variants, bandwidth probes, measurement
-options).  Only the measurement scripts load it (``RT_MI355_LIB``).
+``RT_MI355_LIB`` names another build of the same ABI to load instead
+(measurements that compare two builds in one process: scripts/ab_place.py).
+The laboratory build of rounds 2-4 (probes, rejected kernel variants) is in
+the history of this repository (last present in commit 3b63b5b).
 
 ``-ffp-contract=off`` is part of the numerical contract (see csrc/rt_math.h):
 numpy never fuses a multiply into an add, and planes / spheres / conics are
@@ -25,17 +25,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_mi355.so")
-PROBES_LIB = os.path.join(HERE, "librt_mi355_probes.so")
 UNITS = ["rt_engine.hip", "rt_consumers.hip", "rt_comm.hip"]
-PROBE_UNITS = UNITS + ["rt_probes.hip"]
 SOURCES = [os.path.join(CSRC, u) for u in UNITS]
 HEADERS = [os.path.join(CSRC, h) for h in (
     "rt_math.h", "rt_lay.h", "rt_ctx.h", "rt_march.h", "rt_trace_kernels.h",
     "rt_consumer_kernels.h", "rt_aim.h")] + [
     os.path.join(HERE, "..", "include", "rt_mi355.h")]
-PROBE_HEADERS = HEADERS + [os.path.join(CSRC, "rt_probe_kernels.h"),
-                           os.path.join(HERE, "..", "include",
-                                        "rt_mi355_probes.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
          "-fPIC"]
 
@@ -92,17 +87,5 @@ def build(force=False, verbose=False):
     return _build(LIB, UNITS, [], "product", verbose)
 
 
-def build_probes(force=False, verbose=False):
-    """Compile the laboratory build; returns the path of its .so."""
-    files = [os.path.join(CSRC, u) for u in PROBE_UNITS] + PROBE_HEADERS
-    if not force and not _stale(PROBES_LIB, files):
-        return PROBES_LIB
-    return _build(PROBES_LIB, PROBE_UNITS, ["-DRT_BUILD_PROBES"], "probes",
-                  verbose)
-
-
 if __name__ == "__main__":
-    if "probes" in sys.argv[1:]:
-        print(build_probes(force=True, verbose=True))
-    else:
-        print(build(force=True, verbose=True))
+    print(build(force=True, verbose=True))

@@ -164,12 +164,6 @@ SIGNATURES = {
                                        ctypes.c_int64]),
 }
 
-# only in the laboratory build (librt_mi355_probes.so, RT_MI355_LIB):
-# include/rt_mi355_probes.h
-PROBE_SIGNATURES = {
-    "rt_probes_built": (ctypes.c_int, []),
-    "rt_probe": (ctypes.c_int, [_ctx, ctypes.c_int, _c_double_p, _c_double_p]),
-}
 
 _libs = {}
 
@@ -194,11 +188,6 @@ def load(path=None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for name, (res, args) in PROBE_SIGNATURES.items():
-        fn = getattr(lib, name, None)       # the shipped library has none
-        if fn is not None:
-            fn.restype = res
-            fn.argtypes = args
     if lib.rt_abi_version() != RT_ABI_VERSION:
         raise EngineError(
             "%s speaks ABI version %d, this package %d: rebuild it "

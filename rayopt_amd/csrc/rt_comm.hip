@@ -132,8 +132,6 @@ static int rt_gather_window(rt_ctx *ctx, int which, int surf,
             return rt_fail(ctx, RT_ERR_ARG, "%s: counts[%d] < 0", who, r);
     if (ctx->rank == root && !d_dst)
         return rt_fail(ctx, RT_ERR_ARG, "%s: root needs d_dst", who);
-    if (rt_soa_only(ctx, who) != RT_OK)
-        return RT_ERR_STATE;
     if (nchunks == 1) /* a whole row: not in the middle of a step in pieces */
         RT_ROWS_WHOLE(ctx, who);
     RT_HIP(ctx, hipSetDevice(ctx->device));

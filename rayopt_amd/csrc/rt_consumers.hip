@@ -125,8 +125,6 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
         !ctx->valid[surf])
         return rt_fail(ctx, RT_ERR_STATE, "%s: row %d holds no data", who,
                        surf);
-    if (rt_soa_only(ctx, who) != RT_OK)
-        return RT_ERR_STATE;
     RT_ROWS_WHOLE(ctx, who);
     if (ctx->d_w && ctx->w_n != ctx->n)
         return rt_fail(ctx, RT_ERR_STATE,

@@ -7,9 +7,6 @@
  *                     trace launch, row bookkeeping (served rows), downloads
  *   rt_consumers.hip  aiming kernel, rms / refocus / spot statistics / opd
  *   rt_comm.hip       RCCL communicator and the gather of a result row
- *   rt_probes.hip     laboratory only (-DRT_BUILD_PROBES ->
- *                     librt_mi355_probes.so): rejected kernel variants,
- *                     bandwidth probes, measurement options
  */
 #ifndef RT_CTX_H
 #define RT_CTX_H
@@ -49,41 +46,6 @@ struct rt_rccl_api {
     ncclResult_t (*GetVersion)(int *);
 };
 
-#ifdef RT_BUILD_PROBES
-/* laboratory state (rt_probes.hip) */
-struct rt_lab {
-    int r, nt, xcd;   /* rays per lane, non-temporal stores, XCD dealing */
-    int block;        /* threads per workgroup of the lab kernels */
-    int lds;          /* bytes of unused dynamic LDS per workgroup */
-    int tile;         /* tile-major result layout, rays per tile */
-    int tile_planes;  /* inside a tile the planes of SoA ([Y|U|I|T][L][3][TR])
-                       * instead of [L][10][TR]: "super-blocked SoA" */
-    int tile_pad;     /* ... with rows TR + tile_pad doubles apart */
-    int tile_shipped; /* tile layouts run the shipped kernel, not the lab one */
-    int t_before_i;   /* planes in the order Y | U | T | I */
-    int uniform_fix;  /* input components read as if wave-uniform (mask) */
-    int gate_log2, gate_window; /* chip-wide read windows */
-    int probe_store;  /* rt_probe pattern modes: 0 plain 1 nt 2 sc1 3 sc0sc1 */
-    void *d_probe_in; /* rt_probe modes 13/14: input rows of their own */
-    size_t probe_in_bytes;
-    int probe_in_uc;
-    int vmm_mb;       /* > 0: the arrays live in virtual memory backed by
-                         physical chunks of this many MiB (hipMemCreate /
-                         hipMemMap), mapped in shuffled order if vmm_shuffle */
-    int vmm_shuffle;
-    unsigned vmm_seed;
-    int vmm_align_mb;
-    void *vmm_base;   /* the reservation d_buf points at, if any */
-    size_t vmm_bytes, vmm_chunk;
-    void *vmm_handles; /* hipMemGenericAllocationHandle_t[vmm_n] */
-    size_t vmm_n;
-    int alloc_round;  /* the allocation is rounded up: 0 no, 1..40 to a
-                         multiple of 2^k bytes, 99 to a power of two */
-    size_t base_off;  /* doubles: the arrays start this far into d_buf (the
-                         laboratory build allocates RT_LAB_SLACK more) */
-};
-#define RT_LAB_SLACK ((size_t)1 << 27) /* doubles = 1 GiB */
-#endif
 
 /*
  * Where the result arrays live (rt_place.h): pieces of device memory mapped
@@ -122,6 +84,8 @@ struct rt_place {
      * (create, map, pair tests), the ballast, unmapping / releasing / the
      * final mapping; and of measuring / re-mapping (rt_place_tune) */
     float search_ms, pieces_ms, ballast_ms, remap_ms, tune_ms;
+    int picks;           /* sets of pieces tried (rt_place_settle) */
+    float pick_gbps[3];  /* the pattern behind the best range of each */
 };
 
 struct rt_ctx {
@@ -241,9 +205,6 @@ struct rt_ctx {
     int gather_slot;
     int gather_timed; /* g0 and g1 have both been recorded */
 
-#ifdef RT_BUILD_PROBES
-    rt_lab lab;
-#endif
     char err[512];
 };
 
@@ -282,17 +243,7 @@ static inline double *rt_arr(const rt_ctx *c, int which)
 {
     /* block 0: Y,U,I are [L][3][bs]; T is [L][bs] */
     const size_t plane = (size_t)c->buf_nsurf * 3 * (size_t)c->bs;
-#ifdef RT_BUILD_PROBES
-    if (c->lab.t_before_i) { /* Y | U | T | I: the written planes together */
-        const size_t off = which == RT_T ? 2 * plane
-                         : which == RT_I ? 2 * plane + plane / 3
-                                         : (size_t)which * plane;
-        return c->d_buf + c->lab.base_off + off;
-    }
-    return c->d_buf + c->lab.base_off + (size_t)which * plane;
-#else
     return c->d_buf + (size_t)which * plane;
-#endif
 }
 
 static inline int rt_ncomp(int which) { return which == RT_T ? 1 : 3; }
@@ -303,36 +254,6 @@ static inline rt_lay rt_layout_planes(const rt_ctx *c)
     rt_lay a;
     a.j0 = 0;
     a.wgs = a.wmagic = a.wshift = a.w0 = 0;
-#ifdef RT_BUILD_PROBES
-    if (c->lab.tile && c->lab.tile_planes) {
-        /* [tile][Y U I: [L][3][TR] | T: [L][TR]]: a tile is a batch of TR
-         * rays in the documented SoA layout */
-        const int64_t tr = c->lab.tile, pitch = tr + c->lab.tile_pad;
-        const int64_t lp = (int64_t)c->buf_nsurf * pitch;
-        a.Y = c->d_buf;
-        a.U = c->d_buf + 3 * lp;
-        a.I = c->d_buf + 6 * lp;
-        a.T = c->d_buf + 9 * lp;
-        a.cs = pitch;
-        a.ss = 3 * pitch;
-        a.ssT = pitch;
-        a.bs = tr;
-        a.ts = 10 * lp;
-        return a;
-    }
-    if (c->lab.tile) { /* [tile][L][10][TR] */
-        const int64_t tr = c->lab.tile;
-        a.Y = c->d_buf;
-        a.U = c->d_buf + 3 * tr;
-        a.I = c->d_buf + 6 * tr;
-        a.T = c->d_buf + 9 * tr;
-        a.cs = tr;
-        a.ss = a.ssT = 10 * tr;
-        a.bs = tr;
-        a.ts = (int64_t)c->buf_nsurf * 10 * tr;
-        return a;
-    }
-#endif
     a.Y = rt_arr(c, RT_Y);
     a.U = rt_arr(c, RT_U);
     a.I = rt_arr(c, RT_I);
@@ -351,20 +272,6 @@ static inline rt_lay rt_layout(const rt_ctx *c)
     rt_lay a = rt_layout_planes(c);
     rt_lay_set_window(a, 0, c->ld);
     return a;
-}
-
-/* everything that reads rows back assumes the documented SoA layout */
-static inline int rt_soa_only(rt_ctx *c, const char *who)
-{
-#ifdef RT_BUILD_PROBES
-    if (c && c->lab.tile)
-        return rt_fail(c, RT_ERR_STATE,
-                       "%s: the tile_rays layout is a measurement option; "
-                       "results can only be read back in the SoA layout", who);
-#endif
-    (void)c;
-    (void)who;
-    return RT_OK;
 }
 
 /* device address of one surface row, resolving the I -> U aliasing */
@@ -442,30 +349,5 @@ RT_INTERNAL int rt_d2h(rt_ctx *ctx, void *dst, const void *src, size_t bytes);
 RT_INTERNAL void rt_comm_release(rt_ctx *ctx);
 }
 
-#ifdef RT_BUILD_PROBES
-/* rt_probes.hip: hooks of the laboratory build */
-extern "C" {
-RT_INTERNAL void rt_lab_init(rt_ctx *c);
-RT_INTERNAL void rt_lab_destroy(rt_ctx *c);
-/* 1 = handled, 0 = not a lab key, < 0 = error */
-RT_INTERNAL int rt_lab_set_option(rt_ctx *c, const char *key, int value);
-RT_INTERNAL bool rt_lab_variant(const rt_ctx *c); /* a lab kernel is selected */
-RT_INTERNAL int rt_lab_launch(rt_ctx *c, int start, int stop, int clip);
-/* allocation experiments: hipMalloc, or chunked virtual memory */
-RT_INTERNAL hipError_t rt_lab_alloc(rt_ctx *c, void **out, size_t bytes);
-RT_INTERNAL hipError_t rt_lab_free(rt_ctx *c, void *p);
-}
-static inline int64_t rt_ld_quantum(const rt_ctx *c)
-{
-    return c->lab.tile ? c->lab.tile : 64;
-}
-static inline int rt_group_quantum(const rt_ctx *c) { return 64 * c->lab.r; }
-static inline int rt_gen_block(const rt_ctx *c) { return c->lab.block; }
-static inline size_t rt_gen_lds(const rt_ctx *c) { return (size_t)c->lab.lds; }
-#else
-static inline bool rt_lab_variant(const rt_ctx *) { return false; }
-static inline int64_t rt_ld_quantum(const rt_ctx *) { return 64; }
-static inline int rt_group_quantum(const rt_ctx *) { return 64; }
-#endif
 
 #endif /* RT_CTX_H */

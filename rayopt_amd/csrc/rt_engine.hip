@@ -165,21 +165,11 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
  * can ask for other kinds of allocation instead */
 static hipError_t rt_buf_alloc(rt_ctx *c, void **out, size_t bytes)
 {
-#ifdef RT_BUILD_PROBES
-    if (c->lab.vmm_mb > 0) {
-        memset(&c->place, 0, sizeof c->place);
-        return rt_lab_alloc(c, out, bytes);
-    }
-#endif
     return rt_place_alloc(c, out, bytes);
 }
 
 static hipError_t rt_buf_free(rt_ctx *c, void *p)
 {
-#ifdef RT_BUILD_PROBES
-    if (p && p != c->place.base)
-        return rt_lab_free(c, p);
-#endif
     return rt_place_free(c, p);
 }
 
@@ -203,7 +193,7 @@ static inline void rt_pieces_reset(rt_ctx *c)
  * are wasted FP64 issue, i.e. where rows are traced but not stored */
 static bool rt_use_compact(const rt_ctx *c, int start, int stop)
 {
-    if (!c->opt_compact || rt_lab_variant(c))
+    if (!c->opt_compact)
         return false;
     if (c->ngroups > 1 && (c->n / c->ngroups) % RT_CB)
         return false; /* a 256-ray tile would straddle two tables */
@@ -330,9 +320,6 @@ int rt_create(int device, rt_ctx **out)
     c->d_surf = c->d_tab[0];
     c->h_stage = c->h_pinned[0];
     memset(c->keep, 1, sizeof c->keep);
-#ifdef RT_BUILD_PROBES
-    rt_lab_init(c);
-#endif
 #undef RT_HIP_C
     *out = c;
     return RT_OK;
@@ -377,9 +364,6 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipFree(ctx->d_group);
     if (ctx->d_gen)
         (void)hipFree(ctx->d_gen);
-#ifdef RT_BUILD_PROBES
-    rt_lab_destroy(ctx);
-#endif
     if (ctx->d_opd_ref)
         (void)hipFree(ctx->d_opd_ref);
     if (ctx->d_opd)
@@ -505,7 +489,7 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     if (ctx->nsurf < 2)
         return rt_fail(ctx, RT_ERR_STATE,
                        "rt_reserve: rt_upload_system must come first");
-    const int64_t quantum = rt_ld_quantum(ctx);
+    const int64_t quantum = 64;
     int64_t bs;
     int nblk;
     rt_block_plan(ctx->nsurf, ctx->opt_block, quantum, nrays, &bs, &nblk);
@@ -525,23 +509,7 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     ctx->uni_valid = 0;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-#ifdef RT_BUILD_PROBES
-    size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld + RT_LAB_SLACK;
-    if (ctx->lab.tile && ctx->lab.tile_planes) /* padded rows inside a tile */
-        need += (size_t)ctx->nsurf * 10 * (size_t)(ld / ctx->lab.tile) *
-                (size_t)ctx->lab.tile_pad;
-    if (ctx->lab.alloc_round == 99) {
-        size_t p2 = 1;
-        while (p2 < need)
-            p2 <<= 1;
-        need = p2;
-    } else if (ctx->lab.alloc_round > 3) {
-        const size_t q = ((size_t)1 << ctx->lab.alloc_round) / 8;
-        need = (need + q - 1) / q * q;
-    }
-#else
     const size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld;
-#endif
     if (need > ctx->cap_doubles) {
         /* from here until the new buffer exists the context holds no rays:
          * a failed allocation must not leave the old sizes without a buffer */
@@ -588,8 +556,8 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     ctx->traced = 0;
     /* placed arrays in a new layout: measure the store pattern over them
      * (nothing lives in the rows yet) */
-    if (ctx->place.base && fresh && !rt_lab_variant(ctx)) {
-        rt_place_tune(ctx, ctx->nsurf, ld);
+    if (ctx->place.base && fresh) {
+        rt_place_settle(ctx, ctx->nsurf, ld, ctx->cap_doubles * sizeof(double));
         if (!ctx->d_buf) { /* (the mapping was lost on the way) */
             rt_place_release(&ctx->place);
             ctx->cap_doubles = 0;
@@ -649,14 +617,14 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
         hipLaunchKernelGGL(rt_seed_aos_kernel, dim3(grid), dim3(block), 0,
                            ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
                            !ctx->opt_alias, period,
-                           rt_tiles_of(ctx, 0, !rt_lab_variant(ctx)));
+                           rt_tiles_of(ctx, 0, true));
     else
         hipLaunchKernelGGL(rt_seed_soa_kernel, dim3(grid), dim3(block), 0,
                            ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
                            !ctx->opt_alias, period,
-                           rt_tiles_of(ctx, 0, !rt_lab_variant(ctx)));
+                           rt_tiles_of(ctx, 0, true));
     RT_HIP(ctx, hipGetLastError());
-    ctx->uni_valid = !rt_lab_variant(ctx); /* the notes describe row 0 */
+    ctx->uni_valid = 1; /* the notes describe row 0 */
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
     ctx->u_alias[0] = 0;
     ctx->valid[0] = 1;
@@ -766,7 +734,88 @@ int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
     return RT_OK;
 }
 
-/* device -> pageable host, same double-buffered staging; synchronous */
+/* device -> pageable host through the same two staging buffers: a list of
+ * copies as ONE pipeline (the rows of a download, block segment by block
+ * segment: the buffers stay busy across the borders between them);
+ * synchronous */
+struct rt_copy_job {
+    void *dst;
+    const void *src;
+    size_t bytes;
+};
+
+static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)
+{
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->h_pin[i]) {
+            RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK));
+            RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
+                                                hipEventDisableTiming));
+        }
+    /* the chunks of all jobs in order, at most RT_PIN_CHUNK each */
+    size_t j = 0, off = 0;
+    auto next = [&](void **dst, const void **src, size_t *len) {
+        while (j < njobs && off >= jobs[j].bytes) {
+            ++j;
+            off = 0;
+        }
+        if (j >= njobs)
+            return false;
+        *len = jobs[j].bytes - off < RT_PIN_CHUNK ? jobs[j].bytes - off
+                                                  : RT_PIN_CHUNK;
+        *dst = (char *)jobs[j].dst + off;
+        *src = (const char *)jobs[j].src + off;
+        off += *len;
+        return true;
+    };
+    /* chunk i-1 leaves its staging buffer on the copy threads while the DMA
+     * of chunk i fills the other one.  The threads are started BEFORE the
+     * DMA is issued: hipMemcpyAsync device -> pinned host returns only when
+     * the copy is done on this runtime (measured: issued first, the two
+     * halves of the pipeline ran one after the other, 8.5 ms per 240 MB
+     * whatever the number of threads) */
+    rt_copy_team team;
+    void *prev_dst = NULL;
+    size_t prev_len = 0;
+    bool have_prev = false;
+    for (size_t i = 0;; ++i) {
+        void *dst = NULL;
+        const void *src = NULL;
+        size_t len = 0;
+        const bool more = next(&dst, &src, &len);
+        if (have_prev) { /* chunk i-1 has landed: start draining it */
+            hipError_t e = hipEventSynchronize(ctx->pin_done[(i - 1) & 1]);
+            if (e != hipSuccess)
+                return rt_fail(ctx, RT_ERR_HIP, "rt_d2h: %s",
+                               hipGetErrorString(e));
+            rt_copy_start(&team, prev_dst, ctx->h_pin[(i - 1) & 1], prev_len);
+        }
+        hipError_t e = hipSuccess;
+        if (more) { /* the DMA of chunk i into the other buffer */
+            if (ctx->pin_busy[i & 1]) /* an upload may still read it */
+                e = hipEventSynchronize(ctx->pin_done[i & 1]);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(ctx->h_pin[i & 1], src, len,
+                                   hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipEventRecord(ctx->pin_done[i & 1], ctx->stream);
+        }
+        if (have_prev) { /* the threads are joined whatever the DMA said */
+            rt_copy_finish(&team);
+            ctx->pin_busy[(i - 1) & 1] = 0;
+        }
+        if (e != hipSuccess)
+            return rt_fail(ctx, RT_ERR_HIP, "rt_d2h: %s",
+                           hipGetErrorString(e));
+        if (!more)
+            break;
+        prev_dst = dst;
+        prev_len = len;
+        have_prev = true;
+    }
+    return RT_OK;
+}
+
 int rt_d2h(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
     if (bytes < RT_PIN_CHUNK / 8) {
@@ -775,54 +824,8 @@ int rt_d2h(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return RT_OK;
     }
-    for (int i = 0; i < 2; ++i)
-        if (!ctx->h_pin[i]) {
-            RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK));
-            RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
-                                                hipEventDisableTiming));
-        }
-    /* chunk i-1 leaves its staging buffer on the copy threads while the DMA
-     * of chunk i fills the other one.  The threads are started BEFORE the
-     * DMA is issued: hipMemcpyAsync device -> pinned host returns only when
-     * the copy is done on this runtime (measured: issued first, the two
-     * halves of the pipeline ran one after the other, 8.5 ms per 240 MB
-     * whatever the number of threads) */
-    const size_t nchunk = (bytes + RT_PIN_CHUNK - 1) / RT_PIN_CHUNK;
-    rt_copy_team team;
-    for (size_t i = 0; i <= nchunk; ++i) {
-        if (i > 0) { /* chunk i-1 has landed: start draining it */
-            const size_t off = (i - 1) * RT_PIN_CHUNK;
-            const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
-                                                          : RT_PIN_CHUNK;
-            hipError_t e = hipEventSynchronize(ctx->pin_done[(i - 1) & 1]);
-            if (e != hipSuccess)
-                return rt_fail(ctx, RT_ERR_HIP, "rt_d2h: %s",
-                               hipGetErrorString(e));
-            rt_copy_start(&team, (char *)dst + off, ctx->h_pin[(i - 1) & 1],
-                          len);
-        }
-        hipError_t e = hipSuccess;
-        if (i < nchunk) { /* the DMA of chunk i into the other buffer */
-            const size_t off = i * RT_PIN_CHUNK;
-            const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
-                                                          : RT_PIN_CHUNK;
-            if (ctx->pin_busy[i & 1]) /* an upload may still read it */
-                e = hipEventSynchronize(ctx->pin_done[i & 1]);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(ctx->h_pin[i & 1], (const char *)src + off,
-                                   len, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess)
-                e = hipEventRecord(ctx->pin_done[i & 1], ctx->stream);
-        }
-        if (i > 0) { /* the threads are joined whatever the DMA said */
-            rt_copy_finish(&team);
-            ctx->pin_busy[(i - 1) & 1] = 0;
-        }
-        if (e != hipSuccess)
-            return rt_fail(ctx, RT_ERR_HIP, "rt_d2h: %s",
-                           hipGetErrorString(e));
-    }
-    return RT_OK;
+    const rt_copy_job job = {dst, src, bytes};
+    return rt_d2h_jobs(ctx, &job, 1);
 }
 
 /* nrow rows of ld doubles -> compact rows of n doubles on the host */
@@ -832,22 +835,43 @@ static int rt_rows_to_host(rt_ctx *ctx, double *dst, const double *src,
     const size_t rb = (size_t)ctx->n * sizeof(double);
     if (ctx->ld == ctx->n && ctx->nblk == 1) /* no padding: one contiguous block */
         return rt_d2h(ctx, dst, src, rb * nrow);
-    /* segment by segment (one per block of the batch) */
-    RT_FOR_SEGMENTS(ctx, g, 0, ctx->n) {
-        const size_t sb = (size_t)g.cnt * sizeof(double);
-        if (sb >= RT_PIN_CHUNK / 8) {
-            for (size_t r = 0; r < nrow; ++r) {
-                int rc = rt_d2h(ctx, dst + r * ctx->n + g.ray,
-                                src + r * ctx->bs + g.off, sb);
-                if (rc != RT_OK)
-                    return rc;
+    /* segment by segment (one per block of the batch): the large ones as one
+     * pipeline over all (row, segment) pairs, the small ones as 2-D copies */
+    size_t nbig = 0;
+    RT_FOR_SEGMENTS(ctx, g, 0, ctx->n)
+        nbig += (size_t)g.cnt * sizeof(double) >= RT_PIN_CHUNK / 8 ? nrow : 0;
+    rt_copy_job *jobs = nbig ? (rt_copy_job *)malloc(nbig * sizeof *jobs)
+                             : NULL;
+    if (nbig && !jobs)
+        return rt_fail(ctx, RT_ERR_NOMEM, "rt_download: %zu copies", nbig);
+    size_t k = 0;
+    for (size_t r = 0; r < nrow; ++r) { /* row after row, as the host reads */
+        RT_FOR_SEGMENTS(ctx, g, 0, ctx->n) {
+            const size_t sb = (size_t)g.cnt * sizeof(double);
+            if (sb >= RT_PIN_CHUNK / 8) {
+                jobs[k].dst = dst + r * ctx->n + g.ray;
+                jobs[k].src = src + r * ctx->bs + g.off;
+                jobs[k++].bytes = sb;
             }
-        } else {
-            RT_HIP(ctx, hipMemcpy2DAsync(dst + g.ray, rb, src + g.off,
-                                         ctx->bs * sizeof(double), sb, nrow,
-                                         hipMemcpyDeviceToHost, ctx->stream));
         }
     }
+    hipError_t e = hipSuccess;
+    RT_FOR_SEGMENTS(ctx, g, 0, ctx->n) {
+        const size_t sb = (size_t)g.cnt * sizeof(double);
+        if (sb < RT_PIN_CHUNK / 8 && e == hipSuccess)
+            e = hipMemcpy2DAsync(dst + g.ray, rb, src + g.off,
+                                 ctx->bs * sizeof(double), sb, nrow,
+                                 hipMemcpyDeviceToHost, ctx->stream);
+    }
+    int rc = RT_OK;
+    if (e == hipSuccess && nbig)
+        rc = rt_d2h_jobs(ctx, jobs, nbig);
+    free(jobs);
+    if (e != hipSuccess)
+        return rt_fail(ctx, RT_ERR_HIP, "rt_download: %s",
+                       hipGetErrorString(e));
+    if (rc != RT_OK)
+        return rc;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -968,8 +992,6 @@ int rt_upload_row(rt_ctx *ctx, int which, int surf, const double *src_soa)
     if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
         return rt_fail(ctx, RT_ERR_STATE, "rt_upload_row: no such row %d",
                        surf);
-    if (rt_soa_only(ctx, "rt_upload_row") != RT_OK)
-        return RT_ERR_STATE;
     const int nc = rt_ncomp(which);
     {
         int rc = rt_gen_flush(ctx);
@@ -1054,13 +1076,13 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
                        "rt_trace: seed row %d holds no data (not stored by "
                        "the previous trace)", start - 1);
     if (ctx->ngroups > 1 && (ctx->n % ctx->ngroups ||
-                             (ctx->n / ctx->ngroups) % rt_group_quantum(ctx)))
+                             (ctx->n / ctx->ngroups) % 64))
         return rt_fail(ctx, RT_ERR_ARG,
                        "rt_trace: %lld rays do not split into %d groups of a "
                        "multiple of %d rays", (long long)ctx->n, ctx->ngroups,
-                       rt_group_quantum(ctx));
+                       64);
     const bool windowed = !(lo == 0 && hi == ctx->n);
-    if (windowed && (ctx->ngroups > 1 || rt_lab_variant(ctx)))
+    if (windowed && ctx->ngroups > 1)
         return rt_fail(ctx, RT_ERR_STATE,
                        "rt_trace_chunk: not with ray groups (several surface "
                        "tables in one batch)");
@@ -1160,7 +1182,6 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
     /* a generated batch that no one has looked at yet is built inside this
      * launch (from the first element on) */
     const bool gen_kernel = start == 1 && start < stop &&
-                            !rt_lab_variant(ctx) &&
                             !rt_use_compact(ctx, start, stop);
     const bool fused = ctx->gen_pending && gen_kernel && !windowed;
     /* a later trace of the same generated batch builds the rays again in
@@ -1210,12 +1231,6 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
                            ctx->ngroups, ctx->opt_compact_every);
         RT_HIP(ctx, hipGetLastError());
         ctx->last_compact = 1;
-#ifdef RT_BUILD_PROBES
-    } else if (rt_lab_variant(ctx)) {
-        int rc = rt_lab_launch(ctx, start, stop, clip);
-        if (rc != RT_OK)
-            return rc;
-#endif
     } else {
         /* launch components that are uniform across a 64-ray tile are
          * fetched once per wavefront (the seed kernels' notes on row 0) */
@@ -1388,11 +1403,6 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
             return rt_fail(ctx, RT_ERR_ARG, "compact_every must be in [1, 64]");
         ctx->opt_compact_every = value;
     } else {
-#ifdef RT_BUILD_PROBES
-        const int rc = rt_lab_set_option(ctx, key, value);
-        if (rc != 0)
-            return rc < 0 ? rc : RT_OK;
-#endif
         return rt_fail(ctx, RT_ERR_ARG, "rt_set_option: unknown key '%s'", key);
     }
     return RT_OK;
@@ -1409,8 +1419,6 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
         surf_lo >= surf_hi)
         return rt_fail(ctx, RT_ERR_STATE, "rt_download: rows [%d,%d) of %d",
                        surf_lo, surf_hi, ctx->buf_nsurf);
-    if (rt_soa_only(ctx, "rt_download") != RT_OK)
-        return RT_ERR_STATE;
     const int nc = rt_ncomp(which);
     for (int j = surf_lo; j < surf_hi; ++j)
         if (!ctx->valid[j])
@@ -1446,8 +1454,6 @@ int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
     if (!ctx->d_buf || ray < 0 || ray >= ctx->n)
         return rt_fail(ctx, RT_ERR_STATE, "rt_download_ray: ray %lld of %lld",
                        (long long)ray, (long long)ctx->n);
-    if (rt_soa_only(ctx, "rt_download_ray") != RT_OK)
-        return RT_ERR_STATE;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     {
         int rc = rt_gen_flush(ctx);
@@ -1498,8 +1504,6 @@ int rt_download_rays(rt_ctx *ctx, int which, int64_t ray0, int64_t stride,
                        "rt_download_rays: rays %lld + k * %lld, k < %lld, of "
                        "%lld", (long long)ray0, (long long)stride,
                        (long long)count, (long long)ctx->n);
-    if (rt_soa_only(ctx, "rt_download_rays") != RT_OK)
-        return RT_ERR_STATE;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     int rc = rt_gen_flush(ctx);
     if (rc != RT_OK)
@@ -1538,8 +1542,6 @@ int rt_device_ptr(rt_ctx *ctx, int which, int surf, void **out)
     if (!ctx->valid[surf])
         return rt_fail(ctx, RT_ERR_STATE, "rt_device_ptr: row %d holds no data",
                        surf);
-    if (rt_soa_only(ctx, "rt_device_ptr") != RT_OK)
-        return RT_ERR_STATE;
     int rc = rt_gen_flush(ctx);
     if (rc != RT_OK)
         return rc;
@@ -1631,6 +1633,7 @@ int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
     info[9] = p.class_mix;
     info[10] = p.base ? p.tries : 0;
     info[11] = p.kept;
+    info[12] = p.base ? p.picks : 0;
     ms[0] = p.self_ms;
     ms[1] = p.cross_ms;
     ms[2] = p.store_gbps;
@@ -1639,8 +1642,10 @@ int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
     ms[5] = p.ballast_ms;
     ms[6] = p.remap_ms;
     ms[7] = p.tune_ms;
-    for (int k = 0; k < RT_PLACE_TRIES && k < 8; ++k)
+    for (int k = 0; k < RT_PLACE_TRIES && k < 4; ++k)
         ms[8 + k] = p.gbps[k];
+    for (int k = 0; k < 3; ++k)
+        ms[12 + k] = p.pick_gbps[k];
     return RT_OK;
 }
 

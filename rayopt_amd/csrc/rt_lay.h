@@ -19,11 +19,6 @@
  *
  * Windows (rt_trace_chunk): j0 is added to the ray index, the arrays are not
  * shifted.
- *
- * Laboratory build only (-DRT_BUILD_PROBES, rt_set_option "tile_rays" = TR):
- * the same fields describe tile-major layouts, e.g. [tile][L][10][TR] with
- * the ten components y0 y1 y2 u0 u1 u2 i0 i1 i2 t (cs = TR, ss = ssT = 10 TR,
- * bs = TR, ts = L 10 TR).  Measured no better than SoA (profiles/HISTORY.md).
  */
 #ifndef RT_LAY_H
 #define RT_LAY_H

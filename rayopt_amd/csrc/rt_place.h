@@ -65,8 +65,11 @@ static inline double rt_place_now_ms(void)
 /* the batch's own store pattern (rt_place_tune): at or above GOOD no other
  * range is tried; below FAST the arrays behave like one class whatever the
  * pair tests said (four workgroups per CU then lose to two); two ranges this
- * far apart (GAP): both ends of what this memory does have been seen */
-#define RT_PLACE_GOOD_GBPS 6500.
+ * far apart (GAP): both ends of what this memory does have been seen.
+ * GOOD is set high on purpose: bundles with per-ray launch directions (reads
+ * among the saturated writes) trace at 1.077 ms behind a pattern of 6950 GB/s
+ * and at 1.157 behind one of 6770, same box, same process */
+#define RT_PLACE_GOOD_GBPS 6900.
 #define RT_PLACE_FAST_GBPS 5950.
 #define RT_PLACE_GAP 1.07
 
@@ -525,9 +528,10 @@ static void rt_place_tune(rt_ctx *c, int L, long long ld)
     for (int k = 0; k < RT_PLACE_TRIES; ++k)
         P.gbps[k] = 0.f;
     const double t_start = rt_place_now_ms();
-    /* arrays of tens of GB: fewer ranges (a measurement writes them once) */
-    const int tries = P.bytes > ((size_t)48 << 30) ? 2
-                      : P.bytes > ((size_t)16 << 30) ? 3 : RT_PLACE_TRIES;
+    /* two ranges at most: in this engine's allocations the ranges of one set
+     * of pieces have turned out within 2 % of each other (it is the pieces
+     * that the batches below the fast level want exchanged: rt_place_settle) */
+    const int tries = 2;
     void *range[RT_PLACE_TRIES] = {P.base};
     int n = 1, best = 0;
     P.gbps[0] = rt_place_measure(c, L, ld);
@@ -619,6 +623,57 @@ static void rt_place_tune(rt_ctx *c, int L, long long ld)
     if (P.store_gbps > 0.f) /* whatever the classes said */
         P.fast = P.store_gbps >= RT_PLACE_FAST_GBPS;
     P.tune_ms = (float)(rt_place_now_ms() - t_start);
+}
+
+/*
+ * rt_place_tune, and while the arrays stay below RT_PLACE_GOOD_GBPS ANOTHER
+ * set of pieces: the current one is held (so that the new pieces come from
+ * elsewhere in the device memory), classified, mapped and measured like the
+ * first, and the better set stays.  At most RT_PLACE_PICKS sets, arrays up
+ * to 16 GiB (C2: 0.2414 ms behind pieces whose four ranges all ran the
+ * pattern at 5.45-5.5 TB/s, 0.207-0.218 behind others).  ctx->d_buf follows.
+ */
+#define RT_PLACE_PICKS 3
+static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes);
+
+static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
+{
+    rt_place_tune(c, L, ld);
+    int picks = 1;
+    float seen[RT_PLACE_PICKS] = {c->place.store_gbps};
+    while (picks < RT_PLACE_PICKS && c->d_buf && c->place.base &&
+           c->place.store_gbps > 0.f &&
+           c->place.store_gbps < RT_PLACE_GOOD_GBPS &&
+           c->place.bytes <= ((size_t)16 << 30)) {
+        const rt_place held = c->place; /* pieces and range stay alive */
+        double *const held_buf = c->d_buf;
+        void *nb = NULL;
+        const hipError_t e = rt_place_alloc(c, &nb, bytes);
+        if (e != hipSuccess || !c->place.base) {
+            /* no second set to be had (the fallback's hipMalloc is not one) */
+            (void)hipGetLastError();
+            if (e == hipSuccess && nb)
+                (void)hipFree(nb);
+            c->place = held;
+            c->d_buf = held_buf;
+            break;
+        }
+        c->d_buf = (double *)nb;
+        rt_place_tune(c, L, ld);
+        seen[picks++] = c->place.store_gbps;
+        if (!c->d_buf || c->place.store_gbps <= held.store_gbps) {
+            if (c->place.base || c->place.handles)
+                rt_place_release(&c->place); /* no better: back to the held */
+            c->place = held;
+            c->d_buf = held_buf;
+        } else {
+            rt_place tmp = held;
+            rt_place_release(&tmp);
+        }
+    }
+    c->place.picks = picks;
+    for (int k = 0; k < RT_PLACE_PICKS; ++k)
+        c->place.pick_gbps[k] = k < picks ? seen[k] : 0.f;
 }
 
 #endif /* RT_PLACE_H */

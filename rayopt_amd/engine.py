@@ -204,20 +204,6 @@ class Engine:
             ctypes.byref(hi)), "rt_chunk_bounds")
         return lo.value, hi.value
 
-    def probe(self, mode):
-        """(ms, bytes) of a bandwidth probe kernel (rt_probe): laboratory
-        build only (librt_mi355_probes.so via RT_MI355_LIB)."""
-        if not hasattr(self.lib, "rt_probe"):
-            raise EngineError(
-                "rt_probe is not part of the shipped library: build the "
-                "laboratory one (python -m rayopt_amd._build probes) and "
-                "point RT_MI355_LIB at it")
-        ms, nbytes = ctypes.c_double(), ctypes.c_double()
-        self._check(self.lib.rt_probe(self.ctx, mode, ctypes.byref(ms),
-                                      ctypes.byref(nbytes)), "rt_probe")
-        return ms.value, nbytes.value
-
-    # -- results ----------------------------------------------------------
     def download(self, which, lo, hi, out=None):
         """Rows [lo,hi) of one array as a compact SoA host array:
         (rows,3,N) for y/u/i, (rows,N) for t (into ``out`` if given)."""
@@ -357,6 +343,9 @@ class Engine:
                 "store_pattern_GBps_per_range": [ms[8 + k] for k in
                                                  range(max(info[10], 0))],
                 "store_pattern_GBps": ms[2],
+                "piece_sets_tried": info[12],
+                "store_pattern_GBps_per_piece_set": [
+                    ms[12 + k] for k in range(max(min(info[12], 3), 0))],
                 "pair_test_ms": {"same_piece": ms[0], "other_class": ms[1]},
                 "search_ms": {"all": ms[3], "pieces": ms[4], "ballast": ms[5],
                               "remap": ms[6], "tune": ms[7]}}

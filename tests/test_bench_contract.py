@@ -15,10 +15,17 @@ REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int,
             "data": str, "config": dict, "roofline": dict}
 
 
+def strict_loads(text):
+    """json.loads that refuses NaN / Infinity: the line is STRICT JSON."""
+    def refuse(name):
+        raise ValueError("not strict JSON: %s" % name)
+    return json.loads(text, parse_constant=refuse)
+
+
 def check_line(out, steps, warmup):
     lines = [l for l in out.splitlines() if l.strip()]
     assert len(lines) == 1, "stdout must be ONE JSON line"
-    d = json.loads(lines[0])
+    d = strict_loads(lines[0])
     for key, typ in REQUIRED.items():
         assert isinstance(d[key], typ), key
     assert d["vs_baseline"] is None and d["higher_is_better"] is True
@@ -66,9 +73,10 @@ def test_single_process_line():
         assert r["bound"] in ("hbm", "fp64 valu issue", "launch latency")
         if r["config"].startswith("C4") and r.get("telemetry", {}).get(
                 "gfxclk_mhz"):
-            # the FP64-issue roofline: instructions of the committed PMC
-            # profile x this run's clock and launch time
+            # the FP64-issue roofline: instructions counted in THIS run (a
+            # child pass under rocprofv3) x this leg's clock and launch time
             assert 0 < r["valu"]["valu_issue_frac"] < 1.5, r["valu"]
+            assert r["valu"]["source"].startswith("this run"), r["valu"]
         par = r["parity_subsample"]
         if par is not None:
             assert par["nan_masks_equal"] is True
@@ -98,13 +106,28 @@ def test_single_process_line():
     # the device-side consumers on the resident batch
     calls = {c["call"].split()[0].rstrip(","): c for c in d["consumers"]}
     assert {"rms", "refocus_shift", "spot_stats", "row_rmax", "opd_rays",
-            "aim_pupil"} <= set(calls), calls.keys()
+            "opd_stats", "aim_pupil"} <= set(calls), calls.keys()
+    # the OPD statistics stay on the device: no per-ray copy in the call
+    st = calls["opd_stats"]
+    assert "error" not in st, st
+    assert st["kernel_ms"] > 0 and len(st["opd_rms_waves_per_bundle"]) == 5
+    assert st["ms"] < calls["opd_rays"]["ms"]
     for name in ("rms", "refocus_shift", "spot_stats", "row_rmax"):
         assert calls[name]["ms"] > 0 and calls[name]["bytes_read"] > 0
         # the kernels alone, between HIP events (at this batch size both
         # numbers are launch latency; at 10^7 rays kernel_ms < ms)
         assert 0 < calls[name]["kernel_ms"] < 3*calls[name]["ms"] + .05
     assert calls["rms"]["two_pass_ms"] > 0
+    # the host path, PCIe inclusive (never `value`)
+    e2e = d["end_to_end"]
+    assert "error" not in e2e, e2e
+    assert e2e["h2d_ms"] > 0 and e2e["d2h_image_row_ms"] > 0
+    assert e2e["end_to_end_ms"] > e2e["trace_ms"] > 0
+    assert e2e["pinned_hipMemcpy_ceiling_GBps"]["h2d"] > 1
+    # the 10^8-ray shape (here: --configs5-rays) carries a parity sample
+    # gathered on the device across all blocks
+    c5 = d["configs"][-1]["parity_subsample"]
+    assert c5["bit_identical_to_c_oracle"] is True and c5["rays"] >= 5000
     # where the command's wall time went
     laps = d["wall_s"]["since_start"]
     assert laps and all(b[1] >= a[1] for a, b in zip(laps, laps[1:]))
