@@ -390,7 +390,9 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * workgroups per CU, which the memory side likes better than the seven the
  * registers allow, four where the arrays' own store pattern was measured at the fast
  * level, rt_placement; FP64-bound traces are not capped), "placement"
- * (rt_placement), "range_shortcuts" (1 = default: IEEE quotients and square
+ * (rt_placement), "placement_good_gbps" (default 6800: the store pattern at
+ * which rt_reserve stops looking for a better address range / set of pieces),
+ * "range_shortcuts" (1 = default: IEEE quotients and square
  * roots run without the compiler's range scaffolding where the operands are
  * checked to be inside [2^-100, 2^100] -- the same bits from a third fewer
  * instructions, RT_F_RANGE; 0 = the compiler's sequences everywhere),
@@ -593,7 +595,7 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * at rt_reserve with a ~1 ms pair test each, an even mix of classes mapped
  * behind one address range of its own, the surplus released; then the
  * batch's OWN store pattern (56 B per ray and element) is written over the
- * arrays and timed; while it stays below 6900 GB/s the same pieces are
+ * arrays and timed; while it stays below 6800 GB/s the same pieces are
  * mapped behind a second fresh range and, for arrays up to 16 GiB, ANOTHER
  * set of pieces is searched, classified and measured while the first is held
  * (at most three sets); the best stays (option "placement", default 1;

@@ -171,6 +171,8 @@ struct rt_ctx {
     uint64_t pieces_mask[4];
     int gather_seen, gather_nchunks; /* chunks of the gather in progress */
     int opt_place;    /* large arrays in class-mixed pieces (rt_place.h) */
+    float opt_place_good; /* GB/s of the store pattern at which the search
+                             for a better range / set of pieces ends */
     struct rt_place place;
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
     int opt_compact_every; /* survivors are counted at every k-th element */

@@ -276,6 +276,7 @@ int rt_create(int device, rt_ctx **out)
     {
         const char *e = getenv("RT_MI355_PLACEMENT");
         c->opt_place = (e && !atoi(e)) ? 0 : 1;
+        c->opt_place_good = RT_PLACE_GOOD_GBPS;
     }
     c->opt_uniform = 1;
     c->opt_compact_every = 4; /* measured best, profiles/r02_probes */
@@ -635,6 +636,15 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
 
 #define RT_PIN_CHUNK ((size_t)32 << 20)
 
+/* the staging buffers are read and written by the host's copy threads:
+ * RT_PIN_NONCOHERENT=1 asks for host-cached (non-coherent) pinned memory --
+ * visibility is ordered by the event waits around every DMA */
+static unsigned rt_pin_flags(void)
+{
+    const char *e = getenv("RT_PIN_NONCOHERENT");
+    return e && atoi(e) ? hipHostMallocNonCoherent : hipHostMallocDefault;
+}
+
 /*
  * memcpy between pageable memory and the pinned staging buffers on a few
  * threads: one core copies ~30 GB/s, the DMA engine moves ~55 GB/s over
@@ -715,7 +725,8 @@ int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
     }
     for (int i = 0; i < 2; ++i)
         if (!ctx->h_pin[i]) {
-            RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK));
+            RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK,
+                                      rt_pin_flags()));
             RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
                                                 hipEventDisableTiming));
         }
@@ -748,7 +759,8 @@ static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)
 {
     for (int i = 0; i < 2; ++i)
         if (!ctx->h_pin[i]) {
-            RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK));
+            RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK,
+                                      rt_pin_flags()));
             RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
                                                 hipEventDisableTiming));
         }
@@ -1389,6 +1401,12 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
     } else if (!strcmp(key, "placement")) {
         /* takes effect with the next allocation of the result arrays */
         ctx->opt_place = value ? 1 : 0;
+    } else if (!strcmp(key, "placement_good_gbps")) {
+        /* takes effect with the next allocation (tests: a value no memory
+         * reaches makes every allocation try all its ranges and sets) */
+        if (value < 0)
+            return rt_fail(ctx, RT_ERR_ARG, "placement_good_gbps: >= 0");
+        ctx->opt_place_good = (float)value;
     } else if (!strcmp(key, "resident_lds")) {
         if (value < -1 || value > 65536)
             return rt_fail(ctx, RT_ERR_ARG,

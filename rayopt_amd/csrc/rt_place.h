@@ -66,10 +66,12 @@ static inline double rt_place_now_ms(void)
  * range is tried; below FAST the arrays behave like one class whatever the
  * pair tests said (four workgroups per CU then lose to two); two ranges this
  * far apart (GAP): both ends of what this memory does have been seen.
- * GOOD is set high on purpose: bundles with per-ray launch directions (reads
- * among the saturated writes) trace at 1.077 ms behind a pattern of 6950 GB/s
- * and at 1.157 behind one of 6770, same box, same process */
-#define RT_PLACE_GOOD_GBPS 6900.
+ * Sets of pieces come out anywhere between 6300 and 7050 GB/s in one process
+ * (a lottery the classes narrow but do not end); GOOD is where the search
+ * stops paying: bundles with per-ray launch directions (reads among the
+ * saturated writes) trace at 1.077 ms behind 6950 GB/s, 1.10 behind 6820,
+ * 1.15 behind 6770, C2 at 0.208 behind 6950 and 0.235-0.241 behind 6300 */
+#define RT_PLACE_GOOD_GBPS 6800.
 #define RT_PLACE_FAST_GBPS 5950.
 #define RT_PLACE_GAP 1.07
 
@@ -541,7 +543,7 @@ static void rt_place_tune(rt_ctx *c, int L, long long ld)
             lo = P.gbps[k] < lo ? P.gbps[k] : lo;
             hi = P.gbps[k] > hi ? P.gbps[k] : hi;
         }
-        if (hi >= RT_PLACE_GOOD_GBPS || hi >= RT_PLACE_GAP * lo)
+        if (hi >= c->opt_place_good || hi >= RT_PLACE_GAP * lo)
             break; /* as good as it gets, or both ends seen */
         /* the same pieces behind another range; the ranges tried so far
          * stay reserved so that the next one is a new one */
@@ -638,12 +640,15 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes);
 
 static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
 {
+    if (!c->place.base || L < 2 || 56. * (L - 1) * (double)ld < 5e8)
+        return; /* (a pattern too short to tell anything: what an earlier
+                   layout found out about these arrays stays) */
     rt_place_tune(c, L, ld);
     int picks = 1;
     float seen[RT_PLACE_PICKS] = {c->place.store_gbps};
     while (picks < RT_PLACE_PICKS && c->d_buf && c->place.base &&
            c->place.store_gbps > 0.f &&
-           c->place.store_gbps < RT_PLACE_GOOD_GBPS &&
+           c->place.store_gbps < c->opt_place_good &&
            c->place.bytes <= ((size_t)16 << 30)) {
         const rt_place held = c->place; /* pieces and range stay alive */
         double *const held_buf = c->d_buf;

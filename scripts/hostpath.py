@@ -17,9 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def case(block_rays, threads):
+def case(block_rays, threads, noncoherent=0):
     env = dict(os.environ, RT_COPY_THREADS=str(threads),
-               RT_HOSTPATH_BLOCK=str(block_rays))
+               RT_HOSTPATH_BLOCK=str(block_rays),
+               RT_PIN_NONCOHERENT=str(noncoherent))
     out = subprocess.run([sys.executable, __file__, "--child"], env=env,
                          capture_output=True, text=True)
     sys.stdout.write(out.stdout)
@@ -61,7 +62,8 @@ def child():
         eng.lib.rt_copy_to_host(eng.ctx, flat.ctypes.data, ptr, seg)
         tc.append((time.perf_counter() - t0)*1e3)
     print(json.dumps({"blocks": nb[0], "copy_threads": int(
-        os.environ["RT_COPY_THREADS"]), "download_image_row_ms": t,
+        os.environ["RT_COPY_THREADS"]), "noncoherent_staging": int(
+        os.environ["RT_PIN_NONCOHERENT"]), "download_image_row_ms": t,
         "GBps_best": 24*n/min(t)/1e6,
         "copy_to_host_one_segment_ms": tc, "segment_bytes": seg,
         "segment_GBps_best": seg/min(tc)/1e6}), flush=True)
@@ -71,6 +73,6 @@ if __name__ == "__main__":
     if "--child" in sys.argv:
         child()
     else:
-        for block in (2**31 - 1, 0):
-            for threads in (1, 4, 8):
-                case(block, threads)
+        for noncoherent in (0, 1):
+            for threads in (1, 4, 8, 16):
+                case(0, threads, noncoherent)
