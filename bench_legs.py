@@ -679,6 +679,13 @@ def counters_for_the_line(out, args, n, clip):
                 "FETCH_SIZE / WRITE_SIZE (separate passes, %d launches of "
                 "this workload each in a child process, %.0f s), FETCH_SIZE "
                 "x2 per MI355X_MICROARCH.md (gfx950)" % (h["launches"], took))
+            if "SQ_INSTS_VALU" in h:
+                S = out["config"]["surfaces"]
+                r["valu"] = {
+                    "wave_instructions_per_launch": h["SQ_INSTS_VALU"],
+                    "per_ray_surface_op": h["SQ_INSTS_VALU"]*64/(n*S),
+                    "busy_quad_cycles_per_launch": h["SQ_ACTIVE_INST_VALU"],
+                    "source": "this run (the same child passes)"}
             gb = out.get("generated_batch")
             if gb is not None and "generated" in c:
                 gb["traffic"] = c["generated"]["hbm_bytes_per_launch"]

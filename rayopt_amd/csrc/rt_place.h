@@ -18,7 +18,7 @@
  *     driver hands them out, or a plain hipMalloc, sit at 6.2-6.7 / 5.65-6.0;
  *     arrays built from an even MIX of classes at 6.9-7.0 (round 5, two
  *     builds of this library alternating in one process, ten contexts each:
- *     profiles/r05_probes/ab_r04_r05_builds_one_process.jsonl);
+ *     profiles/r05_probes/s10_ab_r04_vs_pieces_mapped_once_and_hipmalloc.jsonl);
  *   * WHERE they are mapped (round 5): the same ten pieces in the same order
  *     run the pattern at 1.157 ms behind one virtual address range and at
  *     1.008 ms behind another (map_lab, va_lab: reproducible per range, two
@@ -36,10 +36,13 @@
  * the rest of the engine sees is an ordinary device pointer.  rt_place_tune(),
  * once rt_reserve knows the layout, then writes the batch's OWN store pattern
  * over the arrays and times it; below RT_PLACE_GOOD_GBPS the same pieces are
- * mapped behind another fresh range and measured again (at most
- * RT_PLACE_TRIES ranges; the rejected reservations are held until the choice
- * is made, so that the allocator cannot hand them out again), and the best
- * range stays.  10-40 ms once per allocation.  Anything that fails on the way
+ * mapped behind a second fresh range and measured again (the first
+ * reservation is held meanwhile, so that the allocator cannot hand it out
+ * again), and rt_place_settle() goes on to ANOTHER set of pieces while the
+ * first is held -- sets of one process come out anywhere between 6300 and
+ * 7050 GB/s -- at most three sets; the best stays.  15-60 ms once per
+ * allocation (more where the driver is slow to hand out memory it has just
+ * got back).  Anything that fails on the way
  * (no virtual memory management, out of memory for the surplus) falls back
  * to hipMalloc: the placement is a matter of speed, never of results.
  */
