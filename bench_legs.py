@@ -1171,8 +1171,7 @@ def run_configs(ra, device, args, live=None):
                "cpu_reference": ref}
         pl = g.engine.placement()
         rec["placement"] = {k: pl[k] for k in ("pieces", "piece_mib",
-                                               "per_class", "fast", "ranges_tried", "range_kept",
-                                               "store_pattern_GBps_per_range",
+                                               "per_class", "fast", "store_pattern_GBps",
                                                "store_pattern_GBps_per_piece_set",
                                                "created", "ballast_blocks",
                                                "search_ms")}

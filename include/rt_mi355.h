@@ -586,19 +586,18 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * Where the result arrays live.  The speed of a trace's 7-10 simultaneous row
  * streams is not one number (bare store pattern of C3: 7.0 ... 5.65 TB/s on
  * one box) and depends on WHICH pieces of device memory lie behind the arrays
- * -- pieces fall into classes, streams dealt over two or three classes run
- * faster than streams inside one, which is what a plain hipMalloc of 10 GB
- * gets -- and on the ADDRESS RANGE they are mapped behind (the same pieces in
- * the same order: 1.157 ms behind one range, 1.008 behind another);
- * csrc/rt_place.h.  Arrays of > 1.5 GiB are therefore built from pieces
+ * -- pieces fall into classes; streams dealt over three classes run faster
+ * than over two, and both faster than streams inside one, which is what a
+ * plain hipMalloc of 10 GB gets; sets of equal class counts still differ
+ * (csrc/rt_place.h).  Arrays of > 1.5 GiB are therefore built from pieces
  * (hipMemCreate, 1 GiB; 512 MiB below 3 GiB) whose class the library measures
- * at rt_reserve with a ~1 ms pair test each, an even mix of classes mapped
- * behind one address range of its own, the surplus released; then the
+ * at rt_reserve with a ~1 ms pair test each, an even mix of (if they can be
+ * had: three) classes mapped behind one address range, the surplus released;
+ * then the
  * batch's OWN store pattern (56 B per ray and element) is written over the
- * arrays and timed; while it stays below 6800 GB/s the same pieces are
- * mapped behind a second fresh range and, for arrays up to 16 GiB, ANOTHER
- * set of pieces is searched, classified and measured while the first is held
- * (at most three sets); the best stays (option "placement", default 1;
+ * arrays and timed; while it stays below 6800 GB/s ANOTHER set of pieces is
+ * searched, classified and measured while the first is held (arrays up to
+ * 16 GiB; at most three sets); the best stays (option "placement", default 1;
  * RT_MI355_PLACEMENT=0 for the whole process; plain hipMalloc if anything on
  * the way fails; results never depend on it).
  * info[0] = pieces behind the arrays (0: hipMalloc), [1] = MiB per piece,
@@ -606,20 +605,25 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * class 0 / 1 / 2 kept, [7] = 1: store-bound traces run four workgroups per CU
  * instead of two (the measured pattern is at or above 5950 GB/s; where no
  * pattern was measured: at least a third of the pieces lie outside the
- * largest class), [8] = blocks of ballast (4-8 GiB each) held during the
- * search so that it moved on through the device memory (pieces come in runs
- * of one class; search and ballast together never hold more than half of the
- * memory that was free), [9] = what the classes alone said, [10] = address
- * ranges measured for the kept set of pieces, [11] = the one kept, [12] =
- * sets of pieces tried, [13..15] = 0.
+ * largest class), [8] = hops: times the search created and held four to
+ * eight blocks of 1 GiB of ballast so that it moved on through the device
+ * memory (pieces come in runs of one class; search and ballast together
+ * never hold more than half of the
+ * memory that was free), [9] = what the classes alone said, [10..11] = 0, [12] =
+ * sets of pieces tried, [13] = 1 if a placement of this context failed its
+ * check -- tokens written by a kernel into every 2 MiB of the range, read back
+ * by a copy -- and the context (and from then on the process) went back to
+ * plain allocations: on ROCm 7.2 a kernel goes on using the translations of
+ * an EARLIER mapping of an address range after hipMemUnmap + hipMemMap unless
+ * a buffer is freed in between, which the library does after every mapping
+ * (csrc/rt_place.h: rt_place_flush); [14..15] = 0.
  * ms[0] / ms[1] = the pair test's launch time inside one piece / across two
- * classes, ms[2] = GB/s of the store pattern behind the kept range (0: not
+ * classes, ms[2] = GB/s of the batch's store pattern over the arrays (0: not
  * measured -- a pattern below 0.5 GB tells nothing), ms[3] = wall
  * milliseconds the search took, of which ms[4] creating, mapping and testing
  * pieces, ms[5] creating and releasing ballast, ms[6] unmapping, releasing
- * the surplus and mapping the final range; ms[7] = measuring and re-mapping;
- * ms[8..11] = GB/s behind each range tried (0: not tried), ms[12..14] = GB/s
- * of each set of pieces tried (its best range), ms[15] = 0.
+ * the surplus and mapping the final range; ms[7] = measuring the pattern;
+ * ms[8..11] = 0; ms[12..14] = GB/s of each set of pieces tried, ms[15] = 0.
  */
 int rt_placement(rt_ctx *ctx, int info[16], double ms[16]);
 

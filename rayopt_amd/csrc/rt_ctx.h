@@ -60,7 +60,6 @@ struct rt_rccl_api {
 #define RT_BLOCK_ONE 8.5e9
 #define RT_BLOCK_BYTES 7.0e9
 
-#define RT_PLACE_TRIES 4 /* address ranges measured at most per allocation */
 #define RT_PLACE_CLASSES 4
 struct rt_place {
     void *base;      /* the mapped range (= d_buf), NULL: plain hipMalloc */
@@ -74,10 +73,8 @@ struct rt_place {
     int mixed;       /* >= a third of the pieces outside the largest class */
     int class_mix;   /* (the same: what the classes alone said) */
     float self_ms, cross_ms; /* pair test: same piece / another class */
-    int tries;       /* address ranges measured for the current layout */
-    int kept;        /* ... and which of them the arrays live behind */
-    float gbps[RT_PLACE_TRIES]; /* the batch's store pattern behind each */
-    float store_gbps; /* = gbps[kept] (0: not measured) */
+    float store_gbps; /* the batch's own store pattern over the arrays
+                         (0: not measured) */
     int fast;         /* four workgroups per CU: store_gbps at the fast level
                          (where nothing was measured: the classes are mixed) */
     /* wall time of the search (rt_place_alloc): all of it, the pieces
@@ -174,6 +171,8 @@ struct rt_ctx {
     float opt_place_good; /* GB/s of the store pattern at which the search
                              for a better range / set of pieces ends */
     struct rt_place place;
+    int place_incoherent; /* a placement of this context failed its check
+                             (rt_place_coherent) and was given up */
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */
     int opt_compact_every; /* survivors are counted at every k-th element */
     int last_compact; /* the last trace ran the compacting kernel */
@@ -211,6 +210,7 @@ struct rt_ctx {
 };
 
 RT_INTERNAL extern rt_rccl_api g_rccl;
+RT_INTERNAL extern int g_place_distrust; /* placement given up process-wide */
 
 extern "C" RT_INTERNAL int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...);
 

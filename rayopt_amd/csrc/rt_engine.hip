@@ -41,6 +41,7 @@
 #include "rt_place.h"
 
 static char g_err[512] = "";
+int g_place_distrust = 0;
 
 int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -567,6 +568,31 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
             ctx->bts = 0;
             return rt_fail(ctx, RT_ERR_NOMEM,
                            "rt_reserve: the arrays could not be mapped");
+        }
+        if (!rt_place_coherent(ctx)) {
+            /* kernels and copies do not see the same memory behind the range
+             * (translations of an earlier mapping alive in the device, what
+             * rt_place_flush is there to prevent): no results through THAT.
+             * Plain allocations from here on, for every context of the
+             * process */
+            g_place_distrust = 1;
+            ctx->place_incoherent = 1;
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            rt_place_release(&ctx->place);
+            ctx->d_buf = NULL;
+            const size_t bytes = ctx->cap_doubles * sizeof(double);
+            ctx->cap_doubles = 0;
+            hipError_t e = hipMalloc((void **)&ctx->d_buf, bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->n = ctx->ld = ctx->bs = 0;
+                ctx->nblk = 0;
+                ctx->bts = 0;
+                return rt_fail(ctx, RT_ERR_NOMEM,
+                               "rt_reserve: hipMalloc of %.3f GB failed: %s",
+                               bytes * 1e-9, hipGetErrorString(e));
+            }
+            ctx->cap_doubles = bytes / sizeof(double);
         }
     }
     memset(ctx->i_alias, 0, sizeof ctx->i_alias);
@@ -1649,9 +1675,8 @@ int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
     info[7] = p.fast;
     info[8] = p.ballast;
     info[9] = p.class_mix;
-    info[10] = p.base ? p.tries : 0;
-    info[11] = p.kept;
     info[12] = p.base ? p.picks : 0;
+    info[13] = ctx->place_incoherent;
     ms[0] = p.self_ms;
     ms[1] = p.cross_ms;
     ms[2] = p.store_gbps;
@@ -1660,8 +1685,6 @@ int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
     ms[5] = p.ballast_ms;
     ms[6] = p.remap_ms;
     ms[7] = p.tune_ms;
-    for (int k = 0; k < RT_PLACE_TRIES && k < 4; ++k)
-        ms[8 + k] = p.gbps[k];
     for (int k = 0; k < 3; ++k)
         ms[12 + k] = p.pick_gbps[k];
     return RT_OK;

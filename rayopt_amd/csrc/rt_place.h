@@ -2,49 +2,44 @@
  * rt_place.h -- WHERE the result arrays live in HBM.
  *
  * A trace writes 7-10 row streams per element at once (C3: 84 streams of
- * 40-80 MB).  The speed of that store pattern is not one number on MI355X:
+ * 40-80 MB).  The speed of that store pattern is not one number on MI355X --
  * 7.0 / 6.7 / 6.2 / 5.65 TB/s have all been measured for the same pattern on
- * the same box, and the trace follows it (C3, one box, one process: 1.14 ms
- * behind a pattern of 6.97 TB/s, 1.16 at 6.86, 1.22 at 6.7, 1.27-1.29 at
- * 6.2-6.3, 1.28 in a plain hipMalloc).  Two things decide it, as far as four
- * rounds of measurements can tell (profiles/r04_probes/README.md,
+ * one box -- and the trace follows it (C3, one process: 1.14 ms behind a
+ * pattern of 6.97 TB/s, 1.16 at 6.86, 1.22 at 6.7, 1.27-1.29 at 6.2-6.3, 1.28
+ * in a plain hipMalloc).  What decides it is WHICH pieces of device memory lie
+ * behind the arrays (profiles/r04_probes/README.md,
  * profiles/r05_probes/README.md):
  *
- *   * WHICH pieces of device memory lie behind the arrays (round 4): 1 GiB
- *     pieces (hipMemCreate) fall into classes -- three on the boxes seen, in
- *     runs of 1-26 consecutively created pieces; a pair of pieces of one
- *     class runs a short-row store pattern at the slow level, a pair across
- *     classes at the fast one.  Arrays built from consecutive pieces as the
- *     driver hands them out, or a plain hipMalloc, sit at 6.2-6.7 / 5.65-6.0;
- *     arrays built from an even MIX of classes at 6.9-7.0 (round 5, two
- *     builds of this library alternating in one process, ten contexts each:
- *     profiles/r05_probes/s10_ab_r04_vs_pieces_mapped_once_and_hipmalloc.jsonl);
- *   * WHERE they are mapped (round 5): the same ten pieces in the same order
- *     run the pattern at 1.157 ms behind one virtual address range and at
- *     1.008 ms behind another (map_lab, va_lab: reproducible per range, two
- *     scans agree offset by offset); the level is stable over 45 s and across
- *     idle gaps (state_lab).  This is what made C2 bimodal in round 4 -- 0.207
- *     or 0.259 ms with the SAME class mix.  The mechanism is below what user
- *     space can see (page tables live in device memory too); the engine does
- *     not rely on an explanation, it measures.
+ *   * 1 GiB pieces (hipMemCreate) fall into classes -- three on the boxes
+ *     seen, in runs of 1-26 consecutively created pieces; a pair of pieces of
+ *     one class runs a short-row store pattern at the slow level, a pair
+ *     across classes at the fast one.  Arrays built from consecutive pieces
+ *     as the driver hands them out, or a plain hipMalloc, sit at 6.2-6.7 /
+ *     5.65-6.0; arrays built from an even MIX of classes higher (two builds
+ *     of this library alternating in one process:
+ *     profiles/r05_probes/s10_*.jsonl);
+ *   * THREE classes beat two: sets of two classes 6.67-6.77 TB/s in five of
+ *     five contexts, sets of three 6.91-7.02 in nine of ten (round 5), so the
+ *     search goes on for a third class;
+ *   * sets of equal class counts still differ (C2, five 512 MiB pieces: 5.5
+ *     to 7.0 TB/s in one process -- round 4's "bimodal with the same class
+ *     mix"): the batch's OWN pattern is measured over the arrays, and while
+ *     it is low another set of pieces is tried.
  *
  * So large arrays are not hipMalloc'ed.  rt_place_alloc() creates pieces of
  * device memory, finds the class of each with a pair test (42 short row
  * streams in the piece, 42 in a representative of a known class: slow =
  * same class), keeps a balanced mix, releases the rest and maps the kept
- * pieces, classes interleaved, behind ONE contiguous range of its own -- what
- * the rest of the engine sees is an ordinary device pointer.  rt_place_tune(),
- * once rt_reserve knows the layout, then writes the batch's OWN store pattern
- * over the arrays and times it; below RT_PLACE_GOOD_GBPS the same pieces are
- * mapped behind a second fresh range and measured again (the first
- * reservation is held meanwhile, so that the allocator cannot hand it out
- * again), and rt_place_settle() goes on to ANOTHER set of pieces while the
- * first is held -- sets of one process come out anywhere between 6300 and
- * 7050 GB/s -- at most three sets; the best stays.  15-60 ms once per
- * allocation (more where the driver is slow to hand out memory it has just
- * got back).  Anything that fails on the way
- * (no virtual memory management, out of memory for the surplus) falls back
- * to hipMalloc: the placement is a matter of speed, never of results.
+ * pieces, classes interleaved, behind ONE contiguous range -- what the rest
+ * of the engine sees is an ordinary device pointer.  rt_place_settle(), once
+ * rt_reserve knows the layout, writes the batch's own store pattern over the
+ * arrays and times it; below RT_PLACE_GOOD_GBPS it goes on to another set of
+ * pieces while the first is held (at most three sets); the best stays.
+ * 15-60 ms once per allocation (more where the driver is slow to hand out
+ * memory it has just got back).  Anything that fails on the way (no virtual
+ * memory management, out of memory for the surplus) falls back to hipMalloc:
+ * the placement is a matter of speed, never of results -- provided the
+ * platform's hazard below is respected (rt_place_flush, rt_place_coherent).
  */
 #ifndef RT_PLACE_H
 #define RT_PLACE_H
@@ -67,8 +62,7 @@ static inline double rt_place_now_ms(void)
 #define RT_PLACE_SAME 0.91f      /* pair / self time above this: same class */
 /* the batch's own store pattern (rt_place_tune): at or above GOOD no other
  * range is tried; below FAST the arrays behave like one class whatever the
- * pair tests said (four workgroups per CU then lose to two); two ranges this
- * far apart (GAP): both ends of what this memory does have been seen.
+ * pair tests said (four workgroups per CU then lose to two).
  * Sets of pieces come out anywhere between 6300 and 7050 GB/s in one process
  * (a lottery the classes narrow but do not end); GOOD is where the search
  * stops paying: bundles with per-ray launch directions (reads among the
@@ -76,7 +70,6 @@ static inline double rt_place_now_ms(void)
  * 1.15 behind 6770, C2 at 0.208 behind 6950 and 0.235-0.241 behind 6300 */
 #define RT_PLACE_GOOD_GBPS 6800.
 #define RT_PLACE_FAST_GBPS 5950.
-#define RT_PLACE_GAP 1.07
 
 struct rt_place_rows {
     double *row[RT_PLACE_ROWS];
@@ -151,44 +144,75 @@ static hipError_t rt_place_free(rt_ctx *c, void *ptr)
     return ptr ? hipFree(ptr) : hipSuccess;
 }
 
-/* the pieces of `p` behind a fresh address range */
-static hipError_t rt_place_map(rt_ctx *c, rt_place *p, void **out)
+/*
+ * A mapping the GPU has used stays in its address translation after
+ * hipMemUnmap: kernels go on reading and writing the OLD physical memory
+ * behind an address range that has been mapped again with other pieces,
+ * while copies (the DMA engines) see the new one (round 5, ROCm 7.2;
+ * scripts/labsrc/tlb_lab.hip, profiles/r05_probes/s19_*: the kernel's pattern
+ * lands in the pieces mapped there BEFORE, every double of 4 GiB; re-reserving
+ * the range is no cure across a few rounds, hipMemSetAccess is none; a plain
+ * hipMalloc + hipFree in between is -- freeing a buffer makes the driver
+ * invalidate the process's translations).  It is what made "the level
+ * follows the address range" in this round's laboratories, and it would be
+ * silent corruption in an engine that maps, measures and maps again.  So:
+ * after EVERY hipMemMap sequence, before any kernel touches the range,
+ * rt_place_flush(); and once the arrays have settled rt_place_coherent()
+ * proves that kernels and copies see the same memory, or the context falls
+ * back to plain allocations for good.
+ */
+static void rt_place_flush(void)
 {
-    hipMemAccessDesc acc = {};
-    acc.location.type = hipMemLocationTypeDevice;
-    acc.location.id = c->device; /* (this device only: a pointer handed out by
-                                    rt_device_ptr is not a peer / IPC pointer) */
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    const hipMemGenericAllocationHandle_t *h =
-        (const hipMemGenericAllocationHandle_t *)p->handles;
-    void *base = NULL;
-    hipError_t e = hipMemAddressReserve(&base, p->bytes, p->piece, NULL, 0);
-    int nm = 0;
-    for (; e == hipSuccess && nm < p->n; ++nm)
-        e = hipMemMap((char *)base + (size_t)nm * p->piece, p->piece, 0, h[nm],
-                      0);
-    if (e == hipSuccess)
-        e = hipMemSetAccess(base, p->bytes, &acc, 1);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        for (int k = 0; k < nm; ++k) /* (the last one may not have taken) */
-            (void)hipMemUnmap((char *)base + (size_t)k * p->piece, p->piece);
-        (void)hipGetLastError();
-        if (base)
-            (void)hipMemAddressFree(base, p->bytes);
-        return e;
-    }
-    *out = base;
-    return hipSuccess;
+    void *t = NULL;
+    if (hipMalloc(&t, (size_t)64 << 20) == hipSuccess)
+        (void)hipFree(t);
+    (void)hipGetLastError();
 }
 
+__global__ void rt_place_token_kernel(unsigned long long *base, size_t pages,
+                                      size_t stride, unsigned long long salt)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pages)
+        base[i * stride] = salt ^ (i * 0x9E3779B97F4A7C15ull);
+}
 
+/* one token per 2 MiB of the mapped range written by a kernel; the first,
+ * the middle and the last of every piece read back by a copy (the path the
+ * downloads take): true if every one arrives */
+static bool rt_place_coherent(rt_ctx *c)
+{
+    const rt_place &P = c->place;
+    if (!P.base)
+        return true;
+    const size_t page = (size_t)2 << 20, pages = P.bytes / page;
+    const size_t per = P.piece / page;
+    static unsigned long long round_ = 0;
+    const unsigned long long salt = 0xC0FFEE1234567ull + 977 * ++round_;
+    hipLaunchKernelGGL(rt_place_token_kernel,
+                       dim3((unsigned)((pages + 255) / 256)), dim3(256), 0,
+                       c->stream, (unsigned long long *)P.base, pages,
+                       page / 8, salt);
+    bool ok = hipStreamSynchronize(c->stream) == hipSuccess;
+    for (int k = 0; ok && k < P.n; ++k) {
+        const size_t at[3] = {(size_t)k * per, (size_t)k * per + per / 2,
+                              (size_t)(k + 1) * per - 1};
+        for (int q = 0; ok && q < 3; ++q) {
+            unsigned long long got = 0;
+            ok = hipMemcpy(&got, (const char *)P.base + at[q] * page, 8,
+                           hipMemcpyDeviceToHost) == hipSuccess &&
+                 got == (salt ^ (at[q] * 0x9E3779B97F4A7C15ull));
+        }
+    }
+    (void)hipGetLastError();
+    return ok;
+}
 
 static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
 {
     rt_place &P = c->place;
     memset(&P, 0, sizeof P);
-    if (!c->opt_place || bytes < RT_PLACE_MIN_BYTES)
+    if (!c->opt_place || g_place_distrust || bytes < RT_PLACE_MIN_BYTES)
         return hipMalloc(out, bytes);
     const double t_start = rt_place_now_ms();
     double t_ballast = 0.;
@@ -214,10 +238,13 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
      * class is oversupplied the search HOPS -- a block of ballast is created
      * and held, unclassified, so that the next piece lies further on in the
      * device memory -- until another class turns up.  Ballast and surplus
-     * pieces go back to the device before rt_place_alloc returns. */
-    const int max_ballast = 24;
-    hipMemGenericAllocationHandle_t ballast[24];
-    int nballast = 0, hops_in_a_row = 0;
+     * pieces go back to the device before rt_place_alloc returns.  A hop is
+     * four (after three hops in a row: eight) blocks of 1 GiB, not one block
+     * of 4-8 GiB: creating ONE large block has taken 3.5 and 5.5 s where the
+     * device memory was fragmented (round 5), small ones a millisecond. */
+    const int max_ballast = 192;
+    hipMemGenericAllocationHandle_t ballast[192];
+    int nballast = 0, hops_in_a_row = 0, hops = 0;
     /* what the search may hold beyond the `need` pieces it keeps -- surplus
      * pieces and ballast -- stays below half of the memory that is free
      * now: other contexts and processes allocate from the same device */
@@ -254,6 +281,10 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     hipError_t e = h && cls ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess)
         e = hipMemAddressReserve(&scratch, (size_t)cap * piece, align, NULL, 0);
+    /* the range may be one an earlier allocation of the process has used:
+     * nothing of that may be left in the device when the pair tests write
+     * through it (every slot below is then mapped exactly once) */
+    rt_place_flush();
     bool enough = false;
     while (e == hipSuccess && made < cap && !enough) {
         const int k = made;
@@ -324,32 +355,42 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
             cls[k] = (unsigned char)found;
             ++count[found];
         }
-        if (count[cls[k]] > (need + 1) / 2 && made >= (need + 1) / 2 + 1 &&
-            nballast < max_ballast) {
-            const size_t hop = (size_t)(hops_in_a_row < 3 ? 4 : 8) << 30;
+        /* a class is oversupplied: more than half of what is needed while
+         * only two classes have shown, more than 40 % once it is about the
+         * third */
+        const int over = nclass >= 2 && made >= need ? (2 * need + 4) / 5
+                                                     : (need + 1) / 2;
+        if (count[cls[k]] > over && made >= (need + 1) / 2 + 1 &&
+            hops < 24) {
+            const int blocks = hops_in_a_row < 3 ? 4 : 8;
+            const size_t one = (size_t)1 << 30;
             const double tb = rt_place_now_ms();
-            if (extra + hop > budget) {
-                /* (no room left to hop in) */
-            } else if (hipMemCreate(&ballast[nballast], hop, &prop, 0) ==
-                       hipSuccess) {
+            for (int b = 0; b < blocks && nballast < max_ballast &&
+                            extra + one <= budget && t_ballast < 40.; ++b) {
+                if (hipMemCreate(&ballast[nballast], one, &prop, 0) !=
+                    hipSuccess) {
+                    (void)hipGetLastError(); /* the device is full */
+                    break;
+                }
                 ++nballast;
-                extra += hop;
-            } else {
-                (void)hipGetLastError(); /* the device is full: no hopping */
+                extra += one;
+                t_ballast += rt_place_now_ms() - tb;
             }
-            t_ballast += rt_place_now_ms() - tb;
+            ++hops;
             ++hops_in_a_row;
         } else {
             hops_in_a_row = 0;
         }
-        /* enough when `need` pieces can be picked with no class holding
-         * more than half of them (two classes evenly mixed run at 0.98 of
-         * the three-class time: not worth a dozen more pieces) */
+        /* enough when `need` pieces can be picked with no class holding more
+         * than half of them -- and THREE classes are among them, or eight
+         * pieces beyond the need have not turned up a third (sets of two
+         * classes: 6.67-6.77 TB/s in five of five contexts, sets of three:
+         * 6.91-7.02 in nine of ten, profiles/r05_final/boxstat/) */
         if (made >= need && nclass >= 2) {
             int can = 0;
             for (int q = 0; q < nclass; ++q)
                 can += count[q] < (need + 1) / 2 ? count[q] : (need + 1) / 2;
-            enough = can >= need;
+            enough = can >= need && (nclass >= 3 || made >= need + 8);
         }
     }
     const double t_found = rt_place_now_ms(), t_created = t_ballast;
@@ -414,6 +455,8 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     }
     if (e == hipSuccess)
         e = hipMemSetAccess(base, (size_t)need * piece, &acc, 1);
+    if (e == hipSuccess)
+        rt_place_flush();
     for (int k = 0; k < made; ++k) /* the surplus */
         if (h[k])
             (void)hipMemRelease(h[k]);
@@ -449,10 +492,9 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     for (int k = 0; k < nclass; ++k)
         largest = used[k] > largest ? used[k] : largest;
     P.mixed = nclass >= 2 && 3 * (need - largest) >= need;
-    P.ballast = nballast;
+    P.ballast = hops;
     P.class_mix = P.mixed;
     P.fast = P.mixed; /* (until the pattern itself has been measured) */
-    P.tries = 1;
     const double t_end = rt_place_now_ms();
     P.search_ms = (float)(t_end - t_start);
     P.ballast_ms = (float)t_ballast;
@@ -514,117 +556,21 @@ static float rt_place_measure(rt_ctx *c, int L, long long ld)
 }
 
 /*
- * Measure, and while the pattern is below RT_PLACE_GOOD_GBPS map the same
- * pieces behind other fresh ranges: the best one stays (ctx->d_buf follows).
- * What decides between four and two workgroups per CU (rt_resident_lds) is
- * this measurement, not the classes.  Batches whose pattern is too short to
- * tell anything (< 0.5 GB written) keep their first range.
+ * The batch's own pattern over the arrays where they are: what decides
+ * between four and two workgroups per CU (rt_resident_lds) is this
+ * measurement, not the classes.  (Mapping the same pieces behind another
+ * address range and measuring again was built and removed in round 5: the
+ * ranges of one set of pieces lie within 2 % of each other, and what had
+ * looked like more in the laboratories were stale translations,
+ * rt_place_flush.)
  */
 static void rt_place_tune(rt_ctx *c, int L, long long ld)
 {
     rt_place &P = c->place;
-    /* (a pattern too short to measure leaves what the classes said, or
-     * what an earlier layout found out about the range) */
     if (!P.base || L < 2 || 56. * (L - 1) * (double)ld < 5e8)
         return;
-    P.store_gbps = 0.f;
-    P.kept = 0;
-    P.tune_ms = 0.f;
-    for (int k = 0; k < RT_PLACE_TRIES; ++k)
-        P.gbps[k] = 0.f;
     const double t_start = rt_place_now_ms();
-    /* two ranges at most: in this engine's allocations the ranges of one set
-     * of pieces have turned out within 2 % of each other (it is the pieces
-     * that the batches below the fast level want exchanged: rt_place_settle) */
-    const int tries = 2;
-    void *range[RT_PLACE_TRIES] = {P.base};
-    int n = 1, best = 0;
-    P.gbps[0] = rt_place_measure(c, L, ld);
-    while (n < tries && P.gbps[0] > 0.f) {
-        float lo = P.gbps[0], hi = P.gbps[0];
-        for (int k = 1; k < n; ++k) {
-            lo = P.gbps[k] < lo ? P.gbps[k] : lo;
-            hi = P.gbps[k] > hi ? P.gbps[k] : hi;
-        }
-        if (hi >= c->opt_place_good || hi >= RT_PLACE_GAP * lo)
-            break; /* as good as it gets, or both ends seen */
-        /* the same pieces behind another range; the ranges tried so far
-         * stay reserved so that the next one is a new one */
-        if (hipStreamSynchronize(c->stream) != hipSuccess ||
-            hipMemUnmap(range[n - 1], P.bytes) != hipSuccess)
-            break; /* (cannot happen; the arrays stay where they are) */
-        void *next = NULL;
-        if (rt_place_map(c, &P, &next) != hipSuccess) {
-            (void)hipGetLastError();
-            void *again = NULL; /* back behind a range that worked */
-            (void)hipMemAddressFree(range[n - 1], P.bytes);
-            if (rt_place_map(c, &P, &again) == hipSuccess)
-                range[n - 1] = again;
-            else
-                range[n - 1] = NULL;
-            break;
-        }
-        range[n] = next;
-        P.base = next;
-        c->d_buf = (double *)next;
-        P.gbps[n] = rt_place_measure(c, L, ld);
-        ++n;
-    }
-    for (int k = 1; k < n; ++k)
-        if (P.gbps[k] > P.gbps[best])
-            best = k;
-    if (range[n - 1] == NULL) {
-        /* lost the mapping on the way (device out of address space?): the
-         * caller sees a failed allocation */
-        P.base = NULL;
-        c->d_buf = NULL;
-    } else if (best != n - 1 && range[best]) {
-        /* the winner is an earlier range: back behind it.  Its reservation
-         * is still held; the pieces go where they were (va_lab: a range
-         * keeps its level when the same pieces return to it) */
-        const hipMemGenericAllocationHandle_t *h =
-            (const hipMemGenericAllocationHandle_t *)P.handles;
-        hipMemAccessDesc acc = {};
-        acc.location.type = hipMemLocationTypeDevice;
-        acc.location.id = c->device;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        hipError_t e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess)
-            e = hipMemUnmap(range[n - 1], P.bytes);
-        int nm = 0;
-        for (; e == hipSuccess && nm < P.n; ++nm)
-            e = hipMemMap((char *)range[best] + (size_t)nm * P.piece, P.piece,
-                          0, h[nm], 0);
-        if (e == hipSuccess)
-            e = hipMemSetAccess(range[best], P.bytes, &acc, 1);
-        if (e == hipSuccess) {
-            P.base = range[best];
-            c->d_buf = (double *)range[best];
-        } else { /* stay behind the last range */
-            (void)hipGetLastError();
-            for (int k = 0; k < nm; ++k)
-                (void)hipMemUnmap((char *)range[best] + (size_t)k * P.piece,
-                                  P.piece);
-            nm = 0;
-            for (e = hipSuccess; e == hipSuccess && nm < P.n; ++nm)
-                e = hipMemMap((char *)range[n - 1] + (size_t)nm * P.piece,
-                              P.piece, 0, h[nm], 0);
-            if (e == hipSuccess)
-                e = hipMemSetAccess(range[n - 1], P.bytes, &acc, 1);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                P.base = NULL;
-                c->d_buf = NULL;
-            }
-            best = n - 1;
-        }
-    }
-    for (int k = 0; k < n; ++k)
-        if (range[k] && range[k] != P.base)
-            (void)hipMemAddressFree(range[k], P.bytes);
-    P.tries = n;
-    P.kept = best;
-    P.store_gbps = P.gbps[best];
+    P.store_gbps = rt_place_measure(c, L, ld);
     if (P.store_gbps > 0.f) /* whatever the classes said */
         P.fast = P.store_gbps >= RT_PLACE_FAST_GBPS;
     P.tune_ms = (float)(rt_place_now_ms() - t_start);
@@ -682,6 +628,9 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
     c->place.picks = picks;
     for (int k = 0; k < RT_PLACE_PICKS; ++k)
         c->place.pick_gbps[k] = k < picks ? seen[k] : 0.f;
+    /* sets that lost have been unmapped: whatever the device still holds of
+     * their translations goes before anything else is launched */
+    rt_place_flush();
 }
 
 #endif /* RT_PLACE_H */

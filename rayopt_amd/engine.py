@@ -329,21 +329,19 @@ class Engine:
     def placement(self):
         """Where the result arrays live (rt_placement): dict with the pieces
         behind them (0 = plain hipMalloc), MiB per piece, pieces created on
-        the way, classes seen, pieces kept per class, the address ranges the
-        batch's store pattern was measured behind (GB/s each), which one was
-        kept, and ``fast``: four workgroups per CU."""
+        the way, classes seen, pieces kept per class, the batch's own store
+        pattern over the arrays (GB/s; per set of pieces tried) and ``fast``:
+        four workgroups per CU."""
         info = (ctypes.c_int*16)()
         ms = (ctypes.c_double*16)()
         self._check(self.lib.rt_placement(self.ctx, info, ms), "rt_placement")
         return {"pieces": info[0], "piece_mib": info[1], "created": info[2],
                 "classes": info[3], "per_class": [info[4], info[5], info[6]],
                 "fast": bool(info[7]), "ballast_blocks": info[8],
-                "classes_mixed": bool(info[9]),
-                "ranges_tried": info[10], "range_kept": info[11],
-                "store_pattern_GBps_per_range": [ms[8 + k] for k in
-                                                 range(max(info[10], 0))],
+                "classes_mixed": bool(info[9]), "hops": info[8],
                 "store_pattern_GBps": ms[2],
                 "piece_sets_tried": info[12],
+                "gave_up_incoherent": bool(info[13]),
                 "store_pattern_GBps_per_piece_set": [
                     ms[12 + k] for k in range(max(min(info[12], 3), 0))],
                 "pair_test_ms": {"same_piece": ms[0], "other_class": ms[1]},

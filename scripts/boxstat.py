@@ -1,8 +1,8 @@
 """Placement statistics of ONE box (round 5): several contexts per shape --
 C2 (Cooke, 3 x 10^6 rays, one launch), the headline C3 (double-Gauss, 10^7
 rays, collimated bundles) and C3' (the same with per-ray launch directions)
--- each with what rt_placement measured (address ranges tried, GB/s of the
-store pattern behind each, which one was kept) and the settled launch time of
+-- each with what rt_placement measured (classes, sets of pieces tried, GB/s of the
+store pattern over each) and the settled launch time of
 its trace.  One JSON line per context; run on several fresh boxes, the table
 goes to profiles/r05_final/boxstat/.
 

@@ -61,25 +61,16 @@ def test_large_arrays_are_placed_and_results_do_not_depend_on_it():
             assert t["pieces"] + t["ballast"] + t["remap"] <= \
                 t["all"]*1.01 + .01
             if info["pieces"]:
-                # the batch's own store pattern was measured behind 1-4
-                # address ranges and the best one kept
-                k = info["ranges_tried"]
-                rates = info["store_pattern_GBps_per_range"]
-                assert 1 <= k <= 2 and len(rates) == k and min(rates) > 0
-                assert 0 <= info["range_kept"] < k
-                assert info["store_pattern_GBps"] == max(rates) == \
-                    rates[info["range_kept"]]
-                assert info["fast"] == (info["store_pattern_GBps"] >= 5950.)
-                # a further range is tried only while the pattern is below
-                # "good" and no gap has shown
-                assert k == 1 or max(rates[:k - 1]) < 6800.
-                assert t["tune"] > 0
-                # another set of pieces is searched only while the pattern
-                # is below "good"; the best set stays
+                # the batch's own store pattern was measured over the arrays;
+                # another set of pieces is searched only while it is below
+                # "good"; the best set stays
                 sets = info["store_pattern_GBps_per_piece_set"]
                 assert 1 <= info["piece_sets_tried"] == len(sets) <= 3
+                assert min(sets) > 0
                 assert max(sets) == info["store_pattern_GBps"]
                 assert len(sets) == 1 or max(sets[:-1]) < 6800.
+                assert info["fast"] == (info["store_pattern_GBps"] >= 5950.)
+                assert t["tune"] > 0 and not info["gave_up_incoherent"]
         else:
             assert info["pieces"] == 0 and not info["fast"]
             assert info["search_ms"]["all"] == 0.
@@ -95,11 +86,13 @@ def test_large_arrays_are_placed_and_results_do_not_depend_on_it():
 
 @pytest.mark.parametrize("generated", [False, True])
 def test_every_range_and_every_set_of_pieces(generated):
-    """With a "good" no memory reaches, an allocation measures both address
-    ranges of all three sets of pieces and keeps the best: the arrays move
-    behind other ranges and onto other pieces five times before the first
-    ray is traced -- host-seeded and device-built batches, two blocks -- and
-    the results are the bits of a plain allocation."""
+    """With a "good" no memory reaches, an allocation measures all three sets
+    of pieces and keeps the best: the arrays move onto other pieces (and
+    behind addresses other mappings have used) before the first ray is traced
+    -- host-seeded and device-built batches, two blocks -- and the results are
+    the bits of a plain allocation (ROCm 7.2: kernels keep the translations
+    of an earlier mapping unless a buffer is freed in between; rt_place_flush,
+    rt_place_coherent)."""
     system = ra.system_from_yaml(P.DOUBLE_GAUSS)
     L = len(system)
     n = 3_000_000
@@ -120,12 +113,9 @@ def test_every_range_and_every_set_of_pieces(generated):
         g.propagate(clip=True)
         info = eng.placement()
         assert eng.blocks()[0] == 2
+        assert not info["gave_up_incoherent"]
         if info["pieces"]:
-            if good:
-                assert info["piece_sets_tried"] == 3
-                assert info["ranges_tried"] == 2
-            else:
-                assert info["piece_sets_tried"] == info["ranges_tried"] == 1
+            assert info["piece_sets_tried"] == (3 if good else 1)
             assert max(info["store_pattern_GBps_per_piece_set"]) == \
                 info["store_pattern_GBps"]
         rows[good] = _rows(eng, L)
