@@ -390,7 +390,7 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * workgroups per CU, which the memory side likes better than the seven the
  * registers allow, four where the arrays' own store pattern was measured at the fast
  * level, rt_placement; FP64-bound traces are not capped), "placement"
- * (rt_placement), "placement_good_gbps" (default 6800: the store pattern at
+ * (rt_placement), "placement_good_gbps" (default 6900: the store pattern at
  * which rt_reserve stops looking for a better address range / set of pieces),
  * "range_shortcuts" (1 = default: IEEE quotients and square
  * roots run without the compiler's range scaffolding where the operands are
@@ -595,7 +595,7 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * had: three) classes mapped behind one address range, the surplus released;
  * then the
  * batch's OWN store pattern (56 B per ray and element) is written over the
- * arrays and timed; while it stays below 6800 GB/s ANOTHER set of pieces is
+ * arrays and timed; while it stays below 6900 GB/s ANOTHER set of pieces is
  * searched, classified and measured while the first is held (arrays up to
  * 16 GiB; at most three sets); the best stays (option "placement", default 1;
  * RT_MI355_PLACEMENT=0 for the whole process; plain hipMalloc if anything on

@@ -68,7 +68,7 @@ static inline double rt_place_now_ms(void)
  * stops paying: bundles with per-ray launch directions (reads among the
  * saturated writes) trace at 1.077 ms behind 6950 GB/s, 1.10 behind 6820,
  * 1.15 behind 6770, C2 at 0.208 behind 6950 and 0.235-0.241 behind 6300 */
-#define RT_PLACE_GOOD_GBPS 6800.
+#define RT_PLACE_GOOD_GBPS 6900.
 #define RT_PLACE_FAST_GBPS 5950.
 
 struct rt_place_rows {

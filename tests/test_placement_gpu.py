@@ -68,7 +68,7 @@ def test_large_arrays_are_placed_and_results_do_not_depend_on_it():
                 assert 1 <= info["piece_sets_tried"] == len(sets) <= 3
                 assert min(sets) > 0
                 assert max(sets) == info["store_pattern_GBps"]
-                assert len(sets) == 1 or max(sets[:-1]) < 6800.
+                assert len(sets) == 1 or max(sets[:-1]) < 6900.
                 assert info["fast"] == (info["store_pattern_GBps"] >= 5950.)
                 assert t["tune"] > 0 and not info["gave_up_incoherent"]
         else:
