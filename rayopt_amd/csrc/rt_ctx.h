@@ -82,7 +82,7 @@ struct rt_place {
      * final mapping; and of measuring / re-mapping (rt_place_tune) */
     float search_ms, pieces_ms, ballast_ms, remap_ms, tune_ms;
     int picks;           /* sets of pieces tried (rt_place_settle) */
-    float pick_gbps[3];  /* the pattern behind the best range of each */
+    float pick_gbps[5];  /* the batch's store pattern over each */
 };
 
 struct rt_ctx {

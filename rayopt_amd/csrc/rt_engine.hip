@@ -1685,8 +1685,8 @@ int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
     ms[5] = p.ballast_ms;
     ms[6] = p.remap_ms;
     ms[7] = p.tune_ms;
-    for (int k = 0; k < 3; ++k)
-        ms[12 + k] = p.pick_gbps[k];
+    for (int k = 0; k < 5; ++k)
+        ms[8 + k] = p.pick_gbps[k];
     return RT_OK;
 }
 

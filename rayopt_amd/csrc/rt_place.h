@@ -580,11 +580,12 @@ static void rt_place_tune(rt_ctx *c, int L, long long ld)
  * rt_place_tune, and while the arrays stay below RT_PLACE_GOOD_GBPS ANOTHER
  * set of pieces: the current one is held (so that the new pieces come from
  * elsewhere in the device memory), classified, mapped and measured like the
- * first, and the better set stays.  At most RT_PLACE_PICKS sets, arrays up
- * to 16 GiB (C2: 0.2414 ms behind pieces whose four ranges all ran the
+ * first, and the better set stays.  At most three sets (five for arrays
+ * below 4 GiB), arrays up to 16 GiB (C2: 0.2414 ms behind pieces whose four ranges all ran the
  * pattern at 5.45-5.5 TB/s, 0.207-0.218 behind others).  ctx->d_buf follows.
  */
-#define RT_PLACE_PICKS 3
+#define RT_PLACE_PICKS 5 /* arrays below 4 GiB (a set costs them ~10 ms and is
+                            bad in one of three cases); above: three */
 static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes);
 
 static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
@@ -595,7 +596,8 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
     rt_place_tune(c, L, ld);
     int picks = 1;
     float seen[RT_PLACE_PICKS] = {c->place.store_gbps};
-    while (picks < RT_PLACE_PICKS && c->d_buf && c->place.base &&
+    const int most = c->place.bytes < ((size_t)4 << 30) ? RT_PLACE_PICKS : 3;
+    while (picks < most && c->d_buf && c->place.base &&
            c->place.store_gbps > 0.f &&
            c->place.store_gbps < c->opt_place_good &&
            c->place.bytes <= ((size_t)16 << 30)) {

@@ -343,7 +343,7 @@ class Engine:
                 "piece_sets_tried": info[12],
                 "gave_up_incoherent": bool(info[13]),
                 "store_pattern_GBps_per_piece_set": [
-                    ms[12 + k] for k in range(max(min(info[12], 3), 0))],
+                    ms[8 + k] for k in range(max(min(info[12], 5), 0))],
                 "pair_test_ms": {"same_piece": ms[0], "other_class": ms[1]},
                 "search_ms": {"all": ms[3], "pieces": ms[4], "ballast": ms[5],
                               "remap": ms[6], "tune": ms[7]}}

@@ -65,7 +65,7 @@ def test_large_arrays_are_placed_and_results_do_not_depend_on_it():
                 # another set of pieces is searched only while it is below
                 # "good"; the best set stays
                 sets = info["store_pattern_GBps_per_piece_set"]
-                assert 1 <= info["piece_sets_tried"] == len(sets) <= 3
+                assert 1 <= info["piece_sets_tried"] == len(sets) <= 5
                 assert min(sets) > 0
                 assert max(sets) == info["store_pattern_GBps"]
                 assert len(sets) == 1 or max(sets[:-1]) < 6900.
@@ -86,7 +86,7 @@ def test_large_arrays_are_placed_and_results_do_not_depend_on_it():
 
 @pytest.mark.parametrize("generated", [False, True])
 def test_every_range_and_every_set_of_pieces(generated):
-    """With a "good" no memory reaches, an allocation measures all three sets
+    """With a "good" no memory reaches, an allocation measures all five sets
     of pieces and keeps the best: the arrays move onto other pieces (and
     behind addresses other mappings have used) before the first ray is traced
     -- host-seeded and device-built batches, two blocks -- and the results are
@@ -115,7 +115,7 @@ def test_every_range_and_every_set_of_pieces(generated):
         assert eng.blocks()[0] == 2
         assert not info["gave_up_incoherent"]
         if info["pieces"]:
-            assert info["piece_sets_tried"] == (3 if good else 1)
+            assert info["piece_sets_tried"] == (5 if good else 1)
             assert max(info["store_pattern_GBps_per_piece_set"]) == \
                 info["store_pattern_GBps"]
         rows[good] = _rows(eng, L)
