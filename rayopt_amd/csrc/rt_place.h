@@ -233,7 +233,10 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
                         piece" time is then already the fast one */
     const int need = (int)((bytes + piece - 1) / piece);
     size_t align = piece & (~piece + 1); /* largest power of two dividing it */
-    const int cap = need + 24; /* pieces created and classified at most */
+    /* pieces created and classified at most: large arrays may look further
+     * for an even mix (C5, 97 pieces: as they came -- 22 / 45 / 30 -- the
+     * last blocks of the batch lay in one class) */
+    const int cap = need + (need > 48 ? need / 2 : 24);
     /* Pieces come in runs of one class (2-14 seen, 26+ on one box): once a
      * class is oversupplied the search HOPS -- a block of ballast is created
      * and held, unclassified, so that the next piece lies further on in the
@@ -387,9 +390,13 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
          * classes: 6.67-6.77 TB/s in five of five contexts, sets of three:
          * 6.91-7.02 in nine of ten, profiles/r05_final/boxstat/) */
         if (made >= need && nclass >= 2) {
+            /* (with three classes: none above 40 % of the need, as long as
+             * the search may go on) */
+            const int most = nclass >= 3 && made < cap - 1 ? (2 * need + 4) / 5
+                                                          : (need + 1) / 2;
             int can = 0;
             for (int q = 0; q < nclass; ++q)
-                can += count[q] < (need + 1) / 2 ? count[q] : (need + 1) / 2;
+                can += count[q] < most ? count[q] : most;
             enough = can >= need && (nclass >= 3 || made >= need + 8);
         }
     }
