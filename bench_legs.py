@@ -1271,6 +1271,22 @@ def run_configs(ra, device, args, live=None):
                kind="C5 generated")
         out[-1]["finite_fraction_at_image_sampled"] = \
             out[-1]["parity_subsample"].pop("finite_fraction_at_image")
+        if args.extras:
+            # the same launch with 30 ms of idle device before it: what the
+            # batch takes when the socket is NOT held at its power cap
+            # launch after launch
+            t = []
+            for _ in range(12):
+                g.engine.sync()
+                time.sleep(.03)
+                g.propagate(clip=True)
+                g.engine.sync()
+                t.append(g.kernel_ms())
+            out[-1]["launches_30_ms_apart"] = {
+                "kernel_ms": float(np.median(t[2:])),
+                "kernel_ms_min_max": [min(t[2:]), max(t[2:])]}
+            log("[configs] C5, launches 30 ms apart: %.4f ms"
+                % out[-1]["launches_30_ms_apart"]["kernel_ms"])
         del g
         # the same rays as TEN batches of a tenth each, ten contexts traced
         # in turn: the cross-check of the layout in blocks (csrc/rt_lay.h) --
@@ -1298,10 +1314,14 @@ def run_configs(ra, device, args, live=None):
             t_end = time.time() + .5
             while time.time() < t_end:
                 turn()
+            if tele is not None:
+                tele.mark("ten:begin")
             t0 = time.perf_counter()
             for _ in range(20):
                 turn()
             ms = (time.perf_counter() - t0)/20*1e3
+            if tele is not None:
+                tele.mark("ten:end")
             tables = np.stack([pack_system(
                 s5, s5.wavelengths[0],
                 s5.refractive_index(s5.wavelengths[0], 0))[0]])
@@ -1324,6 +1344,14 @@ def run_configs(ra, device, args, live=None):
             out[-1]["as_ten_batches_in_turn"] = {"error": repr(err)[:200]}
     # what bounds each config: the store streams (HBM) or FP64 issue
     t = tele.stop() if tele is not None else None
+    w = (t or {}).get("ten") or {}
+    if w and "as_ten_batches_in_turn" in out[-1]:
+        # the one batch holds the socket at its power cap launch after launch
+        # (power_limited_fraction 1.0, 1.74-1.78 GHz); DESIGN.md section 9
+        out[-1]["as_ten_batches_in_turn"]["telemetry"] = {
+            "gfxclk_mhz": (w.get("gfxclk_mhz") or [None]*3)[1],
+            "socket_power_w": (w.get("socket_power_w") or [None]*3)[1],
+            "power_limited_fraction": w.get("power_limited_fraction")}
     for k, rec in enumerate(out):
         kind = rec.pop("_kind", None)
         w = (t or {}).get(str(k)) or {}

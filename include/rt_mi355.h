@@ -400,6 +400,13 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * the layout above; B > 0: every batch of more than B rays is cut into
  * blocks of about B rays -- for tests; RT_MI355_BLOCK_RAYS=B does the same
  * for every context of the process; takes effect with the next rt_reserve),
+ * "turn_points" (0 = default: a generated batch of several bundles over MORE
+ * than 128 MB of pupil points is traced in turns of 4 Mi points -- turn k of
+ * every bundle before turn k + 1 of any -- so that the points, read once per
+ * bundle, are still in the Infinity Cache the next time; -1 = never; P > 0:
+ * turns of P points whatever the size -- for tests, like
+ * RT_MI355_TURN_POINTS=P for the process.  The order in which workgroups
+ * take the rays, nothing else: every result lands where it did),
  * "consumers_one_pass" (1 = default, see rt_rms; 0 = always two passes),
  * "consumer_events" (measurement: 1 = the reductions bracket their kernels
  * with the events rt_kernel_ms reads; default 0).

@@ -60,6 +60,13 @@ struct rt_rccl_api {
 #define RT_BLOCK_ONE 8.5e9
 #define RT_BLOCK_BYTES 7.0e9
 
+/* generated batches whose pupil points (16 B each, read once per bundle) pass
+ * RT_TURN_ABOVE bytes are traced in turns of RT_TURN_POINTS points
+ * (rt_gen_wg, rt_lay.h): what is read again should still be in the 256 MB
+ * Infinity Cache */
+#define RT_TURN_ABOVE (128. * 1048576.)
+#define RT_TURN_POINTS (4 * 1048576)
+
 #define RT_PLACE_CLASSES 4
 struct rt_place {
     void *base;      /* the mapped range (= d_buf), NULL: plain hipMalloc */
@@ -123,6 +130,8 @@ struct rt_ctx {
     int64_t bs, bts;
     int nblk;
     int opt_block; /* rays per block asked for (0: chosen by rt_reserve) */
+    int64_t opt_turn; /* pupil points per turn of a generated batch (rt_gen_wg):
+                         0 automatic, -1 never */
     int buf_nsurf; /* L the buffer is laid out for */
 
     void *d_scratch;

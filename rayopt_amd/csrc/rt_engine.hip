@@ -273,6 +273,12 @@ int rt_create(int device, rt_ctx **out)
         c->opt_block = e ? atoi(e) : 0;
         if (c->opt_block < 0)
             c->opt_block = 0;
+        /* RT_MI355_TURN_POINTS=P: generated batches of several bundles in
+         * turns of P pupil points whatever their size (tests) */
+        e = getenv("RT_MI355_TURN_POINTS");
+        c->opt_turn = e ? atoll(e) : 0;
+        if (c->opt_turn < -1)
+            c->opt_turn = 0;
     }
     {
         const char *e = getenv("RT_MI355_PLACEMENT");
@@ -1253,13 +1259,28 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
         ctx->gen_pending = 0;
         if (fused)
             ctx->uni_valid = 0; /* this launch writes row 0 */
+        /* bundles over a large pupil: in turns (whole batch, bundles of
+         * whole workgroups only; elsewhere the order stays the rays') */
+        rt_gen_order order = {0, 0, 0};
+        int64_t turn = ctx->opt_turn > 0 ? ctx->opt_turn
+                       : 16. * ctx->gen_np > RT_TURN_ABOVE ? RT_TURN_POINTS
+                                                           : 0;
+        turn = turn / RT_BLOCK * RT_BLOCK;
+        if (ctx->opt_turn >= 0 && turn > 0 && !windowed && lo == 0 &&
+            ctx->gen_np % RT_BLOCK == 0 && ctx->gen_np > turn &&
+            ctx->gen_n % ctx->gen_np == 0 && ctx->gen_n > ctx->gen_np &&
+            ctx->gen_n / RT_BLOCK <= grid) {
+            order.turn = (uint32_t)(turn / RT_BLOCK);
+            order.per = (uint32_t)(ctx->gen_np / RT_BLOCK);
+            order.nf = (uint32_t)(ctx->gen_n / ctx->gen_np);
+        }
         hipLaunchKernelGGL(rt_trace_gen_kernel, dim3(grid), dim3(RT_BLOCK),
                            lds, ctx->stream, ctx->d_surf, stop, clip, lay, cols,
                            group_rays, ctx->nsurf, ctx->ngroups,
                            (const rt_field *)ctx->d_gen,
                            (const double *)((char *)ctx->d_gen + ctx->gen_fpad),
                            ctx->gen_np, ctx->gen_n, lo, ctx->gen_s0,
-                           !ctx->opt_alias, fused ? 1 : 0);
+                           !ctx->opt_alias, fused ? 1 : 0, order);
         RT_HIP(ctx, hipGetLastError());
     } else if (!windowed && rt_use_compact(ctx, start, stop)) {
         hipLaunchKernelGGL(rt_trace_compact_kernel,
@@ -1420,6 +1441,13 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
             return rt_fail(ctx, RT_ERR_ARG, "block_rays: 0 (automatic) or a "
                                             "number of rays");
         ctx->opt_block = value;
+    } else if (!strcmp(key, "turn_points")) {
+        /* pupil points per turn of a generated batch of several bundles
+         * (rt_gen_wg): 0 automatic, -1 never, else that many (tests) */
+        if (value < -1)
+            return rt_fail(ctx, RT_ERR_ARG, "turn_points: -1, 0 or a number "
+                                            "of pupil points");
+        ctx->opt_turn = value;
     } else if (!strcmp(key, "consumers_one_pass")) {
         ctx->opt_onepass = value ? 1 : 0;
     } else if (!strcmp(key, "consumer_events")) {

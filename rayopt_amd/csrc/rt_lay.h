@@ -105,4 +105,43 @@ __device__ __forceinline__ int64_t rt_col_wg(const rt_lay &a, int64_t j,
     return rt_block_col(a.bs, a.ts, j + a.j0);
 }
 
+/*
+ * The order in which the workgroups of a generated batch take its rays.  A
+ * batch of `nf` bundles over the SAME pupil points reads every point nf times,
+ * `per` workgroups (= npupil rays) apart.  While the points (16 B each) fit
+ * the 256 MB Infinity Cache the later bundles find them there; above it every
+ * bundle fetches them from HBM among the saturated stores: C5 on one GPU, 5
+ * bundles over 2*10^7 points = 320 MB, 1.04-1.05 ms per 10^7 rays against
+ * 1.006 with 160 MB (profiles/r05_final/pupil_points_sweep.jsonl).  So large
+ * pupils are taken in TURNS of `turn` workgroups: turn 0 of bundle 0, turn 0
+ * of bundle 1, ..., then turn 1 of every bundle: a turn's points are read
+ * again while they are still cached, and the stores go on in runs of
+ * turn * 256 consecutive rays.  Returns the workgroup's index in ray order
+ * (wave-uniform; workgroups of padding beyond nf * per keep theirs); where
+ * the results land does not change.
+ */
+struct rt_gen_order {
+    uint32_t turn; /* workgroups per turn; 0: in ray order */
+    uint32_t per;  /* workgroups per bundle */
+    uint32_t nf;   /* bundles */
+};
+
+__host__ __device__ __forceinline__ uint32_t rt_gen_wg(const rt_gen_order &o,
+                                                       uint32_t wg)
+{
+    if (!o.turn || wg >= o.per * o.nf)
+        return wg;
+    const uint32_t whole = o.per / o.turn; /* complete turns */
+    const uint32_t lap = o.turn * o.nf;    /* workgroups of one turn of all */
+    if (wg < whole * lap) {
+        const uint32_t q = wg / lap, r = wg - q * lap;
+        const uint32_t f = r / o.turn, t = r - f * o.turn;
+        return f * o.per + q * o.turn + t;
+    }
+    const uint32_t last = o.per - whole * o.turn; /* > 0 here */
+    const uint32_t r = wg - whole * lap;
+    const uint32_t f = r / last, t = r - f * last;
+    return f * o.per + whole * o.turn + t;
+}
+
 #endif /* RT_LAY_H */

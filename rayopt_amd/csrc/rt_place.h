@@ -34,7 +34,8 @@
  * of the engine sees is an ordinary device pointer.  rt_place_settle(), once
  * rt_reserve knows the layout, writes the batch's own store pattern over the
  * arrays and times it; below RT_PLACE_GOOD_GBPS it goes on to another set of
- * pieces while the first is held (at most three sets); the best stays.
+ * pieces while the first is held (at most three sets, five for small arrays
+ * and where three were clearly not enough); the best stays.
  * 15-60 ms once per allocation (more where the driver is slow to hand out
  * memory it has just got back).  Anything that fails on the way (no virtual
  * memory management, out of memory for the surplus) falls back to hipMalloc:
@@ -587,12 +588,13 @@ static void rt_place_tune(rt_ctx *c, int L, long long ld)
  * rt_place_tune, and while the arrays stay below RT_PLACE_GOOD_GBPS ANOTHER
  * set of pieces: the current one is held (so that the new pieces come from
  * elsewhere in the device memory), classified, mapped and measured like the
- * first, and the better set stays.  At most three sets (five for arrays
- * below 4 GiB), arrays up to 16 GiB (C2: 0.2414 ms behind pieces whose four ranges all ran the
- * pattern at 5.45-5.5 TB/s, 0.207-0.218 behind others).  ctx->d_buf follows.
+ * first, and the better set stays.  At most three sets -- five for arrays
+ * below 4 GiB (a set costs them ~10 ms and is bad in one of three cases), and
+ * where the best of three is still 2.5 % below the mark --, arrays up to
+ * 16 GiB (C2: 0.2414 ms behind pieces whose four ranges all ran the pattern
+ * at 5.45-5.5 TB/s, 0.207-0.218 behind others).  ctx->d_buf follows.
  */
-#define RT_PLACE_PICKS 5 /* arrays below 4 GiB (a set costs them ~10 ms and is
-                            bad in one of three cases); above: three */
+#define RT_PLACE_PICKS 5
 static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes);
 
 static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
@@ -603,10 +605,15 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
     rt_place_tune(c, L, ld);
     int picks = 1;
     float seen[RT_PLACE_PICKS] = {c->place.store_gbps};
-    const int most = c->place.bytes < ((size_t)4 << 30) ? RT_PLACE_PICKS : 3;
-    while (picks < most && c->d_buf && c->place.base &&
+    /* at most three sets for arrays of 4 GiB and more (a set costs them
+     * 10-20 ms) -- five where the best of three is still 2.5 % below the
+     * mark (three sets of two classes in a row: 6.59-6.63 TB/s, C3' 0.77
+     * instead of 0.82, profiles/r05_final/boxstat/bench_box_f.json) */
+    while (picks < RT_PLACE_PICKS && c->d_buf && c->place.base &&
            c->place.store_gbps > 0.f &&
            c->place.store_gbps < c->opt_place_good &&
+           (picks < 3 || c->place.bytes < ((size_t)4 << 30) ||
+            c->place.store_gbps < .975 * c->opt_place_good) &&
            c->place.bytes <= ((size_t)16 << 30)) {
         const rt_place held = c->place; /* pieces and range stay alive */
         double *const held_buf = c->d_buf;

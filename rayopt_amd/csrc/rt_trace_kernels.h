@@ -113,11 +113,14 @@ rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
                     int ngroups, const rt_field *__restrict__ fields,
                     const double *__restrict__ pupil, int64_t npupil,
                     int64_t n, int64_t j0, rt_surface S0, int store_i0,
-                    int store0)
+                    int store0, rt_gen_order order)
 {
     /* `a` and `ld` describe the window of columns this launch covers (the
-     * whole batch: j0 = 0); j0 + column = index of the ray in the batch */
-    const int64_t w = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+     * whole batch: j0 = 0); j0 + column = index of the ray in the batch.
+     * Large pupils are taken in turns (rt_gen_wg, rt_lay.h): wg = which 256
+     * rays this workgroup has, wave-uniform */
+    const uint32_t wg = rt_gen_wg(order, blockIdx.x);
+    const int64_t w = (int64_t)wg * RT_BLOCK + threadIdx.x;
     if (w >= ld)
         return;
     const int64_t j = j0 + w;
@@ -132,7 +135,7 @@ rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
         rt_generate_ray(fields + j / npupil, pupil[2 * p], pupil[2 * p + 1],
                         &S0, y, u);
     }
-    const int64_t col = rt_col_wg(a, w, blockIdx.x);
+    const int64_t col = rt_col_wg(a, w, wg);
     if (store0) { /* first trace of the batch; later ones leave row 0 alone */
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

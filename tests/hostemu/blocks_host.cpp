@@ -133,6 +133,43 @@ int main()
             }
         }
     }
+    // the turns of a generated batch (rt_gen_wg): a permutation of the
+    // workgroups of the bundles, padding left alone, runs of `turn`
+    // consecutive workgroups per bundle, a turn of every bundle before the
+    // next turn of any
+    for (int t = 0; t < 400; ++t) {
+        rt_gen_order o;
+        o.per = 1 + rand() % 300;
+        o.nf = 1 + rand() % 7;
+        o.turn = t % 5 == 0 ? 0 : 1 + rand() % (o.per + 20);
+        const uint32_t all = o.per * o.nf, grid = all + rand() % 9;
+        unsigned char *seen = (unsigned char *)calloc(grid, 1);
+        uint32_t before_q = 0;
+        for (uint32_t w = 0; w < grid; ++w) {
+            const uint32_t v = rt_gen_wg(o, w);
+            CHECK(v < grid && !seen[v]);
+            if (v < grid)
+                seen[v] = 1;
+            if (w >= all || !o.turn) {
+                CHECK(v == w);
+                continue;
+            }
+            const uint32_t f = v / o.per, k = v % o.per, q = k / o.turn;
+            CHECK(q >= before_q); // turns never go back
+            before_q = q;
+            if (w + 1 < all) { // the next one: same run, or the next run
+                const uint32_t v1 = rt_gen_wg(o, w + 1);
+                const uint32_t f1 = v1 / o.per, k1 = v1 % o.per;
+                const bool same_run = f1 == f && k1 == k + 1 &&
+                                      k1 / o.turn == q;
+                const bool next_bundle = f1 == f + 1 && k1 == q * o.turn;
+                const bool next_turn = f == o.nf - 1 && f1 == 0 &&
+                                       k1 == (q + 1) * o.turn;
+                CHECK(same_run || next_bundle || next_turn);
+            }
+        }
+        free(seen);
+    }
     free(c);
     printf("blocks_host: %ld failures\n", bad);
     return bad != 0;

@@ -121,6 +121,54 @@ def test_generated_batches_groups_kept_rows_and_compaction():
     assert same(np.asarray(c.u[-1]), np.asarray(d.u[-1]))
 
 
+@pytest.mark.parametrize("points,turn,block", [
+    (256*37, 256, 0), (256*37, 1024, 4096), (256*37, 3000, 0),
+    (256*8, 256, 768), (256*37 + 64, 512, 0), (256*12, 256*12, 0)])
+def test_bundles_over_a_large_pupil_go_in_turns(points, turn, block):
+    """A generated batch of several bundles over the same pupil points is
+    traced in TURNS when the points outgrow the Infinity Cache (rt_gen_wg,
+    csrc/rt_lay.h: 128 MB of them; "turn_points" forces it at test sizes):
+    the order in which workgroups take the rays, nothing else -- every row of
+    the first trace (which also builds row 0) and of a re-trace (which builds
+    the rays again in registers) is the one the ray order gives, with the
+    batch in blocks as well, with several wavelengths in one launch, and
+    where the bundles are no whole workgroups (then the order stays)."""
+    from bench_legs import FIELD_FRACTIONS, BUNDLE_RADIUS
+    import digest_cases as dc
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    nf = len(FIELD_FRACTIONS)
+    pts = dc.disc_points(points, 5)
+    fields = np.c_[np.zeros(nf), FIELD_FRACTIONS]
+    for ls in (None, [587.56e-9, 486.13e-9]):
+        got = []
+        for t in (-1, turn):
+            g = ra.GeometricTrace(system)
+            g.engine.set_option("turn_points", t)
+            g.engine.set_option("block_rays", block or 2**31 - 1)
+            if ls is None:
+                g.rays_fields(fields, pts, P.DOUBLE_GAUSS_PUPIL_Z,
+                              BUNDLE_RADIUS)
+            else:
+                W = len(ls)
+                g.rays_fields(fields, pts, [P.DOUBLE_GAUSS_PUPIL_Z]*W,
+                              [BUNDLE_RADIUS]*W, l=ls)
+            g.propagate(clip=True)
+            first = rows_of(g)
+            g.propagate(clip=True)         # the re-trace
+            for r in (g.y, g.u, g.i, g.t):
+                r.invalidate(1, len(system))
+            again = rows_of(g)
+            assert bool(block) == (g.engine.blocks()[0] > 1)
+            got.append((first, again))
+        for x, z in zip(got[0][0], got[1][0]):
+            assert same(x, z)
+        for x, z in zip(got[0][1], got[1][1]):
+            assert same(x, z)
+        for x, z in zip(got[0][0], got[0][1]):
+            assert same(x, z)
+        assert np.isfinite(got[0][0][0][-1]).mean() > .5
+
+
 @pytest.mark.parametrize("n,block", [(100_003, 4096), (9_999, 512)])
 def test_reductions_in_blocks(n, block):
     """rms / refocus / rmax / spot statistics / opd over a batch in blocks
