@@ -1272,9 +1272,11 @@ def run_configs(ra, device, args, live=None):
         out[-1]["finite_fraction_at_image_sampled"] = \
             out[-1]["parity_subsample"].pop("finite_fraction_at_image")
         if args.extras:
-            # the same launch with 30 ms of idle device before it: what the
-            # batch takes when the socket is NOT held at its power cap
-            # launch after launch
+            # the same launch with 30 ms of idle device before it (round 5:
+            # is the one batch slowed by sitting at the power cap launch
+            # after launch?  No: after an idle gap it is 20 % SLOWER -- the
+            # clocks have to come back -- and ten batches in turn run at the
+            # cap just the same)
             t = []
             for _ in range(12):
                 g.engine.sync()
@@ -1290,8 +1292,10 @@ def run_configs(ra, device, args, live=None):
         del g
         # the same rays as TEN batches of a tenth each, ten contexts traced
         # in turn: the cross-check of the layout in blocks (csrc/rt_lay.h) --
-        # as ONE block this batch took 12.0 ms, the ten batches 10.3
-        # (DESIGN.md section 9); in blocks the two agree
+        # as ONE block this batch took 12.0 ms, the ten batches 10.3; in
+        # blocks 10.25 against 9.9, and with the bundles taken in turns
+        # (rt_gen_wg: the pupil points stay cached) the two agree
+        # 
         try:
             if not args.extras:
                 raise StopIteration
@@ -1346,8 +1350,8 @@ def run_configs(ra, device, args, live=None):
     t = tele.stop() if tele is not None else None
     w = (t or {}).get("ten") or {}
     if w and "as_ten_batches_in_turn" in out[-1]:
-        # the one batch holds the socket at its power cap launch after launch
-        # (power_limited_fraction 1.0, 1.74-1.78 GHz); DESIGN.md section 9
+        # (both forms hold the socket at its power cap: the clocks do not
+        # tell them apart)
         out[-1]["as_ten_batches_in_turn"]["telemetry"] = {
             "gfxclk_mhz": (w.get("gfxclk_mhz") or [None]*3)[1],
             "socket_power_w": (w.get("socket_power_w") or [None]*3)[1],
