@@ -502,8 +502,8 @@ def reference_one_process(text, y, u, l, clip, sample):
 
 def traffic_from_profile():
     """HBM bytes per launch from the committed PMC profile, if one exists
-    for this workload (profiles/traffic.json, written by
-    scripts/pmc_traffic.py on the GPU box); otherwise null."""
+    for this workload (profiles/traffic.json: roofline.traffic_detail of a
+    committed bench line whose counter passes ran); otherwise null."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
