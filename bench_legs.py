@@ -934,7 +934,8 @@ def end_to_end(g, y, u, clip, kernel_ms):
     n, L = len(y), len(g.system)
     rec = {"rays": n, "note": "wall clock of the public calls on pageable "
            "numpy arrays; the copies are staged through two pinned buffers "
-           "(csrc/rt_engine.hip: rt_h2d / rt_d2h)"}
+           "(csrc/rt_engine.hip: rt_h2d / rt_d2h; the way out by a copy "
+           "kernel, not the DMA)"}
     t = []
     for _ in range(3):
         t0 = time.perf_counter()

@@ -96,6 +96,7 @@ struct rt_ctx {
     int device;
     hipStream_t stream;      /* trace + copies */
     hipStream_t comm_stream; /* RCCL gather */
+    hipStream_t copy_stream; /* device -> host DMAs of row downloads (rt_d2h_jobs) */
     hipEvent_t k0, k1;       /* around the last trace kernel */
     hipEvent_t ev[RT_NEVENTS];
     int traced;

@@ -401,6 +401,8 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->comm_stream)
         (void)hipStreamDestroy(ctx->comm_stream);
+    if (ctx->copy_stream)
+        (void)hipStreamDestroy(ctx->copy_stream);
     free(ctx);
     return RT_OK;
 }
@@ -706,7 +708,7 @@ struct rt_copy_team {
 };
 
 static void rt_copy_start(rt_copy_team *team, void *dst, const void *src,
-                          size_t len)
+                          size_t len, bool all = false)
 {
     const int nt = rt_copy_threads();
     team->started = 0;
@@ -715,9 +717,13 @@ static void rt_copy_start(rt_copy_team *team, void *dst, const void *src,
     team->first = len;
     if (nt == 1 || len < ((size_t)4 << 20))
         return;
+    /* `all`: the caller is about to block in a DMA for as long as this copy
+     * takes -- its share, copied afterwards, would be the serial part of the
+     * pipeline (a quarter of every chunk with four threads) -- so the
+     * workers take everything */
     const size_t part = (len / nt + 4095) & ~(size_t)4095;
-    team->first = part < len ? part : len;
-    for (int t = 1; t < nt; ++t) {
+    team->first = all ? 0 : part < len ? part : len;
+    for (int t = all ? 0 : 1; t < nt; ++t) {
         const size_t off = (size_t)t * part;
         if (off >= len)
             break;
@@ -729,7 +735,8 @@ static void rt_copy_start(rt_copy_team *team, void *dst, const void *src,
 
 static void rt_copy_finish(rt_copy_team *team)
 {
-    memcpy(team->dst, team->src, team->first);
+    if (team->first)
+        memcpy(team->dst, team->src, team->first);
     for (int t = 0; t < team->started; ++t)
         team->workers[t].join();
     team->started = 0;
@@ -787,6 +794,44 @@ struct rt_copy_job {
     size_t bytes;
 };
 
+/* device -> pinned host by a KERNEL (the staging buffers are mapped into the
+ * device's address space): 53 GB/s like a DMA at its best -- but the DMA of
+ * hipMemcpyAsync has two levels on this platform, 55 and 24-26 GB/s for the
+ * same 20 MB, and which one a process gets flips while it runs
+ * (profiles/r05_final/d2h_*: a fresh stream of a fresh process at 0.88 ms,
+ * the same stream at 0.38 after a context was created next to it; most boxes
+ * gave the slow one: 10.4-10.7 ms per 240 MB row, 5.3 on two boxes) */
+__global__ void __launch_bounds__(256)
+rt_copy_out_kernel(const double *__restrict__ src, double *__restrict__ dst,
+                   size_t n, int wide)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wide) {
+        const double2 *s2 = (const double2 *)src;
+        double2 *d2 = (double2 *)dst;
+        for (; i < n / 2; i += step)
+            d2[i] = s2[i];
+    } else {
+        for (; i < n; i += step)
+            dst[i] = src[i];
+    }
+}
+
+static hipError_t rt_copy_out(hipStream_t s, void *dst, const void *src,
+                              size_t bytes)
+{
+    static const bool dma = getenv("RT_D2H_DMA") != NULL; /* A/B */
+    if (dma || bytes % sizeof(double))
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+    const int wide = bytes % 16 == 0 && (uintptr_t)src % 16 == 0 &&
+                     (uintptr_t)dst % 16 == 0;
+    hipLaunchKernelGGL(rt_copy_out_kernel, dim3(1024), dim3(256), 0, s,
+                       (const double *)src, (double *)dst,
+                       bytes / sizeof(double), wide);
+    return hipGetLastError();
+}
+
 static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)
 {
     for (int i = 0; i < 2; ++i)
@@ -796,6 +841,13 @@ static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)
             RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
                                                 hipEventDisableTiming));
         }
+    /* the copies run on a stream of their own, behind everything the trace
+     * stream has been given so far */
+    if (!ctx->copy_stream)
+        RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream,
+                                             hipStreamNonBlocking));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const hipStream_t cs = ctx->copy_stream;
     /* the chunks of all jobs in order, at most RT_PIN_CHUNK each */
     size_t j = 0, off = 0;
     auto next = [&](void **dst, const void **src, size_t *len) {
@@ -805,19 +857,23 @@ static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)
         }
         if (j >= njobs)
             return false;
-        *len = jobs[j].bytes - off < RT_PIN_CHUNK ? jobs[j].bytes - off
-                                                  : RT_PIN_CHUNK;
+        /* a job in equal chunks (40 MB: 20 + 20, not 32 + 8: the short
+         * ones cost a DMA call and a team of threads like the long ones) */
+        const size_t pieces = (jobs[j].bytes + RT_PIN_CHUNK - 1) / RT_PIN_CHUNK;
+        const size_t even = ((jobs[j].bytes + pieces - 1) / pieces + 4095) &
+                            ~(size_t)4095;
+        *len = jobs[j].bytes - off < even ? jobs[j].bytes - off : even;
         *dst = (char *)jobs[j].dst + off;
         *src = (const char *)jobs[j].src + off;
         off += *len;
         return true;
     };
-    /* chunk i-1 leaves its staging buffer on the copy threads while the DMA
-     * of chunk i fills the other one.  The threads are started BEFORE the
-     * DMA is issued: hipMemcpyAsync device -> pinned host returns only when
-     * the copy is done on this runtime (measured: issued first, the two
-     * halves of the pipeline ran one after the other, 8.5 ms per 240 MB
-     * whatever the number of threads) */
+    /* chunk i-1 leaves its staging buffer on the copy threads -- all of it:
+     * the caller only waits -- while the copy kernel of chunk i fills the
+     * other one: per 20 MB chunk 0.39 ms of kernel beside 0.3-0.5 ms of
+     * memcpy, 5.6-5.7 ms per 240 MB row (42 GB/s; the caller's own share of
+     * every chunk, copied after its wait, and the DMA's slow level made that
+     * 10.4-10.7 ms on most boxes until round 5) */
     rt_copy_team team;
     void *prev_dst = NULL;
     size_t prev_len = 0;
@@ -832,19 +888,19 @@ static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)
             if (e != hipSuccess)
                 return rt_fail(ctx, RT_ERR_HIP, "rt_d2h: %s",
                                hipGetErrorString(e));
-            rt_copy_start(&team, prev_dst, ctx->h_pin[(i - 1) & 1], prev_len);
+            rt_copy_start(&team, prev_dst, ctx->h_pin[(i - 1) & 1], prev_len,
+                          more);
         }
         hipError_t e = hipSuccess;
-        if (more) { /* the DMA of chunk i into the other buffer */
+        if (more) { /* chunk i into the other buffer */
             if (ctx->pin_busy[i & 1]) /* an upload may still read it */
                 e = hipEventSynchronize(ctx->pin_done[i & 1]);
             if (e == hipSuccess)
-                e = hipMemcpyAsync(ctx->h_pin[i & 1], src, len,
-                                   hipMemcpyDeviceToHost, ctx->stream);
+                e = rt_copy_out(cs, ctx->h_pin[i & 1], src, len);
             if (e == hipSuccess)
-                e = hipEventRecord(ctx->pin_done[i & 1], ctx->stream);
+                e = hipEventRecord(ctx->pin_done[i & 1], cs);
         }
-        if (have_prev) { /* the threads are joined whatever the DMA said */
+        if (have_prev) { /* the threads are joined whatever the copy said */
             rt_copy_finish(&team);
             ctx->pin_busy[(i - 1) & 1] = 0;
         }

@@ -21,6 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+if GOLDEN not in sys.path:      # digest_cases: the seeded bundles of the
+    sys.path.insert(1, GOLDEN)  # full-size cases, shared with bench_legs.py
 
 # tolerances of the parity contract (BASELINE.json north_star)
 RTOL_SPHERICAL = 1e-10   # plane / sphere / conic closed form
