@@ -401,6 +401,19 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
             enough = can >= need && (nclass >= 3 || made >= need + 8);
         }
     }
+    /* RT_MI355_PLACE_LOG=1: the classes in the order the pieces were created
+     * (walked without hops, a fresh process shows runs of 4 / 8 / 15 ...
+     * pieces of 1 GiB: AAAAAAAABBBBCAAAABBBBBBBBAAAAAAAACCCCBBBBBBBBCCCC...,
+     * profiles/r05_final/placement_class_map_60_pieces.txt) */
+    if (getenv("RT_MI355_PLACE_LOG")) {
+        char line[512];
+        int at = 0;
+        for (int k = 0; k < made && at < 500; ++k)
+            line[at++] = (char)('A' + cls[k]);
+        line[at] = 0;
+        fprintf(stderr, "[rt_place] need %d made %d classes %d hops %d: %s\n",
+                need, made, nclass, hops, line);
+    }
     const double t_found = rt_place_now_ms(), t_created = t_ballast;
     for (int b = 0; b < nballast; ++b)
         (void)hipMemRelease(ballast[b]);
