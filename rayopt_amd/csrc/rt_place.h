@@ -616,8 +616,9 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
         return; /* (a pattern too short to tell anything: what an earlier
                    layout found out about these arrays stays) */
     rt_place_tune(c, L, ld);
-    int picks = 1;
+    int picks = 1, nlost = 0;
     float seen[RT_PLACE_PICKS] = {c->place.store_gbps};
+    rt_place lost[RT_PLACE_PICKS];
     /* at most three sets for arrays of 4 GiB and more (a set costs them
      * 10-20 ms) -- five where the best of three is still 2.5 % below the
      * mark (three sets of two classes in a row: 6.59-6.63 TB/s, C3' 0.77
@@ -644,16 +645,21 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
         c->d_buf = (double *)nb;
         rt_place_tune(c, L, ld);
         seen[picks++] = c->place.store_gbps;
+        /* the loser stays mapped until the search is over: given back now,
+         * its pieces would be the first the next search is handed -- five
+         * sets out of the same stretch of the device memory (two classes
+         * five times in a row on one box: 6.51-6.69 TB/s) */
         if (!c->d_buf || c->place.store_gbps <= held.store_gbps) {
             if (c->place.base || c->place.handles)
-                rt_place_release(&c->place); /* no better: back to the held */
+                lost[nlost++] = c->place; /* no better: back to the held */
             c->place = held;
             c->d_buf = held_buf;
         } else {
-            rt_place tmp = held;
-            rt_place_release(&tmp);
+            lost[nlost++] = held;
         }
     }
+    for (int k = 0; k < nlost; ++k)
+        rt_place_release(&lost[k]);
     c->place.picks = picks;
     for (int k = 0; k < RT_PLACE_PICKS; ++k)
         c->place.pick_gbps[k] = k < picks ? seen[k] : 0.f;
