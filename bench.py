@@ -428,8 +428,14 @@ def main():
                      "note": "seconds since this interpreter reached "
                              "bench.py, after each phase"}
     sys.stdout.flush()
-    os.write(real_stdout, (json.dumps(strict(out), allow_nan=False) +
-                           "\n").encode())
+    # the full records go to a side file; the driver's line is the contract
+    # plus one short record per leg (bench_legs.core_line, < 8 KB)
+    full = strict(out)
+    legs.leg_summaries(full)
+    line = json.dumps(legs.core_line(full, legs.write_detail(full)),
+                      allow_nan=False)
+    assert len(line) < legs.CORE_LINE_LIMIT, len(line)
+    os.write(real_stdout, (line + "\n").encode())
     if dist_mode:
         group.barrier()
         group.close()

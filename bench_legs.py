@@ -826,8 +826,10 @@ def legs_before_the_loop(args, job, g, mode, step, mark, plain, side_legs):
         e_nc, ev_nc, _ = job.timed(step, args.steps, args.warmup, False)
         out["unclipped"] = (e_nc, ev_nc/args.steps)
         mode["clip"] = clip
-    if args.extras and plain:
-        eng.set_option("alias_i", 0)        # every row of i written: 80 B/op
+    if plain and (args.extras or side_legs):
+        # SURVEY 8(d)'s literal case: every row of y, u, i, t materialised
+        # (rayopt/geometric_trace.py:41-47), 80 B per ray-surface op
+        eng.set_option("alias_i", 0)
         e_full, ev_full, _ = job.timed(step, args.steps, args.warmup, False)
         out["full_i"] = (e_full, ev_full/args.steps)
         eng.set_option("alias_i", 1)
@@ -1656,3 +1658,219 @@ def run_configs4(ra, system, g, job, group, world, rank, args, clip,
         "kernel_ms_per_rank": per_rank,
     }
 
+
+
+# --------------------------------------------------------------------------
+# the driver's line: the contract's keys and one short record per leg; the
+# full records go to a side file the line names
+# --------------------------------------------------------------------------
+
+CORE_LINE_LIMIT = 8192      # bytes; tests/test_bench_contract.py asserts it
+
+
+def _r(v, digits=5):
+    """Floats of the sub-records to `digits` significant digits."""
+    if isinstance(v, float):
+        return float("%.*g" % (digits, v)) if np.isfinite(v) else None
+    if isinstance(v, (np.floating, np.integer, np.bool_)):
+        return _r(v.item(), digits)
+    if isinstance(v, dict):
+        return {k: _r(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, digits) for x in v]
+    return v
+
+
+def _pick(rec, *keys):
+    return {k: rec[k] for k in keys if isinstance(rec, dict) and k in rec}
+
+
+def _parity_ok(par, default_arith):
+    """One boolean per config: bit identity with the C oracle (exact
+    arithmetic) or <= 1e-8 with equal NaN masks (default asphere)."""
+    if not par:
+        return None
+    if default_arith:
+        return bool(par["nan_masks_equal"] and par["max_rel_err"] <= 1e-8)
+    return bool(par["bit_identical_to_c_oracle"])
+
+
+def write_detail(out, path=None):
+    """The full records as one JSON file; returns the path written (relative
+    to the repository where it lies inside it) or None."""
+    path = path or os.environ.get("RT_BENCH_DETAIL") or os.path.join(
+        ROOT, "gpurun_out", "bench_detail.json")
+    for p in (path, os.path.join("/tmp", "rt_bench_detail_%d.json"
+                                 % os.getpid())):
+        try:
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            with open(p, "w") as f:
+                json.dump(out, f, allow_nan=False)
+            return os.path.relpath(p, ROOT) if p.startswith(ROOT + os.sep) \
+                else p
+        except (OSError, ValueError) as err:
+            log("[bench] detail file %s: %r" % (p, err))
+    return None
+
+
+def core_line(out, detail):
+    """What the driver reads: the contract's keys, `roofline`, `cpu_baseline`
+    and per leg only what a reader needs to recompute its fraction.  Placement
+    records, telemetry samples, VALU detail, wall-clock laps and the prose live
+    in the detail file (``detail``)."""
+    core = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup",
+                 "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config")
+    r = out["roofline"]
+    core["roofline"] = _r(_pick(
+        r, "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+        "kernel_ms", "algorithmic_bytes_per_launch",
+        "bytes_per_ray_surface_op", "input_bytes_per_ray",
+        "frac_if_80B_per_op_and_48B_per_ray_were_moved",
+        "frac_at_observed_hbm_clock"), 7)
+    core["roofline"].update(peak=r["peak"], frac=r["frac"],
+                            achieved=r["achieved"],
+                            kernel_ms=r["kernel_ms"])   # (unrounded)
+    src = r.get("traffic_source") or ""
+    core["roofline"]["traffic_source"] = (
+        "rocprofv3 --pmc in this run" if src.startswith("measured in this")
+        else "profiles/traffic.json" if src else None)
+    pl = r.get("placement") or {}
+    core["roofline"]["placement"] = _r(_pick(
+        pl, "pieces", "per_class", "fast", "store_pattern_GBps",
+        "workgroups_per_cu_cap"))
+    if "valu" in r:
+        core["roofline"]["valu_per_ray_surface_op"] = _r(
+            r["valu"]["per_ray_surface_op"])
+    if "full_i" in out:
+        # SURVEY 8(d)'s own byte count: all of y, u, i, t stored (80 B/op)
+        core["full_i"] = _r(_pick(out["full_i"], "kernel_ms",
+                                  "algorithmic_bytes_per_launch", "achieved",
+                                  "frac"), 7)
+        core["full_i"]["bytes_per_ray_surface_op"] = 80.
+    if "unclipped" in out:
+        core["unclipped"] = _r(_pick(out["unclipped"], "kernel_ms", "frac"))
+    for key in ("cpu_baseline", "cpu_baseline_all_cores", "cpu_baseline_c"):
+        c = out.get(key)
+        if c is None:
+            continue
+        core[key] = _r(_pick(c, "value", "unit", "cores", "kind", "error",
+                             "image_row_bit_identical_to_gpu"))
+        if key == "cpu_baseline":
+            core[key]["sample"] = c.get("sample", "")[:220]
+            core[key]["host"] = c.get("host")
+    gb = out.get("generated_batch")
+    if gb is not None:
+        core["generated_batch"] = _r(_pick(
+            gb, "rays", "kernel_ms", "algorithmic_bytes_per_launch", "frac",
+            "traffic"))
+    io = out.get("image_row_only")
+    if io is not None:
+        core["image_row_only"] = _r(_pick(io, "kernel_ms", "bound"))
+        if "valu" in io:
+            core["image_row_only"].update(_r(_pick(
+                io["valu"], "valu_issue_frac", "valu_busy_frac")))
+    api = out.get("propagate_api")
+    if api is not None:
+        core["propagate_api"] = _r(_pick(api, "engine_trace_ms_per_step",
+                                         "propagate_ms_per_step"))
+    cfgs = out.get("configs")
+    if isinstance(cfgs, list):
+        core["configs"] = []
+        for c in cfgs:
+            rec = _r(_pick(c, "rays", "surfaces", "kernel_ms",
+                           "algorithmic_bytes_per_launch", "frac", "bound"))
+            rec["config"] = c["config"].split(",")[0].split(":")[0][:40]
+            if "exact_asphere" in c["config"]:
+                rec["config"] += " exact"
+            if "per-ray launch" in c["config"]:
+                rec["config"] += " per-ray directions"
+            if "parity_subsample" in c:
+                rec["parity_ok"] = _parity_ok(
+                    c["parity_subsample"], "default (" in c["config"])
+            if "valu" in c:
+                rec.update(_r(_pick(c["valu"], "valu_issue_frac",
+                                    "valu_busy_frac"), 4))
+            for k in ("newton_lane_utilisation",):
+                if k in c:
+                    rec[k] = _r(c[k], 4)
+            sp = (c.get("placement") or {}).get("store_pattern_GBps")
+            if sp:
+                rec["store_pattern_GBps"] = _r(sp, 4)
+            core["configs"].append(rec)
+    elif cfgs is not None:
+        core["configs"] = cfgs
+    e = out.get("end_to_end")
+    if e is not None:
+        core["end_to_end"] = _r(_pick(
+            e, "rays", "h2d_ms", "trace_ms", "d2h_image_row_ms",
+            "d2h_bytes", "end_to_end_ms", "h2d_fraction_of_ceiling",
+            "d2h_fraction_of_ceiling", "error"))
+    cons = out.get("consumers")
+    if isinstance(cons, list):
+        core["consumers"] = []
+        for c in cons:
+            rec = _r(_pick(c, "ms", "kernel_ms", "bytes_read", "frac",
+                           "kernel_frac", "fields_per_s", "error"), 4)
+            rec["call"] = c["call"].split(" ")[0].rstrip(",")
+            core["consumers"].append(rec)
+    elif cons is not None:
+        core["consumers"] = cons
+    t = (out.get("telemetry") or {}).get("loop") or {}
+    if t:
+        core["telemetry"] = _r({
+            "gfxclk_mhz": (t.get("gfxclk_mhz") or [None]*3)[1],
+            "hbm_uclk_mhz": (t.get("hbm_uclk_mhz") or [None]*3)[1],
+            "socket_power_w": (t.get("socket_power_w") or [None]*3)[1],
+            "power_limited_fraction": t.get("power_limited_fraction")}, 4)
+    for key in ("gather_ms", "transport", "kernel_ms_per_rank",
+                "gather_pipelined_ms", "gather_exposed_ms", "gather_chunks",
+                "plain_loop_ms_per_step", "exchange_cost_ratio", "test_mode",
+                "configs4"):
+        if key in out:
+            core[key] = _r(out[key], 6)
+    laps = (out.get("wall_s") or {}).get("since_start")
+    if laps:
+        core["wall_s"] = laps[-1][1]
+    core["detail"] = detail
+    return core
+
+
+def leg_summaries(out):
+    """One line per leg on stderr -- the headline included -- so that the
+    driver's tail of the run carries them whatever happens to stdout."""
+    r = out["roofline"]
+    log("[summary] headline %s: %.4f ms/step, kernel %.4f ms, %.4g %s, "
+        "frac %.4f of %g GB/s (%.0f B/op + %.2f B/ray)" % (
+            out["config"]["workload"].split(":")[0], out["ms_per_step"],
+            r["kernel_ms"], out["value"], out["unit"], r["frac"], r["peak"],
+            r["bytes_per_ray_surface_op"], r["input_bytes_per_ray"]))
+    for key in ("full_i", "unclipped", "generated_batch", "image_row_only"):
+        c = out.get(key)
+        if c:
+            log("[summary] %s: kernel %.4f ms%s" % (
+                key, c["kernel_ms"],
+                ", frac %.4f" % c["frac"] if "frac" in c else ""))
+    for c in (out.get("configs") if isinstance(out.get("configs"), list)
+              else []):
+        pl = c.get("placement") or {}
+        log("[summary] %s: %.4f ms, frac %.4f, bound %s, store pattern per "
+            "piece set %s" % (c["config"][:60], c["kernel_ms"],
+                              c.get("frac", float("nan")), c.get("bound"),
+                              pl.get("store_pattern_GBps_per_piece_set")))
+    e = out.get("end_to_end") or {}
+    if "end_to_end_ms" in e:
+        log("[summary] end_to_end: h2d %.2f + trace %.3f + d2h %.2f = %.2f ms"
+            % (e["h2d_ms"], e["trace_ms"], e["d2h_image_row_ms"],
+               e["end_to_end_ms"]))
+    for c in (out.get("consumers") if isinstance(out.get("consumers"), list)
+              else []):
+        if "ms" in c:
+            log("[summary] consumer %s: %.4f ms (kernel %s), frac %s" % (
+                c["call"].split(" ")[0], c["ms"], c.get("kernel_ms"),
+                c.get("frac")))
+    c = out.get("cpu_baseline")
+    if c:
+        log("[summary] cpu_baseline (%s, %d core): %.4g %s" % (
+            c.get("kind"), c.get("cores", 0), c.get("value", float("nan")),
+            c.get("unit")))

@@ -616,21 +616,31 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * eight blocks of 1 GiB of ballast so that it moved on through the device
  * memory (pieces come in runs of one class; search and ballast together
  * never hold more than half of the
- * memory that was free), [9] = what the classes alone said, [10..11] = 0, [12] =
+ * memory that was free), [9] = what the classes alone said, [10] = the
+ * search ended early: 1 = its time budget was up (everything that is choice
+ * -- surplus pieces, hops, further sets -- ends 250 ms after the allocation
+ * began), 2 = a single hipMemCreate took more than 200 ms; [11] = 1: these
+ * arrays have had their search (a later rt_reserve that reuses the buffer for
+ * another layout only measures the pattern), [12] =
  * sets of pieces tried, [13] = 1 if a placement of this context failed its
  * check -- tokens written by a kernel into every 2 MiB of the range, read back
  * by a copy -- and the context (and from then on the process) went back to
  * plain allocations: on ROCm 7.2 a kernel goes on using the translations of
  * an EARLIER mapping of an address range after hipMemUnmap + hipMemMap unless
  * a buffer is freed in between, which the library does after every mapping
- * (csrc/rt_place.h: rt_place_flush); [14..15] = 0.
+ * (csrc/rt_place.h: rt_place_flush); [14] = hipMemUnmap / hipMemRelease /
+ * hipMemAddressFree calls of this PROCESS that returned an error (rt_reserve
+ * also leaves the first one's text for rt_last_error); [15] = 0.
  * ms[0] / ms[1] = the pair test's launch time inside one piece / across two
  * classes, ms[2] = GB/s of the batch's store pattern over the arrays (0: not
  * measured -- a pattern below 0.5 GB tells nothing), ms[3] = wall
  * milliseconds the search took, of which ms[4] creating, mapping and testing
  * pieces, ms[5] creating and releasing ballast, ms[6] unmapping, releasing
  * the surplus and mapping the final range; ms[7] = measuring the pattern;
- * ms[8..12] = GB/s of each set of pieces tried (0: not tried), ms[13..15] = 0.
+ * ms[8..12] = GB/s of each set of pieces tried (0: not tried), ms[13] = the
+ * longest single hipMemCreate of the search (ms), ms[14] = everything
+ * rt_reserve spent on the placement of this buffer (ms: all sets, the
+ * measurements, the coherence proof), ms[15] = 0.
  */
 int rt_placement(rt_ctx *ctx, int info[16], double ms[16]);
 

@@ -16,6 +16,7 @@ held to the reference's BITS (1e-10 is only the contract's outer bound); even
 aspheres run on explicitly fused arithmetic by default (1e-8 contract) and
 on scipy's operations with ``exact_asphere``.
 """
+import glob
 import os
 import shutil
 import subprocess
@@ -27,9 +28,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_mi355.so")
 UNITS = ["rt_engine.hip", "rt_consumers.hip", "rt_comm.hip"]
 SOURCES = [os.path.join(CSRC, u) for u in UNITS]
-HEADERS = [os.path.join(CSRC, h) for h in (
-    "rt_math.h", "rt_lay.h", "rt_ctx.h", "rt_march.h", "rt_trace_kernels.h",
-    "rt_consumer_kernels.h", "rt_aim.h")] + [
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
     os.path.join(HERE, "..", "include", "rt_mi355.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
          "-fPIC"]

@@ -90,6 +90,14 @@ struct rt_place {
     float search_ms, pieces_ms, ballast_ms, remap_ms, tune_ms;
     int picks;           /* sets of pieces tried (rt_place_settle) */
     float pick_gbps[5];  /* the batch's store pattern over each */
+    float slowest_create_ms; /* the longest single hipMemCreate of the search */
+    int cut_short;       /* the search ended early: 1 = its time budget was
+                            up, 2 = a hipMemCreate stalled */
+    int settled;         /* rt_place_settle has searched for these arrays: a
+                            later layout in the same buffer only measures */
+    float total_ms;      /* wall time of everything rt_reserve spent on the
+                            placement of this buffer (all sets, measurements,
+                            the coherence proof) */
 };
 
 struct rt_ctx {
@@ -181,6 +189,9 @@ struct rt_ctx {
     float opt_place_good; /* GB/s of the store pattern at which the search
                              for a better range / set of pieces ends */
     struct rt_place place;
+    double place_deadline_ms; /* steady clock: when the current allocation's
+                                 search for better memory ends (0: none
+                                 running) */
     int place_incoherent; /* a placement of this context failed its check
                              (rt_place_coherent) and was given up */
     int opt_compact; /* 0 never, 1 when rows are dropped, 2 always */

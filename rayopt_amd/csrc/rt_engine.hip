@@ -186,6 +186,9 @@ static bool rt_in_range(double x)
  * as the rest of the old step */
 static inline void rt_pieces_reset(rt_ctx *c)
 {
+    c->opd_n = 0; /* path differences kept on the device (rt_opd_device) are
+                     those of the rows as they were: every caller of this is
+                     about to replace rays, a row or the table */
     c->pieces_seen = c->pieces_total = 0;
     memset(c->pieces_mask, 0, sizeof c->pieces_mask);
 }
@@ -520,6 +523,10 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld;
+    const int vm_failures_before = g_place_vm_failures;
+    const double t_place = rt_place_now_ms();
+    bool allocated = false;
+    ctx->place_deadline_ms = 0.; /* set by the allocation's first search */
     if (need > ctx->cap_doubles) {
         /* from here until the new buffer exists the context holds no rays:
          * a failed allocation must not leave the old sizes without a buffer */
@@ -543,6 +550,7 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
                            need * 8e-9, hipGetErrorString(e));
         }
         ctx->cap_doubles = need;
+        allocated = true;
     }
     const size_t tiles = (size_t)(ld / 64);
     if (tiles > ctx->uni_cap) {
@@ -566,7 +574,14 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     ctx->traced = 0;
     /* placed arrays in a new layout: measure the store pattern over them
      * (nothing lives in the rows yet) */
-    if (ctx->place.base && fresh) {
+    if (ctx->place.base && fresh && ctx->place.settled && !allocated) {
+        /* a buffer that is being reused has had its search (a
+         * caller alternating batch sizes paid for up to five sets of pieces
+         * at every change): the new layout's pattern is measured over it --
+         * that decides the resident workgroups per CU -- and nothing is
+         * mapped, so there is nothing new to prove either */
+        rt_place_tune(ctx, ctx->nsurf, ld);
+    } else if (ctx->place.base && fresh) {
         rt_place_settle(ctx, ctx->nsurf, ld, ctx->cap_doubles * sizeof(double));
         if (!ctx->d_buf) { /* (the mapping was lost on the way) */
             rt_place_release(&ctx->place);
@@ -602,7 +617,16 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
             }
             ctx->cap_doubles = bytes / sizeof(double);
         }
+        ctx->place.total_ms = (float)(rt_place_now_ms() - t_place);
     }
+    ctx->place_deadline_ms = 0.;
+    if (g_place_vm_failures != vm_failures_before)
+        /* not fatal -- the arrays are there -- but never silent */
+        (void)rt_fail(ctx, RT_OK,
+                      "rt_reserve: %d virtual-memory call(s) failed while "
+                      "giving memory back (first: %s)",
+                      g_place_vm_failures - vm_failures_before,
+                      g_place_vm_first);
     memset(ctx->i_alias, 0, sizeof ctx->i_alias);
     memset(ctx->u_alias, 0, sizeof ctx->u_alias);
     memset(ctx->valid, 0, sizeof ctx->valid);
@@ -648,6 +672,7 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
     const int block = 256;
     const unsigned grid = (unsigned)((ctx->ld + block - 1) / block);
     ctx->uni_valid = 0;
+    ctx->opd_n = 0; /* (kept path differences: of the rays that were here) */
     if (layout == RT_LAYOUT_AOS)
         hipLaunchKernelGGL(rt_seed_aos_kernel, dim3(grid), dim3(block), 0,
                            ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
@@ -677,6 +702,17 @@ static unsigned rt_pin_flags(void)
 {
     const char *e = getenv("RT_PIN_NONCOHERENT");
     return e && atoi(e) ? hipHostMallocNonCoherent : hipHostMallocDefault;
+}
+
+/* what the device wrote into NON-coherent host memory is only guaranteed
+ * visible to the host after waiting for an event that releases to the system
+ * scope (the copy kernel writes the staging buffers and the copy
+ * threads read them right after the wait) */
+static unsigned rt_pin_event_flags(void)
+{
+    return rt_pin_flags() == hipHostMallocNonCoherent
+               ? hipEventDisableTiming | hipEventReleaseToSystem
+               : hipEventDisableTiming;
 }
 
 /*
@@ -767,7 +803,7 @@ int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
             RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK,
                                       rt_pin_flags()));
             RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
-                                                hipEventDisableTiming));
+                                                rt_pin_event_flags()));
         }
     int k = 0;
     for (size_t off = 0; off < bytes; off += RT_PIN_CHUNK, k ^= 1) {
@@ -839,7 +875,7 @@ static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)
             RT_HIP(ctx, hipHostMalloc(&ctx->h_pin[i], RT_PIN_CHUNK,
                                       rt_pin_flags()));
             RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
-                                                hipEventDisableTiming));
+                                                rt_pin_event_flags()));
         }
     /* the copies run on a stream of their own, behind everything the trace
      * stream has been given so far */
@@ -1068,6 +1104,7 @@ int rt_generate_rays(rt_ctx *ctx, const rt_field *fields, int nfields,
     /* row 0 is built by the first trace (rt_trace_gen_kernel), or by
      * rt_gen_flush as soon as anything else asks for it */
     ctx->gen_pending = 1;
+    ctx->opd_n = 0;
     ctx->gen_live = 1;
     ctx->traced = 1;
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0;
@@ -1175,6 +1212,8 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
         return rt_fail(ctx, RT_ERR_STATE,
                        "rt_trace: seed row %d holds no data (not stored by "
                        "the previous trace)", start - 1);
+    ctx->opd_n = 0; /* rt_opd_device hands out nothing of the rows before
+                       this trace */
     if (ctx->ngroups > 1 && (ctx->n % ctx->ngroups ||
                              (ctx->n / ctx->ngroups) % 64))
         return rt_fail(ctx, RT_ERR_ARG,
@@ -1759,8 +1798,11 @@ int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
     info[7] = p.fast;
     info[8] = p.ballast;
     info[9] = p.class_mix;
+    info[10] = p.cut_short;
+    info[11] = p.settled;
     info[12] = p.base ? p.picks : 0;
     info[13] = ctx->place_incoherent;
+    info[14] = g_place_vm_failures;
     ms[0] = p.self_ms;
     ms[1] = p.cross_ms;
     ms[2] = p.store_gbps;
@@ -1771,6 +1813,8 @@ int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
     ms[7] = p.tune_ms;
     for (int k = 0; k < 5; ++k)
         ms[8 + k] = p.pick_gbps[k];
+    ms[13] = p.slowest_create_ms;
+    ms[14] = p.total_ms;
     return RT_OK;
 }
 

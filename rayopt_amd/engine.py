@@ -346,7 +346,13 @@ class Engine:
                     ms[8 + k] for k in range(max(min(info[12], 5), 0))],
                 "pair_test_ms": {"same_piece": ms[0], "other_class": ms[1]},
                 "search_ms": {"all": ms[3], "pieces": ms[4], "ballast": ms[5],
-                              "remap": ms[6], "tune": ms[7]}}
+                              "remap": ms[6], "tune": ms[7],
+                              "slowest_hipMemCreate": ms[13],
+                              "reserve_total": ms[14]},
+                "search_cut_short": {0: None, 1: "time budget",
+                                     2: "hipMemCreate stalled"}.get(info[10]),
+                "settled": bool(info[11]),
+                "vm_call_failures_in_process": info[14]}
 
     def selftest_arith(self, seed, n, span=100):
         """rt_selftest_arith: mismatch counts (refraction quotient, table

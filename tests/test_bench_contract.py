@@ -25,6 +25,9 @@ def strict_loads(text):
 def check_line(out, steps, warmup):
     lines = [l for l in out.splitlines() if l.strip()]
     assert len(lines) == 1, "stdout must be ONE JSON line"
+    # the driver keeps a bounded tail of stdout (round 5: a 21 KB line was
+    # cut and went unparsed): the line stays far below that
+    assert len(lines[0]) < 8192, len(lines[0])
     d = strict_loads(lines[0])
     for key, typ in REQUIRED.items():
         assert isinstance(d[key], typ), key
@@ -41,13 +44,60 @@ def check_line(out, steps, warmup):
     return d
 
 
-def test_single_process_line():
-    out = subprocess.check_output(
+def check_core(core, full):
+    """The driver's line against the full records of the detail file: the
+    contract keys are the same objects, every leg is there in short form."""
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                "ms_per_step", "scaling", "dtype", "data", "config"):
+        assert core[key] == full[key], key
+    for key in ("achieved", "frac", "peak", "kernel_ms", "bound", "unit"):
+        assert core["roofline"][key] == full["roofline"][key], key
+    assert core["roofline"]["traffic"] == pytest.approx(
+        full["roofline"]["traffic"], rel=1e-5)
+    assert "placement" in core["roofline"]
+    assert "search_ms" not in core["roofline"]["placement"]
+    c = core["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(c)
+    assert c["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-4)
+    # SURVEY 8(d)'s literal byte count is a default leg: every row of i
+    # materialised, 80 B per ray-surface op
+    n, S = core["config"]["rays_per_gpu"], core["config"]["surfaces"]
+    fi = core["full_i"]
+    assert fi["bytes_per_ray_surface_op"] == 80.
+    assert fi["algorithmic_bytes_per_launch"] >= n*80*S
+    assert fi["frac"] == pytest.approx(
+        fi["algorithmic_bytes_per_launch"]/(fi["kernel_ms"]*1e-3)/1e9/8000.,
+        rel=1e-4)
+    assert len(core["configs"]) == len(full["configs"])
+    for short, rec in zip(core["configs"], full["configs"]):
+        assert set(short) >= {"config", "rays", "kernel_ms", "frac"}
+        assert short["frac"] == pytest.approx(rec["frac"], rel=1e-4)
+        assert "placement" not in short and "telemetry" not in short
+        if rec.get("parity_subsample") is not None:
+            assert short["parity_ok"] is True
+    assert [c["call"] for c in core["consumers"]] == [
+        c["call"].split(" ")[0].rstrip(",") for c in full["consumers"]]
+    assert core["end_to_end"]["end_to_end_ms"] == pytest.approx(
+        full["end_to_end"]["end_to_end_ms"], rel=1e-4)
+
+
+def test_single_process_line(tmp_path):
+    detail = str(tmp_path / "detail.json")
+    res = subprocess.run(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--rays", "200000",
          "--steps", "4", "--warmup", "1", "--cpu-sample", "50000",
          "--cpu-procs", "4", "--settle", "0.05", "--extras",
-         "--configs5-rays", "2000000"], text=True, cwd=ROOT)
-    d = check_line(out, 4, 1)
+         "--configs5-rays", "2000000"], text=True, cwd=ROOT, check=True,
+        stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+        env=dict(os.environ, RT_BENCH_DETAIL=detail))
+    core = check_line(res.stdout, 4, 1)
+    assert core["detail"] == detail
+    # every leg -- the headline too -- is summarised on stderr
+    assert "[summary] headline" in res.stderr
+    assert res.stderr.count("[summary] C") >= 7
+    with open(detail) as f:
+        d = strict_loads(f.read())
+    check_core(core, d)
     from oracle import refshim
     kind = "reference" if refshim.available() else "port"
     c = d["cpu_baseline"]

@@ -388,6 +388,12 @@ def test_opd_stats_match_reference(name):
     kept = tr.engine.copy_to_host(ptr, 3*n*8).reshape(3, n)
     x, y, t = tr.opd(radius=g["radius"], resample=0)
     assert np.array_equal(kept, np.array([x, y, t]), equal_nan=True)
+    # a new trace of the same rays voids what was kept: the array described
+    # the rows as they were
+    tr.opd_stats(radius=g["radius"], keep=True)
+    tr.propagate(clip=g["clip"])
+    with pytest.raises(ra.EngineError, match="no path differences"):
+        tr.engine.opd_device()
     # without keep nothing is left behind for this batch ...
     tr.rays_given(g["y0"], g["u0"], g["l"], g["w"], g["ref"])
     tr.propagate(clip=g["clip"])
