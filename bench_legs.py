@@ -1450,6 +1450,23 @@ def run_consumers(ra, g, system, n, nf, cpu):
                    "rayopt/geometric_trace.py:185-193 resize()",
                    fn=lambda: eng.row_rmax(L - 1)))
     try:
+        # the three calls above in ONE pass over y0, y1 (rt_row_stats): per
+        # bundle count, centroid, rms about the mean and about the reference
+        # ray, the largest distance from the axis
+        fn = lambda: eng.row_stats(L - 1, n//nf, nf, 0)     # noqa: E731
+        r = rec("row_stats, %d field bundles (ONE pass over y0, y1: count, "
+                "centroid, rms about mean and about the reference ray, r "
+                "max)" % nf, timed(fn), 16*n,
+                "rayopt/geometric_trace.py:171-193 + analysis.py:250-283: "
+                "replaces rms + spot_stats + row_rmax", fn=fn)
+        three = [c for c in out if c["call"].split(" ")[0].rstrip(",") in
+                 ("rms", "spot_stats", "row_rmax")]
+        r["replaces_ms"] = sum(c["ms"] for c in three)
+        r["replaces_bytes_read"] = sum(c["bytes_read"] for c in three)
+        out.append(r)
+    except Exception as err:                  # a reported extra, never fatal
+        out.append({"call": "row_stats", "error": repr(err)[:200]})
+    try:
         nrows = L - 1
         ms = timed(lambda: g.opd_rays(radius=100.), reps=4)
         out.append(rec(
@@ -1811,7 +1828,8 @@ def core_line(out, detail):
         core["consumers"] = []
         for c in cons:
             rec = _r(_pick(c, "ms", "kernel_ms", "bytes_read", "frac",
-                           "kernel_frac", "fields_per_s", "error"), 4)
+                           "kernel_frac", "fields_per_s", "replaces_ms",
+                           "error"), 4)
             rec["call"] = c["call"].split(" ")[0].rstrip(",")
             core["consumers"].append(rec)
     elif cons is not None:

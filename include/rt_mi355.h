@@ -50,13 +50,15 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4 /* 2: rt_surface.rc, rt_selftest_arith, rt_comm_info;
+#define RT_ABI_VERSION 5 /* 2: rt_surface.rc, rt_selftest_arith, rt_comm_info;
                            the default asphere arithmetic; no rt_probe
                            3: rt_placement fills ms[8] (search times);
                               large batches in blocks (rt_blocks)
                            4: rt_opd_stats, rt_opd_device, rt_download_rays;
                               rt_placement(info[16], ms[16]) reports the
-                              address ranges measured */
+                              address ranges measured
+                           5: rt_row_stats, rt_download_xy; rt_placement
+                              reports the search's time budget */
 #define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
 #define RT_MAX_SURFACES 256 /* elements per System */
 
@@ -392,6 +394,10 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * level, rt_placement; FP64-bound traces are not capped), "placement"
  * (rt_placement), "placement_good_gbps" (default 6900: the store pattern at
  * which rt_reserve stops looking for a better address range / set of pieces),
+ * "placement_budget_ms" (default 250: wall time after which an allocation
+ * stops choosing memory -- surplus pieces, hops, further sets; the pieces it
+ * needs it creates whatever that takes; a single hipMemCreate above 200 ms
+ * ends the choosing at once),
  * "range_shortcuts" (1 = default: IEEE quotients and square
  * roots run without the compiler's range scaffolding where the operands are
  * checked to be inside [2^-100, 2^100] -- the same bits from a third fewer
@@ -420,6 +426,13 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value);
  * GeometricTrace.  Synchronises.
  */
 int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst);
+/*
+ * The first two components of ONE row of Y, U or I: dst (2,n).  The host's
+ * spot consumers read `t.y[-1, :, :2]` (rayopt/geometric_trace.py:172,
+ * rayopt/analysis.py:237-283): two thirds of the row's bytes over PCIe.
+ * Synchronises.
+ */
+int rt_download_xy(rt_ctx *ctx, int which, int surf, double *dst);
 
 /* all surfaces of ONE ray: dst[L][ncomp] (print_trace, reference-ray terms) */
 int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst);
@@ -475,6 +488,35 @@ int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax);
  */
 int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
                   double *out);
+
+/*
+ * The statistics of a row in ONE pass over its x, y (and the weights): what
+ * rt_rms (about the mean and about a reference ray), rt_spot_stats (count,
+ * centroid, spread) and rt_row_rmax answer in three calls and four passes
+ * (rayopt/geometric_trace.py:171-183 rms, :185-193 resize; the spot diagrams
+ * of rayopt/analysis.py:250-283 are centred on the reference ray).  The batch
+ * is `ngroups` contiguous bundles of `group_rays` rays as for rt_spot_stats;
+ * `ref` >= 0: the index of the reference ray INSIDE every bundle (< 0: none).
+ * For each bundle, over the rays whose intercept on row `surf` is finite:
+ *   out[g][0] = count                   out[g][1] = sum w
+ *   out[g][2..3] = centroid (plain mean, as y.mean(0))
+ *   out[g][4] = sum w |y - mean|^2 / sum w
+ *   out[g][5] = sum w |y - y_ref|^2 / sum w  (NaN: no reference ray, or it
+ *               did not arrive)
+ *   out[g][6] = max (x^2 + y^2)         (NaN for an empty bundle)
+ *   out[g][7..8] = weighted centroid    out[g][9] = sum w |y - shift|^2 /
+ *               sum w, what the subtractions started from
+ * The sums are taken of coordinates shifted by a ray of the bundle (the
+ * reference ray if it arrived, else the first of the bundle's first rays
+ * that did) and centred afterwards; where that cost more than six bits the
+ * call repeats with rt_spot_stats' two passes.  Tolerances against numpy:
+ * counts exact, 1e-12 (centroids, sum w), 1e-9 (spreads).  Up to 4096 bundles
+ * the result is written into pinned memory by the finishing kernel and the
+ * call does not synchronise the stream (it spins on a ticket).
+ * out: ngroups x 10 doubles (host).
+ */
+int rt_row_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
+                 int64_t ref, double *out);
 
 typedef struct rt_opd_args {
     int32_t nrows;      /* t rows 0..nrows-1 are summed (t[:after + 1]) */

@@ -48,6 +48,38 @@ def spot_stats(y_row, group_rays, w=None):
     return out
 
 
+def row_stats(y_row, group_rays, w=None, ref=None):
+    """What ``rt_row_stats`` returns per bundle, from the reference's own
+    formulas: ``rms`` above about the mean and about the bundle's ray ``ref``
+    (rayopt/geometric_trace.py:171-183), the largest distance from the axis
+    (``resize``, :185-193), over the rays that arrived, weights normalised.
+    Rows: count, sum w, mean x, mean y, sum(w d^2)/sum(w) about the mean,
+    the same about ray ``ref`` (NaN: none, or it did not arrive), max(x^2 +
+    y^2), weighted centroid x, y."""
+    n = y_row.shape[0]
+    groups = n//group_rays
+    assert groups*group_rays == n
+    out = np.full((groups, 9), np.nan)
+    for g in range(groups):
+        sl = slice(g*group_rays, (g + 1)*group_rays)
+        y = y_row[sl, :2]
+        wg = np.ones(group_rays) if w is None else np.asarray(w)[sl]
+        good = np.all(np.isfinite(y), axis=1)
+        yref = y[ref] if ref is not None and ref >= 0 else None
+        y, wg = y[good], wg[good]
+        out[g, :2] = len(y), wg.sum()
+        if not len(y):
+            continue
+        y0 = y.mean(0)
+        out[g, 2:4] = y0
+        out[g, 4] = (np.square(y - y0).sum(1)*wg).sum()/wg.sum()
+        if yref is not None and np.isfinite(yref).all():
+            out[g, 5] = (np.square(y - yref).sum(1)*wg).sum()/wg.sum()
+        out[g, 6] = np.square(y).sum(1).max()
+        out[g, 7:9] = (y*wg[:, None]).sum(0)/wg.sum()
+    return out
+
+
 def refocus_shift(y_row, i_row, w=None):
     """The shift ``t`` GeometricTrace.refocus adds to ``system[at].distance``
     (rayopt/geometric_trace.py:82-97)."""

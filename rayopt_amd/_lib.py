@@ -16,7 +16,7 @@ F_ROTATED, F_CURVED, F_CONIC, F_ASPH, F_ALT, F_REFRACT, F_MIRROR = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40)
 F_FAST = 0x400          # set by the library (default; "exact_asphere" clears)
 RT_Y, RT_U, RT_I, RT_T = 0, 1, 2, 3
-RT_ABI_VERSION = 4      # include/rt_mi355.h
+RT_ABI_VERSION = 5      # include/rt_mi355.h
 RT_OPD_STATS = 8        # doubles per bundle of rt_opd_stats
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 
@@ -110,6 +110,8 @@ SIGNATURES = {
     "rt_set_option": (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int]),
     "rt_download": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_void_p]),
+    "rt_download_xy": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p]),
     "rt_download_ray": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,
                                        ctypes.c_void_p]),
     "rt_download_rays": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,
@@ -127,6 +129,9 @@ SIGNATURES = {
                                     ctypes.c_void_p, ctypes.c_void_p]),
     "rt_spot_stats": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_void_p]),
+    "rt_row_stats": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,
+                                    ctypes.c_int, ctypes.c_int64,
+                                    ctypes.c_void_p]),
     "rt_opd_rays": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_void_p]),
     "rt_opd_stats": (ctypes.c_int, [_ctx, ctypes.c_void_p, ctypes.c_int64,
                                     ctypes.c_int, ctypes.c_int,

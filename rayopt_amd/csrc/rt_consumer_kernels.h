@@ -742,6 +742,191 @@ __global__ void rt_group_finish_kernel(const double *__restrict__ partials,
     f[5] = sw;
 }
 
+/*
+ * rt_row_stats: what a caller asks of the image row -- per bundle the count of
+ * surviving rays, the centroid, the rms about the centroid
+ * (geometric_trace.py:171-183, ref=None), the rms about the bundle's reference
+ * ray (:175, ref given; the spot diagrams of analysis.py:250-283 are centred
+ * there) and the largest distance from the axis (resize, :185-193) -- in ONE
+ * pass over x, y (and w) of the row: rt_rms, rt_spot_stats and rt_row_rmax read
+ * the same 16 B per ray three times (four: the spread is a second pass) and
+ * each pay a launch and a wait.  Sums are taken of coordinates shifted by a
+ * ray of the bundle (the reference ray if it is given and finite, else the
+ * first finite of the bundle's first 255 rays) and centred by subtraction in
+ * rt_row_stats_finish_kernel, which also reports what the subtraction started
+ * from (out[9]); more than six bits lost and the caller repeats with the two
+ * passes.  acc: count, sum dx, sum dy, sum w, sum w dx, sum w dy, sum w d^2;
+ * max r^2 about the axis beside them.
+ */
+#define RT_ROW_STATS 10
+#define RT_ROW_ACC 8
+
+template <bool W>
+__global__ void rt_row_stats_kernel(const double *__restrict__ Yrow,
+                                    const double *__restrict__ w,
+                                    int64_t group_rays, int64_t ref, rt_pitch p,
+                                    double *__restrict__ partials,
+                                    double *__restrict__ shifts)
+{
+    __shared__ double sm[RT_RED_THREADS / 64][RT_ROW_ACC];
+    __shared__ int first_wave[RT_RED_THREADS / 64];
+    const int64_t ld = p.ld;
+    const int64_t base = (int64_t)blockIdx.y * group_rays;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    /* the shift: thread 0 looks at the reference ray (where there is one),
+     * the others at the first rays of the bundle; the first finite one wins --
+     * the same in every workgroup of the bundle */
+    double cx, cy;
+    {
+        int64_t c = ref >= 0 ? (threadIdx.x ? threadIdx.x - 1 : ref)
+                             : threadIdx.x;
+        const bool in = c < group_rays;
+        const int64_t j = RT_AT(p, base + (in ? c : 0));
+        cx = Yrow[j];
+        cy = Yrow[ld + j];
+        const unsigned long long ok =
+            __ballot(in && isfinite(cx) && isfinite(cy));
+        if (lane == 0)
+            first_wave[wave] = ok ? __ffsll((long long)ok) - 1 : -1;
+    }
+    __syncthreads();
+    int src = -1;
+    for (int v = RT_RED_THREADS / 64 - 1; v >= 0; --v)
+        if (first_wave[v] >= 0)
+            src = v * 64 + first_wave[v];
+    /* (broadcast through LDS: the winner writes, everybody reads) */
+    __shared__ double sxy[2];
+    if ((int)threadIdx.x == src) {
+        sxy[0] = cx;
+        sxy[1] = cy;
+    }
+    __syncthreads();
+    const double sx = src >= 0 ? sxy[0] : 0., sy = src >= 0 ? sxy[1] : 0.;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double *sh = shifts + (int64_t)blockIdx.y * 4;
+        sh[0] = sx;
+        sh[1] = sy;
+        sh[2] = ref >= 0 ? cx : __builtin_nan(""); /* thread 0 holds the */
+        sh[3] = ref >= 0 ? cy : __builtin_nan(""); /* reference ray      */
+    }
+    double acc[7] = {0., 0., 0., 0., 0., 0., 0.}, mx = 0.;
+    auto use = [&](double x, double y, double wk) {
+        if (isfinite(x) && isfinite(y)) {
+            const double dx = x - sx, dy = y - sy;
+            const double r2 = x * x + y * y;
+            acc[0] += 1.;
+            acc[1] += dx;
+            acc[2] += dy;
+            acc[3] += wk;
+            acc[4] += wk * dx;
+            acc[5] += wk * dy;
+            acc[6] += wk * (dx * dx + dy * dy);
+            mx = r2 > mx ? r2 : mx;
+        }
+    };
+    if constexpr (W) {
+        const double *const rows[3] = {Yrow, Yrow + ld, w};
+        const int64_t ts[3] = {p.ts, p.ts, ld};
+        auto each = [&](const double(&v)[3]) { use(v[0], v[1], v[2]); };
+        rt_stream_blocks(rows, ts, p, base, base + group_rays, RT_RED_TID,
+                         RT_RED_NTHREADS, each);
+    } else {
+        const double *const rows[2] = {Yrow, Yrow + ld};
+        const int64_t ts[2] = {p.ts, p.ts};
+        auto each = [&](const double(&v)[2]) { use(v[0], v[1], 1.); };
+        rt_stream_blocks(rows, ts, p, base, base + group_rays, RT_RED_TID,
+                         RT_RED_NTHREADS, each);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        for (int off = 32; off > 0; off >>= 1)
+            acc[k] += __shfl_down(acc[k], off);
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            sm[wave][k] = acc[k];
+        sm[wave][7] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x < RT_ROW_ACC) {
+        const int k = threadIdx.x;
+        double v = sm[0][k];
+        for (int q = 1; q < RT_RED_THREADS / 64; ++q)
+            v = k == 7 ? (sm[q][k] > v ? sm[q][k] : v) : v + sm[q][k];
+        partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * RT_ROW_ACC +
+                 k] = v;
+    }
+}
+
+/*
+ * One wavefront per bundle: the pb partials in index order, then
+ * final[g] = {count, sum w, mean x, mean y, sum w |y - mean|^2 / sum w,
+ *             sum w |y - y_ref|^2 / sum w (NaN without a reference ray),
+ *             max (x^2 + y^2) (NaN for an empty bundle), weighted centroid x, y,
+ *             sum w |y - shift|^2 / sum w (what the subtractions started from)}
+ * followed -- `ticket` not NULL -- by the sequence number of the call, after
+ * a system-scope fence: the host spins on it instead of waiting for the
+ * stream.
+ */
+__global__ void rt_row_stats_finish_kernel(const double *__restrict__ partials,
+                                           int pb, int ngroups,
+                                           const double *__restrict__ shifts,
+                                           double *final,
+                                           unsigned long long *ticket,
+                                           unsigned long long seq,
+                                           unsigned int *arrived)
+{
+    const int g = blockIdx.x;
+    double s[7] = {0., 0., 0., 0., 0., 0., 0.}, mx = 0.;
+    for (int b = threadIdx.x; b < pb; b += 64) {
+        const double *q = partials + ((int64_t)g * pb + b) * RT_ROW_ACC;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            s[k] += q[k];
+        mx = q[7] > mx ? q[7] : mx;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        for (int off = 32; off > 0; off >>= 1)
+            s[k] += __shfl_down(s[k], off);
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if (threadIdx.x != 0)
+        return;
+    const double *sh = shifts + (int64_t)g * 4;
+    double *f = final + (int64_t)g * RT_ROW_STATS;
+    const double cnt = s[0], sw = s[3], A = s[6];
+    const double mx_ = s[1] / cnt, my_ = s[2] / cnt;
+    const double rx = sh[2] - sh[0], ry = sh[3] - sh[1];
+    f[0] = cnt;
+    f[1] = sw;
+    f[2] = sh[0] + mx_;
+    f[3] = sh[1] + my_;
+    f[4] = (A - 2. * (mx_ * s[4] + my_ * s[5]) + (mx_ * mx_ + my_ * my_) * sw) /
+           sw;
+    f[5] = (A - 2. * (rx * s[4] + ry * s[5]) + (rx * rx + ry * ry) * sw) / sw;
+    f[6] = cnt > 0. ? mx : __builtin_nan("");
+    f[7] = sh[0] + s[4] / sw;
+    f[8] = sh[1] + s[5] / sw;
+    f[9] = A / sw;
+    if (ticket) {
+        /* the last bundle to finish signs for all of them */
+        __threadfence_system();
+        if (atomicAdd(arrived, 1u) == (unsigned)ngroups - 1) {
+            *arrived = 0;
+            __threadfence_system();
+            __hip_atomic_store(ticket, seq, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 /* reference-ray columns the opd kernel needs, all wave-uniform */
 struct rt_opd_ref {
     double t[RT_MAX_SURFACES]; /* T[row][ref] */

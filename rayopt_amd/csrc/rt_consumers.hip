@@ -328,6 +328,136 @@ int rt_spot_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
     return RT_OK;
 }
 
+/*
+ * The statistics of the image row in one pass (see rt_row_stats_kernel).
+ * Two launches -- the pass, one wavefront per bundle to finish -- and no
+ * stream synchronisation for up to RT_GROUP_PINNED bundles: the finishing
+ * kernel writes the results into pinned memory and signs a ticket there, the
+ * host spins on the ticket (a hipStreamSynchronize costs more than the
+ * finishing kernel takes).
+ */
+int rt_row_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
+                 int64_t ref, double *out)
+{
+    int rc = rt_consumer_ready(ctx, surf, "rt_row_stats");
+    if (rc != RT_OK)
+        return rc;
+    if (!out || group_rays < 1 || ngroups < 1 || ngroups > 65535 ||
+        group_rays * (int64_t)ngroups != ctx->n || ref >= group_rays)
+        return rt_fail(ctx, RT_ERR_ARG,
+                       "rt_row_stats: %d groups of %lld rays do not tile the "
+                       "%lld rays of the batch, or the reference ray %lld is "
+                       "not one of a group's", ngroups, (long long)group_rays,
+                       (long long)ctx->n, (long long)ref);
+    int64_t pb = 2048 / ngroups;
+    const int64_t fit = (group_rays + RT_RED_THREADS - 1) / RT_RED_THREADS;
+    pb = pb > fit ? fit : pb;
+    pb = pb < 1 ? 1 : (pb > 256 ? 256 : pb);
+    /* final (where it stays on the device) | shifts | partials */
+    const size_t need =
+        (size_t)ngroups * (RT_ROW_STATS + 4 + (size_t)pb * RT_ROW_ACC);
+    if (need > ctx->group_cap) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_group)
+            (void)hipFree(ctx->d_group);
+        ctx->d_group = nullptr;
+        ctx->group_cap = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_group, need * sizeof(double)));
+        ctx->group_cap = need;
+    }
+    const bool pinned = ngroups <= RT_GROUP_PINNED;
+    if (pinned && !ctx->h_rows) {
+        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_rows,
+                                  sizeof(double) *
+                                      (RT_ROW_STATS * RT_GROUP_PINNED + 2)));
+        memset(ctx->h_rows, 0,
+               sizeof(double) * (RT_ROW_STATS * RT_GROUP_PINNED + 2));
+    }
+    if (pinned && !ctx->d_arrived) {
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_arrived, 64));
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_arrived, 0, 64, ctx->stream));
+    }
+    double *dfinal = ctx->d_group;
+    double *shifts = dfinal + (size_t)ngroups * RT_ROW_STATS;
+    double *partials = shifts + (size_t)ngroups * 4;
+    double *final = pinned ? ctx->h_rows : dfinal;
+    unsigned long long *ticket =
+        pinned ? (unsigned long long *)(ctx->h_rows +
+                                        RT_ROW_STATS * RT_GROUP_PINNED)
+               : NULL;
+    const unsigned long long seq = ++ctx->row_seq;
+    const double *Yrow = rt_row(ctx, RT_Y, surf);
+    const dim3 grid((unsigned)pb, (unsigned)ngroups), block(RT_RED_THREADS);
+    RT_CONSUMER_BEGIN(ctx);
+    if (ctx->d_w)
+        hipLaunchKernelGGL(rt_row_stats_kernel<true>, grid, block, 0,
+                           ctx->stream, Yrow, ctx->d_w, group_rays, ref,
+                           rt_pitch_of(ctx), partials, shifts);
+    else
+        hipLaunchKernelGGL(rt_row_stats_kernel<false>, grid, block, 0,
+                           ctx->stream, Yrow, ctx->d_w, group_rays, ref,
+                           rt_pitch_of(ctx), partials, shifts);
+    hipLaunchKernelGGL(rt_row_stats_finish_kernel, dim3((unsigned)ngroups),
+                       dim3(64), 0, ctx->stream, partials, (int)pb, ngroups,
+                       shifts, final, ticket, seq, ctx->d_arrived);
+    RT_CONSUMER_END(ctx);
+    RT_HIP(ctx, hipGetLastError());
+    if (pinned && !ctx->opt_cevents) {
+        /* spin on the ticket; a device that does not answer within 2 s is
+         * left to the stream's own error reporting */
+        volatile unsigned long long *t = ticket;
+        const double t0 = rt_now_ms();
+        unsigned spins = 0;
+        while (*t != seq) {
+            __builtin_ia32_pause();
+            if (!(++spins & 0xfff) && rt_now_ms() - t0 > 2000.) {
+                RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                break;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (*t != seq)
+            return rt_fail(ctx, RT_ERR_HIP,
+                           "rt_row_stats: the finishing kernel never signed");
+    } else {
+        if (!pinned)
+            RT_HIP(ctx, hipMemcpyAsync(out, dfinal,
+                                       sizeof(double) * RT_ROW_STATS * ngroups,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (pinned)
+        memcpy(out, final, sizeof(double) * RT_ROW_STATS * ngroups);
+    /* a bundle whose shift ray lay far outside it lost bits in the
+     * subtraction (the spread about the mean below 1/64 of the spread about
+     * the shift): those -- rare: the shift is a ray of the bundle -- get the
+     * textbook's two passes */
+    bool redo = false;
+    for (int g = 0; g < ngroups && !redo; ++g) {
+        const double *f = out + (size_t)g * RT_ROW_STATS;
+        redo = f[0] > 0. && f[4] == f[4] && !(f[4] >= 0. && f[4] * 64. >= f[9]);
+    }
+    if (redo) {
+        double *two = (double *)malloc(sizeof(double) * RT_GRP_STATS * ngroups);
+        if (!two)
+            return rt_fail(ctx, RT_ERR_NOMEM, "rt_row_stats: host allocation");
+        rc = rt_spot_stats(ctx, surf, group_rays, ngroups, two);
+        for (int g = 0; g < ngroups && rc == RT_OK; ++g) {
+            double *f = out + (size_t)g * RT_ROW_STATS;
+            const double *s = two + (size_t)g * RT_GRP_STATS;
+            /* (the spread about the reference ray stays: where that ray is
+             * finite it WAS the shift and nothing was subtracted) */
+            f[2] = s[1];
+            f[3] = s[2];
+            f[4] = s[3];
+        }
+        free(two);
+        if (rc != RT_OK)
+            return rc;
+    }
+    return RT_OK;
+}
+
 int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
 {
     int rc = rt_consumer_ready(ctx, surf, "rt_refocus_shift");

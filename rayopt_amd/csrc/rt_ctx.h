@@ -18,8 +18,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+
 #include "rt_math.h"
 #include "rt_lay.h"
+
+static inline double rt_now_ms(void)
+{
+    return std::chrono::duration<double, std::milli>(
+               std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 #define RT_INTERNAL __attribute__((visibility("hidden")))
 
@@ -160,6 +168,10 @@ struct rt_ctx {
                     * its scalars (no D2H copy after it) */
     double *d_group;    /* rt_spot_stats: stats | partials */
     size_t group_cap;   /* doubles */
+    double *h_rows;     /* pinned: rt_row_stats' results, then the ticket the
+                         * finishing kernel signs (the host spins on it) */
+    unsigned *d_arrived; /* bundles whose statistics are written (one word) */
+    unsigned long long row_seq; /* calls of rt_row_stats so far */
     double *h_group;    /* pinned: the stats as rt_group_finish_kernel writes
                          * them (up to RT_GROUP_PINNED groups) */
     struct rt_opd_ref *d_opd_ref; /* reference-ray columns, one per bundle */
@@ -186,6 +198,8 @@ struct rt_ctx {
     uint64_t pieces_mask[4];
     int gather_seen, gather_nchunks; /* chunks of the gather in progress */
     int opt_place;    /* large arrays in class-mixed pieces (rt_place.h) */
+    float opt_place_budget_ms; /* wall time an allocation may spend choosing
+                                  memory (rt_place.h: RT_PLACE_BUDGET_MS) */
     float opt_place_good; /* GB/s of the store pattern at which the search
                              for a better range / set of pieces ends */
     struct rt_place place;

@@ -287,6 +287,7 @@ int rt_create(int device, rt_ctx **out)
         const char *e = getenv("RT_MI355_PLACEMENT");
         c->opt_place = (e && !atoi(e)) ? 0 : 1;
         c->opt_place_good = RT_PLACE_GOOD_GBPS;
+        c->opt_place_budget_ms = RT_PLACE_BUDGET_MS;
     }
     c->opt_uniform = 1;
     c->opt_compact_every = 4; /* measured best, profiles/r02_probes */
@@ -371,6 +372,10 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipHostFree(ctx->h_res);
     if (ctx->h_group)
         (void)hipHostFree(ctx->h_group);
+    if (ctx->h_rows)
+        (void)hipHostFree(ctx->h_rows);
+    if (ctx->d_arrived)
+        (void)hipFree(ctx->d_arrived);
     if (ctx->d_group)
         (void)hipFree(ctx->d_group);
     if (ctx->d_gen)
@@ -1550,6 +1555,12 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
     } else if (!strcmp(key, "placement")) {
         /* takes effect with the next allocation of the result arrays */
         ctx->opt_place = value ? 1 : 0;
+    } else if (!strcmp(key, "placement_budget_ms")) {
+        /* wall time after which an allocation stops CHOOSING memory (surplus
+         * pieces, hops, further sets); 0: the default of 250 ms */
+        if (value < 0)
+            return rt_fail(ctx, RT_ERR_ARG, "placement_budget_ms: >= 0");
+        ctx->opt_place_budget_ms = value ? (float)value : RT_PLACE_BUDGET_MS;
     } else if (!strcmp(key, "placement_good_gbps")) {
         /* takes effect with the next allocation (tests: a value no memory
          * reaches makes every allocation try all its ranges and sets) */
@@ -1611,6 +1622,32 @@ int rt_download(rt_ctx *ctx, int which, int surf_lo, int surf_hi, double *dst)
     return RT_OK;
 }
 
+/* x and y of ONE row: what the spot consumers of the host read
+ * (`t.y[-1, :, :2]`, rayopt/geometric_trace.py:172, rayopt/analysis.py:237-283)
+ * is two thirds of the row -- 160 instead of 240 MB over PCIe at 10^7 rays */
+int rt_download_xy(rt_ctx *ctx, int which, int surf, double *dst)
+{
+    if (ctx)
+        RT_ROWS_WHOLE(ctx, "rt_download_xy");
+    if (!ctx || !dst || which < RT_Y || which > RT_I)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_download_xy: bad argument");
+    if (!ctx->d_buf || surf < 0 || surf >= ctx->buf_nsurf)
+        return rt_fail(ctx, RT_ERR_STATE, "rt_download_xy: row %d of %d", surf,
+                       ctx->buf_nsurf);
+    if (!ctx->valid[surf])
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_download_xy: row %d holds no data (not kept by "
+                       "rt_set_keep_rows, or not traced yet)", surf);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = rt_gen_flush(ctx);
+    if (rc != RT_OK)
+        return rc;
+    rc = rt_rows_to_host(ctx, dst, rt_row(ctx, which, surf), 2);
+    if (rc != RT_OK)
+        return rc;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
 
 int rt_download_ray(rt_ctx *ctx, int which, int64_t ray, double *dst)
 {

@@ -46,13 +46,8 @@
 #define RT_PLACE_H
 
 #include "rt_ctx.h"
-#include <chrono>
 
-static inline double rt_place_now_ms(void)
-{
-    return std::chrono::duration<double, std::milli>(
-               std::chrono::steady_clock::now().time_since_epoch()).count();
-}
+static inline double rt_place_now_ms(void) { return rt_now_ms(); }
 
 #define RT_PLACE_ROWS 84         /* 12 elements x (y0 y1 y2 u0 u1 u2 t) */
 /* up to 1.5 GiB: hipMalloc.  Above it there are at least four pieces of
@@ -261,7 +256,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     /* rt_place_settle's further sets run on what is left of the first one's
      * budget */
     if (c->place_deadline_ms <= 0.)
-        c->place_deadline_ms = t_start + RT_PLACE_BUDGET_MS;
+        c->place_deadline_ms = t_start + c->opt_place_budget_ms;
     const double deadline = c->place_deadline_ms;
     bool stalled = false, out_of_time = false;
     float slowest_create = 0.f;

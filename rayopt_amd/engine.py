@@ -219,6 +219,20 @@ class Engine:
                                          out.ctypes.data), "rt_download")
         return out
 
+    def download_xy(self, which, surf, out=None):
+        """x and y of one row of y / u / i: (2, N) (rt_download_xy)."""
+        shape = (2, self.nrays)
+        if out is None:
+            out = np.empty(shape)
+        elif out.shape != shape or not out.flags.c_contiguous \
+                or out.dtype != np.float64:
+            raise ValueError("download_xy: `out` must be C-contiguous "
+                             "float64 of shape %r" % (shape,))
+        self._check(self.lib.rt_download_xy(self.ctx, which, int(surf),
+                                            out.ctypes.data),
+                    "rt_download_xy")
+        return out
+
     def download_ray(self, which, ray):
         """One ray across all surfaces: (L,3) for y/u/i, (L,) for t."""
         L = self.nsurf
@@ -271,6 +285,16 @@ class Engine:
         self._check(self.lib.rt_spot_stats(self.ctx, int(surf),
                                            int(group_rays), int(ngroups),
                                            out.ctypes.data), "rt_spot_stats")
+        return out
+
+    def row_stats(self, surf, group_rays, ngroups, ref=-1):
+        """(ngroups, 10): count, sum w, mean x y, spread about the mean,
+        spread about ray ``ref`` of the bundle, max x^2 + y^2, weighted
+        centroid x y, spread about the shift -- one pass (rt_row_stats)."""
+        out = np.empty((int(ngroups), 10))
+        self._check(self.lib.rt_row_stats(
+            self.ctx, int(surf), int(group_rays), int(ngroups),
+            -1 if ref is None else int(ref), out.ctypes.data), "rt_row_stats")
         return out
 
     def refocus_shift(self, surf):

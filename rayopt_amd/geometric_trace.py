@@ -96,6 +96,7 @@ class DeviceRows:
         self._which = which
         self._host = None       # (L,3,N) or (L,N), allocated on first touch
         self._valid = np.zeros(trace.length, dtype=bool)
+        self._valid_xy = np.zeros(trace.length, dtype=bool)
         self.dtype = np.dtype(np.float64)
 
     @property
@@ -120,6 +121,27 @@ class DeviceRows:
 
     def invalidate(self, lo, hi):
         self._valid[lo:hi] = False
+        self._valid_xy[lo:hi] = False
+
+    @staticmethod
+    def _only_xy(rest):
+        """``rows[j, :, :2]`` and its spellings (``0``, ``1``, ``0:2`` on the
+        last axis): the reference's spot consumers read nothing else."""
+        if len(rest) != 2 or rest[0] != slice(None):
+            return False
+        c = rest[1]
+        if isinstance(c, (int, np.integer)):
+            return c in (0, 1)
+        return isinstance(c, slice) and c.step in (None, 1) and \
+            c.start in (None, 0, 1) and c.stop in (1, 2)
+
+    def _view_xy(self, j):
+        """Row j with x and y present (z too if the row is here already)."""
+        host = self._buffer()
+        if not (self._valid[j] or self._valid_xy[j]):
+            self._trace._engine.download_xy(self._which, j, out=host[j, :2])
+            self._valid_xy[j] = True
+        return host[j].T
 
     def put_row(self, j, soa):
         """Host already knows this row (rays_given)."""
@@ -154,6 +176,8 @@ class DeviceRows:
                 j += length
             if not 0 <= j < length:
                 raise IndexError("surface index %d out of range" % first)
+            if self._which != RT_T and self._only_xy(rest):
+                return self._view_xy(j)[rest]       # two thirds of the row
             out = self._view(j, j + 1)[0]
         elif isinstance(first, slice) and first.step in (None, 1):
             idx = range(length)[first]
@@ -631,6 +655,36 @@ class GeometricTrace(Trace):
         out = self.engine.spot_stats(range(self.length)[i], group_rays, groups)
         if np.ndim(self.l) == 1 and groups % len(self.l) == 0:
             out = out.reshape(len(self.l), -1, 6)
+        return out
+
+    ROW_STATS = np.dtype([(k, "f8") for k in (
+        "count", "sum_w", "mean_x", "mean_y", "var_mean", "var_ref", "r2_max",
+        "centroid_x", "centroid_y", "var_shift")])
+
+    def row_stats(self, i=-1, group_rays=None, ref=None):
+        """Everything :meth:`rms` (about the mean and about the reference
+        ray), :meth:`spot_stats` and :meth:`resize` ask of row ``i``, for
+        every bundle of the batch, in ONE pass over the row
+        (``rt_row_stats``; rayopt/geometric_trace.py:171-193): structured
+        array, one record per bundle (leading shape as :meth:`spot_stats`)
+        with ``count, sum_w, mean_x, mean_y, var_mean`` (= rms()**2 of the
+        bundle), ``var_ref`` (= rms(ref=...)**2; ``ref``: index inside a
+        bundle, default ``self.ref``), ``r2_max`` (resize: radius**2),
+        ``centroid_x, centroid_y`` (weighted)."""
+        if group_rays is None:
+            group_rays = self.rays_per_field or self.rays_per_group or \
+                self.nrays
+        groups, rest = divmod(self.nrays, int(group_rays))
+        if rest:
+            raise ValueError("bundles of %d rays do not tile %d rays"
+                             % (group_rays, self.nrays))
+        if ref is None:
+            ref = self.ref if self.ref is not None else -1
+        out = self.engine.row_stats(range(self.length)[i], group_rays, groups,
+                                    ref).view(self.ROW_STATS)[:, 0]
+        if np.ndim(self.l) == 1 and groups % len(self.l) == 0 and \
+                len(self.l) > 1:
+            out = out.reshape(len(self.l), -1)
         return out
 
     def rms_fields(self, i=-1, lost="nan"):

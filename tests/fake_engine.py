@@ -87,6 +87,19 @@ class OracleEngine:
             return out
         return a
 
+    def download_xy(self, which, surf, out=None):
+        assert self.valid[surf], "row holds no data"
+        a = np.ascontiguousarray(self.rows[which][surf].T[:2])
+        if out is not None:
+            out[...] = a
+            return out
+        return a
+
+    def row_stats(self, surf, group_rays, ngroups, ref=-1):
+        s = cn.row_stats(self.rows[RT_Y][surf], int(group_rays), self.w,
+                         None if ref is None or ref < 0 else int(ref))
+        return np.c_[s, np.full(len(s), np.nan)]
+
     def kernel_ms(self):
         return self.ms
 

@@ -155,8 +155,12 @@ def test_single_process_line(tmp_path):
     assert pl["pieces"] == 0 and pl["workgroups_per_cu_cap"] == 2
     # the device-side consumers on the resident batch
     calls = {c["call"].split()[0].rstrip(","): c for c in d["consumers"]}
-    assert {"rms", "refocus_shift", "spot_stats", "row_rmax", "opd_rays",
-            "opd_stats", "aim_pupil"} <= set(calls), calls.keys()
+    assert {"rms", "refocus_shift", "spot_stats", "row_rmax", "row_stats",
+            "opd_rays", "opd_stats", "aim_pupil"} <= set(calls), calls.keys()
+    # one pass for the row's statistics instead of three calls
+    rs = calls["row_stats"]
+    assert "error" not in rs, rs
+    assert 0 < rs["ms"] and rs["replaces_ms"] > 0 and rs["kernel_ms"] > 0
     # the OPD statistics stay on the device: no per-ray copy in the call
     st = calls["opd_stats"]
     assert "error" not in st, st

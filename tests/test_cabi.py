@@ -59,9 +59,9 @@ def test_shipped_library_carries_no_laboratory(dll):
 
 
 def test_struct_layout(dll):
-    assert dll.rt_abi_version() == _lib.RT_ABI_VERSION == 4
+    assert dll.rt_abi_version() == _lib.RT_ABI_VERSION == 5
     assert int(re.search(r"#define RT_ABI_VERSION (\d+)", open(HEADER).read()
-                         ).group(1)) == 4
+                         ).group(1)) == 5
     assert dll.rt_sizeof_surface() == _lib.SURFACE_DTYPE.itemsize == 352
     text = open(HEADER).read()
     assert int(re.search(r"#define RT_MAX_ASPH (\d+)", text).group(1)) == \

@@ -226,6 +226,187 @@ def test_device_spot_stats_vs_oracle(groups, per):
         tr.engine.spot_stats(3, per, groups)      # row not stored (keep)
 
 
+# -- the row's statistics in one pass (rt_row_stats) --------------------------
+
+def test_oracle_row_stats_is_the_reference_formulas():
+    """The per-bundle oracle equals the reference's ``rms`` (about the mean
+    and about a ray) and ``resize`` maximum applied to every bundle on its
+    own; both are pinned to the reference by the consumer goldens."""
+    rng = np.random.default_rng(5)
+    P, G = 41, 4
+    y = rng.normal(size=(P*G, 3))*[.3, .5, 0.] + [30., -7., 0.]
+    w = rng.random(P*G)
+    for g in range(G):
+        w[g*P:(g + 1)*P] /= w[g*P:(g + 1)*P].sum()
+    s = cn.row_stats(y, P, w, ref=3)
+    for g in range(G):
+        sl = slice(g*P, (g + 1)*P)
+        assert s[g, 0] == P
+        assert np.sqrt(s[g, 4]) == pytest.approx(cn.rms(y[sl], w[sl]),
+                                                 rel=1e-13)
+        assert np.sqrt(s[g, 5]) == pytest.approx(cn.rms(y[sl], w[sl], 3),
+                                                 rel=1e-13)
+        assert s[g, 6] == np.square(y[sl, :2]).sum(1).max()
+    for name in consumer_golden_names():
+        g = load_consumer_golden(name)
+        Y = oracle_arrays(make_system(g), g)[0]
+        if np.isnan(g["rms_mean"]):
+            continue
+        s = cn.row_stats(Y[-1], len(Y[-1]), g["w"], int(g["ref"]))[0]
+        assert close(np.sqrt(s[4]), g["rms_mean"], 1e-13)
+        assert close(np.sqrt(s[5]), g["rms_ref"], 1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", consumer_golden_names())
+def test_row_stats_match_reference(name):
+    """rt_row_stats against the REFERENCE's rms() numbers of the consumer
+    goldens (about the mean, about the reference ray, a middle row), and the
+    radius resize() takes."""
+    g = load_consumer_golden(name)
+    system = make_system(g)
+    tr = ra.GeometricTrace(system)
+    tr.rays_given(g["y0"], g["u0"], g["l"], g["w"], g["ref"])
+    tr.propagate(clip=g["clip"])
+    n = len(g["y0"])
+    s = tr.row_stats()[0]
+    lost = s["count"] < n
+    # (a bundle that lost rays: the reference's numbers are NaN, ours cover
+    # the survivors -- compared with the oracle below)
+    assert lost == bool(np.isnan(g["rms_mean"]))
+    if not lost:
+        assert close(np.sqrt(s["var_mean"]), g["rms_mean"], 1e-12)
+        assert close(np.sqrt(s["var_ref"]), g["rms_ref"], 1e-12)
+        assert close(np.sqrt(tr.row_stats(i=2)[0]["var_mean"]),
+                     g["rms_mid"], 1e-12)
+        assert np.sqrt(s["r2_max"]) == pytest.approx(
+            tr.engine.row_rmax(len(system) - 1), rel=1e-15)
+    want = cn.row_stats(np.asarray(tr.y[-1]), n, g["w"], int(g["ref"]))[0]
+    got = np.array(s.tolist())
+    assert got[0] == want[0]
+    for c, rtol in ((1, 1e-12), (2, 1e-12), (3, 1e-12), (4, 1e-9), (5, 1e-9),
+                    (6, 1e-15), (7, 1e-12), (8, 1e-12)):
+        assert close(got[c], want[c], rtol), (name, c, got[c], want[c])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,per,block", [
+    (1, 100_000, 0), (5, 200_000, 0), (1000, 7, 0), (64, 4096, 0),
+    (4001, 129, 0), (5, 60_001, 4096), (3, 1, 0), (4200, 65, 0)])
+def test_device_row_stats_vs_oracle(groups, per, block):
+    """rt_row_stats against the numpy oracle on the row the device itself
+    produced: vignetted rays (also the reference ray's, also the bundle's
+    first rays), weights, bundle sizes that are multiples of nothing, more
+    bundles than fit the pinned result, a batch in blocks; and against the
+    three calls it replaces."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    n = groups*per
+    y, u = ra.bundles.disc_bundle(n, 17.5, 12., 7,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    rng = np.random.default_rng(groups)
+    w = rng.random(n) + .01
+    eng = ra.Engine()
+    if block:
+        eng.set_option("block_rays", block)
+    tr = ra.GeometricTrace(system, engine=eng)
+    L = len(system)
+    for weights, ref in ((None, -1), (w/w.sum(), min(per - 1, 3)),
+                         (None, 0)):
+        tr.rays_given(y, u, None, weights, max(ref, 0))
+        tr.propagate(clip=True, keep=[-1])
+        got = eng.row_stats(L - 1, per, groups, ref)
+        Y = np.asarray(tr.y[-1])
+        want = cn.row_stats(Y, per, weights, ref)
+        assert got.shape == (groups, 10)
+        assert np.array_equal(got[:, 0], want[:, 0])         # counts exact
+        if per > 100:
+            assert 0 < (want[:, 0] < per).sum()              # some vignetted
+        for c, rtol in ((1, 1e-12), (2, 1e-12), (3, 1e-12), (4, 1e-9),
+                        (5, 1e-9), (6, 1e-15), (7, 1e-12), (8, 1e-12)):
+            assert_parity(got[None, :, c], want[None, :, c], rtol,
+                          "row_stats column %d" % c)
+        # the calls it replaces
+        spot = eng.spot_stats(L - 1, per, groups)
+        assert np.array_equal(got[:, 0], spot[:, 0])
+        assert_parity(got[None, :, 4], spot[None, :, 3], 1e-9, "vs spot")
+        rmax = eng.row_rmax(L - 1)
+        if np.isfinite(rmax):
+            assert np.sqrt(got[:, 6].max()) == rmax
+        # run-to-run identical (no atomics in the sums)
+        assert np.array_equal(eng.row_stats(L - 1, per, groups, ref), got,
+                              equal_nan=True)
+    with pytest.raises(ra.EngineError):
+        eng.row_stats(L - 1, per + 1, groups)
+    with pytest.raises(ra.EngineError):
+        eng.row_stats(L - 1, per, groups, per)     # no such ray in a bundle
+    with pytest.raises(ra.EngineError):
+        eng.row_stats(3, per, groups)              # row not stored (keep)
+
+
+@pytest.mark.gpu
+def test_row_stats_far_from_the_axis_and_a_lost_shift_ray():
+    """The shift is a ray of the bundle, so a spot far from the axis costs no
+    bits (spot 1e-3 at 1e3 from the axis: about the mean to 1e-9 of itself);
+    a bundle whose first 300 rays are lost still has its count and maximum,
+    and its spread through the two-pass fallback."""
+    system = ra.system_from_yaml(ra.prescriptions.SINGLET)
+    n = 4096
+    rng = np.random.default_rng(8)
+    Y = np.zeros((n, 3))
+    Y[:, :2] = [1e3, -2e3] + 1e-3*rng.standard_normal((n, 2))
+    tr = ra.GeometricTrace(system)
+    y, u = ra.bundles.disc_bundle(n, 5., 0., 0)
+    tr.rays_given(y, u)
+    tr.propagate()
+    from rayopt_amd._lib import RT_Y
+    L = len(system)
+    for lost in (0, 300):
+        row = Y.copy()
+        row[:lost] = np.nan
+        tr.engine.upload_row(RT_Y, L - 1, np.ascontiguousarray(row.T))
+        got = tr.engine.row_stats(L - 1, n, 1, -1)[0]
+        want = cn.row_stats(row, n, None, None)[0]
+        assert got[0] == want[0] == n - lost
+        for c, rtol in ((2, 1e-14), (3, 1e-14), (4, 1e-9), (6, 1e-15)):
+            assert close(got[c], want[c], rtol), (lost, c, got[c], want[c])
+
+
+@pytest.mark.gpu
+def test_xy_of_a_row_cross_pcie_alone():
+    """``t.y[-1, :, :2]`` -- what rms() and the spot diagrams of the
+    reference read (rayopt/geometric_trace.py:172, analysis.py:237-283) --
+    brings down x and y only (rt_download_xy); the full row, asked for
+    later, is the full row."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    n = 70_001
+    y, u = ra.bundles.disc_bundle(n, 17., 9., 5,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    for block in (0, 4096):
+        eng = ra.Engine()
+        if block:
+            eng.set_option("block_rays", block)
+        a = ra.GeometricTrace(system, engine=eng)
+        b = ra.GeometricTrace(system)
+        for t in (a, b):
+            t.rays_given(y, u)
+            t.propagate(clip=True)
+        full = np.asarray(b.y[-1])
+        xy = a.y[-1, :, :2]
+        assert xy.shape == (n, 2) and not a.y._valid[-1]
+        assert np.array_equal(xy, full[:, :2], equal_nan=True)
+        assert np.array_equal(a.u[-1, :, 1], np.asarray(b.u[-1])[:, 1],
+                              equal_nan=True)
+        assert np.array_equal(a.i[5, :, 0:1], np.asarray(b.i[5])[:, 0:1],
+                              equal_nan=True)
+        assert np.array_equal(a.y[-1], full, equal_nan=True)   # now all of it
+        assert np.array_equal(a.y[-1, :, 2], full[:, 2], equal_nan=True)
+        # a new trace voids both
+        a.propagate(clip=False)
+        assert not a.y._valid_xy[-1] and not a.y._valid[-1]
+        assert np.array_equal(a.y[-1, :, :2],
+                              np.asarray(a.y[-1])[:, :2], equal_nan=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 257, 1001, 99_999, 1_000_002])
 def test_one_pass_reductions_vs_two_pass_and_numpy(n):
