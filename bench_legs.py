@@ -1179,6 +1179,16 @@ def run_configs(ra, device, args, live=None):
                                                "created", "ballast_blocks",
                                                "search_ms")}
         rec["_kind"] = kind
+        if kind and kind.startswith("C4"):
+            # how many of the lanes a wavefront drags through the asphere
+            # iteration are still iterating (rt_newton_census: the batch
+            # marched again by a kernel that counts and stores nothing)
+            try:
+                c = g.engine.newton_census(clip)
+                rec["newton_census"] = c
+                rec["newton_lane_utilisation"] = c["lane_utilisation"]
+            except Exception as err:      # a reported extra, never fatal
+                rec["newton_census"] = {"error": repr(err)[:200]}
         if note:
             rec["note"] = note
         out.append(rec)

@@ -57,8 +57,8 @@ extern "C" {
                            4: rt_opd_stats, rt_opd_device, rt_download_rays;
                               rt_placement(info[16], ms[16]) reports the
                               address ranges measured
-                           5: rt_row_stats, rt_download_xy; rt_placement
-                              reports the search's time budget */
+                           5: rt_row_stats, rt_download_xy, rt_newton_census;
+                              rt_placement reports the search's time budget */
 #define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
 #define RT_MAX_SURFACES 256 /* elements per System */
 
@@ -418,6 +418,20 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * with the events rt_kernel_ms reads; default 0).
  */
 int rt_set_option(rt_ctx *ctx, const char *key, int value);
+
+/*
+ * Measurement: how well the per-wavefront trip count of the asphere Newton
+ * solve (a 64-bit ballot ends the loop when no lane iterates any more;
+ * rayopt/elements.py:333-349 solves ray by ray) fits the rays of this batch.
+ * The batch is marched again from row 0 (table and clip of the last trace,
+ * which must have started at element 1) by a kernel that stores nothing:
+ * out[0] = lane slots spent in the iteration (64 x wavefront trips),
+ * out[1] = iterates the rays needed (lane slots that did work; out[1] / out[0]
+ * is the lane utilisation), out[2] = wavefront trips, out[3] = wavefront
+ * solves (one per wavefront and aspheric element with a live ray).  Rays that
+ * arrive dead (NaN direction) are retired before the loop and count nowhere.
+ */
+int rt_newton_census(rt_ctx *ctx, int clip, uint64_t out[4]);
 
 /*
  * Lazy D2H of surface rows [surf_lo, surf_hi) of one array into a caller

@@ -146,6 +146,12 @@ def surface_normal(s, xyz):
     return q
 
 
+# Census of the iteration (tests of rt_newton_census only): when this is a
+# list, newton_intercept appends one int array per call -- the iterates
+# every ray went through, 0 for a ray that arrived dead (NaN direction).
+ITERATES = None
+
+
 def newton_intercept(s, y, u, tol=1e-7, maxiter=5):
     """Interface.intercept (rayopt/elements.py:333-349).
 
@@ -158,11 +164,13 @@ def newton_intercept(s, y, u, tol=1e-7, maxiter=5):
     p0 = -y[:, 2]/u[:, 2]
     out = np.full(p0.shape, np.nan)
     live = np.ones(p0.shape, dtype=bool)
+    iterates = np.zeros(p0.shape, dtype=np.int64)
     with np.errstate(all="ignore"):
         for itr in range(maxiter):
             if not live.any():
                 break
             idx = np.nonzero(live)[0]
+            iterates[idx] += 1
             yi, ui, pi = y[idx], u[idx], p0[idx]
             xyz = yi + pi[:, None]*ui
             fval = surface_sag(s, xyz)
@@ -182,6 +190,8 @@ def newton_intercept(s, y, u, tol=1e-7, maxiter=5):
             done = zero | dzero | conv
             p0[idx] = p
             live[idx[done]] = False
+    if ITERATES is not None:
+        ITERATES.append(np.where(np.isnan(u[:, 0]), 0, iterates))
     return out
 
 

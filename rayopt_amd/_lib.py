@@ -110,6 +110,8 @@ SIGNATURES = {
     "rt_set_option": (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int]),
     "rt_download": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_void_p]),
+    "rt_newton_census": (ctypes.c_int, [_ctx, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_uint64)]),
     "rt_download_xy": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_void_p]),
     "rt_download_ray": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int64,

@@ -587,6 +587,8 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
          * mapped, so there is nothing new to prove either */
         rt_place_tune(ctx, ctx->nsurf, ld);
     } else if (ctx->place.base && fresh) {
+        if (!allocated) /* (an older buffer that never had its search) */
+            ctx->place_deadline_ms = rt_place_now_ms() + ctx->opt_place_budget_ms;
         rt_place_settle(ctx, ctx->nsurf, ld, ctx->cap_doubles * sizeof(double));
         if (!ctx->d_buf) { /* (the mapping was lost on the way) */
             rt_place_release(&ctx->place);
@@ -1408,6 +1410,51 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
         ctx->u_alias[sidx] = (f & RT_F_SKIP_U) && !(f & RT_F_NOSTORE);
     }
     ctx->traced = 1;
+    return RT_OK;
+}
+
+/*
+ * How many of the lanes a wavefront drags through the asphere iteration are
+ * still iterating (north_star: "wavefront ballots for the asphere
+ * iteration"; rayopt/elements.py:333-349 solves ray by ray): the batch is
+ * marched again from row 0 by a census kernel that stores nothing.  Needs a
+ * completed trace from element 1 (the table as that trace finalised it, row
+ * 0 in place).
+ */
+int rt_newton_census(rt_ctx *ctx, int clip, uint64_t out[4])
+{
+    if (!ctx || !out)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_newton_census: NULL argument");
+    RT_ROWS_WHOLE(ctx, "rt_newton_census");
+    if (!ctx->d_buf || ctx->n < 1 || !ctx->traced || ctx->table_dirty ||
+        ctx->table_start != 1 || !ctx->valid[0])
+        return rt_fail(ctx, RT_ERR_STATE,
+                       "rt_newton_census: trace the batch from element 1 "
+                       "first");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = rt_gen_flush(ctx);
+    if (rc == RT_OK)
+        rc = rt_detach(ctx, RT_U, 0);
+    if (rc == RT_OK)
+        rc = rt_need_scratch(ctx, 4 * sizeof(unsigned long long));
+    if (rc != RT_OK)
+        return rc;
+    unsigned long long *d = (unsigned long long *)ctx->d_scratch;
+    RT_HIP(ctx, hipMemsetAsync(d, 0, 4 * sizeof *d, ctx->stream));
+    rt_lay lay = rt_layout(ctx);
+    rt_lay_set_window(lay, 0, ctx->ld);
+    const int64_t group_rays = ctx->ngroups > 1 ? ctx->n / ctx->ngroups : 0;
+    const unsigned grid = (unsigned)((ctx->ld + RT_BLOCK - 1) / RT_BLOCK);
+    hipLaunchKernelGGL(rt_census_kernel, dim3(grid), dim3(RT_BLOCK), 0,
+                       ctx->stream, ctx->d_surf, 1, ctx->nsurf, clip, lay,
+                       ctx->ld, group_rays, ctx->nsurf, ctx->ngroups, d);
+    RT_HIP(ctx, hipGetLastError());
+    unsigned long long h[4];
+    RT_HIP(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; ++k)
+        out[k] = h[k];
     return RT_OK;
 }
 

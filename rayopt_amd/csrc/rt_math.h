@@ -346,10 +346,25 @@ RT_HD bool rt_newton_iterate(const rt_surface *__restrict__ S, unsigned flags,
     return rt_newton_iterate_t<RT_MAX_ASPH>(A, flags, y, u, s, res);
 }
 
+/*
+ * `census` (measurement only, NULL in every product kernel and then no code):
+ * census[0] counts the trips of this lane's wavefront through the iteration,
+ * census[1] the iterates this lane's own rays needed -- their ratio over a
+ * launch is how many of the lanes a wavefront drags through the loop were
+ * still iterating (rt_newton_census).
+ *
+ * A ray that arrives dead (its direction NaN-poisoned by an earlier clip,
+ * miss or total reflection: the march's own criterion u_x != u_x) can only
+ * leave as NaN -- its first iterate is NaN and NaN is never close to anything,
+ * so the reference's solver runs out of iterations and yields NaN
+ * (elements.py:345-348).  It is retired before the loop: one vignetted ray
+ * no longer holds its whole wavefront for all five trips at every asphere
+ * behind the stop.
+ */
 template <int R, int NA>
 RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
                      const double (&y)[R][3], const double (&u)[R][3],
-                     double (&s)[R])
+                     double (&s)[R], unsigned *census = nullptr)
 {
     rt_asph_terms<NA> A; /* read once, before the iteration */
     rt_asph_read<NA>(S, flags, A);
@@ -360,18 +375,22 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
     for (int r = 0; r < R; ++r) {
         s[r] = -y[r][2] / u[r][2];
         res[r] = RT_NAN;
-        live[r] = true;
-        any = true;
+        live[r] = u[r][0] == u[r][0];
+        any = any || live[r];
     }
 #pragma unroll 1
     for (int itr = 0; itr < 5; ++itr) {
         if (!RT_WAVE_ANY(any))
             break;
         any = false;
+        if (census)
+            ++census[0];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (!live[r])
                 continue;
+            if (census)
+                ++census[1];
             if (rt_newton_iterate_t<NA>(A, flags, y[r], u[r], s[r], res[r]))
                 live[r] = false;
             else
@@ -488,7 +507,7 @@ RT_HD void rt_poly_fast(const double (&a)[NA], const double (&da)[NA],
 template <int R, int NA>
 RT_HD void rt_newton_fast(const rt_surface *__restrict__ S, unsigned flags,
                           const double (&y)[R][3], const double (&u)[R][3],
-                          double (&s)[R])
+                          double (&s)[R], unsigned *census = nullptr)
 {
     /* wave-uniform: read once, live in SGPRs across the iteration */
     double a[NA], da[NA];
@@ -506,18 +525,22 @@ RT_HD void rt_newton_fast(const rt_surface *__restrict__ S, unsigned flags,
     for (int r = 0; r < R; ++r) {
         s[r] = -y[r][2] * rt_rcp_fast<2>(u[r][2]);
         res[r] = RT_NAN;
-        live[r] = true;
-        any = true;
+        live[r] = u[r][0] == u[r][0]; /* (dead on arrival: see rt_newton) */
+        any = any || live[r];
     }
 #pragma unroll 1
     for (int itr = 0; itr < 5; ++itr) {
         if (!RT_WAVE_ANY(any))
             break;
         any = false;
+        if (census)
+            ++census[0];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (!live[r])
                 continue;
+            if (census)
+                ++census[1];
             const double px = rt_fma(s[r], u[r][0], y[r][0]);
             const double py = rt_fma(s[r], u[r][1], y[r][1]);
             const double pz = rt_fma(s[r], u[r][2], y[r][2]);
@@ -718,16 +741,18 @@ RT_HD void rt_bend_fast(const rt_surface *__restrict__ S, unsigned flags,
 template <int R>
 RT_HD void rt_intercept(const rt_surface *__restrict__ S, unsigned flags,
                         const double (&y)[R][3], const double (&iv)[R][3],
-                        double (&s)[R])
+                        double (&s)[R], unsigned *census = nullptr)
 {
     if (flags & RT_F_FAST) {
-        RT_FAST_DISPATCH((rt_newton_fast<R, 4>(S, flags, y, iv, s)),
-                         (rt_newton_fast<R, 7>(S, flags, y, iv, s)),
-                         (rt_newton_fast<R, RT_MAX_ASPH>(S, flags, y, iv, s)));
+        RT_FAST_DISPATCH(
+            (rt_newton_fast<R, 4>(S, flags, y, iv, s, census)),
+            (rt_newton_fast<R, 7>(S, flags, y, iv, s, census)),
+            (rt_newton_fast<R, RT_MAX_ASPH>(S, flags, y, iv, s, census)));
     } else if (flags & RT_F_ASPH) {
-        RT_FAST_DISPATCH((rt_newton<R, 4>(S, flags, y, iv, s)),
-                         (rt_newton<R, 7>(S, flags, y, iv, s)),
-                         (rt_newton<R, RT_MAX_ASPH>(S, flags, y, iv, s)));
+        RT_FAST_DISPATCH((rt_newton<R, 4>(S, flags, y, iv, s, census)),
+                         (rt_newton<R, 7>(S, flags, y, iv, s, census)),
+                         (rt_newton<R, RT_MAX_ASPH>(S, flags, y, iv, s,
+                                                    census)));
     } else if (!(flags & RT_F_CURVED)) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -825,7 +850,8 @@ RT_HD void rt_generate_ray(const rt_field *__restrict__ F, double px,
 template <int R>
 RT_HD void rt_step_hit(const rt_surface *__restrict__ S, unsigned flags,
                        double (&y)[R][3], const double (&u)[R][3],
-                       double (&iv)[R][3], double (&t)[R])
+                       double (&iv)[R][3], double (&t)[R],
+                       unsigned *census = nullptr)
 {
     /* transfer: y - e.offset, then to_normal (system.py:461) */
 #pragma unroll
@@ -844,7 +870,7 @@ RT_HD void rt_step_hit(const rt_surface *__restrict__ S, unsigned flags,
 
     /* intercept */
     double s[R];
-    rt_intercept<R>(S, flags, y, iv, s);
+    rt_intercept<R>(S, flags, y, iv, s, census);
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -236,12 +236,15 @@ static bool rt_place_coherent(rt_ctx *c)
 
 /*
  * The search is bounded in TIME, not only in pieces and bytes (VERDICT r5:
- * single hipMemCreate calls of 1.3-8.7 s were seen where the device memory
- * was fragmented).  What an allocation must have -- its `need` pieces -- it
- * gets whatever that takes (the hipMalloc it would fall back to waits for the
- * same driver); everything that is CHOICE -- surplus pieces, ballast hops,
- * further sets of pieces -- ends RT_PLACE_BUDGET_MS after the allocation
- * began, or at once when a single hipMemCreate took RT_PLACE_STALL_MS.
+ * single hipMemCreate calls of 1.3-8.7 s were seen).  What an allocation must
+ * have -- its `need` pieces -- it gets whatever that takes: the hipMalloc it
+ * would fall back to waits for the same driver, and the stall that was seen
+ * is the FIRST large hipMemCreate of a process (0.9-6 s on five of five boxes
+ * of round 6, a millisecond for every piece after it), which says nothing
+ * about the pieces that follow.  Everything that is CHOICE -- surplus pieces,
+ * ballast hops, further sets of pieces -- ends RT_PLACE_BUDGET_MS after the
+ * first set had the pieces it needs, and at once when a hipMemCreate of a
+ * surplus piece, of ballast or of a further set takes RT_PLACE_STALL_MS.
  */
 #define RT_PLACE_BUDGET_MS 250.
 #define RT_PLACE_STALL_MS 200.
@@ -253,11 +256,11 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     if (!c->opt_place || g_place_distrust || bytes < RT_PLACE_MIN_BYTES)
         return hipMalloc(out, bytes);
     const double t_start = rt_place_now_ms();
-    /* rt_place_settle's further sets run on what is left of the first one's
-     * budget */
-    if (c->place_deadline_ms <= 0.)
-        c->place_deadline_ms = t_start + c->opt_place_budget_ms;
-    const double deadline = c->place_deadline_ms;
+    /* the first set of an allocation starts the clock when it has what it
+     * needs; rt_place_settle's further sets (all of them choice) run on what
+     * is left of that budget */
+    const bool choice = c->place_deadline_ms > 0.;
+    double deadline = choice ? c->place_deadline_ms : 1e300;
     bool stalled = false, out_of_time = false;
     float slowest_create = 0.f;
     double t_ballast = 0.;
@@ -349,9 +352,14 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         {
             const float took = (float)(rt_place_now_ms() - t_create);
             slowest_create = took > slowest_create ? took : slowest_create;
-            stalled = stalled || took > RT_PLACE_STALL_MS;
+            /* (a piece the arrays need is no reason to stop choosing) */
+            stalled = stalled ||
+                      (took > RT_PLACE_STALL_MS && (choice || made >= need));
         }
         ++made;
+        if (!choice && made == need)
+            c->place_deadline_ms = deadline =
+                rt_place_now_ms() + c->opt_place_budget_ms;
         if (made > need)
             extra += piece;
         double *pk = (double *)((char *)scratch + (size_t)k * piece);

@@ -98,6 +98,59 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
 }
 
 /*
+ * MEASUREMENT, not on the path (rt_newton_census): the same march from row
+ * start - 1 with nothing stored, the Newton solves of the aspheric elements
+ * counting -- per wavefront its trips through the iteration, per lane the
+ * iterates its own ray needed.  out[0] += 64 x trips (lane slots the hardware
+ * spent), out[1] += iterates (lane slots that did work), out[2] += trips,
+ * out[3] += wavefronts that entered an iteration at all.
+ */
+__global__ void __launch_bounds__(RT_BLOCK)
+rt_census_kernel(const rt_surface *__restrict__ surf, int start, int stop,
+                 int clip, rt_lay a, int64_t ld, int64_t group_rays, int nsurf,
+                 int ngroups, unsigned long long *__restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (j >= ld)
+        return;
+    if (group_rays) {
+        const int64_t j0 = a.j0 + j - (int64_t)(threadIdx.x & 63);
+        const int g = __builtin_amdgcn_readfirstlane((int)(j0 / group_rays));
+        surf += (int64_t)(g < ngroups ? g : ngroups - 1) * nsurf;
+    }
+    const int64_t col = rt_col_wg(a, j, blockIdx.x);
+    double y[1][3], u[1][3], iv[1][3], t[1];
+    rt_load_state<1>(a, start - 1, col, y, u);
+    unsigned census[2] = {0u, 0u};
+    {
+        const rt_surface *S0 = surf + (start - 1);
+        rt_leave<1>(S0, S0->flags, y, u);
+    }
+    for (int s = start; s < stop; ++s) {
+        const rt_surface *S = surf + s;
+        const unsigned flags = S->flags;
+        if (RT_WAVE_ANY(u[0][0] == u[0][0])) {
+            rt_step_hit<1>(S, flags, y, u, iv, t, census);
+            rt_step_bend<1>(S, flags, clip, y, iv, u);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                y[0][c] = u[0][c] = RT_NAN;
+        }
+        rt_leave<1>(S, flags, y, u);
+    }
+    unsigned mine = census[1];
+    for (int off = 32; off > 0; off >>= 1)
+        mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0 && census[0]) {
+        atomicAdd(out + 0, 64ull * census[0]);
+        atomicAdd(out + 1, (unsigned long long)mine);
+        atomicAdd(out + 2, (unsigned long long)census[0]);
+        atomicAdd(out + 3, 1ull);
+    }
+}
+
+/*
  * The first trace after rt_generate_rays: the launch rays are built in
  * registers (field f = j / npupil through pupil point j % npupil), row 0 is
  * written from there and the march goes on -- the generated batch never

@@ -155,6 +155,20 @@ class Engine:
         self._check(self.lib.rt_trace(self.ctx, int(start), int(stop),
                                       1 if clip else 0), "rt_trace")
 
+    def newton_census(self, clip=False):
+        """How the asphere iteration's per-wavefront trip count fits this
+        batch (rt_newton_census): dict with the lane slots spent, the
+        iterates the rays needed, their ratio (``lane_utilisation``), mean
+        trips per wavefront solve and mean iterates per lane slot entered."""
+        out = (ctypes.c_uint64*4)()
+        self._check(self.lib.rt_newton_census(self.ctx, 1 if clip else 0,
+                                              out), "rt_newton_census")
+        slots, its, trips, solves = (int(v) for v in out)
+        return {"lane_slots": slots, "iterates": its, "wave_trips": trips,
+                "wave_solves": solves,
+                "lane_utilisation": its/slots if slots else None,
+                "trips_per_wave_solve": trips/solves if solves else None}
+
     def set_keep_rows(self, keep):
         """Rows propagate() stores: boolean sequence per element, or None
         for all rows (the reference behaviour)."""

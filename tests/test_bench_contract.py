@@ -127,6 +127,10 @@ def test_single_process_line(tmp_path):
             # child pass under rocprofv3) x this leg's clock and launch time
             assert 0 < r["valu"]["valu_issue_frac"] < 1.5, r["valu"]
             assert r["valu"]["source"].startswith("this run"), r["valu"]
+        if r["config"].startswith("C4"):
+            # lanes still iterating among those a wavefront drags through
+            # the asphere iteration, counted on the device
+            assert .5 < r["newton_lane_utilisation"] <= 1., r["newton_census"]
         par = r["parity_subsample"]
         if par is not None:
             assert par["nan_masks_equal"] is True
