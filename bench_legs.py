@@ -962,7 +962,23 @@ def end_to_end(g, y, u, clip, kernel_ms):
     rec["d2h_image_row_ms"] = min(t[1:])*1e3
     rec["d2h_bytes"] = row.nbytes
     rec["d2h_GBps"] = row.nbytes/min(t[1:])/1e9
-    rec["end_to_end_ms"] = rec["h2d_ms"] + kernel_ms + rec["d2h_image_row_ms"]
+    # what the reference's consumers of the image row read is x and y
+    # (`t.y[-1, :, :2]`: rayopt/geometric_trace.py:172, analysis.py:237-283):
+    # two thirds of the row cross PCIe (rt_download_xy)
+    t = []
+    for k in range(3):
+        g.propagate(clip=clip)
+        g.engine.sync()
+        t0 = time.perf_counter()
+        xy = g.y[L - 1, :, :2]
+        t.append(time.perf_counter() - t0)
+    rec["d2h_image_xy_ms"] = min(t)*1e3
+    rec["d2h_xy_bytes"] = 16*n
+    rec["d2h_xy_GBps"] = 16*n/min(t)/1e9
+    assert xy.shape == (n, 2)
+    rec["end_to_end_ms"] = rec["h2d_ms"] + kernel_ms + rec["d2h_image_xy_ms"]
+    rec["end_to_end_full_row_ms"] = rec["h2d_ms"] + kernel_ms + \
+        rec["d2h_image_row_ms"]
     try:
         hip = _hip()
         nb = 48*n
@@ -985,6 +1001,7 @@ def end_to_end(g, y, u, clip, kernel_ms):
         rec["pinned_hipMemcpy_ceiling_GBps"] = best
         rec["h2d_fraction_of_ceiling"] = rec["h2d_GBps"]/best["h2d"]
         rec["d2h_fraction_of_ceiling"] = rec["d2h_GBps"]/best["d2h"]
+        rec["d2h_xy_fraction_of_ceiling"] = rec["d2h_xy_GBps"]/best["d2h"]
     except Exception as err:      # a reported extra, never fatal
         rec["pinned_hipMemcpy_ceiling_GBps"] = {"error": repr(err)[:200]}
     return rec
@@ -1830,9 +1847,11 @@ def core_line(out, detail):
     e = out.get("end_to_end")
     if e is not None:
         core["end_to_end"] = _r(_pick(
-            e, "rays", "h2d_ms", "trace_ms", "d2h_image_row_ms",
-            "d2h_bytes", "end_to_end_ms", "h2d_fraction_of_ceiling",
-            "d2h_fraction_of_ceiling", "error"))
+            e, "rays", "h2d_ms", "trace_ms", "d2h_image_xy_ms",
+            "d2h_xy_bytes", "d2h_image_row_ms", "d2h_bytes", "end_to_end_ms",
+            "end_to_end_full_row_ms", "h2d_fraction_of_ceiling",
+            "d2h_fraction_of_ceiling", "d2h_xy_fraction_of_ceiling",
+            "error"))
     cons = out.get("consumers")
     if isinstance(cons, list):
         core["consumers"] = []
@@ -1854,7 +1873,7 @@ def core_line(out, detail):
     for key in ("gather_ms", "transport", "kernel_ms_per_rank",
                 "gather_pipelined_ms", "gather_exposed_ms", "gather_chunks",
                 "plain_loop_ms_per_step", "exchange_cost_ratio", "test_mode",
-                "configs4"):
+                "note", "configs4"):
         if key in out:
             core[key] = _r(out[key], 6)
     laps = (out.get("wall_s") or {}).get("since_start")
@@ -1888,9 +1907,11 @@ def leg_summaries(out):
                               pl.get("store_pattern_GBps_per_piece_set")))
     e = out.get("end_to_end") or {}
     if "end_to_end_ms" in e:
-        log("[summary] end_to_end: h2d %.2f + trace %.3f + d2h %.2f = %.2f ms"
-            % (e["h2d_ms"], e["trace_ms"], e["d2h_image_row_ms"],
-               e["end_to_end_ms"]))
+        log("[summary] end_to_end: h2d %.2f + trace %.3f + d2h (x, y of the "
+            "image row) %.2f = %.2f ms; with all of the row (%.2f) %.2f ms"
+            % (e["h2d_ms"], e["trace_ms"], e["d2h_image_xy_ms"],
+               e["end_to_end_ms"], e["d2h_image_row_ms"],
+               e["end_to_end_full_row_ms"]))
     for c in (out.get("consumers") if isinstance(out.get("consumers"), list)
               else []):
         if "ms" in c:

@@ -39,6 +39,7 @@
 #include "rt_ctx.h"
 #include "rt_trace_kernels.h"
 #include "rt_place.h"
+#include "rt_copy_pool.h"
 
 static char g_err[512] = "";
 int g_place_distrust = 0;
@@ -739,59 +740,6 @@ static int rt_copy_threads(void)
     return n;
 }
 
-/* a staging copy on up to 16 threads: `start` leaves the first part to the
- * caller's `finish`, so that the caller can do something else in between
- * (rt_d2h: issue the next DMA) */
-struct rt_copy_team {
-    std::thread workers[16];
-    int started;
-    void *dst;
-    const void *src;
-    size_t first;
-};
-
-static void rt_copy_start(rt_copy_team *team, void *dst, const void *src,
-                          size_t len, bool all = false)
-{
-    const int nt = rt_copy_threads();
-    team->started = 0;
-    team->dst = dst;
-    team->src = src;
-    team->first = len;
-    if (nt == 1 || len < ((size_t)4 << 20))
-        return;
-    /* `all`: the caller is about to block in a DMA for as long as this copy
-     * takes -- its share, copied afterwards, would be the serial part of the
-     * pipeline (a quarter of every chunk with four threads) -- so the
-     * workers take everything */
-    const size_t part = (len / nt + 4095) & ~(size_t)4095;
-    team->first = all ? 0 : part < len ? part : len;
-    for (int t = all ? 0 : 1; t < nt; ++t) {
-        const size_t off = (size_t)t * part;
-        if (off >= len)
-            break;
-        const size_t n = len - off < part ? len - off : part;
-        team->workers[team->started++] = std::thread(
-            [=] { memcpy((char *)dst + off, (const char *)src + off, n); });
-    }
-}
-
-static void rt_copy_finish(rt_copy_team *team)
-{
-    if (team->first)
-        memcpy(team->dst, team->src, team->first);
-    for (int t = 0; t < team->started; ++t)
-        team->workers[t].join();
-    team->started = 0;
-}
-
-static void rt_memcpy_mt(void *dst, const void *src, size_t len)
-{
-    rt_copy_team team;
-    rt_copy_start(&team, dst, src, len);
-    rt_copy_finish(&team);
-}
-
 /*
  * Host -> device copy of a pageable buffer through two pinned staging
  * buffers: the CPU fills one while the DMA engine drains the other.  A plain
@@ -818,7 +766,8 @@ int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
                                                       : RT_PIN_CHUNK;
         if (ctx->pin_busy[k]) /* this call's or an earlier call's DMA */
             RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[k]));
-        rt_memcpy_mt(ctx->h_pin[k], (const char *)src + off, len);
+        rt_memcpy_mt(ctx->h_pin[k], (const char *)src + off, len,
+                     rt_copy_threads());
         RT_HIP(ctx, hipMemcpyAsync((char *)dst + off, ctx->h_pin[k], len,
                                    hipMemcpyHostToDevice, ctx->stream));
         RT_HIP(ctx, hipEventRecord(ctx->pin_done[k], ctx->stream));
@@ -932,7 +881,7 @@ static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)
                 return rt_fail(ctx, RT_ERR_HIP, "rt_d2h: %s",
                                hipGetErrorString(e));
             rt_copy_start(&team, prev_dst, ctx->h_pin[(i - 1) & 1], prev_len,
-                          more);
+                          rt_copy_threads(), more);
         }
         hipError_t e = hipSuccess;
         if (more) { /* chunk i into the other buffer */

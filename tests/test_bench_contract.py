@@ -180,6 +180,8 @@ def test_single_process_line(tmp_path):
     e2e = d["end_to_end"]
     assert "error" not in e2e, e2e
     assert e2e["h2d_ms"] > 0 and e2e["d2h_image_row_ms"] > 0
+    assert e2e["d2h_image_xy_ms"] > 0 and e2e["d2h_xy_bytes"] == 16*200000
+    assert e2e["end_to_end_full_row_ms"] > e2e["trace_ms"] > 0
     assert e2e["end_to_end_ms"] > e2e["trace_ms"] > 0
     assert e2e["pinned_hipMemcpy_ceiling_GBps"]["h2d"] > 1
     # the 10^8-ray shape (here: --configs5-rays) carries a parity sample
