@@ -727,17 +727,52 @@ static unsigned rt_pin_event_flags(void)
  * memcpy between pageable memory and the pinned staging buffers on a few
  * threads: one core copies ~30 GB/s, the DMA engine moves ~55 GB/s over
  * PCIe 5 x16, so the single-threaded staging copy was the slower half of the
- * pipeline (RT_COPY_THREADS overrides the default of 4; 1 = plain memcpy).
+ * pipeline (RT_COPY_THREADS overrides the default of 8; 1 = plain memcpy).
  */
 static int rt_copy_threads(void)
 {
     static int n = 0;
     if (!n) {
         const char *e = getenv("RT_COPY_THREADS");
-        n = e ? atoi(e) : 4;
+        n = e ? atoi(e) : 8;
         n = n < 1 ? 1 : (n > 16 ? 16 : n);
     }
     return n;
+}
+
+/* device -> pinned host by a KERNEL (the staging buffers are mapped into the
+ * device's address space): 53 GB/s like a DMA at its best -- but the DMA of
+ * hipMemcpyAsync has two levels on this platform, 55 and 24-26 GB/s for the
+ * same 20 MB, and which one a process gets flips while it runs
+ * (profiles/r05_final/d2h_*: a fresh stream of a fresh process at 0.88 ms,
+ * the same stream at 0.38 after a context was created next to it; most boxes
+ * gave the slow one: 10.4-10.7 ms per 240 MB row, 5.3 on two boxes) */
+__global__ void __launch_bounds__(256)
+rt_copy_out_kernel(const double *__restrict__ src, double *__restrict__ dst,
+                   size_t n, int wide)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wide) {
+        const double2 *s2 = (const double2 *)src;
+        double2 *d2 = (double2 *)dst;
+        for (; i < n / 2; i += step)
+            d2[i] = s2[i];
+    } else {
+        for (; i < n; i += step)
+            dst[i] = src[i];
+    }
+}
+
+static hipError_t rt_copy_by_kernel(hipStream_t s, void *dst, const void *src,
+                                    size_t bytes)
+{
+    const int wide = bytes % 16 == 0 && (uintptr_t)src % 16 == 0 &&
+                     (uintptr_t)dst % 16 == 0;
+    hipLaunchKernelGGL(rt_copy_out_kernel, dim3(1024), dim3(256), 0, s,
+                       (const double *)src, (double *)dst,
+                       bytes / sizeof(double), wide);
+    return hipGetLastError();
 }
 
 /*
@@ -768,8 +803,15 @@ int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
             RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[k]));
         rt_memcpy_mt(ctx->h_pin[k], (const char *)src + off, len,
                      rt_copy_threads());
-        RT_HIP(ctx, hipMemcpyAsync((char *)dst + off, ctx->h_pin[k], len,
-                                   hipMemcpyHostToDevice, ctx->stream));
+        /* RT_H2D_KERNEL=1 (A/B): a copy kernel reading the mapped staging
+         * buffer instead of the DMA engine */
+        static const bool kern = getenv("RT_H2D_KERNEL") != NULL;
+        if (kern && len % sizeof(double) == 0)
+            RT_HIP(ctx, rt_copy_by_kernel(ctx->stream, (char *)dst + off,
+                                          ctx->h_pin[k], len));
+        else
+            RT_HIP(ctx, hipMemcpyAsync((char *)dst + off, ctx->h_pin[k], len,
+                                       hipMemcpyHostToDevice, ctx->stream));
         RT_HIP(ctx, hipEventRecord(ctx->pin_done[k], ctx->stream));
         ctx->pin_busy[k] = 1;
     }
@@ -786,42 +828,13 @@ struct rt_copy_job {
     size_t bytes;
 };
 
-/* device -> pinned host by a KERNEL (the staging buffers are mapped into the
- * device's address space): 53 GB/s like a DMA at its best -- but the DMA of
- * hipMemcpyAsync has two levels on this platform, 55 and 24-26 GB/s for the
- * same 20 MB, and which one a process gets flips while it runs
- * (profiles/r05_final/d2h_*: a fresh stream of a fresh process at 0.88 ms,
- * the same stream at 0.38 after a context was created next to it; most boxes
- * gave the slow one: 10.4-10.7 ms per 240 MB row, 5.3 on two boxes) */
-__global__ void __launch_bounds__(256)
-rt_copy_out_kernel(const double *__restrict__ src, double *__restrict__ dst,
-                   size_t n, int wide)
-{
-    const size_t step = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wide) {
-        const double2 *s2 = (const double2 *)src;
-        double2 *d2 = (double2 *)dst;
-        for (; i < n / 2; i += step)
-            d2[i] = s2[i];
-    } else {
-        for (; i < n; i += step)
-            dst[i] = src[i];
-    }
-}
-
 static hipError_t rt_copy_out(hipStream_t s, void *dst, const void *src,
                               size_t bytes)
 {
     static const bool dma = getenv("RT_D2H_DMA") != NULL; /* A/B */
     if (dma || bytes % sizeof(double))
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
-    const int wide = bytes % 16 == 0 && (uintptr_t)src % 16 == 0 &&
-                     (uintptr_t)dst % 16 == 0;
-    hipLaunchKernelGGL(rt_copy_out_kernel, dim3(1024), dim3(256), 0, s,
-                       (const double *)src, (double *)dst,
-                       bytes / sizeof(double), wide);
-    return hipGetLastError();
+    return rt_copy_by_kernel(s, dst, src, bytes);
 }
 
 static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)

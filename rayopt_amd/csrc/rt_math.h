@@ -349,7 +349,8 @@ RT_HD bool rt_newton_iterate(const rt_surface *__restrict__ S, unsigned flags,
 /*
  * `census` (measurement only, NULL in every product kernel and then no code):
  * census[0] counts the trips of this lane's wavefront through the iteration,
- * census[1] the iterates this lane's own rays needed -- their ratio over a
+ * census[1] the iterates this lane's own rays needed, census[2] the solves the
+ * wavefront entered with a live ray -- the ratio of the first two over a
  * launch is how many of the lanes a wavefront drags through the loop were
  * still iterating (rt_newton_census).
  *
@@ -378,6 +379,8 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
         live[r] = u[r][0] == u[r][0];
         any = any || live[r];
     }
+    if (census && RT_WAVE_ANY(any))
+        ++census[2]; /* a solve this wavefront enters */
 #pragma unroll 1
     for (int itr = 0; itr < 5; ++itr) {
         if (!RT_WAVE_ANY(any))
@@ -528,6 +531,8 @@ RT_HD void rt_newton_fast(const rt_surface *__restrict__ S, unsigned flags,
         live[r] = u[r][0] == u[r][0]; /* (dead on arrival: see rt_newton) */
         any = any || live[r];
     }
+    if (census && RT_WAVE_ANY(any))
+        ++census[2]; /* a solve this wavefront enters */
 #pragma unroll 1
     for (int itr = 0; itr < 5; ++itr) {
         if (!RT_WAVE_ANY(any))

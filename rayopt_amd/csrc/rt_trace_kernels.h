@@ -103,7 +103,7 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
  * counting -- per wavefront its trips through the iteration, per lane the
  * iterates its own ray needed.  out[0] += 64 x trips (lane slots the hardware
  * spent), out[1] += iterates (lane slots that did work), out[2] += trips,
- * out[3] += wavefronts that entered an iteration at all.
+ * out[3] += solves a wavefront entered with a live ray.
  */
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_census_kernel(const rt_surface *__restrict__ surf, int start, int stop,
@@ -121,7 +121,7 @@ rt_census_kernel(const rt_surface *__restrict__ surf, int start, int stop,
     const int64_t col = rt_col_wg(a, j, blockIdx.x);
     double y[1][3], u[1][3], iv[1][3], t[1];
     rt_load_state<1>(a, start - 1, col, y, u);
-    unsigned census[2] = {0u, 0u};
+    unsigned census[3] = {0u, 0u, 0u};
     {
         const rt_surface *S0 = surf + (start - 1);
         rt_leave<1>(S0, S0->flags, y, u);
@@ -146,7 +146,7 @@ rt_census_kernel(const rt_surface *__restrict__ surf, int start, int stop,
         atomicAdd(out + 0, 64ull * census[0]);
         atomicAdd(out + 1, (unsigned long long)mine);
         atomicAdd(out + 2, (unsigned long long)census[0]);
-        atomicAdd(out + 3, 1ull);
+        atomicAdd(out + 3, (unsigned long long)census[2]);
     }
 }
 
