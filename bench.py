@@ -104,6 +104,10 @@ def parse_args():
     ap.add_argument("--no-configs5", action="store_true",
                     help="skip the 10^8-ray one-GPU batch (104 GB)")
     ap.add_argument("--configs5-rays", type=int, default=0)
+    ap.add_argument("--only-config", choices=legs.CONFIG_KEYS, default=None,
+                    help="ONE config leg and nothing else (a leg's rocprofv3 "
+                         "--kernel-trace --stats run: profiles/r06_final/"
+                         "legs/); prints that leg's own JSON line")
     ap.add_argument("--option", action="append", default=[],
                     help="kernel variant key=value (rt_set_option)")
     return ap.parse_args()
@@ -124,6 +128,11 @@ def strict(obj):
 
 def main():
     args = parse_args()
+    if args.only_config:
+        import rayopt_amd as ra
+        print(json.dumps(strict(legs.only_config(ra, 0, args.only_config,
+                                                 args))))
+        return
     from rayopt_amd import distributed as D
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: one worker per GPU, this process

@@ -1139,6 +1139,120 @@ def parity_sample_of_a_large_batch(g, system, count):
                 np.isfinite(cols[RT_U][-1][:, 0]).mean())}
 
 
+CONFIG_KEYS = ("C1", "C2", "C3p", "C4", "C4x", "C5")
+
+
+def config_trace(ra, device, key, args):
+    """The workload of one BASELINE config, resident: dict with ``g`` (rays
+    set, not traced), ``system``, the host rays ``y, u`` (None for the batch
+    built on the device), wavelength(s) ``l``, ``n`` rays, the engine
+    ``options``, ``generated``, ``name``, ``kind``, ``note`` and the
+    reference's prescription ``text``."""
+    from rayopt_amd import prescriptions as P
+    import digest_cases as dc
+    big = 10_000_000 if not args.rays or args.rays >= 10**6 else args.rays
+    c = {"key": key, "options": {}, "generated": False, "note": "",
+         "kind": None, "y": None, "u": None}
+    if key == "C1":
+        # singlet, 10^4 rays, one wavelength (launch bound: 160 wavefronts)
+        c["system"] = ra.system_from_yaml(P.SINGLET)
+        c["text"] = P.SINGLET
+        c["y"], c["u"] = dc.bundle(10**4, 8., 0., 0)
+        c["l"] = c["system"].wavelengths[0]
+        c["name"] = "C1 singlet, 10^4 rays"
+        c["note"] = ("160 wavefronts on 256 CUs: bound by launch latency, "
+                     "not HBM")
+    elif key == "C2":
+        # Cooke triplet, 10^6 rays x 3 wavelengths as ONE launch (ray groups)
+        c["system"] = ra.system_from_yaml(P.COOKE % dict(
+            air="air", sk16="SCHOTT-SK|N-SK16", f2="SCHOTT-F|N-F2"))
+        c["text"] = None
+        c["y"], c["u"] = dc.bundle(10**6, 5.5, 5., 0)
+        c["l"] = [587.56e-9, 656.27e-9, 486.13e-9]
+        c["name"] = "C2 Cooke triplet, 10^6 rays x 3 wavelengths, one launch"
+        c["kind"] = "C2 3 x 10^6 rays"
+    elif key == "C3p":
+        # C3 with launch directions that differ from ray to ray (a bundle as
+        # rays_given gets it from a caller's own generator): only z = 0 is
+        # uniform across a 64-ray tile, the notes save 8 of 48 B per ray
+        c["system"] = ra.system_from_yaml(P.DOUBLE_GAUSS)
+        c["text"] = P.DOUBLE_GAUSS
+        y, u = workload_rays(big, 7)
+        rng = np.random.default_rng(3)
+        u[:, 0] += 1e-7*rng.standard_normal(big)
+        u[:, 1] += 1e-7*rng.standard_normal(big)
+        u[:, 2] = np.sqrt(1. - u[:, 0]**2 - u[:, 1]**2)
+        c["y"], c["u"] = y, u
+        c["l"] = c["system"].wavelengths[0]
+        c["name"] = ("C3 double-Gauss, %d rays, per-ray launch directions "
+                     "(no uniform direction to fetch once per wavefront)"
+                     % big)
+        c["note"] = ("the headline's bundles are collimated: their direction "
+                     "is read once per 64-ray tile; this is what a bundle "
+                     "with individual directions costs")
+        c["kind"] = "C3 host-seeded clip"
+    elif key in ("C4", "C4x"):
+        # aspheric phone lens, 10^7 rays: default and exact arithmetic
+        c["system"] = ra.system_from_yaml(P.ASPHERE_PHONE)
+        c["text"] = P.ASPHERE_PHONE
+        y, u = dc.bundle(big, .6, 10., 4)
+        y[:, 1] -= .5*np.tan(np.radians(10.))
+        c["y"], c["u"] = y, u
+        c["l"] = c["system"].wavelengths[0]
+        if key == "C4x":
+            c["options"] = {"exact_asphere": 1}
+        c["name"] = "C4 aspheric phone lens, %d rays, %s" % (
+            big, "exact_asphere=True (the reference's bits)" if key == "C4x"
+            else "default (FMA / rcp / rsq Newton, 1e-8 contract)")
+        c["kind"] = "C4 exact" if key == "C4x" else "C4 default"
+    elif key == "C5":
+        # double-Gauss, 10^8 rays built on the device (104 GB), ONE GPU
+        c["system"] = ra.system_from_yaml(P.DOUBLE_GAUSS)
+        c["text"] = P.DOUBLE_GAUSS
+        c["l"] = c["system"].wavelengths[0]
+        c["generated"] = True
+        c["kind"] = "C5 generated"
+        c["note"] = ("the 8-GPU form shards these rays and gathers y[L-1] "
+                     "over RCCL (bench.py --gpus 8 --total-rays 100000000)")
+    else:
+        raise ValueError("config %r: one of %s" % (key, CONFIG_KEYS))
+    g = ra.GeometricTrace(c["system"], device=device, **c["options"])
+    if key == "C5":
+        nf = len(FIELD_FRACTIONS)
+        m = (args.configs5_rays or 100_000_000)//nf//64*64
+        c["pupil_points"] = m
+        g.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS],
+                      dc.disc_points(m, 91), P.DOUBLE_GAUSS_PUPIL_Z,
+                      BUNDLE_RADIUS)
+        c["n"] = m*nf
+        c["name"] = ("C5 on one GPU: double-Gauss, %d rays built on the "
+                     "device" % c["n"])
+    else:
+        g.rays_given(c["y"], c["u"], c["l"])
+        c["n"] = len(c["y"])*len(np.atleast_1d(c["l"]))
+    c["g"] = g
+    return c
+
+
+def only_config(ra, device, key, args):
+    """``bench.py --only-config KEY``: ONE config leg and nothing else in the
+    process -- what a `rocprofv3 --kernel-trace --stats` run of a leg needs
+    (profiles/r06_final/legs/): every launch of the trace kernel in the
+    summary is this workload's.  Prints its own small JSON line."""
+    c = config_trace(ra, device, key, args)
+    g = c["g"]
+    g.propagate(clip=True)
+    ms = kernel_ms_of(g, True)
+    pl = g.engine.placement()
+    return {"only_config": key, "config": c["name"], "rays": c["n"],
+            "surfaces": len(c["system"]) - 1, "kernel_ms": ms,
+            "kernel": "rt_trace_gen_kernel" if c["generated"]
+            else "rt_trace_kernel",
+            "store_pattern_GBps_per_piece_set":
+                pl["store_pattern_GBps_per_piece_set"],
+            "per_class": pl["per_class"]}
+
+
 def run_configs(ra, device, args, live=None):
     """One record per BASELINE config (C3 is the headline itself)."""
     from rayopt_amd import prescriptions as P
@@ -1190,11 +1304,10 @@ def run_configs(ra, device, args, live=None):
                "parity_subsample": parity,
                "cpu_reference": ref}
         pl = g.engine.placement()
-        rec["placement"] = {k: pl[k] for k in ("pieces", "piece_mib",
-                                               "per_class", "fast", "store_pattern_GBps",
-                                               "store_pattern_GBps_per_piece_set",
-                                               "created", "ballast_blocks",
-                                               "search_ms")}
+        rec["placement"] = {k: pl[k] for k in (
+            "pieces", "piece_mib", "per_class", "fast", "store_pattern_GBps",
+            "store_pattern_GBps_per_piece_set", "created", "ballast_blocks",
+            "search_ms", "search_cut_short")}
         rec["_kind"] = kind
         if kind and kind.startswith("C4"):
             # how many of the lanes a wavefront drags through the asphere
@@ -1211,94 +1324,46 @@ def run_configs(ra, device, args, live=None):
         out.append(rec)
         log("[configs] %s: %.4f ms, frac %.3f" % (name, ms, rec["frac"]))
 
-    # C1: singlet, 10^4 rays, one wavelength (launch-latency bound: 40 waves)
-    s1 = ra.system_from_yaml(P.SINGLET)
-    y, u = dc.bundle(10**4, 8., 0., 0)
-    l1 = s1.wavelengths[0]
-    g = ra.GeometricTrace(s1, device=device)
-    g.rays_given(y, u, l1)
-    record("C1 singlet, 10^4 rays", s1, g, len(y), l1, True, False,
-           subsample_parity(ra, device, s1, y, u, l1, True, {}),
-           reference_rate(P.SINGLET, y, u, l1, True, 10**4),
-           "160 wavefronts on 256 CUs: bound by launch latency, not HBM")
-    # C2: Cooke triplet, 10^6 rays x 3 wavelengths as ONE launch (ray groups)
-    s2 = ra.system_from_yaml(P.COOKE % dict(
-        air="air", sk16="SCHOTT-SK|N-SK16", f2="SCHOTT-F|N-F2"))
-    ls = [587.56e-9, 656.27e-9, 486.13e-9]
-    y, u = dc.bundle(10**6, 5.5, 5., 0)
-    g = ra.GeometricTrace(s2, device=device)
-    g.rays_given(y, u, l=ls)
-    ref = None
-    if refshim.available():
-        rates = [reference_rate(P.cooke(lk), y, u, lk, True, 100_000)
-                 for lk in ls]
-        ref = {"value": sum(r["rays"] for r in rates)*(len(s2) - 1) /
-               sum(r["seconds"] for r in rates), "kind": "reference",
-               "rays": rates[0]["rays"], "note": "three traces, one per "
-               "wavelength, as the reference has to run them"}
-    record("C2 Cooke triplet, 10^6 rays x 3 wavelengths, one launch", s2, g,
-           3*len(y), ls, True, False,
-           subsample_parity(ra, device, s2, y, u, ls, True, {}, 64*1500),
-           ref, kind="C2 3 x 10^6 rays")
-    del g
-    # C3 again with launch directions that differ from ray to ray (a bundle
-    # as rays_given gets it from a caller's own generator): only z = 0 is
-    # uniform across a 64-ray tile, the tile notes save 8 of 48 B per ray
-    s3 = ra.system_from_yaml(P.DOUBLE_GAUSS)
-    n3 = 10_000_000 if not args.rays or args.rays >= 10**6 else args.rays
-    y, u = workload_rays(n3, 7)
-    rng = np.random.default_rng(3)
-    u[:, 0] += 1e-7*rng.standard_normal(n3)
-    u[:, 1] += 1e-7*rng.standard_normal(n3)
-    u[:, 2] = np.sqrt(1. - u[:, 0]**2 - u[:, 1]**2)
-    g = ra.GeometricTrace(s3, device=device)
-    g.rays_given(y, u)
-    record("C3 double-Gauss, %d rays, per-ray launch directions (no "
-           "uniform direction to fetch once per wavefront)" % n3, s3, g, n3,
-           s3.wavelengths[0], True, False,
-           subsample_parity(ra, device, s3, y, u, s3.wavelengths[0], True, {}),
-           None, "the headline's bundles are collimated: their direction is "
-           "read once per 64-ray tile; this is what a bundle with individual "
-           "directions costs", kind="C3 host-seeded clip")
-    del g, y, u
-    # C4: aspheric phone lens, 10^7 rays: default and exact arithmetic
-    s4 = ra.system_from_yaml(P.ASPHERE_PHONE)
-    n4 = 10_000_000 if not args.rays or args.rays >= 10**6 else args.rays
-    y, u = dc.bundle(n4, .6, 10., 4)
-    y[:, 1] -= .5*np.tan(np.radians(10.))
-    l4 = s4.wavelengths[0]
-    ref4 = reference_rate(P.ASPHERE_PHONE, y, u, l4, True, 3000)
-    if ref4 is not None:
-        ref4["note"] = ("per-ray scipy.optimize.newton in a Python loop "
-                        "(rayopt/elements.py:333-349): timed on 3000 rays "
-                        "and extrapolated, BASELINE.md 3.4")
-    for label, opts in (("default (FMA / rcp / rsq Newton, 1e-8 contract)",
-                         {}), ("exact_asphere=True (the reference's bits)",
-                               {"exact_asphere": 1})):
-        g = ra.GeometricTrace(s4, device=device, **opts)
-        g.rays_given(y, u, l4)
-        record("C4 aspheric phone lens, %d rays, %s" % (n4, label), s4, g,
-               n4, l4, True, False,
-               subsample_parity(ra, device, s4, y, u, l4, True, opts), ref4,
-               kind="C4 exact" if opts else "C4 default")
-        del g
-    del y, u
-    # C5 on ONE GPU: double-Gauss, 10^8 rays built on the device (104 GB)
-    if not args.no_configs5:
-        s5 = ra.system_from_yaml(P.DOUBLE_GAUSS)
-        nf = len(FIELD_FRACTIONS)
-        m = (args.configs5_rays or 100_000_000)//nf//64*64
-        pts = dc.disc_points(m, 91)
-        g = ra.GeometricTrace(s5, device=device)
-        g.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS], pts,
-                      P.DOUBLE_GAUSS_PUPIL_Z, BUNDLE_RADIUS)
-        g.propagate(clip=True)
-        record("C5 on one GPU: double-Gauss, %d rays built on the device"
-               % (m*nf), s5, g, m*nf, s5.wavelengths[0], True, True,
-               parity_sample_of_a_large_batch(g, s5, 10_000), None,
-               "the 8-GPU form shards these rays and gathers y[L-1] "
-               "over RCCL (bench.py --gpus 8 --total-rays 100000000)",
-               kind="C5 generated")
+    ref4 = None
+    for key in CONFIG_KEYS:
+        if key == "C5" and args.no_configs5:
+            continue
+        c = config_trace(ra, device, key, args)
+        g, system, y, u, l = c["g"], c["system"], c["y"], c["u"], c["l"]
+        if key == "C5":
+            g.propagate(clip=True)
+            parity = parity_sample_of_a_large_batch(g, system, 10_000)
+            ref = None
+        else:
+            m = {"C2": 64*1500}.get(key, 100_000)
+            parity = subsample_parity(ra, device, system, y, u, l, True,
+                                      c["options"], m)
+            ref = None
+            if key == "C1":
+                ref = reference_rate(c["text"], y, u, l, True, 10**4)
+            elif key == "C2" and refshim.available():
+                rates = [reference_rate(P.cooke(lk), y, u, lk, True, 100_000)
+                         for lk in l]
+                ref = {"value": sum(r["rays"] for r in rates) *
+                       (len(system) - 1)/sum(r["seconds"] for r in rates),
+                       "kind": "reference", "rays": rates[0]["rays"],
+                       "note": "three traces, one per wavelength, as the "
+                               "reference has to run them"}
+            elif key in ("C4", "C4x"):
+                if ref4 is None:
+                    ref4 = reference_rate(c["text"], y, u, l, True, 3000)
+                    if ref4 is not None:
+                        ref4["note"] = (
+                            "per-ray scipy.optimize.newton in a Python loop "
+                            "(rayopt/elements.py:333-349): timed on 3000 "
+                            "rays and extrapolated, BASELINE.md 3.4")
+                ref = ref4
+        record(c["name"], system, g, c["n"], l, True, c["generated"], parity,
+               ref, c["note"], kind=c["kind"])
+        if key != "C5":
+            del g, c, y, u
+            continue
+        s5, m, nf = system, c["pupil_points"], len(FIELD_FRACTIONS)
         out[-1]["finite_fraction_at_image_sampled"] = \
             out[-1]["parity_subsample"].pop("finite_fraction_at_image")
         if args.extras:
@@ -1319,7 +1384,7 @@ def run_configs(ra, device, args, live=None):
                 "kernel_ms_min_max": [min(t[2:]), max(t[2:])]}
             log("[configs] C5, launches 30 ms apart: %.4f ms"
                 % out[-1]["launches_30_ms_apart"]["kernel_ms"])
-        del g
+        del g, c
         # the same rays as TEN batches of a tenth each, ten contexts traced
         # in turn: the cross-check of the layout in blocks (csrc/rt_lay.h) --
         # as ONE block this batch took 12.0 ms, the ten batches 10.3; in

@@ -796,9 +796,11 @@ int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
                                                 rt_pin_event_flags()));
         }
     int k = 0;
-    for (size_t off = 0; off < bytes; off += RT_PIN_CHUNK, k ^= 1) {
-        const size_t len = bytes - off < RT_PIN_CHUNK ? bytes - off
-                                                      : RT_PIN_CHUNK;
+    /* the first chunk is a quarter: nothing crosses PCIe while it is staged */
+    size_t len = 0;
+    for (size_t off = 0; off < bytes; off += len, k ^= 1) {
+        const size_t chunk = off ? RT_PIN_CHUNK : RT_PIN_CHUNK / 4;
+        len = bytes - off < chunk ? bytes - off : chunk;
         if (ctx->pin_busy[k]) /* this call's or an earlier call's DMA */
             RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[k]));
         rt_memcpy_mt(ctx->h_pin[k], (const char *)src + off, len,
@@ -865,8 +867,12 @@ static int rt_d2h_jobs(rt_ctx *ctx, const rt_copy_job *jobs, size_t njobs)
         /* a job in equal chunks (40 MB: 20 + 20, not 32 + 8: the short
          * ones cost a DMA call and a team of threads like the long ones) */
         const size_t pieces = (jobs[j].bytes + RT_PIN_CHUNK - 1) / RT_PIN_CHUNK;
-        const size_t even = ((jobs[j].bytes + pieces - 1) / pieces + 4095) &
-                            ~(size_t)4095;
+        size_t even = ((jobs[j].bytes + pieces - 1) / pieces + 4095) &
+                      ~(size_t)4095;
+        /* the very first chunk is short: no host thread copies while it
+         * crosses PCIe */
+        if (j == 0 && off == 0 && even > RT_PIN_CHUNK / 4)
+            even = RT_PIN_CHUNK / 4;
         *len = jobs[j].bytes - off < even ? jobs[j].bytes - off : even;
         *dst = (char *)jobs[j].dst + off;
         *src = (const char *)jobs[j].src + off;
@@ -1409,7 +1415,8 @@ int rt_newton_census(rt_ctx *ctx, int clip, uint64_t out[4])
     const unsigned grid = (unsigned)((ctx->ld + RT_BLOCK - 1) / RT_BLOCK);
     hipLaunchKernelGGL(rt_census_kernel, dim3(grid), dim3(RT_BLOCK), 0,
                        ctx->stream, ctx->d_surf, 1, ctx->nsurf, clip, lay,
-                       ctx->ld, group_rays, ctx->nsurf, ctx->ngroups, d);
+                       ctx->ld, ctx->n, group_rays, ctx->nsurf, ctx->ngroups,
+                       d);
     RT_HIP(ctx, hipGetLastError());
     unsigned long long h[4];
     RT_HIP(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost,

@@ -107,8 +107,8 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
  */
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_census_kernel(const rt_surface *__restrict__ surf, int start, int stop,
-                 int clip, rt_lay a, int64_t ld, int64_t group_rays, int nsurf,
-                 int ngroups, unsigned long long *__restrict__ out)
+                 int clip, rt_lay a, int64_t ld, int64_t n, int64_t group_rays,
+                 int nsurf, int ngroups, unsigned long long *__restrict__ out)
 {
     const int64_t j = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (j >= ld)
@@ -121,6 +121,8 @@ rt_census_kernel(const rt_surface *__restrict__ surf, int start, int stop,
     const int64_t col = rt_col_wg(a, j, blockIdx.x);
     double y[1][3], u[1][3], iv[1][3], t[1];
     rt_load_state<1>(a, start - 1, col, y, u);
+    if (j >= n) /* padding slots (zeros in row 0) are no rays */
+        u[0][0] = u[0][1] = u[0][2] = RT_NAN;
     unsigned census[3] = {0u, 0u, 0u};
     {
         const rt_surface *S0 = surf + (start - 1);
