@@ -428,8 +428,8 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value);
  * out[0] = lane slots spent in the iteration (64 x wavefront trips),
  * out[1] = iterates the rays needed (lane slots that did work; out[1] / out[0]
  * is the lane utilisation), out[2] = wavefront trips, out[3] = wavefront
- * solves (one per wavefront and aspheric element with a live ray).  Rays that
- * arrive dead (NaN direction) are retired before the loop and count nowhere.
+ * solves (one per wavefront and aspheric element).  A ray whose iterate is
+ * NaN -- every ray that arrives dead -- is retired after that iterate.
  */
 int rt_newton_census(rt_ctx *ctx, int clip, uint64_t out[4]);
 

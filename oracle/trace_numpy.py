@@ -147,8 +147,10 @@ def surface_normal(s, xyz):
 
 
 # Census of the iteration (tests of rt_newton_census only): when this is a
-# list, newton_intercept appends one int array per call -- the iterates
-# every ray went through, 0 for a ray that arrived dead (NaN direction).
+# list, newton_intercept appends per call (iterates, dead) -- the iterates
+# every ray went through until its result was decided (an iterate that is NaN
+# decides it: every later one is NaN as well and the solver ends in NaN), and
+# which rays arrived with a NaN direction.
 ITERATES = None
 
 
@@ -187,11 +189,12 @@ def newton_intercept(s, y, u, tol=1e-7, maxiter=5):
             close = np.where(fin, np.abs(p - pi) <= tol, p == pi)
             conv = close & ~zero & ~dzero
             out[idx[conv]] = p[conv]
-            done = zero | dzero | conv
+            # (a NaN iterate: nothing changes any more -- out stays NaN)
+            done = zero | dzero | conv | np.isnan(p)
             p0[idx] = p
             live[idx[done]] = False
     if ITERATES is not None:
-        ITERATES.append(np.where(np.isnan(u[:, 0]), 0, iterates))
+        ITERATES.append((iterates, np.isnan(u[:, 0])))
     return out
 
 

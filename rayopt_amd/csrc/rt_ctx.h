@@ -228,6 +228,8 @@ struct rt_ctx {
     /* per row of U: 1 = identical to I[j] (RT_F_SKIP_U), not materialised */
     unsigned char u_alias[RT_MAX_SURFACES];
     int table_clip; /* clip the device table was finalised for */
+    int table_asph; /* some element of some table is aspheric: the trace
+                       kernels with the Newton solves (else the lean ones) */
 
     /* multi GPU (rt_comm.hip) */
     ncclComm_t comm;

@@ -1240,7 +1240,10 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
             if (ctx->h_surf[jj].flags & RT_F_ROTATED)
                 tilted[jj % ctx->nsurf] = 1;
         }
+        ctx->table_asph = ctx->gen_s0.flags & RT_F_ASPH ? 1 : 0;
         for (int jj = 0; jj < ntab; ++jj) {
+            if (ctx->h_surf[jj].flags & RT_F_ASPH)
+                ctx->table_asph = 1; /* (else: the kernels without Newton) */
             const int j = jj % ctx->nsurf; /* element index in its group */
             unsigned f = ctx->h_stage[jj].flags &
                          ~(RT_F_STORE_I | RT_F_NOSTORE | RT_F_SKIP_U);
@@ -1344,7 +1347,10 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
             order.per = (uint32_t)(ctx->gen_np / RT_BLOCK);
             order.nf = (uint32_t)(ctx->gen_n / ctx->gen_np);
         }
-        hipLaunchKernelGGL(rt_trace_gen_kernel, dim3(grid), dim3(RT_BLOCK),
+        const bool asph = ctx->table_asph || (ctx->gen_s0.flags & RT_F_ASPH);
+        hipLaunchKernelGGL(asph ? rt_trace_gen_kernel<true>
+                                : rt_trace_gen_kernel<false>,
+                           dim3(grid), dim3(RT_BLOCK),
                            lds, ctx->stream, ctx->d_surf, stop, clip, lay, cols,
                            group_rays, ctx->nsurf, ctx->ngroups,
                            (const rt_field *)ctx->d_gen,
@@ -1365,7 +1371,9 @@ static int rt_trace_window(rt_ctx *ctx, int start, int stop, int clip,
          * fetched once per wavefront (the seed kernels' notes on row 0) */
         const rt_tiles tiles = rt_tiles_of(
             ctx, lo / 64, start == 1 && ctx->uni_valid && ctx->opt_uniform);
-        hipLaunchKernelGGL(rt_trace_kernel, dim3(grid), dim3(RT_BLOCK), lds,
+        hipLaunchKernelGGL(ctx->table_asph ? rt_trace_kernel<true>
+                                           : rt_trace_kernel<false>,
+                           dim3(grid), dim3(RT_BLOCK), lds,
                            ctx->stream, ctx->d_surf, start, stop, clip, lay,
                            cols, group_rays, ctx->nsurf, ctx->ngroups, tiles);
         RT_HIP(ctx, hipGetLastError());

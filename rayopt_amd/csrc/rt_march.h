@@ -115,7 +115,21 @@ __device__ __forceinline__ void rt_store_rows(
 }
 
 /* all elements start..stop-1 for the R rays of this lane; state in VGPRs */
-template <int R, int NT>
+/*
+ * ASPH = false: the table holds no aspheric element (the host knows: it
+ * finalises the flags).  Their bits are masked out of `flags` HERE, where the
+ * compiler can see it, so that everything behind them -- both Newton solves,
+ * the fast refraction, the aspheric normals -- is not in that instantiation
+ * at all: the kernel of a system of planes, spheres and conics is a third of
+ * the code, and what the compiler makes of it no longer moves when the
+ * asphere code is touched (round 6: 153 -> 238 VALU instructions per
+ * ray-surface op in the generated-batch kernel of the double-Gauss from a
+ * change inside the Newton loop it never runs).
+ */
+#define RT_FLAGS_OF(S, ASPH)                                                  \
+    ((ASPH) ? (S)->flags : ((S)->flags & ~(RT_F_ASPH | RT_F_FAST)))
+
+template <int R, int NT, bool ASPH = true>
 __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
                                          int start, int stop, int clip,
                                          const rt_lay &a, int64_t col,
@@ -129,7 +143,7 @@ __device__ __forceinline__ void rt_march(const rt_surface *__restrict__ surf,
     }
     for (int s = start; s < stop; ++s) {
         const rt_surface *S = surf + s;
-        const unsigned flags = S->flags;
+        const unsigned flags = RT_FLAGS_OF(S, ASPH);
         /* a ray whose direction is NaN (clipped, missed, TIR, Newton failure:
          * elements.py:206-209,:496,:367,:347) yields NaN in every array of
          * every later element; a wavefront with no other ray left stores

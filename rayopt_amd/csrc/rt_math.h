@@ -347,22 +347,29 @@ RT_HD bool rt_newton_iterate(const rt_surface *__restrict__ S, unsigned flags,
 }
 
 /*
- * `census` (measurement only, NULL in every product kernel and then no code):
+ * CENSUS / `census` (measurement only: a template parameter, so that the
+ * product kernels' instantiations carry no trace of it -- the code the
+ * compiler makes of this file is touchy: round 6 saw 153 -> 238 VALU
+ * instructions per ray-surface op in the generated-batch kernel, on a system
+ * WITHOUT aspheres, from a counter behind a NULL check in here):
  * census[0] counts the trips of this lane's wavefront through the iteration,
  * census[1] the iterates this lane's own rays needed, census[2] the solves the
  * wavefront entered with a live ray -- the ratio of the first two over a
  * launch is how many of the lanes a wavefront drags through the loop were
  * still iterating (rt_newton_census).
  *
- * A ray that arrives dead (its direction NaN-poisoned by an earlier clip,
- * miss or total reflection: the march's own criterion u_x != u_x) can only
- * leave as NaN -- its first iterate is NaN and NaN is never close to anything,
- * so the reference's solver runs out of iterations and yields NaN
- * (elements.py:345-348).  It is retired before the loop: one vignetted ray
- * no longer holds its whole wavefront for all five trips at every asphere
- * behind the stop.
+ * A ray whose iterate has become NaN is retired: NaN is never close to
+ * anything and every later iterate is NaN again, so the reference's solver
+ * runs out of iterations and yields NaN (elements.py:345-348) -- the result is
+ * decided.  That is every ray that ARRIVES dead (its direction NaN-poisoned by
+ * an earlier clip, miss or total reflection): after one trip instead of five,
+ * so that one vignetted ray no longer holds its wavefront for the whole
+ * iteration at every asphere behind the stop.  (Retiring such rays before
+ * the loop, on their direction, does the same in zero trips and was measured
+ * 3.8 % slower on C4, where no ray is dead -- the compiler's doing, not the
+ * compare's; this form costs 0.7 %: scripts/variant_ab.py, round 6.)
  */
-template <int R, int NA>
+template <int R, int NA, bool CENSUS = false>
 RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
                      const double (&y)[R][3], const double (&u)[R][3],
                      double (&s)[R], unsigned *census = nullptr)
@@ -376,25 +383,28 @@ RT_HD void rt_newton(const rt_surface *__restrict__ S, unsigned flags,
     for (int r = 0; r < R; ++r) {
         s[r] = -y[r][2] / u[r][2];
         res[r] = RT_NAN;
-        live[r] = u[r][0] == u[r][0];
-        any = any || live[r];
+        live[r] = true;
+        any = true;
     }
-    if (census && RT_WAVE_ANY(any))
-        ++census[2]; /* a solve this wavefront enters */
+    if constexpr (CENSUS) {
+        if (RT_WAVE_ANY(any))
+            ++census[2]; /* a solve this wavefront enters */
+    }
 #pragma unroll 1
     for (int itr = 0; itr < 5; ++itr) {
         if (!RT_WAVE_ANY(any))
             break;
         any = false;
-        if (census)
+        if constexpr (CENSUS)
             ++census[0];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (!live[r])
                 continue;
-            if (census)
+            if constexpr (CENSUS)
                 ++census[1];
-            if (rt_newton_iterate_t<NA>(A, flags, y[r], u[r], s[r], res[r]))
+            if (rt_newton_iterate_t<NA>(A, flags, y[r], u[r], s[r], res[r]) ||
+                s[r] != s[r])
                 live[r] = false;
             else
                 any = true;
@@ -507,7 +517,7 @@ RT_HD void rt_poly_fast(const double (&a)[NA], const double (&da)[NA],
     dpoly = d;
 }
 
-template <int R, int NA>
+template <int R, int NA, bool CENSUS = false>
 RT_HD void rt_newton_fast(const rt_surface *__restrict__ S, unsigned flags,
                           const double (&y)[R][3], const double (&u)[R][3],
                           double (&s)[R], unsigned *census = nullptr)
@@ -528,23 +538,25 @@ RT_HD void rt_newton_fast(const rt_surface *__restrict__ S, unsigned flags,
     for (int r = 0; r < R; ++r) {
         s[r] = -y[r][2] * rt_rcp_fast<2>(u[r][2]);
         res[r] = RT_NAN;
-        live[r] = u[r][0] == u[r][0]; /* (dead on arrival: see rt_newton) */
-        any = any || live[r];
+        live[r] = true;
+        any = true;
     }
-    if (census && RT_WAVE_ANY(any))
-        ++census[2]; /* a solve this wavefront enters */
+    if constexpr (CENSUS) {
+        if (RT_WAVE_ANY(any))
+            ++census[2]; /* a solve this wavefront enters */
+    }
 #pragma unroll 1
     for (int itr = 0; itr < 5; ++itr) {
         if (!RT_WAVE_ANY(any))
             break;
         any = false;
-        if (census)
+        if constexpr (CENSUS)
             ++census[0];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (!live[r])
                 continue;
-            if (census)
+            if constexpr (CENSUS)
                 ++census[1];
             const double px = rt_fma(s[r], u[r][0], y[r][0]);
             const double py = rt_fma(s[r], u[r][1], y[r][1]);
@@ -594,7 +606,10 @@ RT_HD void rt_newton_fast(const rt_surface *__restrict__ S, unsigned flags,
                 continue;
             }
             s[r] = p;
-            any = true;
+            if (p == p)
+                any = true;
+            else
+                live[r] = false; /* NaN stays NaN: see rt_newton */
         }
     }
 #pragma unroll
@@ -743,21 +758,22 @@ RT_HD void rt_bend_fast(const rt_surface *__restrict__ S, unsigned flags,
  * Ray length to the element's surface: Spheroid.intercept (elements.py:
  * 477-501) -- Newton for aspheres, plane, or the closed-form conic root.
  */
-template <int R>
+template <int R, bool CENSUS = false>
 RT_HD void rt_intercept(const rt_surface *__restrict__ S, unsigned flags,
                         const double (&y)[R][3], const double (&iv)[R][3],
                         double (&s)[R], unsigned *census = nullptr)
 {
     if (flags & RT_F_FAST) {
         RT_FAST_DISPATCH(
-            (rt_newton_fast<R, 4>(S, flags, y, iv, s, census)),
-            (rt_newton_fast<R, 7>(S, flags, y, iv, s, census)),
-            (rt_newton_fast<R, RT_MAX_ASPH>(S, flags, y, iv, s, census)));
-    } else if (flags & RT_F_ASPH) {
-        RT_FAST_DISPATCH((rt_newton<R, 4>(S, flags, y, iv, s, census)),
-                         (rt_newton<R, 7>(S, flags, y, iv, s, census)),
-                         (rt_newton<R, RT_MAX_ASPH>(S, flags, y, iv, s,
+            (rt_newton_fast<R, 4, CENSUS>(S, flags, y, iv, s, census)),
+            (rt_newton_fast<R, 7, CENSUS>(S, flags, y, iv, s, census)),
+            (rt_newton_fast<R, RT_MAX_ASPH, CENSUS>(S, flags, y, iv, s,
                                                     census)));
+    } else if (flags & RT_F_ASPH) {
+        RT_FAST_DISPATCH(
+            (rt_newton<R, 4, CENSUS>(S, flags, y, iv, s, census)),
+            (rt_newton<R, 7, CENSUS>(S, flags, y, iv, s, census)),
+            (rt_newton<R, RT_MAX_ASPH, CENSUS>(S, flags, y, iv, s, census)));
     } else if (!(flags & RT_F_CURVED)) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -811,6 +827,7 @@ RT_HD void rt_intercept(const rt_surface *__restrict__ S, unsigned flags,
  * Infinite/FiniteConjugate.aim after the per-field frame has been built by
  * the host (conjugates.py:137-166, 236-255; Pupil.map pupils.py:97-107).
  */
+template <bool ASPH = true>
 RT_HD void rt_generate_ray(const rt_field *__restrict__ F, double px,
                            double py, const rt_surface *__restrict__ S0,
                            double (&y)[1][3], double (&u)[1][3])
@@ -824,7 +841,8 @@ RT_HD void rt_generate_ray(const rt_field *__restrict__ F, double px,
             y[0][c] = F->base[c] + (px * F->s[c] + py * F->m[c]);
         }
         double t[1]; /* y += surface.intercept(y, u) u  (:253-254) */
-        rt_intercept<1>(S0, S0->flags, y, u, t);
+        rt_intercept<1>(S0, ASPH ? S0->flags
+                             : S0->flags & ~(RT_F_ASPH | RT_F_FAST), y, u, t);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             y[0][c] = y[0][c] + t[0] * u[0][c];
@@ -852,7 +870,7 @@ RT_HD void rt_generate_ray(const rt_field *__restrict__ F, double px,
  * y = intercept, u = outgoing direction, iv = incoming direction, t = OPL,
  * all in the element-normal frame (the tuple System.propagate yields).
  */
-template <int R>
+template <int R, bool CENSUS = false>
 RT_HD void rt_step_hit(const rt_surface *__restrict__ S, unsigned flags,
                        double (&y)[R][3], const double (&u)[R][3],
                        double (&iv)[R][3], double (&t)[R],
@@ -875,7 +893,7 @@ RT_HD void rt_step_hit(const rt_surface *__restrict__ S, unsigned flags,
 
     /* intercept */
     double s[R];
-    rt_intercept<R>(S, flags, y, iv, s, census);
+    rt_intercept<R, CENSUS>(S, flags, y, iv, s, census);
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -66,6 +66,7 @@ __device__ __forceinline__ void rt_load_state_tiles(
     }
 }
 
+template <bool ASPH>
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
                 int clip, rt_lay a, int64_t ld, int64_t group_rays, int nsurf,
@@ -94,7 +95,7 @@ rt_trace_kernel(const rt_surface *__restrict__ surf, int start, int stop,
     } else {
         rt_load_state<1>(a, start - 1, col, y, u);
     }
-    rt_march<1, RT_ROWS_NT>(surf, start, stop, clip, a, col, y, u);
+    rt_march<1, RT_ROWS_NT, ASPH>(surf, start, stop, clip, a, col, y, u);
 }
 
 /*
@@ -132,7 +133,7 @@ rt_census_kernel(const rt_surface *__restrict__ surf, int start, int stop,
         const rt_surface *S = surf + s;
         const unsigned flags = S->flags;
         if (RT_WAVE_ANY(u[0][0] == u[0][0])) {
-            rt_step_hit<1>(S, flags, y, u, iv, t, census);
+            rt_step_hit<1, true>(S, flags, y, u, iv, t, census);
             rt_step_bend<1>(S, flags, clip, y, iv, u);
         } else {
 #pragma unroll
@@ -141,7 +142,7 @@ rt_census_kernel(const rt_surface *__restrict__ surf, int start, int stop,
         }
         rt_leave<1>(S, flags, y, u);
     }
-    unsigned mine = census[1];
+    unsigned mine = j < n ? census[1] : 0u; /* (padding slots: no rays) */
     for (int off = 32; off > 0; off >>= 1)
         mine += __shfl_down(mine, off);
     if ((threadIdx.x & 63) == 0 && census[0]) {
@@ -162,6 +163,7 @@ rt_census_kernel(const rt_surface *__restrict__ surf, int start, int stop,
  * batch from element 1 (store0 = 0) build the rays again the same way --
  * the values row 0 holds, bit for bit -- instead of reading them.
  */
+template <bool ASPH>
 __global__ void __launch_bounds__(RT_BLOCK)
 rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
                     rt_lay a, int64_t ld, int64_t group_rays, int nsurf,
@@ -187,8 +189,9 @@ rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
     double y[1][3] = {{0., 0., 0.}}, u[1][3] = {{0., 0., 0.}};
     if (j < n) {
         const int64_t p = j % npupil;
-        rt_generate_ray(fields + j / npupil, pupil[2 * p], pupil[2 * p + 1],
-                        &S0, y, u);
+        /* (ASPH = false: the first element is no asphere either) */
+        rt_generate_ray<ASPH>(fields + j / npupil, pupil[2 * p],
+                              pupil[2 * p + 1], &S0, y, u);
     }
     const int64_t col = rt_col_wg(a, w, wg);
     if (store0) { /* first trace of the batch; later ones leave row 0 alone */
@@ -201,7 +204,7 @@ rt_trace_gen_kernel(const rt_surface *__restrict__ surf, int stop, int clip,
         }
         a.T[col] = 0.;
     }
-    rt_march<1, RT_ROWS_NT>(surf, 1, stop, clip, a, col, y, u);
+    rt_march<1, RT_ROWS_NT, ASPH>(surf, 1, stop, clip, a, col, y, u);
 }
 
 /*
