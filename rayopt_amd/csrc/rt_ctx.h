@@ -147,6 +147,7 @@ struct rt_ctx {
     int64_t bs, bts;
     int nblk;
     int opt_block; /* rays per block asked for (0: chosen by rt_reserve) */
+    int opt_pitch; /* row pitch rounded up to a multiple of this many rays */
     int64_t opt_turn; /* pupil points per turn of a generated batch (rt_gen_wg):
                          0 automatic, -1 never */
     int buf_nsurf; /* L the buffer is laid out for */

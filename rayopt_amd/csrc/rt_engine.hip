@@ -512,6 +512,11 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     int64_t bs;
     int nblk;
     rt_block_plan(ctx->nsurf, ctx->opt_block, quantum, nrays, &bs, &nblk);
+    if (ctx->opt_pitch > 0) {
+        /* the row pitch (= rays per block) a multiple of opt_pitch rays */
+        bs = (bs + ctx->opt_pitch - 1) / ctx->opt_pitch * ctx->opt_pitch;
+        nblk = nblk > 1 ? (int)((nrays + bs - 1) / bs) : 1;
+    }
     const int64_t ld = bs * nblk;
     rt_pieces_reset(ctx);
     ctx->opd_n = 0; /* path differences kept on the device: of the old batch */
@@ -1565,6 +1570,14 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
             return rt_fail(ctx, RT_ERR_ARG, "block_rays: 0 (automatic) or a "
                                             "number of rays");
         ctx->opt_block = value;
+    } else if (!strcmp(key, "pitch_rays")) {
+        /* takes effect with the next rt_reserve: the row pitch is rounded up
+         * to a multiple of this many rays (a multiple of 256; 0: the
+         * library's choice) */
+        if (value < 0 || value % 256)
+            return rt_fail(ctx, RT_ERR_ARG, "pitch_rays: 0 or a multiple of "
+                                            "256 rays");
+        ctx->opt_pitch = value;
     } else if (!strcmp(key, "turn_points")) {
         /* pupil points per turn of a generated batch of several bundles
          * (rt_gen_wg): 0 automatic, -1 never, else that many (tests) */

@@ -248,6 +248,12 @@ static bool rt_place_coherent(rt_ctx *c)
  */
 #define RT_PLACE_BUDGET_MS 250.
 #define RT_PLACE_STALL_MS 200.
+/* ... unless what there is so far is ONE class: such arrays write at 5.5
+ * instead of 6.9 TB/s for as long as they live (round 6, pitch_lab3: a
+ * single slow ballast block ended a search at [11, 0, 0]), so the search for
+ * a second class goes on past the budget and past a stall, up to this many
+ * milliseconds after the budget's clock started */
+#define RT_PLACE_HARD_MS 3000.
 
 static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
 {
@@ -262,6 +268,8 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     const bool choice = c->place_deadline_ms > 0.;
     double deadline = choice ? c->place_deadline_ms : 1e300;
     bool stalled = false, out_of_time = false;
+    bool have_mix = false; /* `need` pieces could be picked, none of their
+                              classes holding more than half */
     float slowest_create = 0.f;
     double t_ballast = 0.;
 
@@ -271,7 +279,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     {
         const char *e = getenv("RT_MI355_PIECE_MIB");
         const long mib = e ? atol(e) : 0;
-        if (mib >= 512 && mib <= 65536)
+        if (mib >= 64 && mib <= 65536)
             piece = (size_t)mib << 20;
     }
     if (bytes < 3 * piece)
@@ -325,6 +333,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     hipMemGenericAllocationHandle_t *h =
         (hipMemGenericAllocationHandle_t *)calloc(cap, sizeof *h);
     unsigned char *cls = (unsigned char *)calloc(cap, 1);
+    float *ratio = (float *)calloc(cap, sizeof(float)); /* (the log's) */
     void *scratch = NULL; /* every created piece at scratch + k * piece */
     int made = 0, mapped = 0, nclass = 0, rep[RT_PLACE_CLASSES];
     int count[RT_PLACE_CLASSES] = {0};
@@ -342,7 +351,9 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         if (made >= need && extra + piece > budget)
             break; /* the surplus has reached its share of the free memory */
         if (made >= need &&
-            (stalled || (out_of_time = rt_place_now_ms() > deadline)))
+            (stalled || (out_of_time = rt_place_now_ms() > deadline)) &&
+            (have_mix || choice ||
+             rt_place_now_ms() > deadline + RT_PLACE_HARD_MS))
             break; /* no time left to choose: what exists must do */
         const double t_create = rt_place_now_ms();
         if (hipMemCreate(&h[k], piece, &prop, 0) != hipSuccess) {
@@ -402,6 +413,8 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
                 e = rt_place_time(c, pk, pr, nprobe, &ms);
                 if (e != hipSuccess)
                     break;
+                if (ratio && ms / self_ms > ratio[k])
+                    ratio[k] = ms / self_ms; /* the slowest pairing seen */
                 if (ms > RT_PLACE_SAME * self_ms)
                     found = order[q];
                 else
@@ -426,13 +439,17 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         const int over = nclass >= 2 && made >= need ? (2 * need + 4) / 5
                                                      : (need + 1) / 2;
         if (count[cls[k]] > over && made >= (need + 1) / 2 + 1 &&
-            hops < 24 && !stalled && rt_place_now_ms() < deadline) {
+            hops < 24 &&
+            ((!stalled && rt_place_now_ms() < deadline) ||
+             (!have_mix && !choice &&
+              rt_place_now_ms() < deadline + RT_PLACE_HARD_MS))) {
             const int blocks = hops_in_a_row < 3 ? 4 : 8;
             const size_t one = (size_t)1 << 30;
             int hopped = 0;
             for (int b = 0; b < blocks && nballast < max_ballast &&
-                            extra + one <= budget && t_ballast < 40. &&
-                            !stalled; ++b) {
+                            extra + one <= budget &&
+                            (t_ballast < 40. || !have_mix) &&
+                            (!stalled || b == 0); ++b) {
                 const double tb = rt_place_now_ms();
                 if (hipMemCreate(&ballast[nballast], one, &prop, 0) !=
                     hipSuccess) {
@@ -446,7 +463,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
                 t_ballast += took;
                 slowest_create =
                     (float)took > slowest_create ? (float)took : slowest_create;
-                stalled = took > RT_PLACE_STALL_MS;
+                stalled = stalled || took > RT_PLACE_STALL_MS;
             }
             if (hopped) { /* (a hop that created nothing is not one) */
                 ++hops;
@@ -467,9 +484,12 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
              * the search may go on) */
             const int most = nclass >= 3 && made < cap - 1 ? (2 * need + 4) / 5
                                                           : (need + 1) / 2;
-            int can = 0;
-            for (int q = 0; q < nclass; ++q)
+            int can = 0, can2 = 0;
+            for (int q = 0; q < nclass; ++q) {
                 can += count[q] < most ? count[q] : most;
+                can2 += count[q] < (need + 1) / 2 ? count[q] : (need + 1) / 2;
+            }
+            have_mix = can2 >= need;
             enough = can >= need && (nclass >= 3 || made >= need + 8);
         }
     }
@@ -485,7 +505,17 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         line[at] = 0;
         fprintf(stderr, "[rt_place] need %d made %d classes %d hops %d: %s\n",
                 need, made, nclass, hops, line);
+        /* the slowest pairing of every piece against the classes it was
+         * tested with, in units of the one-piece time (above 0.91: same
+         * class) */
+        if (ratio && made <= 40) {
+            at = 0;
+            for (int k = 0; k < made && at < 500; ++k)
+                at += snprintf(line + at, sizeof line - at, " %.2f", ratio[k]);
+            fprintf(stderr, "[rt_place]   pair / self:%s\n", line);
+        }
     }
+    free(ratio);
     const double t_found = rt_place_now_ms(), t_created = t_ballast;
     for (int b = 0; b < nballast; ++b)
         rt_place_vm(hipMemRelease(ballast[b]), "search: ballast hipMemRelease");
@@ -509,6 +539,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     }
     /* pick `need` pieces round-robin over the classes (an even mix, as far
      * as the counts allow), in that order along the address range */
+    /* (the early ways out above leave `ratio` to this free) */
     int *pick = (int *)calloc(need, sizeof(int));
     hipMemGenericAllocationHandle_t *kept =
         (hipMemGenericAllocationHandle_t *)calloc(need, sizeof *kept);
@@ -700,6 +731,7 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
     if (!c->place.base || L < 2 || 56. * (L - 1) * (double)ld < 5e8)
         return; /* (a pattern too short to tell anything: what an earlier
                    layout found out about these arrays stays) */
+    const double t_settle = rt_place_now_ms();
     rt_place_tune(c, L, ld);
     int picks = 1, nlost = 0;
     float seen[RT_PLACE_PICKS] = {c->place.store_gbps};
@@ -719,8 +751,15 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
         /* another set is choice, not need: none once the allocation's time is
          * up or a hipMemCreate has stalled */
         if (cut == 2 || rt_place_now_ms() > c->place_deadline_ms) {
-            cut = cut ? cut : 1;
-            break;
+            /* ... unless the arrays behave like ONE class (a fifth slower for
+             * as long as they live): those get another search with a budget
+             * of its own, while the hard limit lasts */
+            if (!(c->place.store_gbps < RT_PLACE_FAST_GBPS) ||
+                rt_place_now_ms() > t_settle + RT_PLACE_HARD_MS) {
+                cut = cut ? cut : 1;
+                break;
+            }
+            c->place_deadline_ms = rt_place_now_ms() + c->opt_place_budget_ms;
         }
         const rt_place held = c->place; /* pieces and range stay alive */
         double *const held_buf = c->d_buf;
@@ -756,6 +795,14 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
     }
     for (int k = 0; k < nlost; ++k)
         rt_place_release(&lost[k], false); /* (one flush, below) */
+    if (getenv("RT_MI355_PLACE_LOG")) {
+        fprintf(stderr, "[rt_place]   store pattern per set:");
+        for (int k = 0; k < picks; ++k)
+            fprintf(stderr, " %.0f", seen[k]);
+        fprintf(stderr, " GB/s, kept %.0f, [%d %d %d] of %d x %zu MiB\n",
+                c->place.store_gbps, c->place.count[0], c->place.count[1],
+                c->place.count[2], c->place.n, c->place.piece >> 20);
+    }
     c->place.picks = picks;
     c->place.slowest_create_ms = slowest;
     c->place.cut_short = cut;
