@@ -660,7 +660,9 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * batch's OWN store pattern (56 B per ray and element) is written over the
  * arrays and timed; while it stays below 6900 GB/s ANOTHER set of pieces is
  * searched, classified and measured while the first is held (arrays up to
- * 16 GiB; at most three sets, five below 4 GiB); the best stays (option "placement", default 1;
+ * 16 GiB; at most three sets, five where the best of three is 2.5 % below the
+ * mark, eight below 4 GiB with two GiB of ballast between one and the next);
+ * the best stays (option "placement", default 1;
  * RT_MI355_PLACEMENT=0 for the whole process; plain hipMalloc if anything on
  * the way fails; results never depend on it).
  * info[0] = pieces behind the arrays (0: hipMalloc), [1] = MiB per piece,
@@ -693,7 +695,9 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * milliseconds the search took, of which ms[4] creating, mapping and testing
  * pieces, ms[5] creating and releasing ballast, ms[6] unmapping, releasing
  * the surplus and mapping the final range; ms[7] = measuring the pattern;
- * ms[8..12] = GB/s of each set of pieces tried (0: not tried), ms[13] = the
+ * ms[8..12] = GB/s of each set of pieces tried (0: not tried; arrays below
+ * 4 GiB try up to eight, ms[12] is then the best of the fifth and later
+ * sets), ms[13] = the
  * longest single hipMemCreate of the search (ms), ms[14] = everything
  * rt_reserve spent on the placement of this buffer (ms: all sets, the
  * measurements, the coherence proof), ms[15] = 0.

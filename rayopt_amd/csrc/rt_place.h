@@ -723,7 +723,7 @@ static void rt_place_tune(rt_ctx *c, int L, long long ld)
  * 16 GiB (C2: 0.2414 ms behind pieces whose four ranges all ran the pattern
  * at 5.45-5.5 TB/s, 0.207-0.218 behind others).  ctx->d_buf follows.
  */
-#define RT_PLACE_PICKS 5
+#define RT_PLACE_PICKS 8 /* (rt_placement reports the first five) */
 static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes);
 
 static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
@@ -742,10 +742,21 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
      * 10-20 ms) -- five where the best of three is still 2.5 % below the
      * mark (three sets of two classes in a row: 6.59-6.63 TB/s, C3' 0.77
      * instead of 0.82, profiles/r05_final/boxstat/bench_box_f.json) */
-    while (picks < RT_PLACE_PICKS && c->d_buf && c->place.base &&
-           c->place.store_gbps > 0.f &&
+    /* Round 6: sets drawn one after the other come out alike (all five of a
+     * context at 5.5-6.4 TB/s on two boxes of eight, 6.9-7.0 at the first
+     * draw on the others; sets of 256 MiB pieces, which the pair test cannot
+     * tell apart at all, show the same two levels: scripts/c2_lab.py) --
+     * what decides lies beyond the classes, so the draws are made cheaper
+     * and further apart: arrays below 4 GiB (a set costs them 5-10 ms) get
+     * up to eight sets inside the same time budget, and two GiB of ballast
+     * are put between one set and the next. */
+    const bool small = c->place.bytes < ((size_t)4 << 30);
+    hipMemGenericAllocationHandle_t gap[2 * RT_PLACE_PICKS];
+    int ngap = 0;
+    while (picks < (small ? RT_PLACE_PICKS : 5) && c->d_buf &&
+           c->place.base && c->place.store_gbps > 0.f &&
            c->place.store_gbps < c->opt_place_good &&
-           (picks < 3 || c->place.bytes < ((size_t)4 << 30) ||
+           (picks < 3 || small ||
             c->place.store_gbps < .975 * c->opt_place_good) &&
            c->place.bytes <= ((size_t)16 << 30)) {
         /* another set is choice, not need: none once the allocation's time is
@@ -763,6 +774,20 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
         }
         const rt_place held = c->place; /* pieces and range stay alive */
         double *const held_buf = c->d_buf;
+        if (small) { /* the next set from further on in the device memory */
+            hipMemAllocationProp prop = {};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = c->device;
+            for (int b = 0; b < 2; ++b) {
+                if (hipMemCreate(&gap[ngap], (size_t)1 << 30, &prop, 0) !=
+                    hipSuccess) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                ++ngap;
+            }
+        }
         void *nb = NULL;
         const hipError_t e = rt_place_alloc(c, &nb, bytes);
         if (e != hipSuccess || !c->place.base) {
@@ -795,6 +820,8 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
     }
     for (int k = 0; k < nlost; ++k)
         rt_place_release(&lost[k], false); /* (one flush, below) */
+    for (int b = 0; b < ngap; ++b)
+        rt_place_vm(hipMemRelease(gap[b]), "settle: gap hipMemRelease");
     if (getenv("RT_MI355_PLACE_LOG")) {
         fprintf(stderr, "[rt_place]   store pattern per set:");
         for (int k = 0; k < picks; ++k)
@@ -807,8 +834,13 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
     c->place.slowest_create_ms = slowest;
     c->place.cut_short = cut;
     c->place.settled = 1;
-    for (int k = 0; k < RT_PLACE_PICKS; ++k)
+    /* (five slots in rt_placement: the fifth holds the best of the fifth
+     * and later sets) */
+    for (int k = 0; k < 5; ++k)
         c->place.pick_gbps[k] = k < picks ? seen[k] : 0.f;
+    for (int k = 5; k < picks; ++k)
+        if (seen[k] > c->place.pick_gbps[4])
+            c->place.pick_gbps[4] = seen[k];
     /* sets that lost have been unmapped: whatever the device still holds of
      * their translations goes before anything else is launched */
     rt_place_flush();

@@ -65,7 +65,10 @@ def test_large_arrays_are_placed_and_results_do_not_depend_on_it():
                 # another set of pieces is searched only while it is below
                 # "good"; the best set stays
                 sets = info["store_pattern_GBps_per_piece_set"]
-                assert 1 <= info["piece_sets_tried"] == len(sets) <= 5
+                # (up to eight sets for arrays below 4 GiB; five are listed,
+                # the fifth entry = the best of the fifth and later ones)
+                assert 1 <= info["piece_sets_tried"] <= 8
+                assert len(sets) == min(info["piece_sets_tried"], 5)
                 assert min(sets) > 0
                 assert max(sets) == info["store_pattern_GBps"]
                 assert len(sets) == 1 or max(sets[:-1]) < 6900.
@@ -119,7 +122,7 @@ def test_every_range_and_every_set_of_pieces(generated):
         assert not info["gave_up_incoherent"]
         if info["pieces"]:
             stalled = info["search_cut_short"] == "hipMemCreate stalled"
-            assert info["piece_sets_tried"] == (5 if good else 1) or stalled
+            assert info["piece_sets_tried"] == (8 if good else 1) or stalled
             assert max(info["store_pattern_GBps_per_piece_set"]) == \
                 info["store_pattern_GBps"]
         rows[good] = _rows(eng, L)
