@@ -104,7 +104,7 @@ def parse_args():
     ap.add_argument("--no-configs5", action="store_true",
                     help="skip the 10^8-ray one-GPU batch (104 GB)")
     ap.add_argument("--configs5-rays", type=int, default=0)
-    ap.add_argument("--only-config", choices=legs.CONFIG_KEYS, default=None,
+    ap.add_argument("--only-config", choices=legs.ONLY_KEYS, default=None,
                     help="ONE config leg and nothing else (a leg's rocprofv3 "
                          "--kernel-trace --stats run: profiles/r06_final/"
                          "legs/); prints that leg's own JSON line")

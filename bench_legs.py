@@ -1140,6 +1140,8 @@ def parity_sample_of_a_large_batch(g, system, count):
 
 
 CONFIG_KEYS = ("C1", "C2", "C3p", "C4", "C4x", "C5")
+ONLY_KEYS = CONFIG_KEYS + ("C3", "gen")   # + the headline batch, host-seeded
+                                          # and built on the device
 
 
 def config_trace(ra, device, key, args):
@@ -1205,8 +1207,16 @@ def config_trace(ra, device, key, args):
             big, "exact_asphere=True (the reference's bits)" if key == "C4x"
             else "default (FMA / rcp / rsq Newton, 1e-8 contract)")
         c["kind"] = "C4 exact" if key == "C4x" else "C4 default"
-    elif key == "C5":
+    elif key == "C3":
+        # the headline batch itself (--only-config: a leg's profile)
+        c["system"] = ra.system_from_yaml(P.DOUBLE_GAUSS)
+        c["text"] = P.DOUBLE_GAUSS
+        c["y"], c["u"] = workload_rays(big, 0)
+        c["l"] = c["system"].wavelengths[0]
+        c["name"] = "C3 double-Gauss, %d rays in 5 field bundles" % big
+    elif key in ("C5", "gen"):
         # double-Gauss, 10^8 rays built on the device (104 GB), ONE GPU
+        # ("gen": the headline's 10^7 rays built on the device)
         c["system"] = ra.system_from_yaml(P.DOUBLE_GAUSS)
         c["text"] = P.DOUBLE_GAUSS
         c["l"] = c["system"].wavelengths[0]
@@ -1215,18 +1225,19 @@ def config_trace(ra, device, key, args):
         c["note"] = ("the 8-GPU form shards these rays and gathers y[L-1] "
                      "over RCCL (bench.py --gpus 8 --total-rays 100000000)")
     else:
-        raise ValueError("config %r: one of %s" % (key, CONFIG_KEYS))
+        raise ValueError("config %r: one of %s" % (key, ONLY_KEYS))
     g = ra.GeometricTrace(c["system"], device=device, **c["options"])
-    if key == "C5":
+    if c["generated"]:
         nf = len(FIELD_FRACTIONS)
-        m = (args.configs5_rays or 100_000_000)//nf//64*64
+        m = (big if key == "gen" else
+             args.configs5_rays or 100_000_000)//nf//64*64
         c["pupil_points"] = m
         g.rays_fields(np.c_[np.zeros(nf), FIELD_FRACTIONS],
                       dc.disc_points(m, 91), P.DOUBLE_GAUSS_PUPIL_Z,
                       BUNDLE_RADIUS)
         c["n"] = m*nf
-        c["name"] = ("C5 on one GPU: double-Gauss, %d rays built on the "
-                     "device" % c["n"])
+        c["name"] = ("%s: double-Gauss, %d rays built on the device" % (
+            "C5 on one GPU" if key == "C5" else "generated batch", c["n"]))
     else:
         g.rays_given(c["y"], c["u"], c["l"])
         c["n"] = len(c["y"])*len(np.atleast_1d(c["l"]))
