@@ -138,6 +138,32 @@ static inline void rt_place_vm(hipError_t e, const char *what)
 
 static void rt_place_flush(void);
 
+/*
+ * A virtual address range is used for ONE mapping in its life and is never
+ * handed back (round 6).  On ROCm 7.2 a kernel can go on using the
+ * translations of an EARLIER mapping of an address (below: rt_place_flush),
+ * and what was built against that in round 5 -- free a buffer after every
+ * mapping, prove kernels and copies coherent before trusting a placement --
+ * guards the ranges this file maps, not an address that hipMemAddressFree
+ * gave back and that comes round again in a later reservation or in somebody's
+ * hipMalloc: one process in about eight died of "Memory access fault by GPU"
+ * right after a context had mapped and unmapped many ranges (the GPU suite in
+ * one process in round 5, bench.py after C2's eight sets in round 6).  An
+ * address that is never reused cannot be reached through a stale translation,
+ * and address space is not scarce (47 bits; a search reserves 15-150 GiB of
+ * it): retired ranges stay reserved -- they hold no memory -- and the
+ * placement steps aside for plain allocations once RT_PLACE_VA_LIMIT of them
+ * have accumulated (thousands of large allocations in one process).
+ */
+#define RT_PLACE_VA_LIMIT ((size_t)48 << 40)
+static size_t g_place_va_retired = 0;
+
+static inline void rt_place_retire(void *va, size_t bytes)
+{
+    (void)va; /* stays reserved: nothing maps there again */
+    g_place_va_retired += bytes;
+}
+
 /* `flush`: the range was mapped -- whatever the device still holds of its
  * translations goes before the addresses can be handed out again (a plain
  * hipMalloc that follows may receive the same virtual addresses).
@@ -147,8 +173,7 @@ static void rt_place_release(rt_place *p, bool flush = true)
     const bool was_mapped = p->base != NULL;
     if (p->base) {
         rt_place_vm(hipMemUnmap(p->base, p->bytes), "release: hipMemUnmap");
-        rt_place_vm(hipMemAddressFree(p->base, p->bytes),
-                    "release: hipMemAddressFree");
+        rt_place_retire(p->base, p->bytes);
     }
     hipMemGenericAllocationHandle_t *h =
         (hipMemGenericAllocationHandle_t *)p->handles;
@@ -259,7 +284,8 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
 {
     rt_place &P = c->place;
     memset(&P, 0, sizeof P);
-    if (!c->opt_place || g_place_distrust || bytes < RT_PLACE_MIN_BYTES)
+    if (!c->opt_place || g_place_distrust || bytes < RT_PLACE_MIN_BYTES ||
+        g_place_va_retired > RT_PLACE_VA_LIMIT)
         return hipMalloc(out, bytes);
     const double t_start = rt_place_now_ms();
     /* the first set of an allocation starts the clock when it has what it
@@ -547,8 +573,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         for (int k = 0; k < made; ++k)
             rt_place_vm(hipMemRelease(h[k]), "search gave up: hipMemRelease");
         if (scratch)
-            rt_place_vm(hipMemAddressFree(scratch, (size_t)cap * piece),
-                        "search gave up: hipMemAddressFree");
+            rt_place_retire(scratch, (size_t)cap * piece);
         free(h);
         free(cls);
         if (mapped) /* the plain buffer may get these very addresses */
@@ -581,13 +606,10 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     for (int k = 0; k < made; ++k)
         rt_place_vm(hipMemUnmap((char *)scratch + (size_t)k * piece, piece),
                     "search: scratch hipMemUnmap");
-    /* the scratch range goes back first: the final range then begins where
-     * the pair tests ran (measured against a range reserved while the
-     * scratch was still held, two builds alternating in one process: the
-     * store pattern 6750-6865 GB/s here, 6555-6676 there; where even this
-     * range is slow rt_place_tune tries others) */
-    rt_place_vm(hipMemAddressFree(scratch, (size_t)cap * piece),
-                "search: scratch hipMemAddressFree");
+    /* the scratch range is retired, the final range a new one (until round 6
+     * the scratch went back first so that the final range began where the
+     * pair tests had run: addresses mapped twice) */
+    rt_place_retire(scratch, (size_t)cap * piece);
     void *base = NULL;
     e = pick && kept && taken == need ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess)
@@ -623,8 +645,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
             }
         }
         if (base)
-            rt_place_vm(hipMemAddressFree(base, (size_t)need * piece),
-                        "mapping failed: hipMemAddressFree");
+            rt_place_retire(base, (size_t)need * piece);
         free(kept);
         rt_place_flush(); /* the scratch slots were mapped and are gone */
         return hipMalloc(out, bytes);
@@ -732,9 +753,9 @@ static void rt_place_tune(rt_ctx *c, int L, long long ld)
 }
 
 /*
- * The pieces of the current set behind the SAME address range in another
- * order (perm[k] = index of the piece that goes to slot k): unmap, map,
- * flush.  The arrays hold nothing yet (rt_reserve, fresh layout).
+ * The pieces of the current set in another order along a range of their own
+ * (perm[k] = index of the piece that goes to slot k).  The arrays hold
+ * nothing yet (rt_reserve, fresh layout); c->d_buf follows.
  */
 static hipError_t rt_place_reorder(rt_ctx *c, const int *perm)
 {
@@ -749,18 +770,31 @@ static hipError_t rt_place_reorder(rt_ctx *c, const int *perm)
     acc.location.type = hipMemLocationTypeDevice;
     acc.location.id = c->device;
     acc.flags = hipMemAccessFlagsProtReadWrite;
+    /* a NEW range for the new order (an address is mapped once in its life) */
+    void *base = NULL;
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess)
-        e = hipMemUnmap(P.base, P.bytes);
-    for (int k = 0; k < P.n && e == hipSuccess; ++k) {
-        nh[k] = h[perm[k]];
-        e = hipMemMap((char *)P.base + (size_t)k * P.piece, P.piece, 0, nh[k],
-                      0);
-    }
-    if (e == hipSuccess)
-        e = hipMemSetAccess(P.base, P.bytes, &acc, 1);
+        e = hipMemAddressReserve(&base, P.bytes, P.piece & (~P.piece + 1), NULL,
+                                 0);
     if (e == hipSuccess) {
+        e = hipMemUnmap(P.base, P.bytes);
+        if (e != hipSuccess)
+            rt_place_retire(base, P.bytes);
+    }
+    if (e == hipSuccess) {
+        rt_place_retire(P.base, P.bytes);
+        for (int k = 0; k < P.n && e == hipSuccess; ++k) {
+            nh[k] = h[perm[k]];
+            e = hipMemMap((char *)base + (size_t)k * P.piece, P.piece, 0,
+                          nh[k], 0);
+        }
+        if (e == hipSuccess)
+            e = hipMemSetAccess(base, P.bytes, &acc, 1);
+        /* (a failure here leaves the context without arrays: the caller
+         * gives the placement up) */
         memcpy(h, nh, P.n * sizeof *nh);
+        P.base = base;
+        c->d_buf = (double *)base;
         rt_place_flush();
     }
     free(nh);
