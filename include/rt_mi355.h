@@ -688,11 +688,7 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * a buffer is freed in between, which the library does after every mapping
  * (csrc/rt_place.h: rt_place_flush); [14] = hipMemUnmap / hipMemRelease /
  * hipMemAddressFree calls of this PROCESS that returned an error (rt_reserve
- * also leaves the first one's text for rt_last_error); [15] = GiB of virtual
- * address ranges this PROCESS has retired: a range is used for one mapping
- * in its life and never handed back (an address that is not reused cannot be
- * reached through a stale translation; they hold no memory), and once 48 TiB
- * have accumulated large arrays come from hipMalloc.
+ * also leaves the first one's text for rt_last_error); [15] = 0.
  * ms[0] / ms[1] = the pair test's launch time inside one piece / across two
  * classes, ms[2] = GB/s of the batch's store pattern over the arrays (0: not
  * measured -- a pattern below 0.5 GB tells nothing), ms[3] = wall

@@ -1877,7 +1877,6 @@ int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
     info[12] = p.base ? p.picks : 0;
     info[13] = ctx->place_incoherent;
     info[14] = g_place_vm_failures;
-    info[15] = (int)(g_place_va_retired >> 30);
     ms[0] = p.self_ms;
     ms[1] = p.cross_ms;
     ms[2] = p.store_gbps;

@@ -139,29 +139,35 @@ static inline void rt_place_vm(hipError_t e, const char *what)
 static void rt_place_flush(void);
 
 /*
- * A virtual address range is used for ONE mapping in its life and is never
- * handed back (round 6).  On ROCm 7.2 a kernel can go on using the
- * translations of an EARLIER mapping of an address (below: rt_place_flush),
- * and what was built against that in round 5 -- free a buffer after every
- * mapping, prove kernels and copies coherent before trusting a placement --
- * guards the ranges this file maps, not an address that hipMemAddressFree
- * gave back and that comes round again in a later reservation or in somebody's
- * hipMalloc: one process in about eight died of "Memory access fault by GPU"
- * right after a context had mapped and unmapped many ranges (the GPU suite in
- * one process in round 5, bench.py after C2's eight sets in round 6).  An
- * address that is never reused cannot be reached through a stale translation,
- * and address space is not scarce (47 bits; a search reserves 15-150 GiB of
- * it): retired ranges stay reserved -- they hold no memory -- and the
- * placement steps aside for plain allocations once RT_PLACE_VA_LIMIT of them
- * have accumulated (thousands of large allocations in one process).
+ * Handing a virtual address range back.  (Round 6 tried never to do that --
+ * an address that is not reused cannot be reached through a stale
+ * translation -- and ran out of address space after about 1 TiB of
+ * reservations: a search reserves 15-150 GiB, and the device's address space
+ * for them is far smaller than the host's 47 bits.  scripts/vm_stress.py.)
  */
-#define RT_PLACE_VA_LIMIT ((size_t)48 << 40)
-static size_t g_place_va_retired = 0;
-
 static inline void rt_place_retire(void *va, size_t bytes)
 {
-    (void)va; /* stays reserved: nothing maps there again */
-    g_place_va_retired += bytes;
+    rt_place_vm(hipMemAddressFree(va, bytes), "hipMemAddressFree");
+}
+
+/*
+ * A mapping is only safe to launch a kernel on once the driver's page-table
+ * update has landed, and hipMemMap + hipMemSetAccess return before that is
+ * certain: about one process in eight that searched many pieces died of
+ * "Memory access fault by GPU ... Reason: Unknown" (the GPU suite in one
+ * process in round 5, bench.py in round 6 -- there on an address 0x45000
+ * bytes into the SECOND slot of a search's scratch range, i.e. in the pair
+ * test launched right after that slot had been mapped).  Allocating and
+ * freeing a small buffer in between goes through the same driver queue
+ * behind the update (it is also what invalidates stale translations, below):
+ * every new mapping gets that before its first kernel.
+ */
+static inline void rt_place_settle_maps(void)
+{
+    void *t = NULL;
+    if (hipMalloc(&t, (size_t)2 << 20) == hipSuccess)
+        (void)hipFree(t);
+    (void)hipGetLastError();
 }
 
 /* `flush`: the range was mapped -- whatever the device still holds of its
@@ -284,8 +290,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
 {
     rt_place &P = c->place;
     memset(&P, 0, sizeof P);
-    if (!c->opt_place || g_place_distrust || bytes < RT_PLACE_MIN_BYTES ||
-        g_place_va_retired > RT_PLACE_VA_LIMIT)
+    if (!c->opt_place || g_place_distrust || bytes < RT_PLACE_MIN_BYTES)
         return hipMalloc(out, bytes);
     const double t_start = rt_place_now_ms();
     /* the first set of an allocation starts the clock when it has what it
@@ -407,6 +412,7 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
         }
         if (e != hipSuccess)
             break;
+        rt_place_settle_maps(); /* before the first kernel on this slot */
         float ms = 0.f;
         if (k == 0) {
             /* the slow level: all rows in one piece -- repeated until two
@@ -606,9 +612,8 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     for (int k = 0; k < made; ++k)
         rt_place_vm(hipMemUnmap((char *)scratch + (size_t)k * piece, piece),
                     "search: scratch hipMemUnmap");
-    /* the scratch range is retired, the final range a new one (until round 6
-     * the scratch went back first so that the final range began where the
-     * pair tests had run: addresses mapped twice) */
+    /* the scratch range goes back first: the final range then begins where
+     * the pair tests ran */
     rt_place_retire(scratch, (size_t)cap * piece);
     void *base = NULL;
     e = pick && kept && taken == need ? hipSuccess : hipErrorOutOfMemory;

@@ -390,8 +390,7 @@ class Engine:
                 "search_cut_short": {0: None, 1: "time budget",
                                      2: "hipMemCreate stalled"}.get(info[10]),
                 "settled": bool(info[11]),
-                "vm_call_failures_in_process": info[14],
-                "va_retired_gib_in_process": info[15]}
+                "vm_call_failures_in_process": info[14]}
 
     def selftest_arith(self, seed, n, span=100):
         """rt_selftest_arith: mismatch counts (refraction quotient, table
