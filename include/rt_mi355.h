@@ -394,7 +394,8 @@ int rt_event_elapsed(rt_ctx *ctx, int a, int b, double *ms);
  * level, rt_placement; FP64-bound traces are not capped), "placement"
  * (rt_placement), "placement_good_gbps" (default 6900: the store pattern at
  * which rt_reserve stops looking for a better address range / set of pieces),
- * "placement_budget_ms" (default 250: wall time after which an allocation
+ * "placement_orders" (default -1: six orders of a set's pieces for arrays
+ * below 4 GiB, three up to 16 GiB; 0: none), "placement_budget_ms" (default 250: wall time after which an allocation
  * stops choosing memory -- surplus pieces, hops, further sets; the pieces it
  * needs it creates whatever that takes; a single hipMemCreate above 200 ms
  * ends the choosing at once),
@@ -688,7 +689,12 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
  * a buffer is freed in between, which the library does after every mapping
  * (csrc/rt_place.h: rt_place_flush); [14] = hipMemUnmap / hipMemRelease /
  * hipMemAddressFree calls of this PROCESS that returned an error (rt_reserve
- * also leaves the first one's text for rt_last_error); [15] = 0.
+ * also leaves the first one's text for rt_last_error); [15] = other ORDERS of
+ * a set's pieces along the range that were mapped and measured (before another
+ * set is searched the same pieces are tried in up to six -- arrays of 4 GiB
+ * and more: three -- seeded permutations: no memory, 5 ms each; the same five
+ * pieces ran C2's pattern between 5.5 and 6.8 TB/s depending on the order;
+ * option "placement_orders").
  * ms[0] / ms[1] = the pair test's launch time inside one piece / across two
  * classes, ms[2] = GB/s of the batch's store pattern over the arrays (0: not
  * measured -- a pattern below 0.5 GB tells nothing), ms[3] = wall

@@ -101,6 +101,8 @@ struct rt_place {
     float slowest_create_ms; /* the longest single hipMemCreate of the search */
     int cut_short;       /* the search ended early: 1 = its time budget was
                             up, 2 = a hipMemCreate stalled */
+    int orders;          /* other orders of a set's pieces along the range that
+                            were mapped and measured (rt_place_orders) */
     int settled;         /* rt_place_settle has searched for these arrays: a
                             later layout in the same buffer only measures */
     float total_ms;      /* wall time of everything rt_reserve spent on the
@@ -199,6 +201,8 @@ struct rt_ctx {
     uint64_t pieces_mask[4];
     int gather_seen, gather_nchunks; /* chunks of the gather in progress */
     int opt_place;    /* large arrays in class-mixed pieces (rt_place.h) */
+    int opt_place_orders; /* orders of a set's pieces tried (-1: 6 for arrays
+                             below 4 GiB, 3 up to 16 GiB) */
     float opt_place_budget_ms; /* wall time an allocation may spend choosing
                                   memory (rt_place.h: RT_PLACE_BUDGET_MS) */
     float opt_place_good; /* GB/s of the store pattern at which the search

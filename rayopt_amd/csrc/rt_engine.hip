@@ -289,6 +289,7 @@ int rt_create(int device, rt_ctx **out)
         c->opt_place = (e && !atoi(e)) ? 0 : 1;
         c->opt_place_good = RT_PLACE_GOOD_GBPS;
         c->opt_place_budget_ms = RT_PLACE_BUDGET_MS;
+        c->opt_place_orders = -1;
     }
     c->opt_uniform = 1;
     c->opt_compact_every = 4; /* measured best, profiles/r02_probes */
@@ -1592,6 +1593,12 @@ int rt_set_option(rt_ctx *ctx, const char *key, int value)
     } else if (!strcmp(key, "placement")) {
         /* takes effect with the next allocation of the result arrays */
         ctx->opt_place = value ? 1 : 0;
+    } else if (!strcmp(key, "placement_orders")) {
+        /* orders of a set's pieces along the range that are tried while the
+         * store pattern is below the mark; -1: the library's choice */
+        if (value < -1 || value > 64)
+            return rt_fail(ctx, RT_ERR_ARG, "placement_orders: -1 .. 64");
+        ctx->opt_place_orders = value;
     } else if (!strcmp(key, "placement_budget_ms")) {
         /* wall time after which an allocation stops CHOOSING memory (surplus
          * pieces, hops, further sets); 0: the default of 250 ms */
@@ -1877,6 +1884,7 @@ int rt_placement(rt_ctx *ctx, int info[16], double ms[16])
     info[12] = p.base ? p.picks : 0;
     info[13] = ctx->place_incoherent;
     info[14] = g_place_vm_failures;
+    info[15] = p.base ? p.orders : 0;
     ms[0] = p.self_ms;
     ms[1] = p.cross_ms;
     ms[2] = p.store_gbps;

@@ -795,15 +795,88 @@ static hipError_t rt_place_reorder(rt_ctx *c, const int *perm)
         }
         if (e == hipSuccess)
             e = hipMemSetAccess(base, P.bytes, &acc, 1);
-        /* (a failure here leaves the context without arrays: the caller
-         * gives the placement up) */
         memcpy(h, nh, P.n * sizeof *nh);
         P.base = base;
         c->d_buf = (double *)base;
         rt_place_flush();
+        if (e != hipSuccess) { /* no arrays any more: everything goes back */
+            (void)hipGetLastError();
+            rt_place_release(&c->place);
+            c->d_buf = NULL;
+        }
     }
     free(nh);
     return e;
+}
+
+/*
+ * The SAME pieces in another order along the range (round 6).  Which piece
+ * lies under which part of the arrays decides as much as which pieces they
+ * are: five 512 MiB pieces of C2 ran the pattern at 6166, 6080, 6088, 6229,
+ * 5495, 6820 and 5541 GB/s in seven orders (scripts/c2_lab.py with
+ * RT_MI355_PLACE_PERM; three contexts of eight like that, the others between
+ * 6717 and 7067), ten 1 GiB pieces of the headline batch between 6483 and
+ * 7026 with the class-interleaved order near the top.  An order costs a
+ * remap into a range of its own (0.7 ms; an address is mapped once) and one
+ * measurement of the pattern (4.5 ms) -- no memory, no search -- so orders are
+ * tried before another set of pieces is: up to `tries`, seeded permutations,
+ * while the pattern is below the mark and the allocation's time lasts; the
+ * best order stays.  Returns the orders tried.
+ */
+static int rt_place_orders(rt_ctx *c, int L, long long ld, int tries)
+{
+    const int n = c->place.n;
+    if (tries < 1 || n < 2 || n > 64 || !c->place.base ||
+        !(c->place.store_gbps > 0.f))
+        return 0;
+    int best[64], cur[64], trial[64], now[64];
+    for (int k = 0; k < n; ++k)
+        best[k] = cur[k] = k;
+    float best_gbps = c->place.store_gbps;
+    const bool log = getenv("RT_MI355_PLACE_LOG") != NULL;
+    if (log)
+        fprintf(stderr, "[rt_place]   orders: %.0f", best_gbps);
+    unsigned rs = 12345u + 977u * (unsigned)n;
+    int tried = 0;
+    for (int t = 0; t < tries && best_gbps < c->opt_place_good &&
+                    rt_place_now_ms() < c->place_deadline_ms; ++t) {
+        for (int k = 0; k < n; ++k) /* relative to the current mapping */
+            trial[k] = k;
+        for (int k = n - 1; k > 0; --k) {
+            rs = rs * 1664525u + 1013904223u;
+            const int j = (int)((rs >> 8) % (unsigned)(k + 1));
+            const int x = trial[k];
+            trial[k] = trial[j];
+            trial[j] = x;
+        }
+        if (rt_place_reorder(c, trial) != hipSuccess)
+            return -1; /* the context has lost its arrays */
+        for (int k = 0; k < n; ++k)
+            now[k] = cur[trial[k]];
+        memcpy(cur, now, sizeof(int) * n);
+        rt_place_tune(c, L, ld);
+        ++tried;
+        if (log)
+            fprintf(stderr, " %.0f", c->place.store_gbps);
+        if (c->place.store_gbps > best_gbps) {
+            best_gbps = c->place.store_gbps;
+            memcpy(best, cur, sizeof(int) * n);
+        }
+    }
+    if (memcmp(best, cur, sizeof(int) * n)) { /* back to the best order */
+        int inv[64];
+        for (int k = 0; k < n; ++k)
+            inv[cur[k]] = k;
+        for (int k = 0; k < n; ++k)
+            trial[k] = inv[best[k]];
+        if (rt_place_reorder(c, trial) != hipSuccess)
+            return -1;
+        c->place.store_gbps = best_gbps; /* (measured when it was tried) */
+        c->place.fast = best_gbps >= RT_PLACE_FAST_GBPS;
+    }
+    if (log)
+        fprintf(stderr, " -> %.0f\n", c->place.store_gbps);
+    return tried;
 }
 
 /*
@@ -826,55 +899,17 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
                    layout found out about these arrays stays) */
     const double t_settle = rt_place_now_ms();
     rt_place_tune(c, L, ld);
-    /* LAB (RT_MI355_PLACE_PERM=k): the same pieces in k other orders along
-     * the range, the pattern's GB/s of each on stderr; the best order stays */
-    if (getenv("RT_MI355_PLACE_PERM") && c->place.n >= 2 && c->place.n <= 64) {
-        const int tries = atoi(getenv("RT_MI355_PLACE_PERM"));
-        const int n = c->place.n;
-        int best[64], cur[64], trial[64];
-        for (int k = 0; k < n; ++k)
-            best[k] = cur[k] = k;
-        float best_gbps = c->place.store_gbps;
-        fprintf(stderr, "[rt_place]   orders: %.0f", best_gbps);
-        unsigned rs = 12345u + (unsigned)n;
-        for (int t = 0; t < tries; ++t) {
-            /* a random permutation RELATIVE to the current mapping */
-            for (int k = 0; k < n; ++k)
-                trial[k] = k;
-            for (int k = n - 1; k > 0; --k) {
-                rs = rs * 1664525u + 1013904223u;
-                const int j = (int)((rs >> 8) % (unsigned)(k + 1));
-                const int x = trial[k];
-                trial[k] = trial[j];
-                trial[j] = x;
-            }
-            if (rt_place_reorder(c, trial) != hipSuccess) {
-                (void)hipGetLastError();
-                break;
-            }
-            for (int k = 0; k < n; ++k) /* cur o trial */
-                best[k] = best[k]; /* (kept below) */
-            int now[64];
-            for (int k = 0; k < n; ++k)
-                now[k] = cur[trial[k]];
-            memcpy(cur, now, sizeof(int) * n);
-            rt_place_tune(c, L, ld);
-            fprintf(stderr, " %.0f", c->place.store_gbps);
-            if (c->place.store_gbps > best_gbps) {
-                best_gbps = c->place.store_gbps;
-                memcpy(best, cur, sizeof(int) * n);
-            }
-        }
-        /* back to the best order: inverse of cur, then best */
-        int inv[64], back[64];
-        for (int k = 0; k < n; ++k)
-            inv[cur[k]] = k;
-        for (int k = 0; k < n; ++k)
-            back[k] = inv[best[k]];
-        if (rt_place_reorder(c, back) == hipSuccess)
-            rt_place_tune(c, L, ld);
-        fprintf(stderr, " -> %.0f (best seen %.0f)\n", c->place.store_gbps,
-                best_gbps);
+    /* orders of the first set before any further set (arrays up to 16 GiB) */
+    const int order_tries =
+        getenv("RT_MI355_PLACE_PERM") ? atoi(getenv("RT_MI355_PLACE_PERM"))
+        : c->opt_place_orders >= 0    ? c->opt_place_orders
+        : c->place.bytes < ((size_t)4 << 30) ? 6 : 3;
+    int orders = 0;
+    if (c->place.bytes <= ((size_t)16 << 30)) {
+        const int k = rt_place_orders(c, L, ld, order_tries);
+        if (k < 0)
+            return; /* (c->d_buf is NULL: rt_reserve reports it) */
+        orders += k;
     }
     int picks = 1, nlost = 0;
     float seen[RT_PLACE_PICKS] = {c->place.store_gbps};
@@ -944,6 +979,16 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
         }
         c->d_buf = (double *)nb;
         rt_place_tune(c, L, ld);
+        {   /* (a further set gets two orders of its own) */
+            const int k = rt_place_orders(c, L, ld,
+                                          order_tries < 2 ? order_tries : 2);
+            if (k < 0) { /* the new set is gone: the held one stays */
+                c->place = held;
+                c->d_buf = held_buf;
+                break;
+            }
+            orders += k;
+        }
         seen[picks++] = c->place.store_gbps;
         slowest = c->place.slowest_create_ms > slowest
                       ? c->place.slowest_create_ms : slowest;
@@ -974,6 +1019,7 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
                 c->place.count[2], c->place.n, c->place.piece >> 20);
     }
     c->place.picks = picks;
+    c->place.orders = orders;
     c->place.slowest_create_ms = slowest;
     c->place.cut_short = cut;
     c->place.settled = 1;

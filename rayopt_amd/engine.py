@@ -390,7 +390,8 @@ class Engine:
                 "search_cut_short": {0: None, 1: "time budget",
                                      2: "hipMemCreate stalled"}.get(info[10]),
                 "settled": bool(info[11]),
-                "vm_call_failures_in_process": info[14]}
+                "vm_call_failures_in_process": info[14],
+                "orders_tried": info[15]}
 
     def selftest_arith(self, seed, n, span=100):
         """rt_selftest_arith: mismatch counts (refraction quotient, table

@@ -25,6 +25,10 @@ def child(reps):
         air="air", sk16="SCHOTT-SK|N-SK16", f2="SCHOTT-F|N-F2"))
     ls = [587.56e-9, 656.27e-9, 486.13e-9]
     y, u = dc.bundle(10**6, 5.5, 5., 0)
+    if os.environ.get("LAB_SHAPE") == "C3":
+        s2 = ra.system_from_yaml(P.DOUBLE_GAUSS)
+        ls = None
+        y, u = legs.workload_rays(10_000_000, 7)
     for k in range(reps):
         g = ra.GeometricTrace(s2)
         g.rays_given(y, u, ls)
