@@ -101,6 +101,8 @@ struct rt_place {
     float slowest_create_ms; /* the longest single hipMemCreate of the search */
     int cut_short;       /* the search ended early: 1 = its time budget was
                             up, 2 = a hipMemCreate stalled */
+    unsigned char slot_cls[64]; /* class of the piece in each slot of the range
+                                   (the first 64; the log's) */
     int orders;          /* other orders of a set's pieces along the range that
                             were mapped and measured (rt_place_orders) */
     int settled;         /* rt_place_settle has searched for these arrays: a
@@ -208,6 +210,8 @@ struct rt_ctx {
     float opt_place_good; /* GB/s of the store pattern at which the search
                              for a better range / set of pieces ends */
     struct rt_place place;
+    /* the layout rt_reserve is about to make (rt_place_weights) */
+    long long plan_L, plan_bs, plan_nblk;
     double place_deadline_ms; /* steady clock: when the current allocation's
                                  search for better memory ends (0: none
                                  running) */

@@ -535,6 +535,9 @@ int rt_reserve(rt_ctx *ctx, int64_t nrays)
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t need = (size_t)ctx->nsurf * 10 * (size_t)ld;
+    ctx->plan_L = ctx->nsurf; /* what the placement lays its pieces out for */
+    ctx->plan_bs = bs;
+    ctx->plan_nblk = nblk;
     const int vm_failures_before = g_place_vm_failures;
     const double t_place = rt_place_now_ms();
     bool allocated = false;

@@ -55,7 +55,13 @@ static inline double rt_place_now_ms(void) { return rt_now_ms(); }
  * classes in lumps ([2, 1]: two thirds of the streams in one class) and the
  * trace is as often slower as faster (profiles/r04_probes/session26) */
 #define RT_PLACE_MIN_BYTES (((size_t)3 << 29) + 1)
-#define RT_PLACE_SAME 0.91f      /* pair / self time above this: same class */
+/* pair / self time above this: same class.  The pairs of 512 MiB and 1 GiB
+ * pieces fall on THREE levels -- 0.74-0.81 (another class), 0.87-0.93 and
+ * 0.96-1.05 (scripts/c2_lab.py, the 5 x 5 matrices of round 6) -- and only
+ * the first is what the placement is after: until round 6 the mark stood at
+ * 0.91, INSIDE the middle level, and pieces of one class were told apart at
+ * random (a set labelled A B C A B whose B were A in fact) */
+#define RT_PLACE_SAME 0.85f
 /* the batch's own store pattern (rt_place_tune): at or above GOOD no other
  * range is tried; below FAST the arrays behave like one class whatever the
  * pair tests said (four workgroups per CU then lose to two).
@@ -263,6 +269,47 @@ static bool rt_place_coherent(rt_ctx *c)
     }
     (void)hipGetLastError();
     return ok;
+}
+
+/*
+ * How many of the row streams a full trace writes at once fall into each
+ * piece-sized slot of the range (round 6).  What the store pattern wants is
+ * not an even mix of PIECES but of STREAMS: C2's 56 streams lie 18 / 19 / 11 /
+ * 4 / 4 over its five slots, and the one piece of another class a set held
+ * gave 6.85 TB/s in slot 0 or 1, 6.2-6.3 in slot 2 (where round-robin over the
+ * classes put it: "A B C A B"), 5.5 in slot 3 or 4 -- the same five pieces
+ * (scripts/c2_lab.py).  The layout is rt_reserve's plan: per block Y | U | I |
+ * T planes of plan_L rows of plan_bs rays; a trace writes rows 1 .. L-1 of
+ * Y, U and T (I where an element is tilted: not counted).
+ */
+static void rt_place_weights(const rt_ctx *c, size_t piece, int nslots,
+                             float *w)
+{
+    for (int k = 0; k < nslots; ++k)
+        w[k] = 0.f;
+    const long long L = c->plan_L, bs = c->plan_bs;
+    if (L < 2 || bs < 1)
+        return;
+    const long long plane = L * 3 * bs, bts = 10 * L * bs;
+    auto add = [&](long long first) { /* a stream of bs doubles from `first` */
+        const double b0 = 8. * (double)first, b1 = b0 + 8. * (double)bs;
+        for (long long k = (long long)(b0 / (double)piece);
+             k < nslots && (double)k * (double)piece < b1; ++k) {
+            const double lo = (double)k * (double)piece;
+            const double a = b0 > lo ? b0 : lo;
+            const double z = b1 < lo + (double)piece ? b1 : lo + (double)piece;
+            if (z > a)
+                w[k] += (float)((z - a) / (b1 - b0));
+        }
+    };
+    for (long long b = 0; b < (c->plan_nblk > 0 ? c->plan_nblk : 1); ++b)
+        for (long long s = 1; s < L; ++s) {
+            for (int q = 0; q < 3; ++q) {
+                add(b * bts + (s * 3 + q) * bs);         /* Y */
+                add(b * bts + plane + (s * 3 + q) * bs); /* U */
+            }
+            add(b * bts + 3 * plane + s * bs);           /* T */
+        }
 }
 
 /*
@@ -586,29 +633,68 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
             rt_place_flush();
         return hipMalloc(out, bytes);
     }
-    /* pick `need` pieces round-robin over the classes (an even mix, as far
-     * as the counts allow), in that order along the address range */
+    /* pick `need` pieces so that the STREAMS are mixed evenly over the
+     * classes: slots in the order of their stream counts, each to the class
+     * that has been given the least so far and still has a piece (where the
+     * plan is unknown or flat this is the round-robin of rounds 4-5) */
     /* (the early ways out above leave `ratio` to this free) */
     int *pick = (int *)calloc(need, sizeof(int));
     hipMemGenericAllocationHandle_t *kept =
         (hipMemGenericAllocationHandle_t *)calloc(need, sizeof *kept);
-    int next[RT_PLACE_CLASSES] = {0}, taken = 0, q = 0, idle = 0;
+    float *wslot = (float *)calloc(need, sizeof(float));
+    int *by_weight = (int *)calloc(need, sizeof(int));
+    unsigned char *slot_q = (unsigned char *)calloc(need, 1);
+    unsigned char slot_class[64] = {0};
+    int next[RT_PLACE_CLASSES] = {0}, taken = 0;
     int used[RT_PLACE_CLASSES] = {0};
-    while (pick && taken < need && idle < nclass) {
-        int k = next[q];
-        while (k < made && cls[k] != q)
-            ++k;
-        if (k < made) {
-            pick[taken++] = k;
-            next[q] = k + 1;
-            ++used[q];
-            idle = 0;
-        } else {
-            next[q] = made;
-            ++idle;
+    if (pick && kept && wslot && by_weight && slot_q) {
+        rt_place_weights(c, piece, need, wslot);
+        for (int k = 0; k < need; ++k) { /* insertion sort, heaviest first;
+                                            equal weights keep their order */
+            int j = k;
+            while (j > 0 && wslot[by_weight[j - 1]] < wslot[k]) {
+                by_weight[j] = by_weight[j - 1];
+                --j;
+            }
+            by_weight[j] = k;
         }
-        q = (q + 1) % nclass;
+        double given[RT_PLACE_CLASSES] = {0.};
+        int left[RT_PLACE_CLASSES];
+        for (int q = 0; q < RT_PLACE_CLASSES; ++q)
+            left[q] = q < nclass ? count[q] : 0;
+        int rr = 0; /* ties go round the classes */
+        for (int i = 0; i < need; ++i) {
+            const int slot = by_weight[i];
+            int best = -1;
+            for (int d = 0; d < nclass; ++d) {
+                const int q = (rr + d) % nclass;
+                if (left[q] > 0 && (best < 0 || given[q] < given[best] - 1e-9))
+                    best = q;
+            }
+            if (best < 0)
+                break;
+            slot_q[slot] = (unsigned char)best;
+            given[best] += wslot[slot] > 0.f ? wslot[slot] : 1e-3;
+            --left[best];
+            rr = (best + 1) % nclass;
+            ++taken;
+        }
+        if (taken == need)
+            for (int slot = 0; slot < need; ++slot) {
+                const int q = slot_q[slot];
+                int k = next[q];
+                while (k < made && cls[k] != q)
+                    ++k;
+                pick[slot] = k; /* (k < made: left[] counted them) */
+                next[q] = k + 1;
+                ++used[q];
+                if (slot < 64)
+                    slot_class[slot] = (unsigned char)q;
+            }
     }
+    free(wslot);
+    free(by_weight);
+    free(slot_q);
     for (int k = 0; k < made; ++k)
         rt_place_vm(hipMemUnmap((char *)scratch + (size_t)k * piece, piece),
                     "search: scratch hipMemUnmap");
@@ -660,6 +746,8 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
     P.piece = piece;
     P.n = need;
     P.handles = kept;
+    for (int k = 0; k < need && k < 64; ++k)
+        P.slot_cls[k] = slot_class[k];
     P.created = made;
     P.nclass = nclass;
     for (int k = 0; k < RT_PLACE_CLASSES; ++k)
@@ -796,6 +884,12 @@ static hipError_t rt_place_reorder(rt_ctx *c, const int *perm)
         if (e == hipSuccess)
             e = hipMemSetAccess(base, P.bytes, &acc, 1);
         memcpy(h, nh, P.n * sizeof *nh);
+        {
+            unsigned char lab[64];
+            memcpy(lab, P.slot_cls, sizeof lab);
+            for (int k = 0; k < P.n && k < 64; ++k)
+                P.slot_cls[k] = perm[k] < 64 ? lab[perm[k]] : 0;
+        }
         P.base = base;
         c->d_buf = (double *)base;
         rt_place_flush();
@@ -834,8 +928,38 @@ static int rt_place_orders(rt_ctx *c, int L, long long ld, int tries)
         best[k] = cur[k] = k;
     float best_gbps = c->place.store_gbps;
     const bool log = getenv("RT_MI355_PLACE_LOG") != NULL;
-    if (log)
-        fprintf(stderr, "[rt_place]   orders: %.0f", best_gbps);
+    auto labels = [&](char *dst) {
+        for (int k = 0; k < n && k < 63; ++k)
+            dst[k] = (char)('A' + c->place.slot_cls[k]);
+        dst[n < 63 ? n : 63] = 0;
+    };
+    char lab[64];
+    if (log && n <= 12) {
+        /* every pair of the set's pieces: launch time over the one-piece
+         * time (rows = slots; above 0.91: "same class") */
+        const long long np =
+            (long long)(c->place.piece / sizeof(double) / RT_PLACE_ROWS) /
+            256 * 256;
+        for (int i = 0; i < n; ++i) {
+            fprintf(stderr, "[rt_place]   pair matrix %d:", i);
+            float self = 0.f;
+            double *pi = (double *)((char *)c->place.base +
+                                    (size_t)i * c->place.piece);
+            (void)rt_place_time(c, pi, pi, np, &self);
+            for (int j = 0; j < n; ++j) {
+                float ms = 0.f;
+                double *pj = (double *)((char *)c->place.base +
+                                        (size_t)j * c->place.piece);
+                (void)rt_place_time(c, pi, pj, np, &ms);
+                fprintf(stderr, " %.2f", self > 0.f ? ms / self : 0.f);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+    if (log) {
+        labels(lab);
+        fprintf(stderr, "[rt_place]   orders: %s %.0f", lab, best_gbps);
+    }
     unsigned rs = 12345u + 977u * (unsigned)n;
     int tried = 0;
     for (int t = 0; t < tries && best_gbps < c->opt_place_good &&
@@ -856,8 +980,10 @@ static int rt_place_orders(rt_ctx *c, int L, long long ld, int tries)
         memcpy(cur, now, sizeof(int) * n);
         rt_place_tune(c, L, ld);
         ++tried;
-        if (log)
-            fprintf(stderr, " %.0f", c->place.store_gbps);
+        if (log) {
+            labels(lab);
+            fprintf(stderr, " | %s %.0f", lab, c->place.store_gbps);
+        }
         if (c->place.store_gbps > best_gbps) {
             best_gbps = c->place.store_gbps;
             memcpy(best, cur, sizeof(int) * n);
