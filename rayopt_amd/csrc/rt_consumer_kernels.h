@@ -80,6 +80,20 @@ __global__ void __launch_bounds__(64) rt_aim_kernel(const rt_surface *__restrict
 #define RT_RED_BLOCKS 1024
 #define RT_RED_THREADS 256
 
+/* a finishing kernel's last word: its results are in pinned memory, the
+ * sequence number of the call follows them behind a system-scope fence, and
+ * the host spins on that instead of synchronising the stream (a
+ * hipStreamSynchronize costs about what a 30 us reduction's launch does) */
+__device__ __forceinline__ void rt_sign(unsigned long long *ticket,
+                                        unsigned long long seq)
+{
+    if (ticket) {
+        __threadfence_system();
+        __hip_atomic_store(ticket, seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 /* deterministic two-level sum of K accumulators: wave shuffle -> LDS ->
  * one partial per workgroup; the host adds the RT_RED_BLOCKS partials in
  * index order (no atomics, run-to-run identical) */
@@ -314,7 +328,9 @@ __global__ void rt_rms_shifted_kernel(const double *__restrict__ Yrow,
 template <bool W>
 __global__ void rt_rms_finish_kernel(const double *__restrict__ partials,
                                      int nblocks, int centred, double n,
-                                     double *__restrict__ out)
+                                     double *__restrict__ out,
+                                     unsigned long long *ticket,
+                                     unsigned long long seq)
 {
     double s[W ? 6 : 3];
     rt_partial_sums(partials, nblocks, s);
@@ -333,6 +349,7 @@ __global__ void rt_rms_finish_kernel(const double *__restrict__ partials,
         const double mx = centred ? s[0] / n : 0., my = centred ? s[1] / n : 0.;
         out[0] = A - 2. * (mx * swx + my * swy) + (mx * mx + my * my) * sw;
         out[1] = A;
+        rt_sign(ticket, seq);
     }
 }
 
@@ -450,7 +467,9 @@ __global__ void rt_refocus_shifted_kernel(const double *__restrict__ Yrow,
  * subtractions for [1] / [2] started from */
 template <bool W>
 __global__ void rt_refocus_finish_kernel(const double *__restrict__ partials,
-                                         int nblocks, double *__restrict__ out)
+                                         int nblocks, double *__restrict__ out,
+                                         unsigned long long *ticket,
+                                         unsigned long long seq)
 {
     double s[13];
     if constexpr (W) {
@@ -477,6 +496,7 @@ __global__ void rt_refocus_finish_kernel(const double *__restrict__ partials,
                  (my0 * my0 + my1 * my1) * s[8];
         out[3] = s[6];
         out[4] = s[7];
+        rt_sign(ticket, seq);
     }
 }
 
@@ -574,7 +594,9 @@ __global__ void rt_r2max_kernel(const double *__restrict__ Yrow, int64_t n,
 /* second level of rt_r2max_kernel: out[0] = max r^2, out[1] = 1 if any ray
  * was NaN; out may be pinned host memory */
 __global__ void rt_r2max_finish_kernel(const double *__restrict__ partials,
-                                       int nblocks, double *__restrict__ out)
+                                       int nblocks, double *__restrict__ out,
+                                       unsigned long long *ticket,
+                                       unsigned long long seq)
 {
     double mx = 0., bad = 0.;
     for (int b = threadIdx.x; b < nblocks; b += 64) {
@@ -590,6 +612,7 @@ __global__ void rt_r2max_finish_kernel(const double *__restrict__ partials,
     if (threadIdx.x == 0) {
         out[0] = mx;
         out[1] = bad;
+        rt_sign(ticket, seq);
     }
 }
 

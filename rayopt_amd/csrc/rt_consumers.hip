@@ -136,8 +136,10 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
     if (!ctx->d_partials)
         RT_HIP(ctx, hipMalloc((void **)&ctx->d_partials,
                               sizeof(double) * (RT_RED_BLOCKS * 16 + 16)));
-    if (!ctx->h_res)
-        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_res, 8 * sizeof(double)));
+    if (!ctx->h_res) { /* 8 results | the finishing kernel's ticket */
+        RT_HIP(ctx, hipHostMalloc((void **)&ctx->h_res, 16 * sizeof(double)));
+        memset(ctx->h_res, 0, 16 * sizeof(double));
+    }
     return rt_gen_flush(ctx);
 }
 
@@ -155,6 +157,39 @@ static int rt_consumer_ready(rt_ctx *ctx, int surf, const char *who)
             (ctx)->traced = 1;                                              \
         }                                                                   \
     } while (0)
+
+/* where a finishing kernel signs (rt_sign), and the host's wait for it: a
+ * spin on pinned memory instead of a stream synchronisation (with
+ * "consumer_events": the stream, so that the events are complete); a device
+ * that does not sign within 2 s is left to the stream's error reporting */
+static inline unsigned long long *rt_res_ticket(rt_ctx *ctx)
+{
+    return (unsigned long long *)(ctx->h_res + 15);
+}
+
+static int rt_wait_signed(rt_ctx *ctx, unsigned long long *ticket,
+                          unsigned long long seq, const char *who)
+{
+    if (ctx->opt_cevents) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
+    volatile unsigned long long *t = ticket;
+    const double t0 = rt_now_ms();
+    unsigned spins = 0;
+    while (*t != seq) {
+        __builtin_ia32_pause();
+        if (!(++spins & 0xfff) && rt_now_ms() - t0 > 2000.) {
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            break;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (*t != seq)
+        return rt_fail(ctx, RT_ERR_HIP, "%s: the finishing kernel never "
+                                        "signed", who);
+    return RT_OK;
+}
 
 /* how the rows lie in memory, as the reduction kernels take it */
 static inline rt_pitch rt_pitch_of(const rt_ctx *ctx)
@@ -192,6 +227,7 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
          * was built and measured: the 1024 L2 write-backs / invalidates of
          * the fences cost 17 us, the launch they save 5:
          * profiles/r04_probes/session30.) */
+        const unsigned long long seq = ++ctx->row_seq;
         RT_CONSUMER_BEGIN(ctx);
         if (ctx->d_w) {
             hipLaunchKernelGGL(rt_rms_shifted_kernel<true>, dim3(blocks),
@@ -200,7 +236,8 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
                                ctx->d_partials);
             hipLaunchKernelGGL(rt_rms_finish_kernel<true>, dim3(1), dim3(64),
                                0, ctx->stream, ctx->d_partials, (int)blocks,
-                               ref < 0 ? 1 : 0, (double)ctx->n, ctx->h_res);
+                               ref < 0 ? 1 : 0, (double)ctx->n, ctx->h_res,
+                               rt_res_ticket(ctx), seq);
         } else {
             hipLaunchKernelGGL(rt_rms_shifted_kernel<false>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
@@ -208,11 +245,14 @@ int rt_rms(rt_ctx *ctx, int surf, int64_t ref, double *rms)
                                ctx->d_partials);
             hipLaunchKernelGGL(rt_rms_finish_kernel<false>, dim3(1), dim3(64),
                                0, ctx->stream, ctx->d_partials, (int)blocks,
-                               ref < 0 ? 1 : 0, (double)ctx->n, ctx->h_res);
+                               ref < 0 ? 1 : 0, (double)ctx->n, ctx->h_res,
+                               rt_res_ticket(ctx), seq);
         }
         RT_CONSUMER_END(ctx);
         RT_HIP(ctx, hipGetLastError());
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = rt_wait_signed(ctx, rt_res_ticket(ctx), seq, "rt_rms");
+        if (rc != RT_OK)
+            return rc;
         const double r = ctx->h_res[0], a = ctx->h_res[1];
         /* NaN stays NaN (one vignetted ray poisons the reference's mean
          * too); otherwise the subtraction may have cost six bits */
@@ -253,15 +293,19 @@ int rt_row_rmax(rt_ctx *ctx, int surf, double *rmax)
     if (!rmax)
         return rt_fail(ctx, RT_ERR_ARG, "rt_row_rmax: NULL");
     const unsigned blocks = rt_red_blocks(ctx->n);
+    const unsigned long long seq = ++ctx->row_seq;
     RT_CONSUMER_BEGIN(ctx);
     hipLaunchKernelGGL(rt_r2max_kernel, dim3(blocks), dim3(RT_RED_THREADS), 0,
                        ctx->stream, rt_row(ctx, RT_Y, surf), ctx->n, rt_pitch_of(ctx),
                        ctx->d_partials);
     hipLaunchKernelGGL(rt_r2max_finish_kernel, dim3(1), dim3(64), 0,
-                       ctx->stream, ctx->d_partials, (int)blocks, ctx->h_res);
+                       ctx->stream, ctx->d_partials, (int)blocks, ctx->h_res,
+                       rt_res_ticket(ctx), seq);
     RT_CONSUMER_END(ctx);
     RT_HIP(ctx, hipGetLastError());
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = rt_wait_signed(ctx, rt_res_ticket(ctx), seq, "rt_row_rmax");
+    if (rc != RT_OK)
+        return rc;
     *rmax = ctx->h_res[1] != 0. ? __builtin_nan("") : sqrt(ctx->h_res[0]);
     return RT_OK;
 }
@@ -402,23 +446,10 @@ int rt_row_stats(rt_ctx *ctx, int surf, int64_t group_rays, int ngroups,
                        shifts, final, ticket, seq, ctx->d_arrived);
     RT_CONSUMER_END(ctx);
     RT_HIP(ctx, hipGetLastError());
-    if (pinned && !ctx->opt_cevents) {
-        /* spin on the ticket; a device that does not answer within 2 s is
-         * left to the stream's own error reporting */
-        volatile unsigned long long *t = ticket;
-        const double t0 = rt_now_ms();
-        unsigned spins = 0;
-        while (*t != seq) {
-            __builtin_ia32_pause();
-            if (!(++spins & 0xfff) && rt_now_ms() - t0 > 2000.) {
-                RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                break;
-            }
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        if (*t != seq)
-            return rt_fail(ctx, RT_ERR_HIP,
-                           "rt_row_stats: the finishing kernel never signed");
+    if (pinned) {
+        rc = rt_wait_signed(ctx, ticket, seq, "rt_row_stats");
+        if (rc != RT_OK)
+            return rc;
     } else {
         if (!pinned)
             RT_HIP(ctx, hipMemcpyAsync(out, dfinal,
@@ -469,6 +500,7 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
     const double *Irow = rt_row(ctx, RT_I, surf);
     const unsigned blocks = rt_red_blocks(ctx->n);
     if (ctx->opt_onepass) {
+        const unsigned long long seq = ++ctx->row_seq;
         RT_CONSUMER_BEGIN(ctx);
         if (ctx->d_w) {
             hipLaunchKernelGGL(rt_refocus_shifted_kernel<true>, dim3(blocks),
@@ -477,7 +509,8 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
                                ctx->d_partials);
             hipLaunchKernelGGL(rt_refocus_finish_kernel<true>, dim3(1),
                                dim3(64), 0, ctx->stream, ctx->d_partials,
-                               (int)blocks, ctx->h_res);
+                               (int)blocks, ctx->h_res, rt_res_ticket(ctx),
+                               seq);
         } else {
             hipLaunchKernelGGL(rt_refocus_shifted_kernel<false>, dim3(blocks),
                                dim3(RT_RED_THREADS), 0, ctx->stream, Yrow,
@@ -485,11 +518,14 @@ int rt_refocus_shift(rt_ctx *ctx, int surf, double *shift)
                                ctx->d_partials);
             hipLaunchKernelGGL(rt_refocus_finish_kernel<false>, dim3(1),
                                dim3(64), 0, ctx->stream, ctx->d_partials,
-                               (int)blocks, ctx->h_res);
+                               (int)blocks, ctx->h_res, rt_res_ticket(ctx),
+                               seq);
         }
         RT_CONSUMER_END(ctx);
         RT_HIP(ctx, hipGetLastError());
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = rt_wait_signed(ctx, rt_res_ticket(ctx), seq, "rt_refocus_shift");
+        if (rc != RT_OK)
+            return rc;
         const double *h = ctx->h_res;
         /* ray 0 vignetted (nothing finite), or the shift by it cost more
          * than six bits of <u,u> or <y,y>: the two passes below */

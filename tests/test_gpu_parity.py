@@ -561,8 +561,8 @@ def test_parity_sample_at_C5_size():
     fields = np.c_[np.zeros(5), (0, .35, .5, .7, 1.)]
     per = 20_000_000
     g = ra.GeometricTrace(system)
-    g.rays_fields(fields, dc.disc_points(per, 91), P.DOUBLE_GAUSS_PUPIL_Z,
-                  17.)
+    pts = dc.disc_points(per, 91)
+    g.rays_fields(fields, pts, P.DOUBLE_GAUSS_PUPIL_Z, 17.)
     n = g.nrays
     assert n == 100_000_000
     g.propagate(clip=True)
@@ -576,6 +576,22 @@ def test_parity_sample_at_C5_size():
     assert len(np.unique(rays//per)) == 5          # and every bundle
     y0, u0 = cols[RT_Y][0], cols[RT_U][0]
     assert np.array_equal(cols[RT_I][0], u0) and not cols[RT_T][0].any()
+    # the launch rays the device built at this size against the aiming oracle
+    # (oracle/aim_numpy.py, pinned to the reference's System.aim by
+    # tests/test_generate.py): the sampled rays of every bundle from their own
+    # pupil points (generation at the largest shape was only
+    # compared at 5000 points)
+    from test_generate import oracle_rays
+    a2 = 17.*np.array(((-1., -1.), (1., 1.)))
+    for f in range(5):
+        sel = rays//per == f
+        with np.errstate(all="ignore"):
+            yr, ur = oracle_rays(system, fields[f], pts[rays[sel] % per],
+                                 P.DOUBLE_GAUSS_PUPIL_Z, a2)
+        assert_parity(y0[sel][None], yr[None], 1e-13, "C5 launch y, field %d"
+                      % f)
+        assert_parity(u0[sel][None], ur[None], 1e-13, "C5 launch u, field %d"
+                      % f)
     want, _ = oracle_trace(system, y0, u0, g.l, True)
     dead = 0
     for w, ref in zip((RT_Y, RT_U, RT_I, RT_T), want):
