@@ -116,7 +116,9 @@ struct rt_ctx {
     int device;
     hipStream_t stream;      /* trace + copies */
     hipStream_t comm_stream; /* RCCL gather */
-    hipStream_t copy_stream; /* device -> host DMAs of row downloads (rt_d2h_jobs) */
+    hipStream_t copy_stream; /* device -> host DMAs of row downloads (rt_d2h_jobs);
+                                the seed kernels of a windowed upload */
+    hipEvent_t seed_ev;      /* orders those against the uploads */
     hipEvent_t k0, k1;       /* around the last trace kernel */
     hipEvent_t ev[RT_NEVENTS];
     int traced;

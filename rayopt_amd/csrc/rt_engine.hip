@@ -374,6 +374,8 @@ int rt_destroy(rt_ctx *ctx)
         (void)hipHostFree(ctx->h_res);
     if (ctx->h_group)
         (void)hipHostFree(ctx->h_group);
+    if (ctx->seed_ev)
+        (void)hipEventDestroy(ctx->seed_ev);
     if (ctx->h_rows)
         (void)hipHostFree(ctx->h_rows);
     if (ctx->d_arrived)
@@ -683,30 +685,54 @@ int rt_need_scratch(rt_ctx *ctx, size_t bytes)
     return RT_OK;
 }
 
-static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
-                   int64_t n, int layout, int64_t period)
+/* rays lo .. hi - 1 of row 0 from the staged launch rays (hi == n: the
+ * padding columns up to ld too), on `stream` */
+static int rt_seed_window(rt_ctx *ctx, const double *d_y, const double *d_u,
+                          int64_t n, int layout, int64_t period, int64_t lo,
+                          int64_t hi, hipStream_t stream)
 {
     const int block = 256;
-    const unsigned grid = (unsigned)((ctx->ld + block - 1) / block);
-    ctx->uni_valid = 0;
-    ctx->opd_n = 0; /* (kept path differences: of the rays that were here) */
+    const int64_t j1 = hi >= n ? ctx->ld : hi;
+    const unsigned grid = (unsigned)((j1 - lo + block - 1) / block);
     if (layout == RT_LAYOUT_AOS)
         hipLaunchKernelGGL(rt_seed_aos_kernel, dim3(grid), dim3(block), 0,
-                           ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
-                           !ctx->opt_alias, period,
-                           rt_tiles_of(ctx, 0, true));
+                           stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
+                           !ctx->opt_alias, period, rt_tiles_of(ctx, 0, true),
+                           lo, j1);
     else
         hipLaunchKernelGGL(rt_seed_soa_kernel, dim3(grid), dim3(block), 0,
-                           ctx->stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
-                           !ctx->opt_alias, period,
-                           rt_tiles_of(ctx, 0, true));
+                           stream, d_y, d_u, n, rt_layout(ctx), ctx->ld,
+                           !ctx->opt_alias, period, rt_tiles_of(ctx, 0, true),
+                           lo, j1);
     RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+static void rt_seed_begin(rt_ctx *ctx)
+{
+    ctx->uni_valid = 0;
+    ctx->opd_n = 0; /* (kept path differences: of the rays that were here) */
+}
+
+static void rt_seed_done(rt_ctx *ctx)
+{
     ctx->uni_valid = 1; /* the notes describe row 0 */
     ctx->i_alias[0] = ctx->opt_alias ? 2 : 0; /* i[0] = u[0] (:67) */
     ctx->u_alias[0] = 0;
     ctx->valid[0] = 1;
     ctx->gen_pending = 0; /* these rays replace a generated batch */
     ctx->gen_live = 0;
+}
+
+static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
+                   int64_t n, int layout, int64_t period)
+{
+    rt_seed_begin(ctx);
+    const int rc = rt_seed_window(ctx, d_y, d_u, n, layout, period, 0, n,
+                                  ctx->stream);
+    if (rc != RT_OK)
+        return rc;
+    rt_seed_done(ctx);
     return RT_OK;
 }
 
@@ -808,7 +834,8 @@ int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
     /* the first chunk is a quarter: nothing crosses PCIe while it is staged */
     size_t len = 0;
     for (size_t off = 0; off < bytes; off += len, k ^= 1) {
-        const size_t chunk = off ? RT_PIN_CHUNK : RT_PIN_CHUNK / 4;
+        const size_t chunk = off || bytes <= RT_PIN_CHUNK ? RT_PIN_CHUNK
+                                                          : RT_PIN_CHUNK / 4;
         len = bytes - off < chunk ? bytes - off : chunk;
         if (ctx->pin_busy[k]) /* this call's or an earlier call's DMA */
             RT_HIP(ctx, hipEventSynchronize(ctx->pin_done[k]));
@@ -1012,6 +1039,46 @@ int rt_set_rays_repeat(rt_ctx *ctx, const double *y, const double *u,
         return rc;
     double *sy = (double *)ctx->d_scratch;
     double *su = sy + (size_t)p * 3;
+    if (layout == RT_LAYOUT_AOS && copies == 1 && bytes > 2 * RT_PIN_CHUNK) {
+        /* a large (n, 3) upload is seeded WINDOW BY WINDOW: y and u of
+         * ~1.4 * 10^6 rays (one staging chunk each) cross PCIe, then their
+         * seed kernel runs on a second stream while the next window's chunks
+         * follow on the first -- the seed (0.25 ms at 10^7 rays) and the
+         * pipeline's drain no longer stand behind the last byte */
+        if (!ctx->copy_stream)
+            RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream,
+                                                 hipStreamNonBlocking));
+        if (!ctx->seed_ev)
+            RT_HIP(ctx, hipEventCreateWithFlags(&ctx->seed_ev,
+                                                hipEventDisableTiming));
+        const int64_t W = (int64_t)(RT_PIN_CHUNK / 24) / 256 * 256;
+        rt_seed_begin(ctx);
+        /* (everything queued on the trace stream so far comes first) */
+        RT_HIP(ctx, hipEventRecord(ctx->seed_ev, ctx->stream));
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->seed_ev, 0));
+        for (int64_t lo = 0; lo < n;) {
+            const int64_t w = lo ? W : W / 4; /* a short first window */
+            const int64_t hi = lo + w < n ? lo + w : n;
+            const size_t wb = (size_t)(hi - lo) * 3 * sizeof(double);
+            rc = rt_h2d(ctx, sy + lo * 3, y + lo * 3, wb);
+            if (rc == RT_OK)
+                rc = rt_h2d(ctx, su + lo * 3, u + lo * 3, wb);
+            if (rc != RT_OK)
+                return rc;
+            RT_HIP(ctx, hipEventRecord(ctx->seed_ev, ctx->stream));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->seed_ev, 0));
+            rc = rt_seed_window(ctx, sy, su, n, layout, p, lo, hi,
+                                ctx->copy_stream);
+            if (rc != RT_OK)
+                return rc;
+            lo = hi;
+        }
+        RT_HIP(ctx, hipEventRecord(ctx->seed_ev, ctx->copy_stream));
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->seed_ev, 0));
+        rt_seed_done(ctx);
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return RT_OK;
+    }
     rc = rt_h2d(ctx, sy, y, bytes);
     if (rc == RT_OK)
         rc = rt_h2d(ctx, su, u, bytes);

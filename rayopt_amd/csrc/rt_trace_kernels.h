@@ -366,10 +366,12 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
                                    const double *__restrict__ u_aos,
                                    int64_t n, rt_lay a, int64_t ld,
                                    int store_i, int64_t period,
-                                   rt_tiles tiles)
+                                   rt_tiles tiles, int64_t j0, int64_t j1)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ld)
+    /* rays j0 .. j1 - 1 of the batch (a window of whole workgroups: an
+     * upload is seeded window by window while the next one crosses PCIe) */
+    const int64_t j = j0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld || j >= j1)
         return;
     const bool in = j < n;
     const int64_t k = j % period; /* the same rays for every group */
@@ -407,10 +409,12 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
                                    const double *__restrict__ u_soa,
                                    int64_t n, rt_lay a, int64_t ld,
                                    int store_i, int64_t period,
-                                   rt_tiles tiles)
+                                   rt_tiles tiles, int64_t j0, int64_t j1)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ld)
+    /* rays j0 .. j1 - 1 of the batch (a window of whole workgroups: an
+     * upload is seeded window by window while the next one crosses PCIe) */
+    const int64_t j = j0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld || j >= j1)
         return;
     const bool in = j < n;
     const int64_t k = j % period; /* the same rays for every group */
