@@ -119,6 +119,7 @@ struct rt_ctx {
     hipStream_t copy_stream; /* device -> host DMAs of row downloads (rt_d2h_jobs);
                                 the seed kernels of a windowed upload */
     hipEvent_t seed_ev;      /* orders those against the uploads */
+    int pin_next;            /* staging buffer the next upload chunk takes */
     hipEvent_t k0, k1;       /* around the last trace kernel */
     hipEvent_t ev[RT_NEVENTS];
     int traced;

@@ -736,7 +736,18 @@ static int rt_seed(rt_ctx *ctx, const double *d_y, const double *d_u,
     return RT_OK;
 }
 
-#define RT_PIN_CHUNK ((size_t)32 << 20)
+/* bytes of one staging buffer (RT_PIN_CHUNK_MIB: measurements) */
+static size_t rt_pin_chunk(void)
+{
+    static size_t v = 0;
+    if (!v) {
+        const char *e = getenv("RT_PIN_CHUNK_MIB");
+        const long m = e ? atol(e) : 0;
+        v = (size_t)(m >= 4 && m <= 512 ? m : 32) << 20;
+    }
+    return v;
+}
+#define RT_PIN_CHUNK rt_pin_chunk()
 
 /* the staging buffers are read and written by the host's copy threads:
  * RT_PIN_NONCOHERENT=1 asks for host-cached (non-coherent) pinned memory --
@@ -830,10 +841,12 @@ int rt_h2d(rt_ctx *ctx, void *dst, const void *src, size_t bytes)
             RT_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_done[i],
                                                 rt_pin_event_flags()));
         }
-    int k = 0;
+    /* (the buffers alternate ACROSS calls too: a windowed upload is a chain
+     * of one-chunk calls) */
+    int k = ctx->pin_next & 1;
     /* the first chunk is a quarter: nothing crosses PCIe while it is staged */
     size_t len = 0;
-    for (size_t off = 0; off < bytes; off += len, k ^= 1) {
+    for (size_t off = 0; off < bytes; off += len, k ^= 1, ctx->pin_next = k) {
         const size_t chunk = off || bytes <= RT_PIN_CHUNK ? RT_PIN_CHUNK
                                                           : RT_PIN_CHUNK / 4;
         len = bytes - off < chunk ? bytes - off : chunk;
