@@ -120,6 +120,8 @@ struct rt_ctx {
                                 the seed kernels of a windowed upload */
     hipEvent_t seed_ev;      /* orders those against the uploads */
     int pin_next;            /* staging buffer the next upload chunk takes */
+    float uni_share;         /* share of the launch components that is uniform
+                                across a tile, sampled (-1: not known) */
     hipEvent_t k0, k1;       /* around the last trace kernel */
     hipEvent_t ev[RT_NEVENTS];
     int traced;

@@ -151,8 +151,19 @@ static size_t rt_resident_lds(const rt_ctx *c, int start, int stop)
      * (tilted systems: ten streams per element, 1.49 against 1.52) */
     if (2 * stored_i > stored)
         return 65536;
-    if (c->place.fast)
+    if (c->place.fast) {
+        /* ... unless the launch rows are read ray by ray (hardly a component
+         * uniform across a tile: a caller's own bundle): the kernel without
+         * the Newton solves leaves room for eleven wavefronts per SIMD, and
+         * the loads among the saturated stores want them -- C3' 1.080-1.087
+         * ms with eight and more workgroups per CU against 1.093-1.101 with
+         * four, the collimated headline 0.976-0.979 against 0.965-0.980
+         * (scripts/c3p_lab.py, round 6) */
+        if (start == 1 && c->uni_valid && c->uni_share >= 0.f &&
+            c->uni_share < .4f && !c->table_asph)
+            return 0;
         return 32768;
+    }
     /* plain allocations: two per CU (the setting that does not care where
      * it writes), except small batches, short kernels whose launch ramp
      * wants every wavefront (3*10^5 rays: 0.049 ms uncapped, 0.058 with two
@@ -708,8 +719,31 @@ static int rt_seed_window(rt_ctx *ctx, const double *d_y, const double *d_u,
     return RT_OK;
 }
 
+/* What share of the launch components is uniform across a tile, from 64
+ * of the notes the seed kernel has just written (large batches only: the
+ * answer picks the resident workgroups per CU, rt_resident_lds, which small
+ * batches do not cap at all).  The stream has been synchronised. */
+static int rt_sample_notes(rt_ctx *ctx)
+{
+    ctx->uni_share = -1.f;
+    const int64_t tiles = ctx->ld / 64;
+    if (!ctx->uni_valid || !ctx->opt_uniform || !ctx->d_uni ||
+        ctx->n < ((int64_t)1 << 19) || tiles < 64)
+        return RT_OK;
+    unsigned notes[64];
+    const size_t pitch = (size_t)(tiles / 64) * sizeof(unsigned);
+    RT_HIP(ctx, hipMemcpy2D(notes, sizeof(unsigned), ctx->d_uni, pitch,
+                            sizeof(unsigned), 64, hipMemcpyDeviceToHost));
+    int bits = 0;
+    for (int k = 0; k < 64; ++k)
+        bits += __builtin_popcount(notes[k] & 63u);
+    ctx->uni_share = (float)bits / (64.f * 6.f);
+    return RT_OK;
+}
+
 static void rt_seed_begin(rt_ctx *ctx)
 {
+    ctx->uni_share = -1.f;
     ctx->uni_valid = 0;
     ctx->opd_n = 0; /* (kept path differences: of the rays that were here) */
 }
@@ -1090,7 +1124,7 @@ int rt_set_rays_repeat(rt_ctx *ctx, const double *y, const double *u,
         RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->seed_ev, 0));
         rt_seed_done(ctx);
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return RT_OK;
+        return rt_sample_notes(ctx);
     }
     rc = rt_h2d(ctx, sy, y, bytes);
     if (rc == RT_OK)
@@ -1102,7 +1136,7 @@ int rt_set_rays_repeat(rt_ctx *ctx, const double *y, const double *u,
         return rc;
     /* caller's host arrays may be released as soon as we return */
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return RT_OK;
+    return rt_sample_notes(ctx);
 }
 
 int rt_set_rays(rt_ctx *ctx, const double *y, const double *u, int64_t n,
