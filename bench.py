@@ -145,14 +145,26 @@ def supervise(argv):
             env=dict(os.environ, RT_BENCH_WORKER="1"), stdout=subprocess.PIPE)
         lines = [ln for ln in res.stdout.decode(errors="replace").splitlines()
                  if ln.strip()]
-        if res.returncode == 0 and lines:
-            if attempt == 1:
+        line = None
+        if lines:
+            try:
+                line = json.loads(lines[-1])
+                line = line if "metric" in line else None
+            except ValueError:
+                line = None
+        if line is not None and res.returncode <= 0:
+            # (a worker that printed its whole line and was killed while
+            # leaving has measured all the same)
+            if attempt == 1 and res.returncode == 0:
                 sys.stdout.write(lines[-1] + "\n")
             else:
-                out = json.loads(lines[-1])
-                out["attempts"] = attempt
-                out["died"] = died
-                sys.stdout.write(json.dumps(out) + "\n")
+                if attempt > 1:
+                    line["attempts"] = attempt
+                    line["died"] = died
+                if res.returncode:
+                    line["worker_killed_after_its_line_by_signal"] = \
+                        -res.returncode
+                sys.stdout.write(json.dumps(line) + "\n")
             sys.stdout.flush()
             return 0
         if res.returncode >= 0:

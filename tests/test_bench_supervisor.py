@@ -56,3 +56,12 @@ def test_three_deaths_are_a_failure(monkeypatch, capsys):
     rc, calls, out = run_supervisor(monkeypatch, capsys,
                                     [Result(-6, b"")]*3)
     assert rc == 1 and len(calls) == 3 and out == ""
+
+
+def test_a_worker_killed_after_its_line_has_measured(monkeypatch, capsys):
+    line = b'{"metric": "m", "value": 3.0}\n'
+    rc, calls, out = run_supervisor(monkeypatch, capsys, [Result(-11, line)])
+    assert rc == 0 and len(calls) == 1
+    d = json.loads(out)
+    assert d["value"] == 3.0
+    assert d["worker_killed_after_its_line_by_signal"] == 11
