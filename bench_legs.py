@@ -733,11 +733,14 @@ def input_bytes(eng, n):
     to read: 8 per ray and component, except where a component is one bit
     pattern across a 64-ray tile -- the direction of a collimated bundle, z = 0
     of rays starting on a plane: noted by the seed kernel, fetched once per
-    tile (8 B) -- plus the 4-byte note per tile."""
+    tile (8 B) -- plus the 4-byte note per tile; and u2 is not read at all
+    where it is, bit for bit, the completion of u0 and u1 (rt_input_completed:
+    the trace rebuilds it)."""
     uniform, tiles = eng.input_uniform()
-    if not any(uniform):
+    done = eng.input_completed()    # u2 rebuilt from u0, u1: not read
+    if not any(uniform) and not done:
         return 48*n, [0]*6
-    return (sum(8*(n - 64*u) + 8*u for u in uniform) + 4*tiles,
+    return (sum(8*(n - 64*u) + 8*u for u in uniform) + 4*tiles - 8*64*done,
             [u/tiles for u in uniform])
 
 

@@ -57,7 +57,8 @@ extern "C" {
                            4: rt_opd_stats, rt_opd_device, rt_download_rays;
                               rt_placement(info[16], ms[16]) reports the
                               address ranges measured
-                           5: rt_row_stats, rt_download_xy, rt_newton_census;
+                           5: rt_row_stats, rt_download_xy, rt_newton_census,
+                              rt_input_completed;
                               rt_placement reports the search's time budget */
 #define RT_MAX_ASPH 10      /* even-asphere terms r^2 .. r^20 */
 #define RT_MAX_SURFACES 256 /* elements per System */
@@ -645,6 +646,15 @@ int rt_comm_sync(rt_ctx *ctx);
  * tiles.  All zero but tiles7[6] when the notes are void or switched off.
  */
 int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7);
+/*
+ * ... and *tiles = number of 64-ray tiles whose u2 is not read either: the
+ * seed kernels found every u2 of the tile bit for bit the completion of u0,
+ * u1 -- sqrt(1 - (u0^2 + u1^2)), what the reference writes for two-component
+ * directions (rayopt/geometric_trace.py:57-60), or sqrt((1 - u0^2) - u1^2) --
+ * and the trace rebuilds it with the same operations (8 B per ray less among
+ * the saturated stores; tiles in which u2 is uniform anyway are not counted).
+ */
+int rt_input_completed(rt_ctx *ctx, int64_t *tiles);
 
 /*
  * Where the result arrays live.  The speed of a trace's 7-10 simultaneous row

@@ -156,6 +156,7 @@ SIGNATURES = {
     "rt_gather_ms": (ctypes.c_int, [_ctx, _c_double_p, _c_double_p]),
     "rt_comm_sync": (ctypes.c_int, [_ctx]),
     "rt_input_uniform": (ctypes.c_int, [_ctx, _c_int64_p]),
+    "rt_input_completed": (ctypes.c_int, [_ctx, _c_int64_p]),
     "rt_comm_info": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_int),
                                     ctypes.POINTER(ctypes.c_int),
                                     ctypes.POINTER(ctypes.c_int),

@@ -1950,6 +1950,37 @@ int rt_input_uniform(rt_ctx *ctx, int64_t *tiles7)
     return RT_OK;
 }
 
+/* tiles of row 0 whose u_z a trace rebuilds from u_x, u_y instead of reading
+ * it (the seed kernels found it bit for bit the completion of the other two;
+ * tiles in which u_z is uniform anyway are not counted) */
+int rt_input_completed(rt_ctx *ctx, int64_t *tiles)
+{
+    if (!ctx || !tiles)
+        return rt_fail(ctx, RT_ERR_ARG, "rt_input_completed: NULL argument");
+    *tiles = 0;
+    if (!ctx->d_buf || ctx->ld < 64 || !ctx->uni_valid || !ctx->opt_uniform)
+        return RT_OK;
+    const int64_t nt = ctx->ld / 64;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned *host = (unsigned *)malloc((size_t)nt * sizeof(unsigned));
+    if (!host)
+        return rt_fail(ctx, RT_ERR_NOMEM, "rt_input_completed: host allocation");
+    hipError_t e = hipMemcpyAsync(host, ctx->d_uni, (size_t)nt * sizeof(unsigned),
+                                  hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        free(host);
+        return rt_fail(ctx, RT_ERR_HIP, "rt_input_completed: %s",
+                       hipGetErrorString(e));
+    }
+    for (int64_t t = 0; t < nt; ++t)
+        *tiles += !(host[t] & 32u) &&
+                  (host[t] & (RT_NOTE_UZ_A | RT_NOTE_UZ_B)) != 0;
+    free(host);
+    return RT_OK;
+}
+
 int rt_selftest_arith(rt_ctx *ctx, uint64_t seed, int64_t n, int span,
                       uint64_t mismatches[4])
 {

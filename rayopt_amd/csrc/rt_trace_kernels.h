@@ -42,6 +42,32 @@
  * bundles from an object point 24; the values, hence the results, are the
  * same bits.  Note and index are wave-uniform (SGPRs): nothing diverges.
  */
+/*
+ * A direction's third component is redundant where it IS the completion of
+ * the other two (the reference completes two-component directions itself:
+ * u_z = sqrt(1 - (u_x^2 + u_y^2)), rayopt/geometric_trace.py:57-60; a caller's
+ * own generator usually writes sqrt(1 - u_x^2 - u_y^2)).  The seed kernels
+ * evaluate both forms with the device's own operations and note, per 64-ray
+ * tile, whether every stored u_z equals one of them BIT FOR BIT (bits 6 and
+ * 7 of the tile's note); the trace then rebuilds u_z of such a tile with the
+ * same function instead of reading 8 B per ray among the saturated stores.
+ * Same values by construction; -u_z, NaN rays, anything else: read.
+ */
+#define RT_NOTE_UZ_A 64u  /* u_z == sqrt((1 - u_x^2) - u_y^2) */
+#define RT_NOTE_UZ_B 128u /* u_z == sqrt(1 - (u_x^2 + u_y^2)) */
+
+__device__ __forceinline__ double rt_complete_uz(double ux, double uy, bool b)
+{
+    return b ? sqrt(1. - (ux * ux + uy * uy)) : sqrt((1. - ux * ux) - uy * uy);
+}
+
+__device__ __forceinline__ unsigned rt_same_bits(double v, double w,
+                                                 unsigned bit)
+{
+    return __ballot(__double_as_longlong(v) != __double_as_longlong(w)) == 0ull
+               ? bit : 0u;
+}
+
 struct rt_tiles {
     unsigned *note;   /* [tiles], already offset to the launch's first tile */
     double *first;    /* [6][stride], likewise */
@@ -61,6 +87,8 @@ __device__ __forceinline__ void rt_load_state_tiles(
             y[0][c] = RT_INPUT_LOAD(&a.Y[srow * a.ss + c * a.cs + col]);
         if ((m >> (3 + c)) & 1)
             u[0][c] = tl.first[(3 + c) * tl.stride + tile];
+        else if (c == 2 && (m & (RT_NOTE_UZ_A | RT_NOTE_UZ_B)))
+            u[0][2] = rt_complete_uz(u[0][0], u[0][1], !(m & RT_NOTE_UZ_A));
         else
             u[0][c] = RT_INPUT_LOAD(&a.U[srow * a.ss + c * a.cs + col]);
     }
@@ -390,6 +418,10 @@ __global__ void rt_seed_aos_kernel(const double *__restrict__ y_aos,
             a.I[c * a.cs + col] = q;
         note |= rt_uniform_bit(p, c) | rt_uniform_bit(q, 3 + c);
     }
+    note |= rt_same_bits(first[5], rt_complete_uz(first[3], first[4], false),
+                         RT_NOTE_UZ_A) |
+            rt_same_bits(first[5], rt_complete_uz(first[3], first[4], true),
+                         RT_NOTE_UZ_B);
     a.T[col] = 0.;
     if (tiles.note && (threadIdx.x & 63) == 0) {
         /* (ld is a multiple of 64: a wavefront is one tile; a tile with
@@ -433,6 +465,10 @@ __global__ void rt_seed_soa_kernel(const double *__restrict__ y_soa,
             a.I[c * a.cs + col] = q;
         note |= rt_uniform_bit(p, c) | rt_uniform_bit(q, 3 + c);
     }
+    note |= rt_same_bits(first[5], rt_complete_uz(first[3], first[4], false),
+                         RT_NOTE_UZ_A) |
+            rt_same_bits(first[5], rt_complete_uz(first[3], first[4], true),
+                         RT_NOTE_UZ_B);
     a.T[col] = 0.;
     if (tiles.note && (threadIdx.x & 63) == 0) {
         /* (ld is a multiple of 64: a wavefront is one tile; a tile with

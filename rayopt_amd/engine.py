@@ -364,6 +364,14 @@ class Engine:
         self._check(self.lib.rt_input_uniform(self.ctx, t), "rt_input_uniform")
         return list(t[:6]), int(t[6])
 
+    def input_completed(self):
+        """Tiles of row 0 whose u_z a trace rebuilds from u_x, u_y instead of
+        reading it (rt_input_completed)."""
+        t = ctypes.c_int64()
+        self._check(self.lib.rt_input_completed(self.ctx, ctypes.byref(t)),
+                    "rt_input_completed")
+        return int(t.value)
+
     def placement(self):
         """Where the result arrays live (rt_placement): dict with the pieces
         behind them (0 = plain hipMalloc), MiB per piece, pieces created on

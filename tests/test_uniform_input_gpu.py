@@ -119,3 +119,44 @@ def test_partial_traces_and_ray_groups_keep_their_bits():
     a.propagate(start=3, clip=False)
     b.propagate(start=3, clip=False)
     assert same(rows_of(a), rows_of(b))
+
+
+@pytest.mark.parametrize("n", [64*50, 64*50 + 17, 200_000])
+def test_a_direction_s_third_component_is_rebuilt_where_it_is_the_completion(n):
+    """u_z that is, bit for bit, sqrt(1 - (u_x^2 + u_y^2)) (what the reference
+    writes for two-component directions, rayopt/geometric_trace.py:57-60) or
+    sqrt((1 - u_x^2) - u_y^2) is not read by the trace but rebuilt with the
+    same operations: noted per tile by the seed kernels, same bits always;
+    a tile with one ray that is anything else (-u_z, a perturbed u_z, NaN)
+    is read."""
+    system = ra.system_from_yaml(P.DOUBLE_GAUSS)
+    rng = np.random.default_rng(n)
+    y, u = disc_bundle(n, 15., 5., 3, P.DOUBLE_GAUSS_PUPIL_Z)
+    u[:, :2] += 1e-3*rng.standard_normal((n, 2))
+    full = n//64
+    for form in (0, 1):
+        if form:
+            u[:, 2] = np.sqrt(1. - np.square(u[:, :2]).sum(1))
+        else:
+            u[:, 2] = np.sqrt(1. - u[:, 0]**2 - u[:, 1]**2)
+        g = traced(system, y, u)
+        assert g.engine.input_uniform()[0][3:] == [0, 0, 0]
+        assert g.engine.input_completed() == full
+        plain = traced(system, y, u, uniform_input=0)
+        assert plain.engine.input_completed() == 0
+        assert same(rows_of(g), rows_of(plain))
+        assert np.array_equal(np.asarray(g.u[0]), u)
+        g.rays_given(y, u)
+        g.propagate(clip=True, chunks=3)
+        assert same(rows_of(g), rows_of(plain))
+    # tiles 3, 7 and 11 hold one ray each that is not the completion
+    v = u.copy()
+    v[3*64 + 5, 2] *= -1.
+    v[7*64 + 63, 2] = np.nextafter(v[7*64 + 63, 2], 2.)
+    v[11*64, :] = np.nan
+    g = traced(system, y, v)
+    assert g.engine.input_completed() == full - 3
+    assert same(rows_of(g), rows_of(traced(system, y, v, uniform_input=0)))
+    # a collimated bundle: u_z is uniform, not "completed"
+    yc, uc = disc_bundle(6400, 17., 7., 2, P.DOUBLE_GAUSS_PUPIL_Z)
+    assert traced(system, yc, uc).engine.input_completed() == 0
