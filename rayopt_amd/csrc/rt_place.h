@@ -444,6 +444,13 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
             /* (a piece the arrays need is no reason to stop choosing) */
             stalled = stalled ||
                       (took > RT_PLACE_STALL_MS && (choice || made >= need));
+            /* (while what there is is ONE class the clock stops for a stall:
+             * the hard limit is for the search's own work -- a 4 s create in
+             * a 20 GiB stretch of one class had used it up, round 6) */
+            if (took > RT_PLACE_STALL_MS && !have_mix && deadline < 1e299) {
+                deadline += took;
+                c->place_deadline_ms = deadline;
+            }
         }
         ++made;
         if (!choice && made == need)
@@ -553,6 +560,10 @@ static hipError_t rt_place_alloc(rt_ctx *c, void **out, size_t bytes)
                 slowest_create =
                     (float)took > slowest_create ? (float)took : slowest_create;
                 stalled = stalled || took > RT_PLACE_STALL_MS;
+                if (took > RT_PLACE_STALL_MS && !have_mix && deadline < 1e299) {
+                    deadline += took;
+                    c->place_deadline_ms = deadline;
+                }
             }
             if (hopped) { /* (a hop that created nothing is not one) */
                 ++hops;
@@ -1055,7 +1066,7 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
      * up to eight sets inside the same time budget, and two GiB of ballast
      * are put between one set and the next. */
     const bool small = c->place.bytes < ((size_t)4 << 30);
-    hipMemGenericAllocationHandle_t gap[2 * RT_PLACE_PICKS];
+    hipMemGenericAllocationHandle_t gap[8 * RT_PLACE_PICKS];
     int ngap = 0;
     while (picks < (small ? RT_PLACE_PICKS : 5) && c->d_buf &&
            c->place.base && c->place.store_gbps > 0.f &&
@@ -1083,7 +1094,11 @@ static void rt_place_settle(rt_ctx *c, int L, long long ld, size_t bytes)
             prop.type = hipMemAllocationTypePinned;
             prop.location.type = hipMemLocationTypeDevice;
             prop.location.id = c->device;
-            for (int b = 0; b < 2; ++b) {
+            /* (eight GiB where the set behaves like ONE class: such
+             * stretches are 4 ... 64 GiB long) */
+            const int blocks =
+                c->place.store_gbps < RT_PLACE_FAST_GBPS ? 8 : 2;
+            for (int b = 0; b < blocks && ngap < 8 * RT_PLACE_PICKS; ++b) {
                 if (hipMemCreate(&gap[ngap], (size_t)1 << 30, &prop, 0) !=
                     hipSuccess) {
                     (void)hipGetLastError();
