@@ -47,9 +47,11 @@ struct rt_copy_pool {
     size_t len = 0, part = 0;
     int first = 0;
 
-    void run(int w)
+    void run(int w, unsigned long long seen)
     {
-        unsigned long long seen = 0;
+        /* `seen`: the generation at the worker's birth -- one that joins a
+         * pool which has worked before must not take the last job for a new
+         * one (its buffers may be gone) */
         for (;;) {
             /* hot for ~1 ms after the last job, then asleep */
             const auto t0 = std::chrono::steady_clock::now();
@@ -93,8 +95,10 @@ struct rt_copy_pool {
             gen.store(0);
             left.store(0);
         }
+        /* (no job is in flight: the caller holds `owner`) */
+        const unsigned long long born = gen.load(std::memory_order_acquire);
         for (; n < workers && n < RT_POOL_MAX; ++n)
-            th[n] = std::thread([this, w = n] { run(w); });
+            th[n] = std::thread([this, w = n, born] { run(w, born); });
     }
 
     ~rt_copy_pool()
