@@ -694,12 +694,12 @@ class GeometricTrace(Trace):
         batch at once.  ``lost``: "nan" = a bundle that lost a ray gives NaN
         as the reference does; "omit" = statistics of the rays that
         arrived."""
-        s = self.spot_stats(i)
-        r = np.sqrt(s[..., 3])
+        s = self.row_stats(i, ref=-1)       # one pass over the row
+        r = np.sqrt(s["var_mean"])
         if lost == "nan":
             alive = self.rays_alive_per_field or \
-                self.nrays//max(1, s[..., 0].size)
-            r = np.where(s[..., 0] < alive, np.nan, r)
+                self.nrays//max(1, s["count"].size)
+            r = np.where(s["count"] < alive, np.nan, r)
         elif lost != "omit":
             raise ValueError("lost must be 'nan' or 'omit'")
         return r

@@ -6,8 +6,9 @@ Same public names, argument meaning and result object as the reference's
 written for rayopt run unchanged; the difference is what an operand costs.
 :class:`SpotOperand` evaluates the RMS spot of every field at every
 wavelength with ONE batched trace that stores only the image row
-(``propagate(keep=[-1])``) and ONE device reduction (``rt_spot_stats``):
-a few milliseconds and ``6 x fields x wavelengths`` doubles over PCIe per
+(``propagate(keep=[-1])``) and ONE device reduction (``rt_row_stats``, one
+pass over the image row):
+a few milliseconds and ``10 x fields x wavelengths`` doubles over PCIe per
 merit evaluation, where the reference traces bundle after bundle on the host.
 
 The minimiser itself is scipy's, driven exactly as the reference drives it
@@ -255,7 +256,9 @@ class SpotOperand(Operand):
         engine.set_keep_rows(mask)
         engine.trace(1, 0, self.clip)
         self.kernel_ms.append(engine.kernel_ms())
-        stats = engine.spot_stats(len(self.system) - 1, len(yp), len(frames))
+        # count and spread of every bundle in one pass (rt_row_stats)
+        stats = engine.row_stats(len(self.system) - 1, len(yp), len(frames))
+        stats = stats[:, (0, 2, 3, 4)]      # count, centroid, spread
         r = np.sqrt(stats[:, 3])
         if self.lost == "nan":
             r = np.where(stats[:, 0] < alive, np.nan, r)
