@@ -627,3 +627,30 @@ def test_opd_stats_per_bundle(n, bundles, block):
     with pytest.raises(ValueError, match="do not split"):
         tr.opd_stats(radius=100.,
                      bundles=next(k for k in range(2, n) if n % k))
+
+
+@pytest.mark.gpu
+def test_opd_rays_takes_its_host_buffer_again_only_when_nobody_holds_it():
+    """The per-ray OPD lands in the buffer of the previous call (fresh host
+    pages cost more than PCIe) -- unless the caller still holds that result
+    or a view of it, which then stays what it was."""
+    system = ra.system_from_yaml(ra.prescriptions.DOUBLE_GAUSS)
+    y, u = ra.bundles.disc_bundle(50_000, 12., 3., 1,
+                                  ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    tr = ra.GeometricTrace(system)
+    tr.rays_given(y, u)
+    tr.propagate()
+    x1, y1, t1 = tr.opd_rays(radius=100.)
+    keep = t1.copy()
+    y2, u2 = ra.bundles.disc_bundle(50_000, 12., 9., 2,
+                                    ra.prescriptions.DOUBLE_GAUSS_PUPIL_Z)
+    tr.rays_given(y2, u2)
+    tr.propagate()
+    x2, yy2, t2 = tr.opd_rays(radius=100.)     # t1 is still held
+    assert np.array_equal(t1, keep, equal_nan=True)
+    assert not np.shares_memory(t1, t2)
+    assert not np.array_equal(t1, t2, equal_nan=True)
+    where = x2.ctypes.data
+    del x2, yy2, t2
+    x3, y3, t3 = tr.opd_rays(radius=100.)      # nobody held the second
+    assert x3.ctypes.data == where
