@@ -256,3 +256,18 @@ def test_two_ranks_host_side_on_one_device():
     c4 = d["configs4"]
     assert c4["total_rays"] > 99_000_000 and len(c4["kernel_ms_per_rank"]) == 2
     assert c4["value"] > 0
+
+
+def test_only_config_runs_one_leg():
+    """`bench.py --only-config KEY`: ONE leg and nothing else in the process
+    (what a leg's `rocprofv3 --kernel-trace --stats` run uses:
+    profiles/r06_final/legs/); its own small JSON line."""
+    out = subprocess.check_output(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--only-config", "C2",
+         "--rays", "200000"], text=True, cwd=ROOT, stderr=subprocess.DEVNULL,
+        timeout=300)
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = strict_loads(lines[0])
+    assert d["only_config"] == "C2" and d["rays"] == 3_000_000
+    assert d["kernel"] == "rt_trace_kernel" and d["kernel_ms"] > 0
